@@ -1,0 +1,155 @@
+/* smr_hip.h -- C-ABI of libsmr_hip.so, the MI355X (gfx950) back end for smrender's
+ * projection -> draw (raster) -> caption-scan hot path.
+ *
+ * Every entry point is extern "C", takes plain pointers and sizes, returns 0 on success
+ * and a negative SMR_E_* code on failure (smr_hip_last_error() gives the text).  There
+ * is no CPU fallback: without a usable GPU every compute entry point fails with
+ * SMR_E_NODEVICE.  One process drives one GPU (multi-GPU = one process per GPU, each
+ * owning a band of canvas rows).
+ *
+ * Each declaration cites the reference interface (file:line under the smrender tree)
+ * it replaces.  INTEGRATION.md shows the plugin-side binding.
+ */
+#ifndef SMR_HIP_H
+#define SMR_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum
+{
+   SMR_OK = 0,
+   SMR_E_NODEVICE = -1,     /* no HIP device / init not called */
+   SMR_E_INVAL = -2,        /* bad argument */
+   SMR_E_NOMEM = -3,        /* hipMalloc failed */
+   SMR_E_HIP = -4,          /* a HIP runtime call failed */
+   SMR_E_UNSUPPORTED = -5,  /* style feature not implemented on the GPU path (fails loudly) */
+   SMR_E_CAPACITY = -6,     /* a fixed device-side capacity was exceeded (see DESIGN.md limits) */
+};
+
+/* ---- life cycle ------------------------------------------------------------------ */
+int smr_hip_init(int device);                 /* selects the device, creates the stream */
+int smr_hip_shutdown(void);
+const char *smr_hip_last_error(void);
+int smr_hip_device_name(char *buf, size_t len);
+
+/* ---- projection: replaces geo2pxf/geo2pt/geo2pxi + is_on_page -------------------------
+ * src/rdata.c:188-230 (Mercator branch :221-225), :240-255, :482-487; constants are the
+ * ones init_bbox_mll (src/smrender.c:278-311) leaves in struct rdata (src/rdata.h:99-158). */
+typedef struct
+{
+   double lon0;              /* rd->bb.ll.lon */
+   double w, h;              /* rd->w, rd->h  (pixels, double) */
+   double wc;                /* rd->wc */
+   double lath, lath_len;    /* rd->lath, rd->lath_len */
+   double lat_ll, lon_ru, lat_ru;   /* rd->bb (is_on_page) */
+   int32_t dpi;              /* rd->dpi */
+   int32_t pad_;
+} smr_proj_t;
+
+/* restates init_bbox_mll (src/smrender.c:278-311) + mean_lat_len from scale (:697) on the host */
+int smr_hip_proj_from_window(smr_proj_t *p, double mean_lat, double mean_lon, double scale,
+                             double w_px, double h_px, int dpi);
+int smr_hip_set_projection(const smr_proj_t *p);
+
+/* Batched geo2pxf over SoA node arrays.  All pointers are DEVICE pointers; x,y are
+ * required, ix/iy (C round() of x,y: src/rdata.c:253-254) and onpage (is_on_page) may be
+ * NULL.  Runs on the library stream; returns after enqueueing (smr_hip_sync() waits). */
+int smr_hip_project(const double *d_lat, const double *d_lon, int64_t n,
+                    double *d_x, double *d_y, int32_t *d_ix, int32_t *d_iy, uint8_t *d_onpage);
+/* inverse, src/rdata.c:68-72 (pxf2geo) */
+int smr_hip_unproject(const double *d_x, const double *d_y, int64_t n, double *d_lon, double *d_lat);
+
+/* ---- canvas: replaces the recording surface sfc_ + its replay into ARGB32 --------------
+ * src/smrules_cairo.c:308-330 (cairo_smr_init_main_image: bg paint),
+ * :339-356 (cairo_smr_image_surface_from_bg: the pixels), :568-580 (get_pixel). */
+typedef struct smr_canvas smr_canvas_t;
+
+/* Full chart is W x H px at `dpi`; this process owns rows [band_y0, band_y0+band_h).
+ * bgcolor uses the reference's colour ints 0xTTRRGGBB (src/smrparse.c:222-258). */
+int smr_hip_canvas_create(int W, int H, int dpi, uint32_t bgcolor, int band_y0, int band_h, smr_canvas_t **out);
+int smr_hip_canvas_destroy(smr_canvas_t *c);
+/* copy a rectangle (band-local rows) of premultiplied ARGB32 to host memory */
+int smr_hip_canvas_read(smr_canvas_t *c, int x, int y, int w, int h, uint32_t *host_dst);
+/* device pointer + row stride (pixels) of the band, for zero-copy consumers */
+int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *stride_px);
+
+/* ---- draw: replaces act_draw_ini/_main/_fini for one rule --------------------------------
+ * src/smrules_cairo.c:583-694 (style), :845-863 (path), :880-895 (widths), :953-1016
+ * (render_poly_line: border stroke then fill / open stroke), :1019-1073, :1076-1148
+ * (group pop + paint).  One call == one rule == one pushed group layer. */
+typedef struct
+{
+   int32_t fill_used, border_used;          /* color= / bcolor= given */
+   uint32_t fill_col, border_col;           /* 0xTTRRGGBB */
+   double fill_width_mm, border_width_mm;   /* width= / bwidth= (0 -> 1 px hairline) */
+   int32_t ignore_open;                     /* ignore_open=1 */
+   int32_t fill_style, border_style;        /* DRAW_SOLID=0; anything else -> SMR_E_UNSUPPORTED */
+   int32_t curve;                           /* curve=/wavy= -> SMR_E_UNSUPPORTED */
+   int32_t directional;                     /* directional=1 -> SMR_E_UNSUPPORTED */
+   int32_t pad_;
+} smr_draw_style_t;
+
+typedef struct
+{
+   /* nodes, already projected to pixel coordinates (output of smr_hip_project) */
+   const double *d_x, *d_y;        /* [n_nodes] device */
+   int64_t n_nodes;
+   /* ways in the order the host's rule executor visits them (id order) */
+   const int64_t *d_way_off;       /* [n_ways+1] device: first ref of each way */
+   const int32_t *d_ref;           /* [n_refs] device: node index per ref; NULL = identity */
+   int64_t n_ways, n_refs;
+   /* optional per-way colours (color=%key): NULL = use the style's */
+   const uint32_t *d_way_fill_col, *d_way_border_col;
+} smr_draw_batch_t;
+
+int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b);
+
+/* ---- caption auto-rotation: replaces find_angle ----------------------------------------
+ * src/smrules_cairo.c:1959-2019 (find_angle), :1828-1861 (dv_sample), :1746-1759
+ * (rotated OVER paint), :1670-1743 (cairo_smr_dist), :1598-1619 (bw stretch),
+ * :1813-1821, :1868-1890, :1900-1956 (weight, quantize, peaks).  The cut-out is taken from
+ * the device canvas at the rounded centre (difference to :1511-1533). */
+typedef struct
+{
+   const double *d_cx, *d_cy;      /* [n] device: caption anchor in px (geo2pxf of the node) */
+   int64_t n;
+   int32_t fg_w, fg_h;             /* caption plane in px (cairo_smr_plane :1536-1558) */
+   int32_t fg_x;                   /* first opaque column of the plane (E/W alignment), px */
+   uint32_t col;                   /* caption colour 0xTTRRGGBB */
+   double phase_deg, weight;       /* struct auto_rot (src/smrender_dev.h:168-174) */
+} smr_cap_batch_t;
+
+/* d_angle[n]: chosen angle in rad (find_angle's return value); d_dv may be NULL or
+ * [n * num_steps] raw per-angle differences (dv_diff before weighting). */
+int smr_hip_caprot(smr_canvas_t *c, const smr_cap_batch_t *b, double *d_angle, double *d_dv);
+int smr_hip_caprot_steps(int fg_w, int fg_h, int dpi, int *num_steps, int *r_px);
+
+/* ---- stream / timing helpers --------------------------------------------------------- */
+int smr_hip_sync(void);
+void *smr_hip_stream(void);                    /* hipStream_t of the library */
+/* when enabled, every stage of smr_hip_draw/_project/_caprot is bracketed by HIP events on
+ * the library stream; smr_hip_timings() returns the last call's per-stage ms (and syncs). */
+typedef struct
+{
+   float proj_ms, setup_ms, bin_ms, sort_ms, raster_ms, caprot_ms, total_ms;
+   uint64_t n_prims, n_edges, n_tile_refs, n_tiles;
+} smr_timings_t;
+int smr_hip_set_profiling(int on);
+int smr_hip_timings(smr_timings_t *t);
+
+/* device memory helpers so hosts without a HIP binding (ctypes, cgo, the C plugin) can
+ * stage SoA arrays */
+int smr_hip_malloc(void **d_ptr, size_t bytes);
+int smr_hip_free(void *d_ptr);
+int smr_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
+int smr_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

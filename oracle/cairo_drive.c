@@ -1,0 +1,243 @@
+/* cairo_drive.c -- TEST INFRASTRUCTURE (oracle side), not product code.
+ *
+ * Drives the real third-party rasterizer (libcairo 1.16.0 + pixman 0.40.0, the
+ * un-vendored dependency of the reference: configure.ac:52) with the SAME call
+ * sequence the reference issues for the draw path, restated from
+ *   src/smrules_cairo.c:308-330  (main recording surface in pt, bg paint)
+ *   src/smrules_cairo.c:653-660  (per-rule context + push_group)
+ *   src/smrules_cairo.c:845-863  (new_sub_path + line_to per ref)
+ *   src/smrules_cairo.c:953-1016 (border stroke, then fill / open stroke)
+ *   src/smrules_cairo.c:1081-1082 (pop_group_to_source + paint)
+ *   src/smrules_cairo.c:339-356  (replay: scale(dpi/72), set_source_surface, paint)
+ *   src/smrules_cairo.c:1511-1558, 1746-1759 (caption cut-out / plane / rotated diff)
+ * It is used (a) here, to generate the golden fixtures in tests/golden and to pin
+ * the C restatement in smr_oracle.c, and (b) on the GPU box as the "reference
+ * CPU render" timed beside the HIP path (bench.py cpu_baseline). Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * libcairo is dlopen()ed so the file builds without cairo headers.
+ */
+#include <dlfcn.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct _cairo cairo_t;
+typedef struct _cairo_surface cairo_surface_t;
+typedef struct _cairo_pattern cairo_pattern_t;
+typedef struct { double x, y, width, height; } cairo_rectangle_t;
+enum { CAIRO_CONTENT_COLOR_ALPHA = 0x3000, CAIRO_FORMAT_ARGB32 = 0,
+       CAIRO_LINE_CAP_BUTT = 0, CAIRO_LINE_CAP_ROUND = 1, CAIRO_OPERATOR_OVER = 2 };
+
+#define FN(ret, name, args) static ret (*p_##name) args;
+FN(cairo_surface_t*, cairo_recording_surface_create, (int, const cairo_rectangle_t*))
+FN(cairo_surface_t*, cairo_image_surface_create, (int, int, int))
+FN(cairo_surface_t*, cairo_image_surface_create_for_data, (unsigned char*, int, int, int, int))
+FN(cairo_t*, cairo_create, (cairo_surface_t*))
+FN(void, cairo_destroy, (cairo_t*))
+FN(void, cairo_surface_destroy, (cairo_surface_t*))
+FN(void, cairo_surface_flush, (cairo_surface_t*))
+FN(void, cairo_surface_mark_dirty, (cairo_surface_t*))
+FN(unsigned char*, cairo_image_surface_get_data, (cairo_surface_t*))
+FN(int, cairo_image_surface_get_stride, (cairo_surface_t*))
+FN(void, cairo_set_source_rgba, (cairo_t*, double, double, double, double))
+FN(void, cairo_set_source_surface, (cairo_t*, cairo_surface_t*, double, double))
+FN(void, cairo_paint, (cairo_t*))
+FN(void, cairo_push_group, (cairo_t*))
+FN(void, cairo_pop_group_to_source, (cairo_t*))
+FN(void, cairo_new_sub_path, (cairo_t*))
+FN(void, cairo_move_to, (cairo_t*, double, double))
+FN(void, cairo_line_to, (cairo_t*, double, double))
+FN(void, cairo_curve_to, (cairo_t*, double, double, double, double, double, double))
+FN(void, cairo_rectangle, (cairo_t*, double, double, double, double))
+FN(void, cairo_set_line_width, (cairo_t*, double))
+FN(void, cairo_set_line_cap, (cairo_t*, int))
+FN(void, cairo_set_dash, (cairo_t*, const double*, int, double))
+FN(void, cairo_stroke, (cairo_t*))
+FN(void, cairo_fill, (cairo_t*))
+FN(void, cairo_scale, (cairo_t*, double, double))
+FN(void, cairo_translate, (cairo_t*, double, double))
+FN(void, cairo_rotate, (cairo_t*, double))
+FN(void, cairo_save, (cairo_t*))
+FN(void, cairo_restore, (cairo_t*))
+FN(void, cairo_set_operator, (cairo_t*, int))
+FN(int, cairo_status, (cairo_t*))
+FN(int, cairo_surface_status, (cairo_surface_t*))
+FN(const char*, cairo_version_string, (void))
+
+static void *lib_;
+#define LOAD(name) do { *(void**)(&p_##name) = dlsym(lib_, #name); if (!p_##name) { fprintf(stderr, "cairo_drive: missing %s\n", #name); return -2; } } while (0)
+
+int cd_init(const char *path)
+{
+   if (lib_) return 0;
+   const char *cand[] = { path, "libcairo.so.2", "/opt/conda/lib/libcairo.so.2",
+                          "/usr/lib/x86_64-linux-gnu/libcairo.so.2", NULL };
+   for (int i = 0; cand[i] != NULL || i == 0; i++)
+   {
+      if (cand[i] == NULL) continue;
+      if ((lib_ = dlopen(cand[i], RTLD_NOW | RTLD_GLOBAL)) != NULL) break;
+   }
+   if (!lib_) return -1;
+   LOAD(cairo_recording_surface_create); LOAD(cairo_image_surface_create);
+   LOAD(cairo_image_surface_create_for_data); LOAD(cairo_create); LOAD(cairo_destroy);
+   LOAD(cairo_surface_destroy); LOAD(cairo_surface_flush); LOAD(cairo_surface_mark_dirty);
+   LOAD(cairo_image_surface_get_data); LOAD(cairo_image_surface_get_stride);
+   LOAD(cairo_set_source_rgba); LOAD(cairo_set_source_surface); LOAD(cairo_paint);
+   LOAD(cairo_push_group); LOAD(cairo_pop_group_to_source); LOAD(cairo_new_sub_path);
+   LOAD(cairo_move_to); LOAD(cairo_line_to); LOAD(cairo_curve_to); LOAD(cairo_rectangle);
+   LOAD(cairo_set_line_width); LOAD(cairo_set_line_cap); LOAD(cairo_set_dash);
+   LOAD(cairo_stroke); LOAD(cairo_fill); LOAD(cairo_scale); LOAD(cairo_translate);
+   LOAD(cairo_rotate); LOAD(cairo_save); LOAD(cairo_restore); LOAD(cairo_set_operator);
+   LOAD(cairo_status); LOAD(cairo_surface_status); LOAD(cairo_version_string);
+   return 0;
+}
+
+const char *cd_version(void) { return lib_ ? p_cairo_version_string() : "unloaded"; }
+
+/* colour model of the reference: src/smrules_cairo.c:90-95, :271-274 */
+static void set_color(cairo_t *ctx, uint32_t col)
+{
+   double r = (double) ((col >> 16) & 0xff) / 255.0;
+   double g = (double) ((col >> 8) & 0xff) / 255.0;
+   double b = (double) (col & 0xff) / 255.0;
+   double a = 1.0 - (double) (((col & 0x7f000000) >> 23) & 0xff) / 255.0;
+   p_cairo_set_source_rgba(ctx, r, g, b, a);
+}
+
+/* ---- chart state: one main recording surface (sfc_) + the current rule ctx ---- */
+static cairo_surface_t *sfc_;
+static cairo_rectangle_t ext_;
+static cairo_t *rule_;
+
+int cd_begin(double w_pt, double h_pt, uint32_t bgcolor)
+{
+   if (!lib_) return -1;
+   if (sfc_) { p_cairo_surface_destroy(sfc_); sfc_ = NULL; }
+   ext_.x = 0; ext_.y = 0; ext_.width = w_pt; ext_.height = h_pt;
+   sfc_ = p_cairo_recording_surface_create(CAIRO_CONTENT_COLOR_ALPHA, &ext_);
+   cairo_t *ctx = p_cairo_create(sfc_);
+   set_color(ctx, bgcolor);
+   p_cairo_paint(ctx);
+   p_cairo_destroy(ctx);
+   return p_cairo_surface_status(sfc_);
+}
+
+int cd_rule_begin(void)
+{
+   rule_ = p_cairo_create(sfc_);
+   p_cairo_push_group(rule_);
+   return p_cairo_status(rule_);
+}
+
+int cd_rule_end(void)
+{
+   p_cairo_pop_group_to_source(rule_);
+   p_cairo_paint(rule_);
+   int e = p_cairo_status(rule_);
+   p_cairo_destroy(rule_);
+   rule_ = NULL;
+   return e;
+}
+
+/* new_sub_path + line_to per point (cairo_smr_poly_line) */
+void cd_poly_line(const double *xy, int n)
+{
+   p_cairo_new_sub_path(rule_);
+   for (int i = 0; i < n; i++)
+      p_cairo_line_to(rule_, xy[2 * i], xy[2 * i + 1]);
+}
+
+/* move_to + n curve_to (cairo_smr_poly_curve); c = [c1x c1y c2x c2y x y] * n */
+void cd_poly_curve(double x0, double y0, const double *c, int n)
+{
+   p_cairo_new_sub_path(rule_);
+   p_cairo_move_to(rule_, x0, y0);
+   for (int i = 0; i < n; i++, c += 6)
+      p_cairo_curve_to(rule_, c[0], c[1], c[2], c[3], c[4], c[5]);
+}
+
+void cd_set_dash(const double *dash, int n, int round_cap)
+{
+   if (round_cap) p_cairo_set_line_cap(rule_, CAIRO_LINE_CAP_ROUND);
+   p_cairo_set_dash(rule_, dash, n, 0);
+}
+
+void cd_stroke(uint32_t col, double width_pt)
+{
+   set_color(rule_, col);
+   p_cairo_set_line_width(rule_, width_pt);
+   p_cairo_stroke(rule_);
+}
+
+void cd_fill(uint32_t col)
+{
+   set_color(rule_, col);
+   p_cairo_fill(rule_);
+}
+
+/* replay the chart into a W x H ARGB32 window whose top-left pixel is (x0,y0)
+ * of the full canvas (cairo_smr_image_surface_from_bg convention + integer tile origin) */
+int cd_render(double dpi, int x0, int y0, int W, int H, uint32_t *out)
+{
+   cairo_surface_t *img = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, W, H);
+   if (p_cairo_surface_status(img)) return -1;
+   cairo_t *dst = p_cairo_create(img);
+   p_cairo_translate(dst, -x0, -y0);
+   p_cairo_scale(dst, dpi / 72, dpi / 72);
+   p_cairo_set_source_surface(dst, sfc_, 0, 0);
+   p_cairo_paint(dst);
+   int e = p_cairo_status(dst);
+   p_cairo_destroy(dst);
+   p_cairo_surface_flush(img);
+   unsigned char *d = p_cairo_image_surface_get_data(img);
+   int stride = p_cairo_image_surface_get_stride(img);
+   for (int y = 0; y < H; y++)
+      memcpy(out + (size_t) y * W, d + (size_t) y * stride, (size_t) W * 4);
+   p_cairo_surface_destroy(img);
+   return e;
+}
+
+/* direct (no recording surface) variant used for micro-probes: draw a polygon in
+ * device px straight onto an image */
+int cd_direct_fill(const double *xy, int n, uint32_t col, uint32_t bg, int W, int H, uint32_t *out)
+{
+   cairo_surface_t *img = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, W, H);
+   cairo_t *c = p_cairo_create(img);
+   set_color(c, bg); p_cairo_paint(c);
+   p_cairo_new_sub_path(c);
+   for (int i = 0; i < n; i++) p_cairo_line_to(c, xy[2 * i], xy[2 * i + 1]);
+   set_color(c, col); p_cairo_fill(c);
+   p_cairo_destroy(c);
+   p_cairo_surface_flush(img);
+   unsigned char *d = p_cairo_image_surface_get_data(img);
+   int stride = p_cairo_image_surface_get_stride(img);
+   for (int y = 0; y < H; y++) memcpy(out + (size_t) y * W, d + (size_t) y * stride, (size_t) W * 4);
+   p_cairo_surface_destroy(img);
+   return 0;
+}
+
+/* ---- caption scan pieces (cairo_smr_diff): paint src rotated by a about the
+ * centre of dst, OVER, default (bilinear) filter.  dst is updated in place. ---- */
+int cd_rot_paint(uint32_t *dstpix, int dw, int dh, const uint32_t *srcpix, int sw, int sh, double a)
+{
+   cairo_surface_t *dst = p_cairo_image_surface_create_for_data((unsigned char*) dstpix, CAIRO_FORMAT_ARGB32, dw, dh, dw * 4);
+   cairo_surface_t *src = p_cairo_image_surface_create_for_data((unsigned char*) srcpix, CAIRO_FORMAT_ARGB32, sw, sh, sw * 4);
+   cairo_t *ctx = p_cairo_create(dst);
+   double x = dw, y = dh;
+   p_cairo_save(ctx);
+   p_cairo_translate(ctx, x / 2.0, y / 2.0);
+   p_cairo_rotate(ctx, a);
+   p_cairo_set_operator(ctx, CAIRO_OPERATOR_OVER);
+   p_cairo_set_source_surface(ctx, src, sw / -2.0, sh / -2.0);
+   p_cairo_paint(ctx);
+   p_cairo_restore(ctx);
+   int e = p_cairo_status(ctx);
+   p_cairo_destroy(ctx);
+   p_cairo_surface_flush(dst);
+   p_cairo_surface_destroy(dst);
+   p_cairo_surface_destroy(src);
+   return e;
+}

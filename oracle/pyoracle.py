@@ -1,0 +1,225 @@
+"""ctypes front end of the TEST-ONLY checker libraries (oracle/liboracle.so, oracle/libcairo_drive.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build():
+    """(Re)build the checker libraries with gcc (seconds)."""
+    subprocess.run(["make", "-C", _HERE, "all"], check=True, stdout=subprocess.DEVNULL)
+
+
+def _load(name):
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        build()
+    return C.CDLL(path)
+
+
+class Proj(C.Structure):
+    _fields_ = [("lon0", C.c_double), ("w", C.c_double), ("h", C.c_double), ("wc", C.c_double),
+                ("lath", C.c_double), ("lath_len", C.c_double), ("lat_ll", C.c_double),
+                ("lon_ru", C.c_double), ("lat_ru", C.c_double), ("dpi", C.c_int)]
+
+
+class Style(C.Structure):
+    _fields_ = [("fill_used", C.c_int), ("border_used", C.c_int), ("fill_col", C.c_uint32), ("border_col", C.c_uint32),
+                ("fill_width_mm", C.c_double), ("border_width_mm", C.c_double), ("ignore_open", C.c_int)]
+
+
+def P(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+_orc = None
+
+
+def orc():
+    global _orc
+    if _orc is None:
+        L = _load("liboracle.so")
+        L.orc_init_bbox_mll.argtypes = [C.POINTER(Proj)] + [C.c_double] * 5 + [C.c_int]
+        L.orc_project.argtypes = [C.POINTER(Proj), C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+        L.orc_geo2pxf.argtypes = [C.POINTER(Proj), C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_pxf2geo.argtypes = [C.POINTER(Proj), C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_fixed_from_double.argtypes = [C.c_double]
+        L.orc_pt_to_dev.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.orc_px_to_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.orc_stroke_edges.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
+        L.orc_fill_edges.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_color_pixel.argtypes = [C.c_uint32]
+        L.orc_color_pixel.restype = C.c_uint32
+        L.orc_canvas_new.restype = C.c_void_p
+        L.orc_canvas_new.argtypes = [C.c_int] * 5 + [C.c_uint32]
+        L.orc_canvas_pixels.restype = C.c_void_p
+        L.orc_canvas_pixels.argtypes = [C.c_void_p]
+        L.orc_canvas_free.argtypes = [C.c_void_p]
+        L.orc_rule_begin.argtypes = [C.c_void_p]
+        L.orc_rule_end.argtypes = [C.c_void_p]
+        L.orc_layer_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]
+        L.orc_draw_way.argtypes = [C.c_void_p, C.POINTER(Style), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                   C.c_int, C.c_uint32, C.c_int, C.c_uint32]
+        L.tor_coverage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_rot_paint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]
+        L.orc_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
+        L.orc_dist.restype = C.c_double
+        L.orc_dist_int.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        L.orc_find_angle.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p]
+        L.orc_find_angle.restype = C.c_double
+        L.orc_pick_angle.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double]
+        L.orc_pick_angle.restype = C.c_double
+        L.orc_num_steps.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        L.orc_make_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32]
+        L.orc_bw_stretch.argtypes = [C.c_uint32]
+        L.orc_bw_stretch.restype = C.c_uint32
+        _orc = L
+    return _orc
+
+
+_cd = None
+
+
+def cairo():
+    """The real libcairo driven with the reference's call sequence; None if libcairo is absent."""
+    global _cd
+    if _cd is None:
+        L = _load("libcairo_drive.so")
+        if L.cd_init(None) != 0:
+            _cd = False
+            return None
+        L.cd_version.restype = C.c_char_p
+        L.cd_begin.argtypes = [C.c_double, C.c_double, C.c_uint32]
+        L.cd_poly_line.argtypes = [C.c_void_p, C.c_int]
+        L.cd_stroke.argtypes = [C.c_uint32, C.c_double]
+        L.cd_fill.argtypes = [C.c_uint32]
+        L.cd_render.argtypes = [C.c_double] + [C.c_int] * 4 + [C.c_void_p]
+        L.cd_direct_fill.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+        L.cd_rot_paint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]
+        _cd = L
+    return _cd or None
+
+
+# ---------------------------------------------------------------- projection
+def make_proj(mean_lat, mean_lon, scale, w_px, h_px, dpi):
+    p = Proj()
+    orc().orc_init_bbox_mll(C.byref(p), mean_lat, mean_lon, scale, w_px, h_px, dpi)
+    return p
+
+
+def project(p, lat, lon):
+    lat = np.ascontiguousarray(lat, np.float64)
+    lon = np.ascontiguousarray(lon, np.float64)
+    n = lat.size
+    x, y = np.empty(n), np.empty(n)
+    ix, iy = np.empty(n, np.int32), np.empty(n, np.int32)
+    on = np.empty(n, np.uint8)
+    orc().orc_project(C.byref(p), P(lat), P(lon), n, P(x), P(y), P(ix), P(iy), P(on))
+    return x, y, ix, iy, on
+
+
+# ---------------------------------------------------------------- draw
+def mm2wu(mm, dpi):
+    return 72.0 / dpi if mm == 0 else mm * 72 / 25.4
+
+
+def tor_coverage(edges, W, H, x0=0, y0=0, nonzero=1):
+    e = np.ascontiguousarray(edges, np.int32)
+    out = np.zeros((H, W), np.uint8)
+    orc().tor_coverage(P(e), len(e), nonzero, x0, y0, W, H, P(out))
+    return out
+
+
+def oracle_scene(rules, dpi, W, H, bg, x0=0, y0=0):
+    """rules: list of (Style, [(x_px, y_px, closed), ...]).  Returns premultiplied ARGB32 (H,W)."""
+    L = orc()
+    c = L.orc_canvas_new(x0, y0, W, H, dpi, bg)
+    for st, ways in rules:
+        L.orc_rule_begin(c)
+        for x, y, closed in ways:
+            x = np.ascontiguousarray(x, np.float64)
+            y = np.ascontiguousarray(y, np.float64)
+            L.orc_draw_way(c, C.byref(st), P(x), P(y), len(x), int(closed), 0, 0, 0, 0)
+        L.orc_rule_end(c)
+    out = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (H, W)).copy()
+    L.orc_canvas_free(c)
+    return out
+
+
+def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None):
+    """Same scene through the real libcairo with the reference's call sequence."""
+    L = cairo()
+    fw = (full_w or (x0 + W)) * 72 / dpi
+    fh = (full_h or (y0 + H)) * 72 / dpi
+    L.cd_begin(fw, fh, bg)
+    for st, ways in rules:
+        L.cd_rule_begin()
+        for x, y, closed in ways:
+            if len(x) < 2 or (not closed and st.ignore_open):
+                continue
+            xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
+            if st.border_used:
+                if not st.fill_used:
+                    bw = mm2wu(st.border_width_mm, dpi)
+                elif not closed:
+                    bw = mm2wu(2 * st.border_width_mm, dpi) + mm2wu(st.fill_width_mm, dpi)
+                else:
+                    bw = mm2wu(2 * st.border_width_mm, dpi)
+                L.cd_poly_line(P(xy), len(xy))
+                L.cd_stroke(st.border_col, bw)
+            if st.fill_used:
+                L.cd_poly_line(P(xy), len(xy))
+                if not closed:
+                    L.cd_stroke(st.fill_col, mm2wu(st.fill_width_mm, dpi))
+                else:
+                    L.cd_fill(st.fill_col)
+        L.cd_rule_end()
+    out = np.zeros((H, W), np.uint32)
+    assert L.cd_render(float(dpi), x0, y0, W, H, P(out)) == 0
+    return out
+
+
+def chan_diff(a, b):
+    d = np.zeros(a.shape, np.int64)
+    for s in (0, 8, 16, 24):
+        d = np.maximum(d, np.abs(((a >> s) & 255).astype(np.int64) - ((b >> s) & 255).astype(np.int64)))
+    return d
+
+
+# ---------------------------------------------------------------- synthetic data
+def synth_ways(n_ways, W, H, seed=1234, rmin=4.0, rmax=64.0, mean_nodes=32):
+    """Star-shaped closed polygons; returns (x_px, y_px, way_off, ref) with a closing ref per way."""
+    rng = np.random.default_rng(seed)
+    nv = np.clip(rng.poisson(mean_nodes, n_ways), 4, 256)
+    node_off = np.concatenate([[0], np.cumsum(nv)])
+    way_off = np.concatenate([[0], np.cumsum(nv + 1)]).astype(np.int64)
+    N = int(node_off[-1])
+    wid = np.repeat(np.arange(n_ways), nv)
+    k = np.arange(N) - node_off[wid]
+    cx, cy = rng.uniform(0, W, n_ways), rng.uniform(0, H, n_ways)
+    r = np.exp(rng.uniform(np.log(rmin), np.log(rmax), n_ways))
+    sgn = rng.choice([-1.0, 1.0], n_ways)
+    ph = rng.uniform(0, 2 * np.pi, n_ways)
+    ang = ph[wid] + sgn[wid] * 2 * np.pi * k / nv[wid]
+    rr = r[wid] * rng.uniform(0.7, 1.0, N)
+    x = cx[wid] + rr * np.cos(ang)
+    y = cy[wid] + rr * np.sin(ang)
+    ref = np.empty(int(way_off[-1]), np.int32)
+    pos = np.arange(N) + wid            # slot of node k of way w in the ref array
+    ref[pos] = np.arange(N, dtype=np.int32)
+    ref[way_off[1:] - 1] = node_off[:-1].astype(np.int32)
+    return x, y, way_off, ref
+
+
+def ways_from_arrays(x, y, way_off, ref):
+    out = []
+    for w in range(len(way_off) - 1):
+        r = ref[way_off[w]:way_off[w + 1]]
+        closed = len(r) >= 4 and r[0] == r[-1]
+        out.append((x[r], y[r], closed))
+    return out

@@ -1,0 +1,953 @@
+/* raster.hip -- draw path of libsmr_hip: device-space vertex setup, stroke expansion, edge
+ * setup, per-tile binning/sort and the wave-per-tile Cairo-compatible rasterizer.
+ *
+ * Replaces (reference file:line): cairo_smr_poly_line src/smrules_cairo.c:845-863,
+ * cairo_smr_border_width :880-889, render_poly_line :953-1016, act_draw_fini's group
+ * pop+paint :1081-1082 and the libcairo/pixman replay that save_main_image triggers
+ * (:388-412).  The coverage arithmetic is the one of libcairo 1.16's tor scan converter
+ * (256 x 15 sample grid, sub-row centre sampling, exact full-row path), restated and
+ * pinned in oracle/tor.c; this file must stay bit-equal to it.
+ */
+#include "smr_dev.h"
+#include "smr_host.h"
+
+/* ------------------------------------------------------------------------------------ */
+/* vertex setup: px (double) -> pt -> 24.8 -> replay scale (fixed * fixed(dpi/72) >> 8)   */
+/* ------------------------------------------------------------------------------------ */
+__global__ void k_dev_points(const double *__restrict__ x, const double *__restrict__ y,
+                             const int32_t *__restrict__ ref, int64_t n_refs, int dpi, int32_t sfix,
+                             int2 *__restrict__ pts)
+{
+   int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   int64_t stride = (int64_t) gridDim.x * blockDim.x;
+   for (; g < n_refs; g += stride)
+   {
+      int64_t node = ref ? (int64_t) ref[g] : g;
+      double xp = x[node] * 72 / dpi, yp = y[node] * 72 / dpi;      /* rdata_px_unit(.., U_PT) */
+      int32_t fx = (int32_t) rint(xp * 256.0), fy = (int32_t) rint(yp * 256.0);
+      int2 p;
+      p.x = (int32_t) (((int64_t) fx * sfix) >> 8);
+      p.y = (int32_t) (((int64_t) fy * sfix) >> 8);
+      pts[g] = p;
+   }
+}
+
+/* per-way classification: is_closed_poly (src/smcoast.c:115-125), short-way skip
+ * (src/smrules_cairo.c:962-966), ignore_open (:1030-1033); decides which of the two
+ * primitives of the way exist.  wayflags: bit0 closed, bit1 border prim, bit2 fill polygon,
+ * bit3 fill-as-stroke (open way) */
+__global__ void k_way_info(const int64_t *__restrict__ way_off, const int32_t *__restrict__ ref, int64_t n_ways,
+                           int border_used, int fill_used, int ignore_open, uint8_t *__restrict__ wayflags,
+                           uint32_t *__restrict__ any_open_fill)
+{
+   int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (w >= n_ways) return;
+   int64_t a = way_off[w], b = way_off[w + 1];
+   int64_t n = b - a;
+   int closed = 0;
+   if (n >= 4)
+   {
+      int64_t first = ref ? (int64_t) ref[a] : a, last = ref ? (int64_t) ref[b - 1] : b - 1;
+      closed = first == last;
+   }
+   uint8_t f = closed ? 1 : 0;
+   if (n >= 2 && !(!closed && ignore_open))
+   {
+      if (border_used) f |= 2;
+      if (fill_used) f |= closed ? 4 : 8;
+   }
+   wayflags[w] = f;
+   if (f & 8) atomicOr(any_open_fill, 1u);
+}
+
+__device__ __forceinline__ int64_t smr_find_way(const int64_t *__restrict__ way_off, int64_t n_ways, int64_t g)
+{
+   int64_t lo = 0, hi = n_ways;       /* way_off[lo] <= g < way_off[hi] */
+   while (hi - lo > 1)
+   {
+      int64_t mid = (lo + hi) >> 1;
+      if (way_off[mid] <= g) lo = mid; else hi = mid;
+   }
+   return lo;
+}
+
+__global__ void k_prim_init(smr_prim_t *prims, int64_t n_prims)
+{
+   int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_prims) return;
+   smr_prim_t p;
+   p.edge_off = 0; p.edge_cnt = 0; p.color = 0;
+   p.minx = INT32_MAX; p.miny = INT32_MAX; p.maxx = INT32_MIN; p.maxy = INT32_MIN;
+   p.flags = 0; p.pad_[0] = p.pad_[1] = p.pad_[2] = 0;
+   prims[i] = p;
+}
+
+__device__ __forceinline__ void smr_bbox_add(smr_prim_t *p, int32_t x, int32_t y)
+{
+   atomicMin(&p->minx, x); atomicMax(&p->maxx, x);
+   atomicMin(&p->miny, y); atomicMax(&p->maxy, y);
+}
+
+/* fill polygon: edge g = pts[g] -> pts[g+1]; the slot of the last ref closes the polygon
+ * (cairo_fill closes sub-paths implicitly) */
+__global__ void k_fill_edges(const int2 *__restrict__ pts, const int64_t *__restrict__ way_off, int64_t n_ways,
+                             int64_t n_refs, const uint8_t *__restrict__ wayflags, smr_edge_t *__restrict__ edges,
+                             smr_prim_t *__restrict__ prims)
+{
+   int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= n_refs) return;
+   int64_t w = smr_find_way(way_off, n_ways, g);
+   smr_edge_t e; e.x1 = e.y1 = e.x2 = e.y2 = 0;
+   if (wayflags[w] & 4)
+   {
+      int64_t a = way_off[w], b = way_off[w + 1];
+      int2 p = pts[g], q = pts[g + 1 < b ? g + 1 : a];
+      e.x1 = p.x; e.y1 = p.y; e.x2 = q.x; e.y2 = q.y;
+      smr_bbox_add(&prims[2 * w + 1], p.x, p.y);
+   }
+   edges[g] = e;
+}
+
+/* ---- stroker (cairo-path-stroke-polygon.c semantics, see oracle/smr_oracle.c): butt caps,
+ * miter joins limit 10; one quad per segment + one wedge per join, all wound the same way ---- */
+struct smr_face_t { int2 ccw, cw; double sx, sy; int32_t ddx, ddy; };
+
+__device__ __forceinline__ void smr_normalize(double &dx, double &dy)
+{
+   if (dx == 0.0) { dy = dy > 0.0 ? 1.0 : -1.0; }
+   else if (dy == 0.0) { dx = dx > 0.0 ? 1.0 : -1.0; }
+   else { double mag = hypot(dx, dy); dx = dx / mag; dy = dy / mag; }
+}
+
+__device__ __forceinline__ smr_face_t smr_face(int2 p, int32_t ddx, int32_t ddy, double hw_pt, double s)
+{
+   smr_face_t f;
+   double sx = ddx / 256.0, sy = ddy / 256.0;
+   smr_normalize(sx, sy);
+   f.sx = sx; f.sy = sy; f.ddx = ddx; f.ddy = ddy;
+   double ux = sx * (1.0 / s), uy = sy * (1.0 / s);
+   smr_normalize(ux, uy);
+   double fx = -uy * hw_pt, fy = ux * hw_pt;
+   fx *= s; fy *= s;
+   int32_t ox = (int32_t) rint(fx * 256.0), oy = (int32_t) rint(fy * 256.0);
+   f.ccw = make_int2(p.x + ox, p.y + oy);
+   f.cw = make_int2(p.x - ox, p.y - oy);
+   return f;
+}
+
+__device__ __forceinline__ int smr_emit_poly(const int2 *p, int n, smr_edge_t *out, smr_prim_t *prim)
+{
+   int64_t a = 0;
+   for (int i = 0; i < n; i++)
+   {
+      int j = i + 1 == n ? 0 : i + 1;
+      a += (int64_t) p[i].x * p[j].y - (int64_t) p[j].x * p[i].y;
+   }
+   if (a == 0) return 0;
+   for (int i = 0; i < n; i++)
+   {
+      int j = i + 1 == n ? 0 : i + 1;
+      int2 s = a > 0 ? p[i] : p[j], e = a > 0 ? p[j] : p[i];
+      smr_edge_t ed; ed.x1 = s.x; ed.y1 = s.y; ed.x2 = e.x; ed.y2 = e.y;
+      out[i] = ed;
+      smr_bbox_add(prim, p[i].x, p[i].y);
+   }
+   return n;
+}
+
+__device__ __forceinline__ int smr_sgn_cmp(double dx1, double dy1, double dx2, double dy2)
+{
+   double c = dx1 * dy2 - dx2 * dy1;
+   return c > 0 ? 1 : c < 0 ? -1 : 0;
+}
+
+/* mode 0: border strokes (prim 2w), widths per cairo_smr_border_width; mode 1: fill of open
+ * ways drawn as a stroke of the fill width (prim 2w+1, src/smrules_cairo.c:1003-1008) */
+__global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__restrict__ way_off, int64_t n_ways,
+                               int64_t n_refs, const uint8_t *__restrict__ wayflags, int mode, int dpi,
+                               double hw_nofill_pt, double hw_open_pt, double hw_closed_pt, double hw_fill_pt,
+                               int fill_used, smr_edge_t *__restrict__ edges, smr_prim_t *__restrict__ prims)
+{
+   int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= n_refs) return;
+   int64_t w = smr_find_way(way_off, n_ways, g);
+   smr_edge_t *out = edges + (size_t) SMR_SLOTS * g;
+   smr_edge_t z; z.x1 = z.y1 = z.x2 = z.y2 = 0;
+   int cnt = 0;
+   uint8_t wf = wayflags[w];
+   int64_t a = way_off[w], b = way_off[w + 1];
+   bool on = mode == 0 ? (wf & 2) != 0 : (wf & 8) != 0;
+   if (on && g + 1 < b)
+   {
+      int2 p1 = pts[g], p2 = pts[g + 1];
+      if (p1.x != p2.x || p1.y != p2.y)
+      {
+         double hw = mode == 1 ? hw_fill_pt : (!fill_used ? hw_nofill_pt : ((wf & 1) ? hw_closed_pt : hw_open_pt));
+         double s = (double) dpi / 72;
+         smr_prim_t *prim = &prims[2 * w + mode];
+         int32_t ddx = p2.x - p1.x, ddy = p2.y - p1.y;
+         smr_face_t start = smr_face(p1, ddx, ddy, hw, s);
+         /* previous non-degenerate segment of the same way ends at p1 */
+         int64_t k = g - 1;
+         int2 p0 = p1;
+         bool have = false;
+         while (k >= a)
+         {
+            p0 = pts[k];
+            if (p0.x != p1.x || p0.y != p1.y) { have = true; break; }
+            k--;
+         }
+         if (have)
+         {
+            int32_t pdx = p1.x - p0.x, pdy = p1.y - p0.y;
+            smr_face_t cur = smr_face(p1, pdx, pdy, hw, s);     /* face of the previous segment at its END point */
+            if (!(cur.cw.x == start.cw.x && cur.cw.y == start.cw.y && cur.ccw.x == start.ccw.x && cur.ccw.y == start.ccw.y))
+            {
+               int64_t l = (int64_t) cur.ddy * start.ddx, r = (int64_t) start.ddy * cur.ddx;
+               bool clockwise = l != r ? l < r : (cur.ddx > 0 || (cur.ddx == 0 && cur.ddy > 0));
+               int2 inpt = clockwise ? cur.cw : cur.ccw, outpt = clockwise ? start.cw : start.ccw;
+               double in_dot_out = cur.sx * start.sx + cur.sy * start.sy;
+               bool mitered = false;
+               if (2 <= 100.0 * (1 + in_dot_out))
+               {
+                  double x1 = inpt.x / 256.0, y1 = inpt.y / 256.0, dx1 = cur.sx, dy1 = cur.sy;
+                  double x2 = outpt.x / 256.0, y2 = outpt.y / 256.0, dx2 = start.sx, dy2 = start.sy;
+                  double my = (((x2 - x1) * dy1 * dy2 - y2 * dx2 * dy1 + y1 * dx1 * dy2) / (dx1 * dy2 - dx2 * dy1));
+                  double mx;
+                  if (fabs(dy1) >= fabs(dy2)) mx = (my - y1) * dx1 / dy1 + x1;
+                  else mx = (my - y2) * dx2 / dy2 + x2;
+                  double ix = p1.x / 256.0, iy = p1.y / 256.0;
+                  double fdx1 = x1 - ix, fdy1 = y1 - iy, fdx2 = x2 - ix, fdy2 = y2 - iy, mdx = mx - ix, mdy = my - iy;
+                  if (smr_sgn_cmp(fdx1, fdy1, mdx, mdy) != smr_sgn_cmp(fdx2, fdy2, mdx, mdy))
+                  {
+                     int2 q[4] = { p1, inpt, make_int2((int32_t) rint(mx * 256.0), (int32_t) rint(my * 256.0)), outpt };
+                     cnt += smr_emit_poly(q, 4, out + cnt, prim);
+                     mitered = true;
+                  }
+               }
+               if (!mitered)
+               {
+                  int2 q[3] = { p1, inpt, outpt };
+                  cnt += smr_emit_poly(q, 3, out + cnt, prim);
+               }
+            }
+         }
+         int2 q[4] = { start.ccw, make_int2(start.ccw.x + ddx, start.ccw.y + ddy),
+                       make_int2(start.cw.x + ddx, start.cw.y + ddy), start.cw };
+         cnt += smr_emit_poly(q, 4, out + cnt, prim);
+      }
+   }
+   for (; cnt < SMR_SLOTS; cnt++) out[cnt] = z;
+}
+
+/* finalise the primitive table: edge ranges, colours, validity against the full chart, and
+ * the index of the first primitive that draws at all (it meets a still-clear group layer,
+ * which libcairo composites with SOURCE semantics) */
+__global__ void k_prim_finish(smr_prim_t *__restrict__ prims, int64_t n_ways, const int64_t *__restrict__ way_off,
+                              const uint8_t *__restrict__ wayflags, uint64_t off_border, uint64_t off_fill,
+                              uint64_t off_openfill, uint32_t border_pix, uint32_t fill_pix,
+                              const uint32_t *__restrict__ way_border_pix, const uint32_t *__restrict__ way_fill_pix,
+                              int W, int H, uint32_t *__restrict__ first_prim)
+{
+   int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (w >= n_ways) return;
+   uint8_t wf = wayflags[w];
+   int64_t a = way_off[w], n = way_off[w + 1] - a;
+   for (int k = 0; k < 2; k++)
+   {
+      smr_prim_t *p = &prims[2 * w + k];
+      bool on = k == 0 ? (wf & 2) != 0 : (wf & 12) != 0;
+      if (!on || p->minx > p->maxx) { p->flags = 0; continue; }
+      if (k == 0) { p->edge_off = off_border + (uint64_t) SMR_SLOTS * a; p->edge_cnt = (uint32_t) (SMR_SLOTS * n); }
+      else if (wf & 4) { p->edge_off = off_fill + (uint64_t) a; p->edge_cnt = (uint32_t) n; }
+      else { p->edge_off = off_openfill + (uint64_t) SMR_SLOTS * a; p->edge_cnt = (uint32_t) (SMR_SLOTS * n); }
+      p->color = k == 0 ? (way_border_pix ? way_border_pix[w] : border_pix) : (way_fill_pix ? way_fill_pix[w] : fill_pix);
+      int c0 = p->minx >> 8, c1 = p->maxx >> 8, r0 = p->miny >> 8, r1 = p->maxy >> 8;
+      if (c1 < 0 || r1 < 0 || c0 >= W || r0 >= H) { p->flags = 0; continue; }
+      p->flags = SMR_PF_VALID;
+      atomicMin(first_prim, (uint32_t) (2 * w + k));
+   }
+}
+
+/* 0xTTRRGGBB -> premultiplied source pixel, per way (color=%key rules) */
+__global__ void k_color_pixels(const uint32_t *__restrict__ col, int64_t n, uint32_t *__restrict__ pix)
+{
+   int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   uint32_t c = col[i];
+   double r = (double) ((c >> 16) & 0xff) / 255.0, g = (double) ((c >> 8) & 0xff) / 255.0, b = (double) (c & 0xff) / 255.0;
+   double a = 1.0 - (double) (((c & 0x7f000000u) >> 23) & 0xff) / 255.0;
+   auto d2s = [](double d) { uint32_t i = (uint32_t) (d * 65536); i -= (i >> 16); return i; };
+   pix[i] = ((d2s(a) >> 8) << 24) | ((d2s(r * a) >> 8) << 16) | ((d2s(g * a) >> 8) << 8) | (d2s(b * a) >> 8);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* binning: primitive bbox -> 64x4 tiles of this band                                      */
+/* ------------------------------------------------------------------------------------ */
+__device__ __forceinline__ bool smr_prim_tiles(const smr_prim_t &p, int W, int band_y0, int band_h,
+                                               int &tx0, int &tx1, int &ty0, int &ty1)
+{
+   if (!(p.flags & SMR_PF_VALID)) return false;
+   int c0 = p.minx >> 8, c1 = p.maxx >> 8, r0 = (p.miny >> 8) - band_y0, r1 = (p.maxy >> 8) - band_y0;
+   if (c1 < 0 || r1 < 0 || c0 >= W || r0 >= band_h) return false;
+   if (c0 < 0) c0 = 0;
+   if (r0 < 0) r0 = 0;
+   if (c1 >= W) c1 = W - 1;
+   if (r1 >= band_h) r1 = band_h - 1;
+   tx0 = c0 / SMR_TW; tx1 = c1 / SMR_TW; ty0 = r0 / SMR_TH; ty1 = r1 / SMR_TH;
+   return true;
+}
+
+template <bool SCATTER>
+__global__ void k_bin(const smr_prim_t *__restrict__ prims, int64_t n_prims, int W, int band_y0, int band_h, int TX,
+                      uint32_t *__restrict__ counts, const uint32_t *__restrict__ tile_off, uint32_t *__restrict__ entries)
+{
+   int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n_prims) return;
+   smr_prim_t p = prims[i];
+   int tx0, tx1, ty0, ty1;
+   if (!smr_prim_tiles(p, W, band_y0, band_h, tx0, tx1, ty0, ty1)) return;
+   for (int ty = ty0; ty <= ty1; ty++)
+      for (int tx = tx0; tx <= tx1; tx++)
+      {
+         uint32_t t = (uint32_t) ty * TX + tx;
+         uint32_t pos = atomicAdd(&counts[t], 1u);
+         if (SCATTER) entries[tile_off[t] + pos] = (uint32_t) i;
+      }
+}
+
+/* exclusive scan of n uint32 (three small kernels; n up to a few 10 M) */
+#define SCAN_B 1024
+__global__ __launch_bounds__(256) void k_scan_block(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                    uint32_t *__restrict__ sums, uint32_t n)
+{
+   __shared__ uint32_t s[256];
+   uint32_t base = blockIdx.x * SCAN_B, t = threadIdx.x;
+   uint32_t v[4], tot = 0;
+#pragma unroll
+   for (int k = 0; k < 4; k++) { uint32_t i = base + t * 4 + k; v[k] = i < n ? in[i] : 0; tot += v[k]; }
+   s[t] = tot;
+   __syncthreads();
+   for (int d = 1; d < 256; d <<= 1)
+   {
+      uint32_t x = t >= (uint32_t) d ? s[t - d] : 0;
+      __syncthreads();
+      s[t] += x;
+      __syncthreads();
+   }
+   uint32_t excl = s[t] - tot;
+#pragma unroll
+   for (int k = 0; k < 4; k++) { uint32_t i = base + t * 4 + k; if (i < n) out[i] = excl; excl += v[k]; }
+   if (t == 255) sums[blockIdx.x] = s[255];
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums(uint32_t *__restrict__ sums, uint32_t nb, uint32_t *__restrict__ total)
+{
+   /* single block, serial over chunks of 1024 */
+   __shared__ uint32_t s[1024];
+   __shared__ uint32_t carry;
+   uint32_t t = threadIdx.x;
+   if (t == 0) carry = 0;
+   __syncthreads();
+   for (uint32_t base = 0; base < nb; base += 1024)
+   {
+      uint32_t i = base + t, v = i < nb ? sums[i] : 0;
+      s[t] = v;
+      __syncthreads();
+      for (int d = 1; d < 1024; d <<= 1)
+      {
+         uint32_t x = t >= (uint32_t) d ? s[t - d] : 0;
+         __syncthreads();
+         s[t] += x;
+         __syncthreads();
+      }
+      if (i < nb) sums[i] = carry + s[t] - v;
+      __syncthreads();
+      if (t == 1023) carry += s[1023];
+      __syncthreads();
+   }
+   if (t == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t *__restrict__ out, const uint32_t *__restrict__ sums, uint32_t n)
+{
+   uint32_t base = blockIdx.x * SCAN_B, t = threadIdx.x, add = sums[blockIdx.x];
+#pragma unroll
+   for (int k = 0; k < 4; k++) { uint32_t i = base + t * 4 + k; if (i < n) out[i] += add; }
+   if (blockIdx.x == gridDim.x - 1 && t == 0) out[n] = 0;   /* overwritten by the host-side total below */
+}
+
+__global__ void k_set_u32(uint32_t *p, const uint32_t *v) { *p = *v; }
+
+/* per-tile sort of the scattered primitive indices (ascending = drawing order) */
+#define SORT_LDS 4096
+__global__ __launch_bounds__(64) void k_tile_sort(const uint32_t *__restrict__ tile_off, uint32_t *__restrict__ entries,
+                                                  uint32_t n_tiles)
+{
+   __shared__ uint32_t s[SORT_LDS];
+   uint32_t tile = smr_xcd_remap(blockIdx.x, n_tiles);
+   uint32_t beg = tile_off[tile], n = tile_off[tile + 1] - beg;
+   if (n < 2) return;
+   uint32_t lane = threadIdx.x;
+   uint32_t N = 2;
+   while (N < n) N <<= 1;
+   if (N <= SORT_LDS)
+   {
+      for (uint32_t i = lane; i < N; i += 64) s[i] = i < n ? entries[beg + i] : 0xffffffffu;
+      __syncthreads();
+      for (uint32_t k = 2; k <= N; k <<= 1)
+      {
+         for (uint32_t j = k >> 1; j > 0; j >>= 1)
+         {
+            for (uint32_t i = lane; i < N; i += 64)
+            {
+               uint32_t p = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);
+               if (p > i)
+               {
+                  uint32_t a = s[i], b = s[p];
+                  if (a > b) { s[i] = b; s[p] = a; }
+               }
+            }
+            __syncthreads();
+         }
+      }
+      for (uint32_t i = lane; i < n; i += 64) entries[beg + i] = s[i];
+   }
+   else
+   {
+      /* rare: more primitives on one 64x4 tile than fit in LDS -- same network in global
+       * memory through L1-bypassing (agent-scope) accesses */
+      uint32_t *e = entries + beg;
+      for (uint32_t k = 2; k <= N; k <<= 1)
+      {
+         for (uint32_t j = k >> 1; j > 0; j >>= 1)
+         {
+            for (uint32_t i = lane; i < N; i += 64)
+            {
+               uint32_t p = (j == (k >> 1)) ? (i ^ (k - 1)) : (i ^ j);
+               if (p > i && p < n)
+               {
+                  uint32_t a = __hip_atomic_load(&e[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  uint32_t b = __hip_atomic_load(&e[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  if (a > b)
+                  {
+                     __hip_atomic_store(&e[i], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                     __hip_atomic_store(&e[p], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                  }
+               }
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+         }
+      }
+   }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* the rasterizer: one wavefront per 64x4 tile                                             */
+/* ------------------------------------------------------------------------------------ */
+struct raster_args_t
+{
+   const smr_prim_t *prims;
+   const smr_edge_t *edges;
+   const uint32_t *tile_off;
+   const uint32_t *entries;
+   const uint32_t *first_prim;
+   uint32_t *canvas;          /* band pixels, stride W */
+   uint32_t *status;
+   int W, band_y0, band_h, TX;
+   uint32_t n_tiles;
+};
+
+struct raster_lds_t
+{
+   int cover[SMR_TH][SMR_TW];
+   int uarea[SMR_TH][SMR_TW];
+   int left[SMR_TH];
+   int e_p1x[64], e_p1y[64], e_dxs[64], e_D[64], e_ytop[64], e_ybot[64], e_dir[64];
+   uint32_t rowlist[SMR_TH][SMR_ROWCAP];
+   unsigned long long key[64];
+   int perm[64];
+   uint16_t bucket[SMR_NSUB][SMR_BKS];
+};
+
+__device__ __forceinline__ void smr_cell_add(raster_lds_t &L, int row, int ix, int dcover, int duarea)
+{
+   if (ix < 0) { atomicAdd(&L.left[row], dcover); return; }
+   if (ix >= SMR_TW) return;
+   if (dcover) atomicAdd(&L.cover[row][ix], dcover);
+   if (duarea) atomicAdd(&L.uarea[row][ix], duarea);
+}
+
+/* libcairo tor: cell_list_render_edge -- exact coverage of one edge across a full pixel
+ * row.  (q1,r1) = x at the first sub-row centre of the row, (q2,r2) = same one row below,
+ * X0 = left edge of the tile in 24.8.  All remainders are in units of 1/D. */
+__device__ void smr_render_edge(raster_lds_t &L, int row, int32_t X0, int32_t dxs, int32_t D,
+                                int64_t q1, int32_t r1_, int64_t q2, int32_t r2_, int sign)
+{
+   int64_t r1 = r1_, r2 = r2_;
+   if (dxs != 0)
+   {
+      /* step back from the sample location (half a sub-row) to the row boundary */
+      int64_t n = (int64_t) dxs * 1024;
+      int64_t dq = n / D, dr = n % D;          /* C truncation, like the original */
+      q1 -= dq / 2; r1 -= dr / 2;
+      if (r1 < 0) { --q1; r1 += D; } else if (r1 >= D) { ++q1; r1 -= D; }
+      q2 -= dq / 2; r2 -= dr / 2;
+      if (r2 < 0) { --q2; r2 += D; } else if (r2 >= D) { ++q2; r2 -= D; }
+   }
+   q1 -= X0; q2 -= X0;
+   int64_t ix1 = q1 >> 8, ix2 = q2 >> 8;
+   int fx1 = (int) (q1 & 255), fx2 = (int) (q2 & 255);
+   if (ix1 == ix2)
+   {
+      int ix = ix1 < -1 ? -1 : ix1 > SMR_TW ? SMR_TW : (int) ix1;
+      smr_cell_add(L, row, ix, sign * SMR_GRID_Y, sign * (fx1 + fx2) * SMR_GRID_Y);
+      return;
+   }
+   if (ix2 < ix1)
+   {
+      int64_t t = ix1; ix1 = ix2; ix2 = t;
+      int f = fx1; fx1 = fx2; fx2 = f;
+      t = q1; q1 = q2; q2 = t;
+      t = r1; r1 = r2; r2 = t;
+   }
+   int64_t dx = (q2 - q1) * D + (r2 - r1);
+   int64_t tmp = (ix1 + 1) * 256 * (int64_t) D;
+   tmp -= q1 * D + r1;
+   tmp *= SMR_GRID_Y;
+   int64_t yq = tmp / dx, yr = tmp % dx;
+   {
+      int ix = ix1 < -1 ? -1 : ix1 > SMR_TW ? SMR_TW : (int) ix1;
+      smr_cell_add(L, row, ix, (int) (sign * yq), (int) (sign * yq * (256 + fx1)));
+   }
+   int64_t y_last = yq;
+   if (ix1 + 1 < ix2)
+   {
+      int64_t fq = (int64_t) SMR_GRID_Y * 256 * D / dx, fr = (int64_t) SMR_GRID_Y * 256 * D % dx;
+      ++ix1;
+      do
+      {
+         yq += fq; yr += fr;
+         if (yr >= dx) { yq++; yr -= dx; }
+         int ix = ix1 < -1 ? -1 : ix1 > SMR_TW ? SMR_TW : (int) ix1;
+         smr_cell_add(L, row, ix, (int) (sign * (yq - y_last)), (int) (sign * (yq - y_last) * 256));
+         y_last = yq;
+         ++ix1;
+      } while (ix1 != ix2);
+   }
+   {
+      int ix = ix2 < -1 ? -1 : ix2 > SMR_TW ? SMR_TW : (int) ix2;
+      smr_cell_add(L, row, ix, (int) (sign * (SMR_GRID_Y - y_last)), (int) (sign * (SMR_GRID_Y - y_last) * fx2));
+   }
+}
+
+__global__ __launch_bounds__(64) void k_raster(raster_args_t A)
+{
+   __shared__ raster_lds_t L;
+   const uint32_t tile = smr_xcd_remap(blockIdx.x, A.n_tiles);
+   const uint32_t beg = A.tile_off[tile], end = A.tile_off[tile + 1];
+   if (beg == end) return;
+   const int lane = threadIdx.x;
+   const int tx = tile % A.TX, ty = tile / A.TX;
+   const int32_t X0 = tx * SMR_TW * 256, X1 = X0 + SMR_TW * 256;
+   const int row0 = A.band_y0 + ty * SMR_TH;          /* absolute pixel row of the tile */
+   const int ysbase = row0 * SMR_GRID_Y;
+   const uint32_t first_prim = *A.first_prim;
+   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+   uint32_t layer[SMR_TH] = { 0, 0, 0, 0 };
+   const int my_row = lane / SMR_GRID_Y;               /* sub-row lane -> pixel row (lanes 60..63 idle) */
+   const int my_ys = ysbase + lane;
+
+   for (uint32_t ei = beg; ei < end; ei++)
+   {
+      const uint32_t pi = A.entries[ei];
+      const smr_prim_t P = A.prims[pi];
+      const smr_edge_t *E = A.edges + P.edge_off;
+      const uint32_t mask = (P.flags & SMR_PF_EVENODD) ? 1u : ~0u;
+
+#pragma unroll
+      for (int r = 0; r < SMR_TH; r++) { L.cover[r][lane] = 0; L.uarea[r][lane] = 0; }
+      if (lane < SMR_TH) L.left[lane] = 0;
+
+      /* ---- pass 1: per pixel row, who is active and does any edge start/end inside it ---- */
+      uint32_t partial = 0, rowcnt[SMR_TH] = { 0, 0, 0, 0 };
+      bool any = false;
+      for (uint32_t base = 0; base < P.edge_cnt; base += 64)
+      {
+         uint32_t idx = base + lane;
+         smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0;
+         if (idx < P.edge_cnt) o = smr_orient(E[idx]);
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++)
+         {
+            int rs0 = ysbase + r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
+            bool act = o.dir != 0 && o.ytop < rs1 && o.ybot > rs0;
+            bool part = act && (o.ytop > rs0 || o.ybot < rs1);
+            unsigned long long am = __ballot(act), pm = __ballot(part);
+            if (pm) partial |= 1u << r;
+            if (am)
+            {
+               any = true;
+               uint32_t pos = rowcnt[r] + __popcll(am & lt_mask);
+               if (act && pos < SMR_ROWCAP) L.rowlist[r][pos] = idx;
+               rowcnt[r] += __popcll(am);
+            }
+         }
+      }
+      if (!any) continue;
+      __syncthreads();
+
+      /* ---- pass 1b: rows that may take libcairo's exact full-row path ---- */
+      for (int r = 0; r < SMR_TH; r++)
+      {
+         if ((partial >> r) & 1u) continue;
+         uint32_t cnt = rowcnt[r];
+         if (cnt == 0) continue;
+         if (cnt > SMR_ROWCAP) { partial |= 1u << r; if (lane == 0) atomicOr(A.status, SMR_ST_ROWCAP); continue; }
+         const int rs0 = ysbase + r * SMR_GRID_Y;
+         int64_t q0 = 0, q1 = 0; int32_t r0 = 0, r1 = 0, c0 = 0, c1 = 0, dxs = 0, D = 1, dir = 0;
+         const bool on = (uint32_t) lane < cnt;
+         if (on)
+         {
+            smr_oedge_t o = smr_orient(E[L.rowlist[r][lane]]);
+            dxs = o.dxs; D = o.D; dir = o.dir;
+            smr_edge_x(o.p1x, o.p1y, o.dxs, o.D, rs0, q0, r0);
+            smr_edge_x(o.p1x, o.p1y, o.dxs, o.D, rs0 + SMR_GRID_Y, q1, r1);
+            c0 = smr_cell(q0, r0, D, dxs); c1 = smr_cell(q1, r1, D, dxs);
+         }
+         /* rank sort by (cell, next cell) */
+         unsigned long long key = ((unsigned long long) (uint32_t) (c0 + 0x40000000) << 32) | (uint32_t) (c1 + 0x40000000);
+         L.key[lane] = key;
+         __syncthreads();
+         int rank = 0;
+         for (uint32_t j = 0; j < cnt; j++)
+         {
+            unsigned long long kj = L.key[j];
+            rank += (kj < key || (kj == key && j < (uint32_t) lane)) ? 1 : 0;
+         }
+         if (on) L.perm[rank] = lane;
+         __syncthreads();
+         int src = on ? L.perm[lane] : lane;
+         /* gather the sorted order */
+         q0 = __shfl(q0, src); q1 = __shfl(q1, src);
+         r0 = __shfl(r0, src); r1 = __shfl(r1, src); c0 = __shfl(c0, src); c1 = __shfl(c1, src);
+         dxs = __shfl(dxs, src); D = __shfl(D, src); dir = __shfl(dir, src);
+         int c1n = __shfl_down(c1, 1), c0n = __shfl_down(c0, 1);
+         bool viol = on && (uint32_t) (lane + 1) < cnt && c1n < c1;
+         if (__ballot(viol)) { partial |= 1u << r; __syncthreads(); continue; }
+         /* winding prefix */
+         int wsum = on ? dir : 0;
+#pragma unroll
+         for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(wsum, d); if (lane >= d) wsum += t; }
+         bool last = (uint32_t) lane + 1 == cnt;
+         bool is_end = on && ((((uint32_t) wsum & mask) == 0 && (last || c0n != c0)) || last);
+         int prev_end = __shfl_up((int) is_end, 1);
+         bool is_start = on && (lane == 0 || prev_end);
+         if (is_start) smr_render_edge(L, r, X0, dxs, D, q0, r0, q1, r1, +1);
+         else if (is_end) smr_render_edge(L, r, X0, dxs, D, q0, r0, q1, r1, -1);
+         __syncthreads();
+      }
+
+      /* ---- pass 2: sub-sampled rows; lane = sub-row ---- */
+      if (partial)
+      {
+         const bool mine = lane < SMR_NSUB && ((partial >> my_row) & 1u);
+         int cnt = 0, lw = 0;
+         bool ovf = false;
+         for (uint32_t base = 0; base < P.edge_cnt; base += 64)
+         {
+            uint32_t idx = base + lane;
+            smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0; o.p1x = o.p1y = o.dxs = 0; o.D = 1;
+            if (idx < P.edge_cnt) o = smr_orient(E[idx]);
+            bool ov = o.dir != 0 && o.ytop < ysbase + SMR_NSUB && o.ybot > ysbase && o.p1x + (o.dxs < 0 ? o.dxs : 0) < X1;
+            unsigned long long om = __ballot(ov);
+            if (!om) continue;
+            __syncthreads();
+            L.e_p1x[lane] = o.p1x; L.e_p1y[lane] = o.p1y; L.e_dxs[lane] = o.dxs; L.e_D[lane] = o.D;
+            L.e_ytop[lane] = o.ytop; L.e_ybot[lane] = o.ybot; L.e_dir[lane] = o.dir;
+            __syncthreads();
+            while (om)
+            {
+               int j = __ffsll((long long) om) - 1;
+               om &= om - 1;
+               int ytop = L.e_ytop[j], ybot = L.e_ybot[j];
+               if (mine && my_ys >= ytop && my_ys < ybot)
+               {
+                  int64_t q; int32_t rem;
+                  int32_t dxs = L.e_dxs[j], D = L.e_D[j];
+                  smr_edge_x(L.e_p1x[j], L.e_p1y[j], dxs, D, my_ys, q, rem);
+                  int32_t cell = smr_cell(q, rem, D, dxs);
+                  int dir = L.e_dir[j];
+                  if (cell < X0) lw += dir;
+                  else if (cell < X1)
+                  {
+                     if (cnt < SMR_BK) L.bucket[lane][cnt++] = (uint16_t) (((cell - X0) << 1) | (dir > 0 ? 1 : 0));
+                     else ovf = true;
+                  }
+               }
+            }
+         }
+         if (__ballot(ovf) && lane == 0) atomicOr(A.status, SMR_ST_BUCKET_OVERFLOW);
+         if (mine)
+         {
+            uint16_t *b = L.bucket[lane];
+            for (int i = 1; i < cnt; i++)
+            {
+               uint16_t v = b[i];
+               int k = i - 1;
+               while (k >= 0 && (b[k] >> 1) > (v >> 1)) { b[k + 1] = b[k]; k--; }
+               b[k + 1] = v;
+            }
+            int winding = lw;
+            int xstart = (((uint32_t) winding & mask) != 0) ? 0 : -1;
+            for (int i = 0; i <= cnt; i++)
+            {
+               int x1, x2;
+               if (i < cnt)
+               {
+                  int xend = b[i] >> 1;
+                  winding += (b[i] & 1) ? 1 : -1;
+                  if (((uint32_t) winding & mask) == 0)
+                  {
+                     if (i + 1 < cnt && (b[i + 1] >> 1) == xend) continue;
+                     if (xstart < 0) continue;
+                     x1 = xstart; x2 = xend; xstart = -1;
+                  }
+                  else { if (xstart < 0) xstart = xend; continue; }
+               }
+               else
+               {
+                  if (xstart < 0) break;
+                  x1 = xstart; x2 = SMR_TW * 256;
+               }
+               if (x1 == x2) continue;
+               int ix1 = x1 >> 8, ix2 = x2 >> 8, fx1 = x1 & 255, fx2 = x2 & 255;
+               if (ix1 != ix2)
+               {
+                  smr_cell_add(L, my_row, ix1, 1, 2 * fx1);
+                  smr_cell_add(L, my_row, ix2, -1, -2 * fx2);
+               }
+               else smr_cell_add(L, my_row, ix1, 0, 2 * (fx1 - fx2));
+            }
+         }
+      }
+      __syncthreads();
+
+      /* ---- pass 3: cells -> alpha -> ordered blend into the group layer; lane = column ---- */
+      const uint32_t spix = P.color;
+      const bool lerp = (spix >> 24) == 255u || pi == first_prim;
+#pragma unroll
+      for (int r = 0; r < SMR_TH; r++)
+      {
+         int c = L.cover[r][lane];
+#pragma unroll
+         for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(c, d); if (lane >= d) c += t; }
+         c += L.left[r];
+         int area = c * 512 - L.uarea[r][lane];
+         int a = (area + (area << 4) + 256) >> 9;
+         a = a < 0 ? 0 : a > 255 ? 255 : a;
+         if (a) layer[r] = lerp ? smr_blend_lerp(spix, (uint32_t) a, layer[r]) : smr_blend_over_mask(spix, (uint32_t) a, layer[r]);
+      }
+      __syncthreads();
+   }
+
+   /* pop_group_to_source + paint: layer OVER canvas */
+   const int px = tx * SMR_TW + lane;
+   if (px < A.W)
+   {
+#pragma unroll
+      for (int r = 0; r < SMR_TH; r++)
+      {
+         int row = ty * SMR_TH + r;
+         if (row < A.band_h && layer[r])
+         {
+            uint32_t *d = A.canvas + (size_t) row * A.W + px;
+            *d = smr_blend_over(layer[r], *d);
+         }
+      }
+   }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* host side                                                                             */
+/* ------------------------------------------------------------------------------------ */
+static uint32_t host_color_pixel(uint32_t c)
+{
+   double r = (double) ((c >> 16) & 0xff) / 255.0, g = (double) ((c >> 8) & 0xff) / 255.0, b = (double) (c & 0xff) / 255.0;
+   double a = 1.0 - (double) (((c & 0x7f000000u) >> 23) & 0xff) / 255.0;
+   auto d2s = [](double d) { uint32_t i = (uint32_t) (d * 65536); i -= (i >> 16); return i; };
+   return ((d2s(a) >> 8) << 24) | ((d2s(r * a) >> 8) << 16) | ((d2s(g * a) >> 8) << 8) | (d2s(b * a) >> 8);
+}
+
+__global__ void k_fill_u32(uint32_t *p, size_t n, uint32_t v)
+{
+   size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t) gridDim.x * blockDim.x;
+   for (; i < n; i += stride) p[i] = v;
+}
+
+extern "C" int smr_hip_canvas_create(int W, int H, int dpi, uint32_t bgcolor, int band_y0, int band_h, smr_canvas_t **out)
+{
+   SMR_NEED_INIT();
+   if (!out || W <= 0 || H <= 0 || dpi <= 0 || band_y0 < 0 || band_h <= 0 || band_y0 + band_h > H || W > 65536 || H > 65536)
+      return smr_fail(SMR_E_INVAL, "canvas_create: bad geometry %dx%d band %d+%d dpi %d", W, H, band_y0, band_h, dpi);
+   smr_canvas_t *c = new smr_canvas_t();
+   c->W = W; c->H = H; c->dpi = dpi; c->band_y0 = band_y0; c->band_h = band_h; c->bg = bgcolor;
+   size_t n = (size_t) W * band_h;
+   if (hipMalloc(&c->pix, n * 4) != hipSuccess) { delete c; return smr_fail(SMR_E_NOMEM, "canvas_create: hipMalloc %zu bytes", n * 4); }
+   /* cairo_paint of the background onto the clear image == SOURCE */
+   k_fill_u32<<<2048, 256, 0, smr_g.stream>>>(c->pix, n, host_color_pixel(bgcolor));
+   SMR_HIP(hipGetLastError());
+   *out = c;
+   return SMR_OK;
+}
+
+extern "C" int smr_hip_canvas_destroy(smr_canvas_t *c)
+{
+   if (!c) return SMR_OK;
+   hipStreamSynchronize(smr_g.stream);
+   if (c->pix) hipFree(c->pix);
+   for (auto &b : c->buf) if (b.p) hipFree(b.p);
+   delete c;
+   return SMR_OK;
+}
+
+extern "C" int smr_hip_canvas_read(smr_canvas_t *c, int x, int y, int w, int h, uint32_t *host_dst)
+{
+   SMR_NEED_INIT();
+   if (!c || !host_dst || x < 0 || y < 0 || w <= 0 || h <= 0 || x + w > c->W || y + h > c->band_h)
+      return smr_fail(SMR_E_INVAL, "canvas_read: rectangle outside the band");
+   SMR_HIP(hipMemcpy2DAsync(host_dst, (size_t) w * 4, c->pix + (size_t) y * c->W + x, (size_t) c->W * 4,
+                            (size_t) w * 4, h, hipMemcpyDeviceToHost, smr_g.stream));
+   SMR_HIP(hipStreamSynchronize(smr_g.stream));
+   return SMR_OK;
+}
+
+extern "C" int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *stride_px)
+{
+   if (!c || !d_pix || !stride_px) return smr_fail(SMR_E_INVAL, "canvas_device: NULL argument");
+   *d_pix = c->pix; *stride_px = c->W;
+   return SMR_OK;
+}
+
+static double mm2wu(double mm, int dpi) { return mm == 0.0 ? 1.0 * 72 / dpi : mm * 72 / 25.4; }
+
+extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b)
+{
+   SMR_NEED_INIT();
+   if (!c || !st || !b) return smr_fail(SMR_E_INVAL, "draw: NULL argument");
+   if (st->fill_style != 0 || st->border_style != 0)
+      return smr_fail(SMR_E_UNSUPPORTED, "draw: only style=solid is implemented on the GPU path (dashed/dotted/pipe pending)");
+   if (st->curve) return smr_fail(SMR_E_UNSUPPORTED, "draw: curve/wavy not implemented on the GPU path");
+   if (st->directional) return smr_fail(SMR_E_UNSUPPORTED, "draw: directional=1 not implemented on the GPU path");
+   if (b->n_ways < 0 || b->n_refs < 0 || b->n_ways > 0x7ffffff0ll / 2 || b->n_refs > 0x7fffffffll)
+      return smr_fail(SMR_E_INVAL, "draw: batch too large (n_ways %lld, n_refs %lld)", (long long) b->n_ways, (long long) b->n_refs);
+   if (b->n_ways == 0 || b->n_refs == 0 || (!st->fill_used && !st->border_used)) return SMR_OK;
+   if (!b->d_x || !b->d_y || !b->d_way_off) return smr_fail(SMR_E_INVAL, "draw: missing device arrays");
+
+   hipStream_t s = smr_g.stream;
+   const int64_t n_ways = b->n_ways, n_refs = b->n_refs, n_prims = 2 * n_ways;
+   const int TX = (c->W + SMR_TW - 1) / SMR_TW, TY = (c->band_h + SMR_TH - 1) / SMR_TH;
+   const uint32_t n_tiles = (uint32_t) TX * TY;
+   smr_timer_t T(smr_g.profiling);
+   T.mark(s);                                                   /* 0 */
+
+   int2 *pts; uint8_t *wayflags; uint32_t *small; smr_prim_t *prims; uint32_t *way_pix = nullptr;
+   SMR_TRY(c->ensure(SMR_BUF_PTS, (size_t) n_refs * sizeof(int2), (void **) &pts));
+   SMR_TRY(c->ensure(SMR_BUF_WAYFLAGS, (size_t) n_ways, (void **) &wayflags));
+   SMR_TRY(c->ensure(SMR_BUF_SMALL, 64, (void **) &small));     /* [0] any_open_fill [1] first_prim [2] status [3] total */
+   SMR_TRY(c->ensure(SMR_BUF_PRIMS, (size_t) n_prims * sizeof(smr_prim_t), (void **) &prims));
+   uint32_t init_small[4] = { 0, 0xffffffffu, 0, 0 };
+   SMR_HIP(hipMemcpyAsync(small, init_small, sizeof(init_small), hipMemcpyHostToDevice, s));
+
+   const int TB = 256;
+   auto blocks = [](int64_t n, int tb) { return (unsigned) ((n + tb - 1) / tb); };
+   int32_t sfix = (int32_t) nearbyint((double) c->dpi / 72 * 256.0);
+   {
+      unsigned nb = blocks(n_refs, TB); if (nb > 65536u * 4) nb = 65536u * 4;
+      k_dev_points<<<nb, TB, 0, s>>>(b->d_x, b->d_y, b->d_ref, n_refs, c->dpi, sfix, pts);
+   }
+   k_way_info<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, b->d_ref, n_ways, st->border_used, st->fill_used,
+                                                st->ignore_open, wayflags, &small[0]);
+   k_prim_init<<<blocks(n_prims, TB), TB, 0, s>>>(prims, n_prims);
+   uint32_t h_small[4];
+   SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
+   SMR_HIP(hipStreamSynchronize(s));
+   const bool open_fill = h_small[0] != 0;
+
+   /* edge arena: [border strokes: 8/ref][fill polygons: 1/ref][open-way fill strokes: 8/ref] */
+   uint64_t off_border = 0, off_fill = st->border_used ? (uint64_t) SMR_SLOTS * n_refs : 0;
+   uint64_t off_open = off_fill + (st->fill_used ? (uint64_t) n_refs : 0);
+   uint64_t n_edges = off_open + (open_fill ? (uint64_t) SMR_SLOTS * n_refs : 0);
+   smr_edge_t *edges;
+   SMR_TRY(c->ensure(SMR_BUF_EDGES, (size_t) n_edges * sizeof(smr_edge_t), (void **) &edges));
+
+   double hw_nofill = mm2wu(st->border_width_mm, c->dpi) / 2;
+   double hw_open = (mm2wu(2 * st->border_width_mm, c->dpi) + mm2wu(st->fill_width_mm, c->dpi)) / 2;
+   double hw_closed = mm2wu(2 * st->border_width_mm, c->dpi) / 2;
+   double hw_fill = mm2wu(st->fill_width_mm, c->dpi) / 2;
+   if (st->border_used)
+      k_stroke_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, n_ways, n_refs, wayflags, 0, c->dpi, hw_nofill,
+                                                       hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border, prims);
+   if (st->fill_used)
+      k_fill_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, n_ways, n_refs, wayflags, edges + off_fill, prims);
+   if (open_fill)
+      k_stroke_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, n_ways, n_refs, wayflags, 1, c->dpi, hw_nofill,
+                                                       hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open, prims);
+   uint32_t *wb_pix = nullptr, *wf_pix = nullptr;
+   if (b->d_way_border_col || b->d_way_fill_col)
+   {
+      SMR_TRY(c->ensure(SMR_BUF_WAYPIX, (size_t) n_ways * 8, (void **) &way_pix));
+      if (b->d_way_border_col) { wb_pix = way_pix; k_color_pixels<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_border_col, n_ways, wb_pix); }
+      if (b->d_way_fill_col) { wf_pix = way_pix + n_ways; k_color_pixels<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_fill_col, n_ways, wf_pix); }
+   }
+   k_prim_finish<<<blocks(n_ways, TB), TB, 0, s>>>(prims, n_ways, b->d_way_off, wayflags, off_border, off_fill, off_open,
+                                                   host_color_pixel(st->border_col), host_color_pixel(st->fill_col),
+                                                   wb_pix, wf_pix, c->W, c->H, &small[1]);
+   SMR_HIP(hipGetLastError());
+   T.mark(s);                                                   /* 1: setup done */
+
+   /* binning */
+   uint32_t *counts, *tile_off, *sums;
+   const uint32_t nb_scan = (n_tiles + SCAN_B - 1) / SCAN_B;
+   SMR_TRY(c->ensure(SMR_BUF_COUNTS, (size_t) n_tiles * 4, (void **) &counts));
+   SMR_TRY(c->ensure(SMR_BUF_TILEOFF, ((size_t) n_tiles + 1) * 4, (void **) &tile_off));
+   SMR_TRY(c->ensure(SMR_BUF_SUMS, (size_t) nb_scan * 4, (void **) &sums));
+   SMR_HIP(hipMemsetAsync(counts, 0, (size_t) n_tiles * 4, s));
+   k_bin<false><<<blocks(n_prims, TB), TB, 0, s>>>(prims, n_prims, c->W, c->band_y0, c->band_h, TX, counts, nullptr, nullptr);
+   k_scan_block<<<nb_scan, 256, 0, s>>>(counts, tile_off, sums, n_tiles);
+   k_scan_sums<<<1, 1024, 0, s>>>(sums, nb_scan, &small[3]);
+   k_scan_add<<<nb_scan, 256, 0, s>>>(tile_off, sums, n_tiles);
+   k_set_u32<<<1, 1, 0, s>>>(&tile_off[n_tiles], &small[3]);
+   SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
+   SMR_HIP(hipStreamSynchronize(s));
+   const uint32_t n_entries = h_small[3];
+   uint32_t *entries;
+   SMR_TRY(c->ensure(SMR_BUF_ENTRIES, ((size_t) n_entries + 1) * 4, (void **) &entries));
+   SMR_HIP(hipMemsetAsync(counts, 0, (size_t) n_tiles * 4, s));
+   k_bin<true><<<blocks(n_prims, TB), TB, 0, s>>>(prims, n_prims, c->W, c->band_y0, c->band_h, TX, counts, tile_off, entries);
+   SMR_HIP(hipGetLastError());
+   T.mark(s);                                                   /* 2: binned */
+   k_tile_sort<<<n_tiles, 64, 0, s>>>(tile_off, entries, n_tiles);
+   SMR_HIP(hipGetLastError());
+   T.mark(s);                                                   /* 3: sorted */
+
+   raster_args_t A;
+   A.prims = prims; A.edges = edges; A.tile_off = tile_off; A.entries = entries; A.first_prim = &small[1];
+   A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
+   A.n_tiles = n_tiles;
+   k_raster<<<n_tiles, 64, 0, s>>>(A);
+   SMR_HIP(hipGetLastError());
+   T.mark(s);                                                   /* 4: rastered */
+   SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
+   SMR_HIP(hipStreamSynchronize(s));
+   if (smr_g.profiling)
+   {
+      smr_timings_t &t = smr_g.last;
+      t.setup_ms = T.ms(0, 1); t.bin_ms = T.ms(1, 2); t.sort_ms = T.ms(2, 3); t.raster_ms = T.ms(3, 4); t.total_ms = T.ms(0, 4);
+      t.n_prims = (uint64_t) n_prims; t.n_edges = n_edges; t.n_tile_refs = n_entries; t.n_tiles = n_tiles;
+   }
+   if (h_small[2] & SMR_ST_BUCKET_OVERFLOW)
+      return smr_fail(SMR_E_CAPACITY, "draw: more than %d edge crossings on one sub-scanline inside a 64-px tile", SMR_BK);
+   return SMR_OK;
+}

@@ -1,0 +1,141 @@
+/* smr_dev.h -- shared device-side definitions of libsmr_hip (gfx950 only). */
+#ifndef SMR_DEV_H
+#define SMR_DEV_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SMR_TW 64            /* tile width in px  = one wavefront of columns */
+#define SMR_TH 4             /* tile height in px = 60 sub-rows, one per lane */
+#define SMR_GRID_Y 15        /* sub-rows per pixel row (libcairo tor scan converter) */
+#define SMR_NSUB (SMR_TH * SMR_GRID_Y)
+#define SMR_BK 30            /* crossings kept per sub-row inside one tile */
+#define SMR_BKS 31           /* bucket stride in uint16 (odd dword count would be better; 31 halves keeps banks spread) */
+#define SMR_ROWCAP 64        /* active edges per pixel row that the exact full-row path handles */
+#define SMR_SLOTS 8          /* stroke edge slots per segment */
+
+/* one polygon edge in device space, 24.8 fixed point; direction carries the winding sign.
+ * y1 == y2 marks an empty slot (horizontal edges never contribute). */
+struct __attribute__((aligned(16))) smr_edge_t { int32_t x1, y1, x2, y2; };
+
+/* one primitive = one cairo_stroke()/cairo_fill() of the reference (render_poly_line,
+ * src/smrules_cairo.c:953-1016): an edge range + a solid source pixel */
+struct __attribute__((aligned(16))) smr_prim_t
+{
+   uint64_t edge_off;        /* first edge slot in the edge arena */
+   uint32_t edge_cnt;        /* number of slots (empty ones included) */
+   uint32_t color;           /* premultiplied ARGB32 source pixel */
+   int32_t minx, miny, maxx, maxy;   /* bbox of the emitted vertices, 24.8 */
+   uint32_t flags;           /* SMR_PF_* */
+   uint32_t pad_[3];
+};
+#define SMR_PF_VALID 1u
+#define SMR_PF_EVENODD 2u
+
+/* status word bits reported back to the host */
+#define SMR_ST_BUCKET_OVERFLOW 1u
+#define SMR_ST_ROWCAP 2u
+
+__device__ __forceinline__ int smr_to_grid_y(int32_t y) { return (int) ((15ll * y + 128) >> 8); }
+
+/* floor division of a 64-bit numerator by a positive 31-bit denominator through fp64 with
+ * an exact integer correction */
+__device__ __forceinline__ void smr_floordiv(int64_t n, int32_t d, int64_t &q, int32_t &r)
+{
+   double qd = floor((double) n / (double) d);
+   q = (int64_t) qd;
+   int64_t rr = n - q * (int64_t) d;
+   if (rr < 0) { q--; rr += d; }
+   else if (rr >= d) { q++; rr -= d; }
+   if (rr < 0) { q--; rr += d; }
+   else if (rr >= d) { q++; rr -= d; }
+   r = (int32_t) rr;
+}
+
+/* oriented (downward) edge, derived form.  D = 60*dy: libcairo's Ey / 128 (all remainders
+ * of the tor scan converter are exact multiples of 128, so the reduced form is bit-equal). */
+struct smr_oedge_t
+{
+   int32_t p1x, p1y, dxs, D, ytop, ybot, dir;   /* dir == 0: empty */
+};
+
+__device__ __forceinline__ smr_oedge_t smr_orient(const smr_edge_t e)
+{
+   smr_oedge_t o;
+   int32_t ax = e.x1, ay = e.y1, bx = e.x2, by = e.y2;
+   o.dir = 1;
+   if (ay > by) { int32_t t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; o.dir = -1; }
+   o.p1x = ax; o.p1y = ay; o.dxs = bx - ax; o.D = 60 * (by - ay);
+   o.ytop = smr_to_grid_y(ay); o.ybot = smr_to_grid_y(by);
+   if (ay == by || o.ytop >= o.ybot) o.dir = 0;
+   return o;
+}
+
+/* x of the edge at the centre of sub-row ys: quo + rem/D, 0 <= rem < D */
+__device__ __forceinline__ void smr_edge_x(int32_t p1x, int32_t p1y, int32_t dxs, int32_t D, int ys, int64_t &quo, int32_t &rem)
+{
+   if (dxs == 0) { quo = p1x; rem = 0; return; }
+   int64_t diff = ((int64_t) (2 * (int64_t) ys + 1) << 8) - (int64_t) p1y * 30;
+   int64_t q;
+   smr_floordiv(2 * diff * (int64_t) dxs, D, q, rem);
+   quo = q + p1x;
+}
+
+__device__ __forceinline__ int32_t smr_cell(int64_t quo, int32_t rem, int32_t D, int32_t dxs)
+{
+   return (int32_t) quo + ((dxs != 0 && rem >= (D >> 1)) ? 1 : 0);
+}
+
+/* ---- 8-bit compositing arithmetic (libcairo image spans / pixman 0.40) ---- */
+__device__ __forceinline__ uint32_t smr_mul7f(uint32_t a, uint32_t b) { uint32_t t = a * b + 0x7f; return (t + (t >> 8)) >> 8; }
+__device__ __forceinline__ uint32_t smr_mul80(uint32_t a, uint32_t b) { uint32_t t = a * b + 0x80; return (t + (t >> 8)) >> 8; }
+__device__ __forceinline__ uint32_t smr_sat(uint32_t v) { return v > 255u ? 255u : v; }
+
+__device__ __forceinline__ uint32_t smr_blend_lerp(uint32_t s, uint32_t a, uint32_t d)
+{
+   if (a == 255u) return s;
+   uint32_t o = 0;
+#pragma unroll
+   for (int sh = 0; sh < 32; sh += 8)
+      o |= smr_sat(smr_mul7f((s >> sh) & 0xff, a) + smr_mul7f((d >> sh) & 0xff, 255u - a)) << sh;
+   return o;
+}
+
+__device__ __forceinline__ uint32_t smr_blend_over_mask(uint32_t s, uint32_t m, uint32_t d)
+{
+   if (m != 255u)
+   {
+      uint32_t t = 0;
+#pragma unroll
+      for (int sh = 0; sh < 32; sh += 8) t |= smr_mul80((s >> sh) & 0xff, m) << sh;
+      s = t;
+   }
+   uint32_t ia = 255u - (s >> 24), o = 0;
+#pragma unroll
+   for (int sh = 0; sh < 32; sh += 8)
+      o |= smr_sat(((s >> sh) & 0xff) + smr_mul80((d >> sh) & 0xff, ia)) << sh;
+   return o;
+}
+
+__device__ __forceinline__ uint32_t smr_blend_over(uint32_t s, uint32_t d)
+{
+   uint32_t a = s >> 24;
+   if (a == 255u) return s;
+   if (s == 0u) return d;
+   uint32_t o = 0;
+#pragma unroll
+   for (int sh = 0; sh < 32; sh += 8)
+      o |= smr_sat(((s >> sh) & 0xff) + smr_mul80((d >> sh) & 0xff, 255u - a)) << sh;
+   return o;
+}
+
+/* XCD-aware, bijective blockIdx -> work item map: blocks b and b+8 share an XCD (and its
+ * L2), so give every XCD one contiguous range of work items */
+__device__ __forceinline__ uint32_t smr_xcd_remap(uint32_t b, uint32_t n)
+{
+   uint32_t q = n >> 3, r = n & 7u, xcd = b & 7u, k = b >> 3;
+   uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+   return base + k;
+}
+
+#endif

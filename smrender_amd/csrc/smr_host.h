@@ -1,0 +1,68 @@
+/* smr_host.h -- host-side internals shared by the translation units of libsmr_hip. */
+#ifndef SMR_HOST_H
+#define SMR_HOST_H
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <math.h>
+#include "../../include/smr_hip.h"
+
+struct smr_global_t
+{
+   bool init = false;
+   int device = -1;
+   hipStream_t stream = nullptr;
+   smr_proj_t proj;
+   bool have_proj = false;
+   bool profiling = false;
+   smr_timings_t last;
+   char err[512] = "";
+};
+extern smr_global_t smr_g;
+
+int smr_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define SMR_NEED_INIT() do { if (!smr_g.init) return smr_fail(SMR_E_NODEVICE, "libsmr_hip: smr_hip_init() has not succeeded (no GPU, no work: there is no CPU fallback)"); } while (0)
+#define SMR_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return smr_fail(SMR_E_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); } while (0)
+#define SMR_TRY(call) do { int r_ = (call); if (r_ != SMR_OK) return r_; } while (0)
+
+enum { SMR_BUF_PTS, SMR_BUF_WAYFLAGS, SMR_BUF_SMALL, SMR_BUF_PRIMS, SMR_BUF_EDGES, SMR_BUF_WAYPIX, SMR_BUF_COUNTS,
+       SMR_BUF_TILEOFF, SMR_BUF_SUMS, SMR_BUF_ENTRIES, SMR_BUF_CAP0, SMR_BUF_CAP1, SMR_BUF_MAX };
+
+struct smr_devbuf_t { void *p = nullptr; size_t cap = 0; };
+
+struct smr_canvas
+{
+   int W = 0, H = 0, dpi = 0, band_y0 = 0, band_h = 0;
+   uint32_t bg = 0;
+   uint32_t *pix = nullptr;
+   smr_devbuf_t buf[SMR_BUF_MAX];      /* grow-only work buffers, reused across draw calls */
+
+   int ensure(int id, size_t bytes, void **out)
+   {
+      smr_devbuf_t &b = buf[id];
+      if (bytes < 256) bytes = 256;
+      if (b.cap < bytes)
+      {
+         if (b.p) { hipStreamSynchronize(smr_g.stream); hipFree(b.p); b.p = nullptr; b.cap = 0; }
+         size_t want = bytes + bytes / 8;
+         if (hipMalloc(&b.p, want) != hipSuccess) { b.p = nullptr; return smr_fail(SMR_E_NOMEM, "hipMalloc of %zu bytes failed", want); }
+         b.cap = want;
+      }
+      *out = b.p;
+      return SMR_OK;
+   }
+};
+
+/* HIP-event stage timer on the library stream (only active when profiling is on) */
+struct smr_timer_t
+{
+   bool on; int n = 0; hipEvent_t ev[12];
+   explicit smr_timer_t(bool enable) : on(enable) {}
+   ~smr_timer_t() { for (int i = 0; i < n; i++) hipEventDestroy(ev[i]); }
+   void mark(hipStream_t s) { if (!on || n >= 12) return; hipEventCreate(&ev[n]); hipEventRecord(ev[n], s); n++; }
+   float ms(int a, int b) { float t = 0; if (!on || b >= n) return 0; hipEventSynchronize(ev[b]); hipEventElapsedTime(&t, ev[a], ev[b]); return t; }
+};
+
+#endif

@@ -1,0 +1,226 @@
+"""ctypes binding of libsmr_hip.so (include/smr_hip.h).  Mirrors the C-ABI one to one."""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libsmr_hip.so")
+
+
+class SmrHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsmr_hip error {code}: {msg}")
+        self.code = code
+
+
+class Projection(C.Structure):
+    """smr_proj_t: the members of struct rdata (src/rdata.h:99-158) geo2pxf reads."""
+    _fields_ = [("lon0", C.c_double), ("w", C.c_double), ("h", C.c_double), ("wc", C.c_double),
+                ("lath", C.c_double), ("lath_len", C.c_double), ("lat_ll", C.c_double),
+                ("lon_ru", C.c_double), ("lat_ru", C.c_double), ("dpi", C.c_int32), ("pad_", C.c_int32)]
+
+    @classmethod
+    def from_window(cls, mean_lat, mean_lon, scale, w_px, h_px, dpi):
+        p = cls()
+        _chk(lib().smr_hip_proj_from_window(C.byref(p), mean_lat, mean_lon, scale, w_px, h_px, dpi))
+        return p
+
+
+class DrawStyle(C.Structure):
+    """smr_draw_style_t: the solid subset of struct actDraw (src/smrender_dev.h:252-268)."""
+    _fields_ = [("fill_used", C.c_int32), ("border_used", C.c_int32), ("fill_col", C.c_uint32),
+                ("border_col", C.c_uint32), ("fill_width_mm", C.c_double), ("border_width_mm", C.c_double),
+                ("ignore_open", C.c_int32), ("fill_style", C.c_int32), ("border_style", C.c_int32),
+                ("curve", C.c_int32), ("directional", C.c_int32), ("pad_", C.c_int32)]
+
+
+class _DrawBatch(C.Structure):
+    _fields_ = [("d_x", C.c_void_p), ("d_y", C.c_void_p), ("n_nodes", C.c_int64), ("d_way_off", C.c_void_p),
+                ("d_ref", C.c_void_p), ("n_ways", C.c_int64), ("n_refs", C.c_int64),
+                ("d_way_fill_col", C.c_void_p), ("d_way_border_col", C.c_void_p)]
+
+
+class _CapBatch(C.Structure):
+    _fields_ = [("d_cx", C.c_void_p), ("d_cy", C.c_void_p), ("n", C.c_int64), ("fg_w", C.c_int32), ("fg_h", C.c_int32),
+                ("fg_x", C.c_int32), ("col", C.c_uint32), ("phase_deg", C.c_double), ("weight", C.c_double)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("proj_ms", C.c_float), ("setup_ms", C.c_float), ("bin_ms", C.c_float), ("sort_ms", C.c_float),
+                ("raster_ms", C.c_float), ("caprot_ms", C.c_float), ("total_ms", C.c_float),
+                ("n_prims", C.c_uint64), ("n_edges", C.c_uint64), ("n_tile_refs", C.c_uint64), ("n_tiles", C.c_uint64)]
+
+
+# every symbol include/smr_hip.h declares (tests/test_abi.py checks the list against the header)
+EXPORTS = [
+    "smr_hip_init", "smr_hip_shutdown", "smr_hip_last_error", "smr_hip_device_name",
+    "smr_hip_proj_from_window", "smr_hip_set_projection", "smr_hip_project", "smr_hip_unproject",
+    "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_read", "smr_hip_canvas_device",
+    "smr_hip_draw", "smr_hip_caprot", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
+    "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
+    "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libsmr_hip.so (built in-tree by `make`).  Raises if it is missing: no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise SmrHipError(-1, f"{_LIB_PATH} not built (run `make` / __graft_entry__.build()); there is no CPU fallback")
+        L = C.CDLL(_LIB_PATH)
+        L.smr_hip_last_error.restype = C.c_char_p
+        L.smr_hip_stream.restype = C.c_void_p
+        L.smr_hip_proj_from_window.argtypes = [C.POINTER(Projection), C.c_double, C.c_double, C.c_double,
+                                               C.c_double, C.c_double, C.c_int]
+        L.smr_hip_set_projection.argtypes = [C.POINTER(Projection)]
+        L.smr_hip_project.argtypes = [C.c_void_p, C.c_void_p, C.c_int64] + [C.c_void_p] * 5
+        L.smr_hip_unproject.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.smr_hip_canvas_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.smr_hip_canvas_destroy.argtypes = [C.c_void_p]
+        L.smr_hip_canvas_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.smr_hip_canvas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+        L.smr_hip_draw.argtypes = [C.c_void_p, C.POINTER(DrawStyle), C.POINTER(_DrawBatch)]
+        L.smr_hip_caprot.argtypes = [C.c_void_p, C.POINTER(_CapBatch), C.c_void_p, C.c_void_p]
+        L.smr_hip_caprot_steps.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.smr_hip_timings.argtypes = [C.POINTER(Timings)]
+        L.smr_hip_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        L.smr_hip_free.argtypes = [C.c_void_p]
+        L.smr_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.smr_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.smr_hip_device_name.argtypes = [C.c_char_p, C.c_size_t]
+        _lib = L
+    return _lib
+
+
+def _chk(code):
+    if code != 0:
+        raise SmrHipError(code, lib().smr_hip_last_error().decode())
+
+
+def init(device=0):
+    _chk(lib().smr_hip_init(int(device)))
+
+
+def shutdown():
+    _chk(lib().smr_hip_shutdown())
+
+
+def sync():
+    _chk(lib().smr_hip_sync())
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    _chk(lib().smr_hip_device_name(buf, 256))
+    return buf.value.decode()
+
+
+def set_profiling(on):
+    _chk(lib().smr_hip_set_profiling(int(bool(on))))
+
+
+def timings():
+    t = Timings()
+    _chk(lib().smr_hip_timings(C.byref(t)))
+    return {k: getattr(t, k) for k, _ in Timings._fields_}
+
+
+class DeviceArray:
+    """A typed device allocation made through the C-ABI (smr_hip_malloc/_memcpy_*)."""
+
+    def __init__(self, shape, dtype):
+        self.shape = tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = C.c_void_p()
+        _chk(lib().smr_hip_malloc(C.byref(p), max(self.nbytes, 16)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        d = cls(a.shape, a.dtype)
+        if a.nbytes:
+            _chk(lib().smr_hip_memcpy_h2d(d.ptr, a.ctypes.data, a.nbytes))
+        return d
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            _chk(lib().smr_hip_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().smr_hip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def set_projection(p):
+    _chk(lib().smr_hip_set_projection(C.byref(p)))
+
+
+def project(d_lat, d_lon, d_x, d_y, d_ix=None, d_iy=None, d_on=None):
+    """geo2pxf over device SoA arrays (DeviceArray)."""
+    n = int(np.prod(d_lat.shape))
+    _chk(lib().smr_hip_project(d_lat.ptr, d_lon.ptr, n, d_x.ptr, d_y.ptr,
+                               d_ix.ptr if d_ix else None, d_iy.ptr if d_iy else None, d_on.ptr if d_on else None))
+
+
+def unproject(d_x, d_y, d_lon, d_lat):
+    n = int(np.prod(d_x.shape))
+    _chk(lib().smr_hip_unproject(d_x.ptr, d_y.ptr, n, d_lon.ptr, d_lat.ptr))
+
+
+def caprot_steps(fg_w, fg_h, dpi):
+    n, r = C.c_int(), C.c_int()
+    _chk(lib().smr_hip_caprot_steps(fg_w, fg_h, dpi, C.byref(n), C.byref(r)))
+    return n.value, r.value
+
+
+class Canvas:
+    """Device canvas band: the GPU counterpart of smrender's recording surface + replay."""
+
+    def __init__(self, W, H, dpi, bgcolor=0xffffff, band_y0=0, band_h=None):
+        self.W, self.H, self.dpi = W, H, dpi
+        self.band_y0 = band_y0
+        self.band_h = H - band_y0 if band_h is None else band_h
+        h = C.c_void_p()
+        _chk(lib().smr_hip_canvas_create(W, H, dpi, bgcolor, self.band_y0, self.band_h, C.byref(h)))
+        self.h = h.value
+
+    def draw(self, style, d_x, d_y, d_way_off, d_ref, n_ways, n_refs, d_fill_col=None, d_border_col=None):
+        b = _DrawBatch(d_x.ptr, d_y.ptr, int(np.prod(d_x.shape)), d_way_off.ptr, d_ref.ptr if d_ref else None,
+                       n_ways, n_refs, d_fill_col.ptr if d_fill_col else None, d_border_col.ptr if d_border_col else None)
+        _chk(lib().smr_hip_draw(self.h, C.byref(style), C.byref(b)))
+
+    def caprot(self, d_cx, d_cy, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_angle, d_dv=None):
+        b = _CapBatch(d_cx.ptr, d_cy.ptr, n, fg_w, fg_h, fg_x, col, phase_deg, weight)
+        _chk(lib().smr_hip_caprot(self.h, C.byref(b), d_angle.ptr, d_dv.ptr if d_dv else None))
+
+    def read(self, x=0, y=0, w=None, h=None):
+        w = self.W - x if w is None else w
+        h = self.band_h - y if h is None else h
+        out = np.empty((h, w), np.uint32)
+        _chk(lib().smr_hip_canvas_read(self.h, x, y, w, h, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().smr_hip_canvas_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
