@@ -173,7 +173,10 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
    int64_t w = smr_find_way(way_off, n_ways, g);
    smr_edge_t *out = edges + (size_t) SMR_SLOTS * g;
    smr_edge_t z; z.x1 = z.y1 = z.x2 = z.y2 = 0;
-   int cnt = 0;
+   /* slots 0..3: join wedge at the segment's start point, slots 4..7: the segment's quad;
+    * every 4 aligned slots hold one closed convex piece (or nothing) */
+#pragma unroll
+   for (int i = 0; i < SMR_SLOTS; i++) out[i] = z;
    uint8_t wf = wayflags[w];
    int64_t a = way_off[w], b = way_off[w + 1];
    bool on = mode == 0 ? (wf & 2) != 0 : (wf & 8) != 0;
@@ -221,23 +224,22 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
                   if (smr_sgn_cmp(fdx1, fdy1, mdx, mdy) != smr_sgn_cmp(fdx2, fdy2, mdx, mdy))
                   {
                      int2 q[4] = { p1, inpt, make_int2((int32_t) rint(mx * 256.0), (int32_t) rint(my * 256.0)), outpt };
-                     cnt += smr_emit_poly(q, 4, out + cnt, prim);
+                     smr_emit_poly(q, 4, out, prim);
                      mitered = true;
                   }
                }
                if (!mitered)
                {
                   int2 q[3] = { p1, inpt, outpt };
-                  cnt += smr_emit_poly(q, 3, out + cnt, prim);
+                  smr_emit_poly(q, 3, out, prim);
                }
             }
          }
          int2 q[4] = { start.ccw, make_int2(start.ccw.x + ddx, start.ccw.y + ddy),
                        make_int2(start.cw.x + ddx, start.cw.y + ddy), start.cw };
-         cnt += smr_emit_poly(q, 4, out + cnt, prim);
+         smr_emit_poly(q, 4, out + 4, prim);
       }
    }
-   for (; cnt < SMR_SLOTS; cnt++) out[cnt] = z;
 }
 
 /* finalise the primitive table: edge ranges, colours, validity against the full chart, and
@@ -264,7 +266,7 @@ __global__ void k_prim_finish(smr_prim_t *__restrict__ prims, int64_t n_ways, co
       p->color = k == 0 ? (way_border_pix ? way_border_pix[w] : border_pix) : (way_fill_pix ? way_fill_pix[w] : fill_pix);
       int c0 = p->minx >> 8, c1 = p->maxx >> 8, r0 = p->miny >> 8, r1 = p->maxy >> 8;
       if (c1 < 0 || r1 < 0 || c0 >= W || r0 >= H) { p->flags = 0; continue; }
-      p->flags = SMR_PF_VALID;
+      p->flags = SMR_PF_VALID | ((k == 0 || (wf & 8)) ? SMR_PF_PIECES : 0u);
       atomicMin(first_prim, (uint32_t) (2 * w + k));
    }
 }
@@ -653,15 +655,29 @@ __global__ __launch_bounds__(64) void k_raster(raster_args_t A)
       if (partial)
       {
          const bool mine = lane < SMR_NSUB && ((partial >> my_row) & 1u);
+         const bool pieces = (P.flags & SMR_PF_PIECES) != 0;
          int cnt = 0, lw = 0;
          bool ovf = false;
+         uint16_t *bk = L.bucket[lane];
          for (uint32_t base = 0; base < P.edge_cnt; base += 64)
          {
             uint32_t idx = base + lane;
             smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0; o.p1x = o.p1y = o.dxs = 0; o.D = 1;
             if (idx < P.edge_cnt) o = smr_orient(E[idx]);
-            bool ov = o.dir != 0 && o.ytop < ysbase + SMR_NSUB && o.ybot > ysbase && o.p1x + (o.dxs < 0 ? o.dxs : 0) < X1;
+            const int32_t eminx = o.p1x + (o.dxs < 0 ? o.dxs : 0), emaxx = o.p1x + (o.dxs > 0 ? o.dxs : 0);
+            bool ov = o.dir != 0 && o.ytop < ysbase + SMR_NSUB && o.ybot > ysbase && eminx < X1;
             unsigned long long om = __ballot(ov);
+            if (pieces)
+            {
+               /* a piece (4 aligned lanes) is needed when any of its edges meets the strip and
+                * its x-extent meets the tile */
+               int32_t pmax = o.dir != 0 ? emaxx : INT32_MIN;
+               pmax = max(pmax, __shfl_xor(pmax, 1)); pmax = max(pmax, __shfl_xor(pmax, 2));
+               unsigned long long right = __ballot(pmax > X0);
+               om = om & right;
+               om |= om >> 1; om |= om >> 2;            /* gather the piece's bits into its first lane */
+               om &= 0x1111111111111111ull;
+            }
             if (!om) continue;
             __syncthreads();
             L.e_p1x[lane] = o.p1x; L.e_p1y[lane] = o.p1y; L.e_dxs[lane] = o.dxs; L.e_D[lane] = o.D;
@@ -671,65 +687,104 @@ __global__ __launch_bounds__(64) void k_raster(raster_args_t A)
             {
                int j = __ffsll((long long) om) - 1;
                om &= om - 1;
-               int ytop = L.e_ytop[j], ybot = L.e_ybot[j];
-               if (mine && my_ys >= ytop && my_ys < ybot)
+               if (!pieces)
                {
-                  int64_t q; int32_t rem;
-                  int32_t dxs = L.e_dxs[j], D = L.e_D[j];
-                  smr_edge_x(L.e_p1x[j], L.e_p1y[j], dxs, D, my_ys, q, rem);
-                  int32_t cell = smr_cell(q, rem, D, dxs);
-                  int dir = L.e_dir[j];
-                  if (cell < X0) lw += dir;
-                  else if (cell < X1)
+                  int ytop = L.e_ytop[j], ybot = L.e_ybot[j];
+                  if (mine && my_ys >= ytop && my_ys < ybot)
                   {
-                     if (cnt < SMR_BK) L.bucket[lane][cnt++] = (uint16_t) (((cell - X0) << 1) | (dir > 0 ? 1 : 0));
+                     int64_t q; int32_t rem;
+                     int32_t dxs = L.e_dxs[j], D = L.e_D[j];
+                     smr_edge_x(L.e_p1x[j], L.e_p1y[j], dxs, D, my_ys, q, rem);
+                     int32_t cell = smr_cell(q, rem, D, dxs);
+                     int dir = L.e_dir[j];
+                     if (cell < X0) lw += dir;
+                     else if (cell < X1)
+                     {
+                        if (cnt < SMR_BK) bk[cnt++] = (uint16_t) (((cell - X0) << 1) | (dir > 0 ? 1 : 0));
+                        else ovf = true;
+                     }
+                  }
+               }
+               else if (mine)
+               {
+                  /* convex piece: its two crossings bound one covered interval; the stroke is
+                   * the union of the intervals of all pieces (every piece winds the same way) */
+                  int32_t lo = INT32_MAX, hi = INT32_MIN;
+#pragma unroll
+                  for (int k = 0; k < 4; k++)
+                  {
+                     int jj = j + k;
+                     if (L.e_dir[jj] != 0 && my_ys >= L.e_ytop[jj] && my_ys < L.e_ybot[jj])
+                     {
+                        int64_t q; int32_t rem;
+                        int32_t dxs = L.e_dxs[jj], D = L.e_D[jj];
+                        smr_edge_x(L.e_p1x[jj], L.e_p1y[jj], dxs, D, my_ys, q, rem);
+                        int32_t cell = smr_cell(q, rem, D, dxs);
+                        lo = min(lo, cell); hi = max(hi, cell);
+                     }
+                  }
+                  if (lo < hi && hi > X0 && lo < X1)
+                  {
+                     int l = (lo < X0 ? X0 : lo) - X0, r = (hi > X1 ? X1 : hi) - X0;
+                     /* merge with every stored interval it overlaps or touches */
+                     for (int i = 0; i < cnt;)
+                     {
+                        int ia = bk[2 * i], ib = bk[2 * i + 1];
+                        if (ia <= r && l <= ib)
+                        {
+                           l = min(l, ia); r = max(r, ib);
+                           cnt--;
+                           bk[2 * i] = bk[2 * cnt]; bk[2 * i + 1] = bk[2 * cnt + 1];
+                           i = 0;
+                        }
+                        else i++;
+                     }
+                     if (2 * cnt + 2 <= SMR_BK) { bk[2 * cnt] = (uint16_t) l; bk[2 * cnt + 1] = (uint16_t) r; cnt++; }
                      else ovf = true;
                   }
                }
             }
          }
          if (__ballot(ovf) && lane == 0) atomicOr(A.status, SMR_ST_BUCKET_OVERFLOW);
-         if (mine)
+         auto add_span = [&](int x1, int x2)
          {
-            uint16_t *b = L.bucket[lane];
+            if (x1 == x2) return;
+            int ix1 = x1 >> 8, ix2 = x2 >> 8, fx1 = x1 & 255, fx2 = x2 & 255;
+            if (ix1 != ix2)
+            {
+               smr_cell_add(L, my_row, ix1, 1, 2 * fx1);
+               smr_cell_add(L, my_row, ix2, -1, -2 * fx2);
+            }
+            else smr_cell_add(L, my_row, ix1, 0, 2 * (fx1 - fx2));
+         };
+         if (mine && pieces)
+         {
+            for (int i = 0; i < cnt; i++) add_span(bk[2 * i], bk[2 * i + 1]);
+         }
+         else if (mine)
+         {
             for (int i = 1; i < cnt; i++)
             {
-               uint16_t v = b[i];
+               uint16_t v = bk[i];
                int k = i - 1;
-               while (k >= 0 && (b[k] >> 1) > (v >> 1)) { b[k + 1] = b[k]; k--; }
-               b[k + 1] = v;
+               while (k >= 0 && (bk[k] >> 1) > (v >> 1)) { bk[k + 1] = bk[k]; k--; }
+               bk[k + 1] = v;
             }
             int winding = lw;
             int xstart = (((uint32_t) winding & mask) != 0) ? 0 : -1;
-            for (int i = 0; i <= cnt; i++)
+            for (int i = 0; i < cnt; i++)
             {
-               int x1, x2;
-               if (i < cnt)
+               int xend = bk[i] >> 1;
+               winding += (bk[i] & 1) ? 1 : -1;
+               if (((uint32_t) winding & mask) == 0)
                {
-                  int xend = b[i] >> 1;
-                  winding += (b[i] & 1) ? 1 : -1;
-                  if (((uint32_t) winding & mask) == 0)
-                  {
-                     if (i + 1 < cnt && (b[i + 1] >> 1) == xend) continue;
-                     if (xstart < 0) continue;
-                     x1 = xstart; x2 = xend; xstart = -1;
-                  }
-                  else { if (xstart < 0) xstart = xend; continue; }
+                  if (i + 1 < cnt && (bk[i + 1] >> 1) == xend) continue;
+                  if (xstart >= 0) add_span(xstart, xend);
+                  xstart = -1;
                }
-               else
-               {
-                  if (xstart < 0) break;
-                  x1 = xstart; x2 = SMR_TW * 256;
-               }
-               if (x1 == x2) continue;
-               int ix1 = x1 >> 8, ix2 = x2 >> 8, fx1 = x1 & 255, fx2 = x2 & 255;
-               if (ix1 != ix2)
-               {
-                  smr_cell_add(L, my_row, ix1, 1, 2 * fx1);
-                  smr_cell_add(L, my_row, ix2, -1, -2 * fx2);
-               }
-               else smr_cell_add(L, my_row, ix1, 0, 2 * (fx1 - fx2));
+               else if (xstart < 0) xstart = xend;
             }
+            if (xstart >= 0) add_span(xstart, SMR_TW * 256);
          }
       }
       __syncthreads();

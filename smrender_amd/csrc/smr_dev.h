@@ -31,6 +31,7 @@ struct __attribute__((aligned(16))) smr_prim_t
 };
 #define SMR_PF_VALID 1u
 #define SMR_PF_EVENODD 2u
+#define SMR_PF_PIECES 4u     /* every 4 aligned edge slots form one closed convex piece, all wound alike (strokes) */
 
 /* status word bits reported back to the host */
 #define SMR_ST_BUCKET_OVERFLOW 1u
