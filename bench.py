@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of libsmr_hip on MI355X.
+
+One "step" = one pass of the hot path over the synthetic C2 batch: Mercator
+projection of every node (kernel 1) + the full draw of one rule (vertex/edge setup, stroke
+expansion, tile binning + sort, wave-per-tile raster; kernel 2) onto a freshly cleared
+16384 x 16384 canvas.  Inputs (lat/lon SoA, way table) are resident in HBM before the timed
+region.  N GPUs: one process per GPU, rank r owns band r of a 16384 x (16384*N) chart (weak
+scaling, no data-path collective); value = all pixels rendered / max-over-ranks time.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import smrender_amd as sa                      # noqa: E402
+from smrender_amd import synth                 # noqa: E402
+
+HBM_PEAK = 8.0e12        # B/s, MI355X_MICROARCH.md
+
+
+def make_band(args, band, n_bands):
+    """ways of band `band` plus the neighbours' ways that reach into it"""
+    W, H = args.size, args.size
+    parts = []
+    for b in (band - 1, band, band + 1):
+        if b < 0 or b >= n_bands:
+            continue
+        x, y, off, ref = synth.synth_ways(args.ways, W, H, seed=1234 + b, y_off=float(b * H))
+        if b != band:
+            _, y0, _, y1 = synth.way_bbox(x, y, off, ref)
+            keep = (y1 > band * H - 4) & (y0 < (band + 1) * H + 4)
+            x, y, off, ref = synth.select_ways(x, y, off, ref, keep)
+        parts.append((x, y, off, ref))
+    # neighbours first/last keeps the global drawing order (band-major way ids)
+    xs = np.concatenate([p[0] for p in parts])
+    ys = np.concatenate([p[1] for p in parts])
+    node_base = np.cumsum([0] + [len(p[0]) for p in parts])
+    ref_base = np.cumsum([0] + [len(p[3]) for p in parts])
+    refs = np.concatenate([p[3] + node_base[i] for i, p in enumerate(parts)]).astype(np.int32)
+    offs = np.concatenate([p[2][:-1] + ref_base[i] for i, p in enumerate(parts)] + [[ref_base[-1]]]).astype(np.int64)
+    return xs, ys, offs, refs
+
+
+def cpu_baseline(args):
+    """The reference's CPU path on a bounded sample of the same workload: our restatement of
+    smrender's Cairo call sequence over the real libcairo (oracle/cairo_drive.c), else the
+    plain-C oracle.  Test infrastructure used only as the timed baseline."""
+    from oracle import pyoracle as po
+    S = args.cpu_window
+    n = max(1, int(round(args.ways * (S / args.size) ** 2)))
+    x, y, off, ref = synth.synth_ways(n, S, S, seed=1234)
+    ways = po.ways_from_arrays(x, y, off, ref)
+    st = po.Style(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / args.dpi, 0)
+    out = {"cores": 1, "kind": "port", "unit": "Mpx/s"}
+    t0 = time.perf_counter()
+    p = po.make_proj(45.0, 15.0, 100000.0, float(S), float(S), args.dpi)
+    lat, lon = synth.px_to_geo(p, x, y)
+    t0 = time.perf_counter()
+    po.project(p, lat, lon)
+    t_proj = time.perf_counter() - t0
+    if po.cairo() is not None:
+        t0 = time.perf_counter()
+        po.cairo_scene([(st, ways)], args.dpi, S, S, 0xffffff)
+        t = time.perf_counter() - t0
+        out["sample"] = (f"{n} ways of the C2 generator on a {S}x{S} window, smrender's Cairo call sequence "
+                         f"(recording surface, group per rule, replay at dpi/72) over libcairo {po.cairo().cd_version().decode()}, 1 thread")
+    else:
+        t0 = time.perf_counter()
+        po.oracle_scene([(st, ways)], args.dpi, S, S, 0xffffff)
+        t = time.perf_counter() - t0
+        out["sample"] = f"{n} ways of the C2 generator on a {S}x{S} window, plain-C oracle (libcairo not loadable), 1 thread"
+    out["value"] = round(S * S / 1e6 / t, 3)
+    out["seconds"] = round(t, 3)
+    out["proj_nodes_per_s"] = round(len(lat) / t_proj, 1)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--ways", type=int, default=1000000)
+    ap.add_argument("--size", type=int, default=16384)
+    ap.add_argument("--dpi", type=int, default=300)
+    ap.add_argument("--cpu-window", type=int, default=3072)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    sa.init(local)
+
+    W, H = args.size, args.size
+    n_bands = world
+    x_px, y_px, way_off, ref = make_band(args, rank, n_bands)
+    # chart: W x (H * n_bands) px; window chosen so that the chart spans ~1.4 deg at 45N
+    proj = sa.Projection.from_window(45.0, 15.0, 100000.0 * (W / 16384.0), float(W), float(H * n_bands), args.dpi)
+    sa.set_projection(proj)
+    lat, lon = synth.px_to_geo(proj, x_px, y_px)
+    n_nodes, n_ways, n_refs = len(lat), len(way_off) - 1, len(ref)
+    if n_nodes & 1:      # keep 16-byte alignment of every array trivially (pad one unused node)
+        lat = np.append(lat, lat[-1]); lon = np.append(lon, lon[-1])
+    d_lat, d_lon = sa.DeviceArray.from_numpy(lat), sa.DeviceArray.from_numpy(lon)
+    d_x, d_y = sa.DeviceArray((len(lat),), np.float64), sa.DeviceArray((len(lat),), np.float64)
+    d_off, d_ref = sa.DeviceArray.from_numpy(way_off), sa.DeviceArray.from_numpy(ref)
+    style = sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / args.dpi, 0, 0, 0, 0, 0, 0)
+    cv = sa.Canvas(W, H * n_bands, args.dpi, 0xffffff, rank * H, H)
+    sa.set_profiling(True)
+
+    def step():
+        sa.project(d_lat, d_lon, d_x, d_y)
+        cv.clear()
+        cv.draw(style, d_x, d_y, d_off, d_ref, n_ways, n_refs)
+
+    def barrier():
+        sa.sync()
+        if dist is not None:
+            import torch
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    stage = {k: 0.0 for k in ("proj_ms", "setup_ms", "bin_ms", "sort_ms", "raster_ms")}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        t = sa.timings()
+        for k in stage:
+            stage[k] += t[k]
+    barrier()
+    dt = time.perf_counter() - t0
+    tm = sa.timings()
+    if dist is not None:
+        import torch
+        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    checksum = int(cv.read(0, 0, W, min(64, H)).astype(np.uint64).sum())
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        mpx = W * H * n_bands / 1e6
+        stage = {k: v / args.steps for k, v in stage.items()}
+        alg_bytes = 4.0 * W * H + 16.0 * n_refs + 64.0 * n_ways      # SURVEY 8d, per launch of k_raster on one band
+        achieved = alg_bytes / (stage["raster_ms"] * 1e-3)
+        res = {
+            "metric": "rasterized Mpixels/s (full-chart render: projection + draw)",
+            "value": round(mpx / (dt / args.steps), 2),
+            "unit": "Mpx/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i64 fixed 24.8 (raster) + f64 (projection)", "data": "synthetic",
+            "config": {"workload": f"C2: {args.ways} closed ways x ~32 nodes (non-zero winding), fill #4080c0 + 2 px AA border, "
+                                   f"{W}x{H} px canvas per GPU @ {args.dpi} dpi",
+                       "ways_per_gpu": n_ways, "refs_per_gpu": n_refs, "nodes_per_gpu": n_nodes,
+                       "canvas_total": [W, H * n_bands], "partition": f"{world} row band(s), one per GPU"},
+            "nodes_per_s": round(n_nodes / (stage["proj_ms"] * 1e-3), 1) if stage["proj_ms"] > 0 else None,
+            "stage_ms": {k: round(v, 3) for k, v in stage.items()},
+            "counts": {"prims": tm["n_prims"], "edge_slots": tm["n_edges"], "tile_refs": tm["n_tile_refs"], "tiles": tm["n_tiles"]},
+            "roofline": {"kernel": "k_raster", "bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5), "traffic": None,
+                         "algorithmic_bytes": alg_bytes},
+            "roofline_proj": {"kernel": "k_project", "bound": "hbm",
+                              "achieved": round(32.0 * len(lat) / (stage["proj_ms"] * 1e-3) / 1e9, 2) if stage["proj_ms"] > 0 else None,
+                              "peak": HBM_PEAK / 1e9, "unit": "GB/s"},
+            "device": sa.device_name(), "checksum": checksum,
+        }
+        if res["roofline_proj"]["achieved"]:
+            res["roofline_proj"]["frac"] = round(res["roofline_proj"]["achieved"] * 1e9 / HBM_PEAK, 4)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(res), flush=True)
+    cv.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -73,6 +73,8 @@ typedef struct smr_canvas smr_canvas_t;
  * bgcolor uses the reference's colour ints 0xTTRRGGBB (src/smrparse.c:222-258). */
 int smr_hip_canvas_create(int W, int H, int dpi, uint32_t bgcolor, int band_y0, int band_h, smr_canvas_t **out);
 int smr_hip_canvas_destroy(smr_canvas_t *c);
+/* repaint the background (what cairo_smr_init_main_image does once per chart, :320-326) */
+int smr_hip_canvas_clear(smr_canvas_t *c);
 /* copy a rectangle (band-local rows) of premultiplied ARGB32 to host memory */
 int smr_hip_canvas_read(smr_canvas_t *c, int x, int y, int w, int h, uint32_t *host_dst);
 /* device pointer + row stride (pixels) of the band, for zero-copy consumers */

@@ -191,29 +191,7 @@ def chan_diff(a, b):
     return d
 
 
-# ---------------------------------------------------------------- synthetic data
-def synth_ways(n_ways, W, H, seed=1234, rmin=4.0, rmax=64.0, mean_nodes=32):
-    """Star-shaped closed polygons; returns (x_px, y_px, way_off, ref) with a closing ref per way."""
-    rng = np.random.default_rng(seed)
-    nv = np.clip(rng.poisson(mean_nodes, n_ways), 4, 256)
-    node_off = np.concatenate([[0], np.cumsum(nv)])
-    way_off = np.concatenate([[0], np.cumsum(nv + 1)]).astype(np.int64)
-    N = int(node_off[-1])
-    wid = np.repeat(np.arange(n_ways), nv)
-    k = np.arange(N) - node_off[wid]
-    cx, cy = rng.uniform(0, W, n_ways), rng.uniform(0, H, n_ways)
-    r = np.exp(rng.uniform(np.log(rmin), np.log(rmax), n_ways))
-    sgn = rng.choice([-1.0, 1.0], n_ways)
-    ph = rng.uniform(0, 2 * np.pi, n_ways)
-    ang = ph[wid] + sgn[wid] * 2 * np.pi * k / nv[wid]
-    rr = r[wid] * rng.uniform(0.7, 1.0, N)
-    x = cx[wid] + rr * np.cos(ang)
-    y = cy[wid] + rr * np.sin(ang)
-    ref = np.empty(int(way_off[-1]), np.int32)
-    pos = np.arange(N) + wid            # slot of node k of way w in the ref array
-    ref[pos] = np.arange(N, dtype=np.int32)
-    ref[way_off[1:] - 1] = node_off[:-1].astype(np.int32)
-    return x, y, way_off, ref
+from smrender_amd.synth import synth_ways  # noqa: E402,F401  (seeded generators live on the product side)
 
 
 def ways_from_arrays(x, y, way_off, ref):

@@ -857,6 +857,15 @@ extern "C" int smr_hip_canvas_create(int W, int H, int dpi, uint32_t bgcolor, in
    return SMR_OK;
 }
 
+extern "C" int smr_hip_canvas_clear(smr_canvas_t *c)
+{
+   SMR_NEED_INIT();
+   if (!c) return smr_fail(SMR_E_INVAL, "canvas_clear: NULL");
+   k_fill_u32<<<2048, 256, 0, smr_g.stream>>>(c->pix, (size_t) c->W * c->band_h, host_color_pixel(c->bg));
+   SMR_HIP(hipGetLastError());
+   return SMR_OK;
+}
+
 extern "C" int smr_hip_canvas_destroy(smr_canvas_t *c)
 {
    if (!c) return SMR_OK;

@@ -1,0 +1,54 @@
+"""Seeded synthetic inputs of SURVEY 8d (plain numpy; shared by tests and bench.py)."""
+import numpy as np
+
+
+def synth_ways(n_ways, W, H, seed=1234, rmin=4.0, rmax=64.0, mean_nodes=32, y_off=0.0):
+    """C2: star-shaped closed polygons (centre uniform, radius log-uniform rmin..rmax px,
+    ~Poisson(mean_nodes) vertices, radial jitter U(0.7,1), random orientation).
+    Returns (x_px, y_px, way_off, ref): one closing ref per way (ref[last] == ref[first])."""
+    rng = np.random.default_rng(seed)
+    nv = np.clip(rng.poisson(mean_nodes, n_ways), 4, 256)
+    node_off = np.concatenate([[0], np.cumsum(nv)])
+    way_off = np.concatenate([[0], np.cumsum(nv + 1)]).astype(np.int64)
+    N = int(node_off[-1])
+    wid = np.repeat(np.arange(n_ways), nv)
+    k = np.arange(N) - node_off[wid]
+    cx, cy = rng.uniform(0, W, n_ways), rng.uniform(0, H, n_ways)
+    r = np.exp(rng.uniform(np.log(rmin), np.log(rmax), n_ways))
+    sgn = rng.choice([-1.0, 1.0], n_ways)
+    ph = rng.uniform(0, 2 * np.pi, n_ways)
+    ang = ph[wid] + sgn[wid] * 2 * np.pi * k / nv[wid]
+    rr = r[wid] * rng.uniform(0.7, 1.0, N)
+    x = cx[wid] + rr * np.cos(ang)
+    y = cy[wid] + rr * np.sin(ang) + y_off
+    ref = np.empty(int(way_off[-1]), np.int32)
+    pos = np.arange(N) + wid            # slot of node k of way w in the ref array
+    ref[pos] = np.arange(N, dtype=np.int32)
+    ref[way_off[1:] - 1] = node_off[:-1].astype(np.int32)
+    return x, y, way_off, ref
+
+
+def select_ways(x, y, way_off, ref, keep):
+    """Sub-set of ways (boolean mask over ways) with nodes/refs re-packed."""
+    nref = np.diff(way_off)
+    ref_keep = np.repeat(keep, nref)
+    r = ref[ref_keep]
+    used = np.zeros(len(x), bool)
+    used[r] = True
+    remap = np.cumsum(used) - 1
+    new_off = np.concatenate([[0], np.cumsum(nref[keep])]).astype(np.int64)
+    return x[used], y[used], new_off, remap[r].astype(np.int32)
+
+
+def way_bbox(x, y, way_off, ref):
+    xs, ys = x[ref], y[ref]
+    a = way_off[:-1]
+    return (np.minimum.reduceat(xs, a), np.minimum.reduceat(ys, a),
+            np.maximum.reduceat(xs, a), np.maximum.reduceat(ys, a))
+
+
+def px_to_geo(p, x, y):
+    """pxf2geo (src/rdata.c:68-72) in numpy: used only to synthesise lat/lon inputs."""
+    lon = x * p.wc / p.w + p.lon0
+    lat = np.degrees(np.arctan(np.sinh(p.lath_len * (0.5 - y / p.h) + p.lath)))
+    return lat, lon
