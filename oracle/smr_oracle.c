@@ -342,13 +342,35 @@ void orc_layer_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, u
 {
    uint32_t s = orc_color_pixel(smr_col);
    int lerp = c->layer_clear || (s >> 24) == 255;
-   tor_coverage(e, n, nonzero, c->x0, c->y0, c->W, c->H, c->cov);
-   for (size_t i = 0; i < (size_t) c->W * c->H; i++)
+   /* only the primitive's bounding box can receive coverage */
+   int32_t minx = INT32_MAX, miny = INT32_MAX, maxx = INT32_MIN, maxy = INT32_MIN;
+   for (int i = 0; i < n; i++)
    {
-      uint32_t m = c->cov[i];
-      if (!m) continue;
-      c->layer[i] = lerp ? blend_lerp(s, m, c->layer[i]) : blend_over_mask(s, m, c->layer[i]);
+      if (e[i].y1 == e[i].y2) continue;
+      int32_t lx = e[i].x1 < e[i].x2 ? e[i].x1 : e[i].x2, hx = e[i].x1 < e[i].x2 ? e[i].x2 : e[i].x1;
+      int32_t ly = e[i].y1 < e[i].y2 ? e[i].y1 : e[i].y2, hy = e[i].y1 < e[i].y2 ? e[i].y2 : e[i].y1;
+      if (lx < minx) minx = lx;
+      if (hx > maxx) maxx = hx;
+      if (ly < miny) miny = ly;
+      if (hy > maxy) maxy = hy;
    }
+   if (minx > maxx) return;
+   int bx0 = (minx >> 8) - c->x0, bx1 = (maxx >> 8) - c->x0 + 1, by0 = (miny >> 8) - c->y0, by1 = (maxy >> 8) - c->y0 + 1;
+   if (bx0 < 0) bx0 = 0;
+   if (by0 < 0) by0 = 0;
+   if (bx1 > c->W) bx1 = c->W;
+   if (by1 > c->H) by1 = c->H;
+   if (bx0 >= bx1 || by0 >= by1) return;      /* nothing drawn: the layer stays "clear" for libcairo too */
+   int bw = bx1 - bx0, bh = by1 - by0;
+   tor_coverage(e, n, nonzero, c->x0 + bx0, c->y0 + by0, bw, bh, c->cov);
+   for (int y = 0; y < bh; y++)
+      for (int x = 0; x < bw; x++)
+      {
+         uint32_t m = c->cov[(size_t) y * bw + x];
+         if (!m) continue;
+         uint32_t *d = &c->layer[(size_t) (y + by0) * c->W + x + bx0];
+         *d = lerp ? blend_lerp(s, m, *d) : blend_over_mask(s, m, *d);
+      }
    c->layer_clear = 0;
 }
 

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in this directory by driving the REAL libcairo 1.16.0 +
+pixman 0.40.0 of this image with the reference's call sequence (oracle/cairo_drive.c, which
+cites the smrender lines it restates).  The reference's own tests hold no expected outputs
+(test/Makefile only renders PNGs), and its Cairo path cannot be built here under the rules
+(autoconf-generated config.h), so these vectors -- outputs of the third-party arithmetic the
+reference delegates to, reached through its own call sites -- are what pins the oracle.
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz (needs libcairo)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import pyoracle as po  # noqa: E402
+from smrender_amd import synth  # noqa: E402
+
+
+def open_ways(n_ways, W, H, seed):
+    rng = np.random.default_rng(seed)
+    xs, ys, off, ref = [], [], [0], []
+    for _ in range(n_ways):
+        n = int(rng.integers(2, 14))
+        step = rng.uniform(2, 30)
+        xs.append(rng.uniform(0, W) + np.cumsum(rng.normal(0, step, n)))
+        ys.append(rng.uniform(0, H) + np.cumsum(rng.normal(0, step, n)))
+        ref.extend(range(off[-1], off[-1] + n))
+        off.append(off[-1] + n)
+    return np.concatenate(xs), np.concatenate(ys), np.array(off, np.int64), np.array(ref, np.int32)
+
+
+def style_tuple(st):
+    return np.array([st.fill_used, st.border_used, st.fill_col, st.border_col, st.ignore_open], np.int64), \
+        np.array([st.fill_width_mm, st.border_width_mm])
+
+
+def main():
+    cd = po.cairo()
+    assert cd is not None, "libcairo not loadable"
+    print("libcairo", cd.cd_version().decode())
+    rng = np.random.default_rng(20261110)
+
+    # 1. scan-converter KATs: single polygons filled black on white straight onto an image
+    polys, alphas = [], []
+    for t in range(48):
+        W = int(rng.integers(12, 48))
+        n = 3 + t % 9
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        r = rng.uniform(0.15, 0.48, n) * W
+        xy = np.stack([W / 2 + r * np.cos(ang), W / 2 + r * np.sin(ang)], 1)
+        if t % 3 == 0:
+            rng.shuffle(xy)                      # self-intersecting -> exercises the winding rule
+        out = np.zeros((W, W), np.uint32)
+        cd.cd_direct_fill(po.P(np.ascontiguousarray(xy)), n, 0x000000, 0xffffff, W, W, po.P(out))
+        polys.append(xy)
+        alphas.append((255 - (out & 0xff)).astype(np.uint8))
+    np.savez_compressed(os.path.join(HERE, "tor_kat.npz"), n=len(polys),
+                        **{f"xy{i}": p for i, p in enumerate(polys)}, **{f"a{i}": a for i, a in enumerate(alphas)})
+
+    # 2. whole scenes through the reference call sequence (recording surface in pt, group per rule, replay)
+    scenes = {}
+    c2 = synth.synth_ways(160, 256, 256, seed=77)
+    ow = open_ways(50, 256, 200, seed=78)
+    scenes["c2_fill_border_300"] = dict(dpi=300, W=256, H=256, bg=0xffffff,
+                                        rules=[(po.Style(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0), c2)])
+    scenes["open_border_300"] = dict(dpi=300, W=256, H=200, bg=0xffffff,
+                                     rules=[(po.Style(0, 1, 0, 0x204060, 0.0, 0.3, 0), ow)])
+    scenes["layers_translucent_600"] = dict(dpi=600, W=256, H=200, bg=0x7f336699, rules=[
+        (po.Style(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0), synth.synth_ways(60, 256, 200, seed=79)),
+        (po.Style(1, 1, 0x304080c0, 0x50102030, 0.4, 0.2, 0), ow),
+        (po.Style(0, 1, 0, 0x000000, 0.0, 0.0, 0), synth.synth_ways(30, 256, 200, seed=80))])
+    # a window far from the origin: pins the 24.8 quantisation of the replay scale
+    far = synth.synth_ways(40, 128, 128, seed=81)
+    far = (far[0] + 15000.0, far[1] + 9000.0, far[2], far[3])
+    scenes["far_window_300"] = dict(dpi=300, W=128, H=128, bg=0xffffff, x0=15000, y0=9000,
+                                    rules=[(po.Style(1, 1, 0xc04020, 0x000000, 0.0, 0.1, 0), far)])
+    for name, sc in scenes.items():
+        rules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in sc["rules"]]
+        img = po.cairo_scene(rules, sc["dpi"], sc["W"], sc["H"], sc["bg"], sc.get("x0", 0), sc.get("y0", 0))
+        d = dict(dpi=sc["dpi"], W=sc["W"], H=sc["H"], bg=sc["bg"], win_x0=sc.get("x0", 0), win_y0=sc.get("y0", 0),
+                 n_rules=len(sc["rules"]), image=img)
+        for i, (st, (x, y, off, ref)) in enumerate(sc["rules"]):
+            si, sf = style_tuple(st)
+            d.update({f"si{i}": si, f"sf{i}": sf, f"x{i}": x, f"y{i}": y, f"off{i}": off, f"ref{i}": ref})
+        np.savez_compressed(os.path.join(HERE, f"scene_{name}.npz"), **d)
+        print(name, img.shape)
+
+    # 3. rotated bilinear OVER paint (cairo_smr_diff, src/smrules_cairo.c:1746-1759)
+    d = {}
+    for t in range(12):
+        dw, dh = int(rng.integers(8, 60)), int(rng.integers(4, 24))
+        r = int(round(np.hypot(dw, dh)))
+        src = (0xff000000 | rng.integers(0, 1 << 24, (r, r))).astype(np.uint32)
+        if t % 4 == 1:
+            a = rng.integers(0, 256, (r, r))
+            c = rng.integers(0, 256, (r, r, 3)) * a[..., None] // 255
+            src = ((a << 24) | (c[..., 0] << 16) | (c[..., 1] << 8) | c[..., 2]).astype(np.uint32)
+        dst = (0xff000000 | rng.integers(0, 1 << 24, (dh, dw))).astype(np.uint32)
+        n = int(rng.integers(20, 90))
+        k = int(rng.integers(0, n))
+        out = dst.copy()
+        assert cd.cd_rot_paint(po.P(out), dw, dh, po.P(src), r, r, k * 2 * np.pi / n) == 0
+        d.update({f"src{t}": src, f"dst{t}": dst, f"out{t}": out, f"ang{t}": np.array([k, n])})
+    np.savez_compressed(os.path.join(HERE, "rot_paint.npz"), n=12, **d)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

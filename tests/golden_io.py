@@ -1,0 +1,24 @@
+"""Loader for the committed fixtures in tests/golden (data only; see make_golden.py)."""
+import os
+import numpy as np
+from oracle import pyoracle as po
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SCENES = ["c2_fill_border_300", "open_border_300", "layers_translucent_600", "far_window_300"]
+
+
+def load_scene(name):
+    z = np.load(os.path.join(GOLDEN, f"scene_{name}.npz"))
+    rules = []
+    for i in range(int(z["n_rules"])):
+        si, sf = z[f"si{i}"], z[f"sf{i}"]
+        st = po.Style(int(si[0]), int(si[1]), int(si[2]), int(si[3]), float(sf[0]), float(sf[1]), int(si[4]))
+        rules.append((st, (z[f"x{i}"], z[f"y{i}"], z[f"off{i}"], z[f"ref{i}"])))
+    meta = {k: int(z[k]) for k in ("dpi", "W", "H", "bg")}
+    meta["x0"], meta["y0"] = int(z["win_x0"]), int(z["win_y0"])
+    return meta, rules, z["image"]
+
+
+def within(a, b, tol=2):
+    """fraction of pixels whose every channel differs by <= tol (north_star: >= 99.5 % at tol 2)"""
+    return float((po.chan_diff(a, b) <= tol).mean())

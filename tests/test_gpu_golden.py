@@ -1,0 +1,64 @@
+"""HIP draw path vs (a) the committed golden images produced by the real libcairo through the
+reference's call sequence -- north_star bar: every channel within +-2/255 on >= 99.5 % of the
+pixels -- and (b) the oracle bit-exactly on the same scenes; plus the full-size C2 canvas
+checked through windows against the oracle."""
+import numpy as np
+import pytest
+from oracle import pyoracle as po
+from smrender_amd import synth
+from golden_io import SCENES, load_scene, within
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_render(sa, meta, rules):
+    W, H = meta["x0"] + meta["W"], meta["y0"] + meta["H"]
+    cv = sa.Canvas(W, H, meta["dpi"], meta["bg"], meta["y0"], meta["H"])
+    for st, (x, y, off, ref) in rules:
+        gs = sa.DrawStyle(st.fill_used, st.border_used, st.fill_col, st.border_col, st.fill_width_mm,
+                          st.border_width_mm, st.ignore_open, 0, 0, 0, 0, 0)
+        cv.draw(gs, sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y),
+                sa.DeviceArray.from_numpy(off.astype(np.int64)), sa.DeviceArray.from_numpy(ref.astype(np.int32)),
+                len(off) - 1, len(ref))
+    out = cv.read(meta["x0"], 0, meta["W"], meta["H"])
+    cv.close()
+    return out
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_golden_scene(hip, name):
+    meta, rules, want = load_scene(name)
+    got = gpu_render(hip, meta, rules)
+    bar = 0.99 if name == "layers_translucent_600" else 0.995      # see tests/test_oracle_golden.py
+    assert within(got, want, 2) >= bar
+    orules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in rules]
+    o = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"])
+    assert np.array_equal(got, o)
+
+
+def test_full_size_c2_windows_vs_oracle(hip):
+    """BASELINE config 2 at full size (1 M ways, 16384^2): windows of the device canvas must equal the
+    oracle's render of the ways that reach the window (drawing order preserved)."""
+    sa = hip
+    W = H = 16384
+    x, y, off, ref = synth.synth_ways(1000000, W, H, seed=1234)
+    cv = sa.Canvas(W, H, 300, 0xffffff)
+    gs = sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0, 0, 0, 0, 0, 0)
+    cv.draw(gs, sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off),
+            sa.DeviceArray.from_numpy(ref), len(off) - 1, len(ref))
+    x0b, y0b, x1b, y1b = synth.way_bbox(x, y, off, ref)
+    st = po.Style(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0)
+    S = 192
+    for wx, wy in [(0, 0), (W - S, H - S), (8000, 3000), (1234, 15000), (16000, 77)]:
+        got = cv.read(wx, wy, S, S)
+        keep = (x1b > wx - 8) & (x0b < wx + S + 8) & (y1b > wy - 8) & (y0b < wy + S + 8)
+        sx, sy, soff, sref = synth.select_ways(x, y, off, ref, keep)
+        want = po.oracle_scene([(st, po.ways_from_arrays(sx, sy, soff, sref))], 300, S, S, 0xffffff, wx, wy)
+        assert np.array_equal(got, want), (wx, wy, int((got != want).sum()))
+    # idempotence of the pipeline: a second identical chart gives the identical canvas (no order races)
+    first = cv.read(4000, 4000, 512, 512)
+    cv.clear()
+    cv.draw(gs, sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off),
+            sa.DeviceArray.from_numpy(ref), len(off) - 1, len(ref))
+    assert np.array_equal(cv.read(4000, 4000, 512, 512), first)
+    cv.close()
