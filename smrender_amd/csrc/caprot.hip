@@ -1,6 +1,24 @@
-/* caprot.hip -- caption auto-rotation scan (placeholder until the kernel lands). */
+/* caprot.hip -- caption auto-rotation scan of libsmr_hip: one wavefront per caption.
+ *
+ * Replaces find_angle (src/smrules_cairo.c:1959-2019) and what it calls per caption:
+ * dv_sample :1828-1861 (loop over num_steps angles), cairo_smr_diff :1746-1759 (paint the
+ * cut-out rotated, OVER, bilinear -- libcairo/pixman arithmetic restated and pinned in
+ * oracle/caprot.c), cairo_smr_dist :1670-1743 (transparency skip, bw-stretch :1598-1619,
+ * luminosity difference, gray write-back), dv_weight :1813-1821, dv_quantize :1868-1890,
+ * dp_get :1900-1956 and the widest-peak pick :2007-2013.
+ *
+ * Difference to the reference, by design: the r x r cut-out is a crop of the
+ * device canvas at the rounded centre instead of a re-rasterisation of the whole chart at a
+ * sub-pixel offset (cairo_smr_cut_out :1511-1533).
+ */
 #include "smr_dev.h"
 #include "smr_host.h"
+#include <float.h>
+#include <vector>
+
+#define M_2PI (2.0 * M_PI)
+#define SMR_TRANSPIX 0x7fffffffu
+#define SMR_DP_LIMIT 0.95
 
 extern "C" int smr_hip_caprot_steps(int fg_w, int fg_h, int dpi, int *num_steps, int *r_px)
 {
@@ -11,8 +29,314 @@ extern "C" int smr_hip_caprot_steps(int fg_w, int fg_h, int dpi, int *num_steps,
    return SMR_OK;
 }
 
+/* ---- host: the per-angle pixman transform.  It depends only on the plane size, the cut-out
+ * size and the angle, never on the caption, so it is computed once per batch with the host
+ * libm (the same one libcairo uses) and handed to the kernel as a table. ---- */
+struct smr_rotmat_t { int32_t m[2][3]; int32_t xoff, yoff; };
+
+static int32_t fixed16(double d) { return (int32_t) nearbyint(d * 65536.0); }
+
+static void xform_point_h(const int32_t m[2][3], int32_t vx, int32_t vy, int64_t *ox, int64_t *oy)
+{
+   for (int i = 0; i < 2; i++)
+   {
+      int64_t hi = (int64_t) m[i][0] * (vx >> 16) + (int64_t) m[i][1] * (vy >> 16) + (int64_t) m[i][2];
+      int64_t lo = (int64_t) m[i][0] * (vx & 0xffff) + (int64_t) m[i][1] * (vy & 0xffff);
+      int64_t r = hi + ((lo + 0x8000) >> 16);
+      if (i == 0) *ox = r; else *oy = r;
+   }
+}
+
+/* cairo 1.16: _cairo_matrix_to_pixman_matrix_offset + _cairo_matrix_to_pixman_matrix for
+ * pattern(dev) = R(-a)(dev - dst centre) + src centre (translate, rotate, set_source_surface
+ * of cairo_smr_diff) */
+static void rot_matrix(int dw, int dh, int sw, int sh, double a, smr_rotmat_t *out)
+{
+   double c = cos(a), s = sin(a);
+   double cdx = dw / 2.0, cdy = dh / 2.0, csx = sw / 2.0, csy = sh / 2.0;
+   double xx = c, xy = s, yx = -s, yy = c;
+   double x0 = csx - (xx * cdx + xy * cdy), y0 = csy - (yx * cdx + yy * cdy);
+   int32_t (*m)[3] = out->m;
+   out->xoff = 0; out->yoff = 0;
+   if (x0 != 0.0 || y0 != 0.0)
+   {
+      double tx = x0, ty = y0, norm = fmax(fabs(tx), fabs(ty));
+      for (int i = -1; i < 2; i += 2)
+         for (int j = -1; j < 2; j += 2)
+         {
+            double den = (xx + i) * (yy + j) - xy * yx;
+            if (fabs(den) < DBL_EPSILON) continue;
+            double x = y0 * xy - x0 * (yy + j);
+            double y = x0 * yx - y0 * (xx + i);
+            den = 1 / den;
+            x *= den; y *= den;
+            double nn = fmax(fabs(x), fabs(y));
+            if (norm > nn) { norm = nn; tx = x; ty = y; }
+         }
+      tx = floor(tx); ty = floor(ty);
+      out->xoff = (int) -tx; out->yoff = (int) -ty;
+      x0 = x0 + tx * xx + ty * xy;
+      y0 = y0 + tx * yx + ty * yy;
+   }
+   m[0][0] = fixed16(xx); m[0][1] = fixed16(xy); m[0][2] = fixed16(x0);
+   m[1][0] = fixed16(yx); m[1][1] = fixed16(yy); m[1][2] = fixed16(y0);
+   bool unity = (xx == 1.0 || xx == -1.0 || xx == 0.0) && (xy == 1.0 || xy == -1.0 || xy == 0.0) &&
+                (yx == 1.0 || yx == -1.0 || yx == 0.0) && (yy == 1.0 || yy == -1.0 || yy == 0.0);
+   if (unity) return;
+   double det = xx * yy - xy * yx;
+   double ixx = yy / det, ixy = -xy / det, iyx = -yx / det, iyy = xx / det;
+   double ix0 = -(ixx * x0 + ixy * y0), iy0 = -(iyx * x0 + iyy * y0);
+   double xc = dw / 2.0, yc = dh / 2.0;
+   for (int it = 0; it < 5; it++)
+   {
+      int64_t vx, vy;
+      xform_point_h(m, fixed16(xc), fixed16(yc), &vx, &vy);
+      double x = vx / 65536.0, y = vy / 65536.0;
+      double tx = ixx * x + ixy * y + ix0, ty = iyx * x + iyy * y + iy0;
+      tx -= xc; ty -= yc;
+      double dx = xx * tx + xy * ty, dy = yx * tx + yy * ty;
+      int32_t fdx = fixed16(dx), fdy = fixed16(dy);
+      m[0][2] -= fdx; m[1][2] -= fdy;
+      if (fdx == 0 && fdy == 0) break;
+   }
+}
+
+/* ---- device ---- */
+struct caprot_args_t
+{
+   const uint32_t *canvas;           /* band pixels */
+   int W, band_y0, band_h;
+   const double *cx, *cy;
+   int64_t n;
+   int fg_w, fg_h, fg_x, r, num_steps;
+   uint32_t fg_pix;
+   double weight;
+   const smr_rotmat_t *mats;         /* [num_steps] */
+   const double *ang, *wfac;         /* [num_steps] */
+   double *out_angle, *out_dv;
+};
+
+__device__ __forceinline__ double smr_alphad(uint32_t p) { return 1.0 - (double) (((p & 0x7f000000u) >> 23) & 0xff) / 255.0; }
+
+/* cairo_smr_color_bw_stretch: the rotate / divide by 1.25 / rotate back chain is the affine
+ * map c' = m + (c - m) / 1.25 about the gray value m; in 8-bit units round((S + 12 c) / 15),
+ * which has no ties (odd denominator), so integers reproduce the double chain exactly */
+__device__ __forceinline__ void smr_bw_stretch(uint32_t col, int &r, int &g, int &b)
+{
+   int R = (col >> 16) & 0xff, G = (col >> 8) & 0xff, B = col & 0xff, S = R + G + B;
+   r = (2 * (S + 12 * R) + 15) / 30; g = (2 * (S + 12 * G) + 15) / 30; b = (2 * (S + 12 * B) + 15) / 30;
+}
+
+__device__ __forceinline__ double smr_lum(int r, int g, int b)
+{
+   return 0.2125 * ((double) r / 255.0) + 0.7154 * ((double) g / 255.0) + 0.0721 * ((double) b / 255.0);
+}
+
+__device__ __forceinline__ uint32_t smr_cut_fetch(const caprot_args_t &A, int ox, int oy, int x, int y)
+{
+   if (x < 0 || y < 0 || x >= A.r || y >= A.r) return 0;      /* REPEAT_NONE on the r x r cut-out */
+   int gx = ox + x, gy = oy + y - A.band_y0;
+   if (gx < 0 || gx >= A.W || gy < 0 || gy >= A.band_h) return 0;
+   return A.canvas[(size_t) gy * A.W + gx];
+}
+
+__global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
+{
+   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+   double *dv = (double *) smem;                              /* [num_steps] */
+   uint32_t *dst = (uint32_t *) (smem + (((size_t) A.num_steps * 8 + 15) & ~(size_t) 15));   /* [fg_w * fg_h] */
+   const int64_t cap = blockIdx.x;
+   const int lane = threadIdx.x;
+   const int npix = A.fg_w * A.fg_h;
+   const int ox = (int) round(A.cx[cap] - A.r / 2.0), oy = (int) round(A.cy[cap] - A.r / 2.0);
+   const bool fg_skip = smr_alphad(A.fg_pix) > 0.2;
+   int sr, sg, sb;
+   smr_bw_stretch(A.fg_pix, sr, sg, sb);
+   const double lum_s = smr_lum(sr, sg, sb);
+
+   for (int p = lane; p < npix; p += 64) dst[p] = 0;
+   __syncthreads();
+
+   for (int i = 0; i < A.num_steps; i++)
+   {
+      const smr_rotmat_t M = A.mats[i];
+      long long ksum = 0;
+      int cnt = 0;
+      if (!fg_skip)
+      {
+         for (int p = lane; p < npix; p += 64)
+         {
+            int line = p / A.fg_w, col = p - line * A.fg_w;
+            if (col < A.fg_x) continue;                       /* transparent part of the plane: never counted */
+            /* pixman: transform the scanline start (pixel centre), then step by the first matrix column */
+            int32_t vx = M.xoff * 65536 + 0x8000, vy = (line + M.yoff) * 65536 + 0x8000;
+            int64_t X = (int64_t) M.m[0][0] * (vx >> 16) + (int64_t) M.m[0][1] * (vy >> 16) + M.m[0][2] +
+                        (((int64_t) M.m[0][0] * (vx & 0xffff) + (int64_t) M.m[0][1] * (vy & 0xffff) + 0x8000) >> 16);
+            int64_t Y = (int64_t) M.m[1][0] * (vx >> 16) + (int64_t) M.m[1][1] * (vy >> 16) + M.m[1][2] +
+                        (((int64_t) M.m[1][0] * (vx & 0xffff) + (int64_t) M.m[1][1] * (vy & 0xffff) + 0x8000) >> 16);
+            X += (int64_t) col * M.m[0][0]; Y += (int64_t) col * M.m[1][0];
+            int64_t x1 = X - 0x8000, y1 = Y - 0x8000;
+            uint32_t distx = (uint32_t) ((x1 >> 9) & 0x7f) << 1, disty = (uint32_t) ((y1 >> 9) & 0x7f) << 1;
+            int ix = (int) (x1 >> 16), iy = (int) (y1 >> 16);
+            uint32_t s = 0;
+            if (!(ix >= A.r || ix + 1 < 0 || iy >= A.r || iy + 1 < 0))
+            {
+               uint32_t tl = smr_cut_fetch(A, ox, oy, ix, iy), tr = smr_cut_fetch(A, ox, oy, ix + 1, iy);
+               uint32_t bl = smr_cut_fetch(A, ox, oy, ix, iy + 1), br = smr_cut_fetch(A, ox, oy, ix + 1, iy + 1);
+               uint32_t wxy = distx * disty, wxiy = distx * (256 - disty), wixy = (256 - distx) * disty,
+                        wixiy = (256 - distx) * (256 - disty);
+#pragma unroll
+               for (int sh = 0; sh < 32; sh += 8)
+               {
+                  uint32_t f = ((tl >> sh) & 0xff) * wixiy + ((tr >> sh) & 0xff) * wxiy +
+                               ((bl >> sh) & 0xff) * wixy + ((br >> sh) & 0xff) * wxy;
+                  s |= ((f >> 16) & 0xff) << sh;
+               }
+            }
+            /* OVER onto what the previous angle left in dst */
+            uint32_t d = dst[p];
+            uint32_t al = s >> 24;
+            if (al == 0xff) d = s;
+            else if (s)
+            {
+               uint32_t ia = al ^ 0xff, o = 0;
+#pragma unroll
+               for (int sh = 0; sh < 32; sh += 8)
+                  o |= smr_sat(((s >> sh) & 0xff) + smr_mul80((d >> sh) & 0xff, ia)) << sh;
+               d = o;
+            }
+            /* cairo_smr_dist */
+            if (smr_alphad(d) > 0.2) { dst[p] = SMR_TRANSPIX; continue; }
+            int dr, dg, db;
+            smr_bw_stretch(d, dr, dg, db);
+            long long k = 2125ll * (dr - sr) + 7154ll * (dg - sg) + 721ll * (db - sb);
+            ksum += k < 0 ? -k : k;
+            cnt++;
+            double dist = fabs(smr_lum(dr, dg, db) - lum_s);
+            if (dist > 1.0) dist = 1;
+            if (dist < 0.0) dist = 0.0;
+            uint32_t c = (uint32_t) (int) round(dist * 255.0);
+            dst[p] = c | c << 8 | c << 16 | 0xff000000u;
+         }
+      }
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) { ksum += __shfl_down(ksum, d); cnt += __shfl_down(cnt, d); }
+      if (lane == 0)
+      {
+         double avg = (double) ksum / 2550000.0;
+         if (cnt) avg /= cnt;
+         dv[i] = avg;
+         if (A.out_dv) A.out_dv[cap * A.num_steps + i] = avg;
+      }
+      __syncthreads();
+   }
+
+   /* dv_weight, dv_quantize, dp_get, widest peak: a few hundred scalar operations */
+   if (lane == 0)
+   {
+      const int n = A.num_steps;
+      double mn = 1.0, mx = 0.0;
+      for (int i = 0; i < n; i++)
+      {
+         double v = dv[i];
+         if (A.weight < 0.0) v = 1.0 - v;
+         v *= A.wfac[i];
+         dv[i] = v;
+         if (v > mx) mx = v;
+         if (v < mn) mn = v;
+      }
+      for (int i = 0; i < n; i++)
+      {
+         double q = (dv[i] - mn) / (mx - mn);
+         if (isnan(q)) q = 1.0;
+         dv[i] = q;
+      }
+      int peak = dv[0] >= SMR_DP_LIMIT ? 1 : 0, pcnt = 0, last = n;
+      double best_w = -1.0, best_s = 0, best_e = 0, cur_s = 0;
+      for (int i = 1; i <= last; i++)
+      {
+         int a = i % n, b = (i - 1) % n;
+         if (peak && dv[a] < SMR_DP_LIMIT)
+         {
+            peak = 0;
+            if (pcnt)
+            {
+               double e;
+               if (A.ang[a] > A.ang[b]) e = (A.ang[a] + A.ang[b]) / 2;
+               else e = (A.ang[a] + A.ang[b] + M_2PI) / 2;
+               if (e < cur_s) e += M_2PI;
+               /* qsort by width, descending; glibc's merge sort is stable, so the first of equals wins */
+               if (e - cur_s > best_w) { best_w = e - cur_s; best_s = cur_s; best_e = e; }
+            }
+            continue;
+         }
+         if (!peak && dv[a] >= SMR_DP_LIMIT)
+         {
+            peak = 1;
+            if (!pcnt) last = i + n - 1;
+            pcnt++;
+            if (A.ang[a] > A.ang[b]) cur_s = (A.ang[a] + A.ang[b]) / 2;
+            else cur_s = (A.ang[a] + A.ang[b] + M_2PI) / 2;
+         }
+      }
+      A.out_angle[cap] = best_w >= 0.0 ? M_2PI - (best_e + best_s) / 2 : 0.0;
+   }
+}
+
+static uint32_t cap_color_pixel(uint32_t c)
+{
+   double r = (double) ((c >> 16) & 0xff) / 255.0, g = (double) ((c >> 8) & 0xff) / 255.0, b = (double) (c & 0xff) / 255.0;
+   double a = 1.0 - (double) (((c & 0x7f000000u) >> 23) & 0xff) / 255.0;
+   auto d2s = [](double d) { uint32_t i = (uint32_t) (d * 65536); i -= (i >> 16); return i; };
+   return ((d2s(a) >> 8) << 24) | ((d2s(r * a) >> 8) << 16) | ((d2s(g * a) >> 8) << 8) | (d2s(b * a) >> 8);
+}
+
 extern "C" int smr_hip_caprot(smr_canvas_t *c, const smr_cap_batch_t *b, double *d_angle, double *d_dv)
 {
    SMR_NEED_INIT();
-   return smr_fail(SMR_E_UNSUPPORTED, "caprot: kernel not built yet");
+   if (!c || !b || !d_angle) return smr_fail(SMR_E_INVAL, "caprot: NULL argument");
+   if (b->n < 0 || b->fg_w <= 0 || b->fg_h <= 0 || b->fg_x < 0 || b->fg_x > b->fg_w)
+      return smr_fail(SMR_E_INVAL, "caprot: bad plane geometry");
+   if (b->n == 0) return SMR_OK;
+   if (!b->d_cx || !b->d_cy) return smr_fail(SMR_E_INVAL, "caprot: missing caption coordinates");
+   int n_steps, r;
+   SMR_TRY(smr_hip_caprot_steps(b->fg_w, b->fg_h, c->dpi, &n_steps, &r));
+   if (n_steps < 1) return smr_fail(SMR_E_INVAL, "caprot: plane too small (num_steps = %d)", n_steps);
+   size_t lds = (((size_t) n_steps * 8 + 15) & ~(size_t) 15) + (size_t) b->fg_w * b->fg_h * 4;
+   if (lds > 64 * 1024)
+      return smr_fail(SMR_E_CAPACITY, "caprot: plane of %dx%d px needs %zu bytes of LDS (limit 65536)", b->fg_w, b->fg_h, lds);
+
+   /* per-batch tables with the host libm: angles accumulate like dv_sample's loop (:1842) */
+   std::vector<smr_rotmat_t> mats(n_steps);
+   std::vector<double> ang(n_steps), wfac(n_steps);
+   double a = 0, phase = b->phase_deg * M_PI / 180.0;
+   for (int i = 0; i < n_steps; a += M_2PI / n_steps, i++)
+   {
+      ang[i] = a;
+      rot_matrix(b->fg_w, b->fg_h, r, r, a, &mats[i]);
+      wfac[i] = 1.0 - (1.0 - fabs(b->weight)) * (1.0 - cos(a * 2.0 + phase)) / 2.0;      /* dv_weight :1819 */
+   }
+   hipStream_t s = smr_g.stream;
+   smr_rotmat_t *d_m; double *d_t;
+   SMR_TRY(c->ensure(SMR_BUF_CAP0, sizeof(smr_rotmat_t) * n_steps, (void **) &d_m));
+   SMR_TRY(c->ensure(SMR_BUF_CAP1, sizeof(double) * 2 * n_steps, (void **) &d_t));
+   SMR_HIP(hipMemcpyAsync(d_m, mats.data(), sizeof(smr_rotmat_t) * n_steps, hipMemcpyHostToDevice, s));
+   SMR_HIP(hipMemcpyAsync(d_t, ang.data(), sizeof(double) * n_steps, hipMemcpyHostToDevice, s));
+   SMR_HIP(hipMemcpyAsync(d_t + n_steps, wfac.data(), sizeof(double) * n_steps, hipMemcpyHostToDevice, s));
+   SMR_HIP(hipStreamSynchronize(s));      /* the host vectors go out of scope below */
+
+   caprot_args_t A;
+   A.canvas = c->pix; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h;
+   A.cx = b->d_cx; A.cy = b->d_cy; A.n = b->n;
+   A.fg_w = b->fg_w; A.fg_h = b->fg_h; A.fg_x = b->fg_x; A.r = r; A.num_steps = n_steps;
+   A.fg_pix = cap_color_pixel(b->col); A.weight = b->weight;
+   A.mats = d_m; A.ang = d_t; A.wfac = d_t + n_steps;
+   A.out_angle = d_angle; A.out_dv = d_dv;
+   smr_timer_t T(smr_g.profiling);
+   T.mark(s);
+   k_caprot<<<(unsigned) b->n, 64, lds, s>>>(A);
+   SMR_HIP(hipGetLastError());
+   T.mark(s);
+   if (smr_g.profiling) smr_g.last.caprot_ms = T.ms(0, 1);
+   return SMR_OK;
 }

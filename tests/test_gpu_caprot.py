@@ -1,0 +1,97 @@
+"""Kernel 3 (caption auto-rotation scan, one wavefront per caption) through the C-ABI vs the
+oracle restatement of find_angle (src/smrules_cairo.c:1959-2019) run on the same canvas pixels.
+Chosen angles must be bit-exact; the raw per-angle differences agree to 1e-12 (the kernel sums
+the exact integer |2125 dR + 7154 dG + 721 dB|, the reference adds doubles sequentially)."""
+import ctypes as C
+import numpy as np
+import pytest
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_angles(img, cx, cy, fg_w, fg_h, fg_x, col, dpi, phase, weight):
+    L = po.orc()
+    r = C.c_int()
+    n = L.orc_num_steps(fg_w, fg_h, dpi, C.byref(r))
+    r = r.value
+    fg = np.zeros((fg_h, fg_w), np.uint32)
+    L.orc_make_plane(po.P(fg), fg_w, fg_h, fg_x, col)
+    H, W = img.shape
+    angles, dvs = [], []
+    for x, y in zip(cx, cy):
+        cround = lambda v: int(np.sign(v) * np.floor(abs(v) + 0.5))      # C round(): half away from zero
+        ox, oy = cround(x - r / 2.0), cround(y - r / 2.0)
+        cut = np.zeros((r, r), np.uint32)
+        xs0, ys0 = max(ox, 0), max(oy, 0)
+        xs1, ys1 = min(ox + r, W), min(oy + r, H)
+        if xs1 > xs0 and ys1 > ys0:
+            cut[ys0 - oy:ys1 - oy, xs0 - ox:xs1 - ox] = img[ys0:ys1, xs0:xs1]
+        dv = np.zeros(n)
+        angles.append(L.orc_find_angle(po.P(cut), r, po.P(fg), fg_w, fg_h, n, phase, weight, po.P(dv)))
+        dvs.append(dv)
+    return np.array(angles), np.array(dvs), n, r
+
+
+def make_canvas(sa, W, H, bg, style):
+    arrs = po.synth_ways(int(W * H / 900), W, H, seed=W + H)
+    cv = sa.Canvas(W, H, 300, bg)
+    x, y, off, ref = arrs
+    cv.draw(style, sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off),
+            sa.DeviceArray.from_numpy(ref), len(off) - 1, len(ref))
+    return cv
+
+
+@pytest.mark.parametrize("fg_w,fg_h,fg_x,col,phase,weight,bg", [
+    (90, 14, 45, 0x000000, 0.0, 1.0, 0xffffff),      # E-aligned caption: left half of the plane is empty
+    (64, 20, 0, 0x203040, 0.0, 0.7, 0xffffff),       # centred, weighted ellipse (test/rules/0180.osm: weight=0.7)
+    (48, 10, 24, 0xffffff, 90.0, -0.5, 0xc0d0e0),    # negative weight inverts the metric (:1817-1818)
+    (40, 12, 20, 0x000000, 0.0, 1.0, 0x10ffffff),    # background alpha byte 0xdf: (A & 0x7f) = 95 <= 101 -> "transparent" by the 0x7f-mask quirk (:1692)
+])
+def test_angles_match_oracle(hip, fg_w, fg_h, fg_x, col, phase, weight, bg):
+    sa = hip
+    W, H = 420, 300
+    st = sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0, 0, 0, 0, 0, 0)
+    cv = make_canvas(sa, W, H, bg, st)
+    img = cv.read()
+    rng = np.random.default_rng(fg_w)
+    n_cap = 48
+    cx = rng.uniform(-5, W + 5, n_cap)
+    cy = rng.uniform(-5, H + 5, n_cap)
+    cx[:4] = [0.0, W, W / 2 + 0.5, 17.25]
+    cy[:4] = [0.0, H, H / 2 + 0.5, 290.75]
+    want, want_dv, n, r = oracle_angles(img, cx, cy, fg_w, fg_h, fg_x, col, 300, phase, weight)
+    assert sa.caprot_steps(fg_w, fg_h, 300) == (n, r)
+    d_ang = sa.DeviceArray((n_cap,), np.float64)
+    d_dv = sa.DeviceArray((n_cap, n), np.float64)
+    cv.caprot(sa.DeviceArray.from_numpy(cx), sa.DeviceArray.from_numpy(cy), n_cap, fg_w, fg_h, fg_x, col, phase, weight,
+              d_ang, d_dv)
+    sa.sync()
+    got, got_dv = d_ang.numpy(), d_dv.numpy()
+    assert np.max(np.abs(got_dv - want_dv)) < 1e-12
+    assert np.array_equal(got, want), np.argwhere(got != want).ravel().tolist()
+    assert len(np.unique(got)) > 3          # the scan really discriminates between positions
+    cv.close()
+
+
+def test_bw_stretch_integer_form_equals_double_chain():
+    """the kernel's integer bw-stretch vs the reference's rotate/scale/rotate chain (src/smrules_cairo.c:1598-1619)"""
+    rng = np.random.default_rng(0)
+    cols = np.concatenate([rng.integers(0, 1 << 24, 200000), np.array([0, 0xffffff, 0xff0000, 0x00ff00, 0x0000ff, 0x808080])])
+    L = po.orc()
+    for c in cols[:20000].tolist() + cols[-6:].tolist():
+        R, G, B = (c >> 16) & 255, (c >> 8) & 255, c & 255
+        S = R + G + B
+        want = L.orc_bw_stretch(c) & 0xffffff
+        got = (((2 * (S + 12 * R) + 15) // 30) << 16) | (((2 * (S + 12 * G) + 15) // 30) << 8) | ((2 * (S + 12 * B) + 15) // 30)
+        assert got == want, hex(c)
+
+
+def test_caprot_rejects_oversized_plane(hip):
+    sa = hip
+    cv = sa.Canvas(64, 64, 300, 0xffffff)
+    d = sa.DeviceArray((2,), np.float64)
+    with pytest.raises(sa.SmrHipError) as e:
+        cv.caprot(d, d, 1, 400, 80, 0, 0, 0.0, 1.0, d)
+    assert e.value.code == -6
+    cv.close()
