@@ -124,6 +124,8 @@ typedef struct
    int32_t fg_x;                   /* first opaque column of the plane (E/W alignment), px */
    uint32_t col;                   /* caption colour 0xTTRRGGBB */
    double phase_deg, weight;       /* struct auto_rot (src/smrender_dev.h:168-174) */
+   const uint32_t *d_fg;           /* optional [fg_h * fg_w] device: explicit plane pixels (premultiplied ARGB32);
+                                      NULL = columns [fg_x, fg_w) opaque in `col`, the rest transparent */
 } smr_cap_batch_t;
 
 /* d_angle[n]: chosen angle in rad (find_angle's return value); d_dv may be NULL or
@@ -150,6 +152,31 @@ int smr_hip_malloc(void **d_ptr, size_t bytes);
 int smr_hip_free(void *d_ptr);
 int smr_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
 int smr_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
+
+/* ---- the plugin boundary itself: what smrender's rule parser binds with dlsym() --------
+ * src/smrparse.c:286-300, :446-448 look up act_<func>_ini/_main/_fini in the library named
+ * by `_action_ = func@libsmr_hip.so:params`; prototypes as doc/inc/lib_protos.h:1-3 and
+ * libsmrender/smaction.h:99-113.  Arguments are smrule_t* / osm_obj_t* of the host
+ * (smrender_amd/csrc/smr_abi.h restates their layout); declared with void* here so that this
+ * header stays free of host types.
+ *   draw    : act_draw_ini/_main/_fini   src/smrules_cairo.c:583, :1019, :1076
+ *   cap     : act_cap_ini/_main/_fini    src/smrules_cairo.c:1243, :2447, :2487 (angle=auto scan:
+ *             writes "<key>:autoangle" / "<key>:autoalign" tags, :2294-2349; glyphs stay on host Cairo)
+ *   hipsave : writes the device canvas to `file=` (replaces save_main_image :388-412 for the GPU canvas) */
+int act_draw_ini(void *rule);
+int act_draw_main(void *rule, void *obj);
+int act_draw_fini(void *rule);
+int act_cap_ini(void *rule);
+int act_cap_main(void *rule, void *obj);
+int act_cap_fini(void *rule);
+int act_hipsave_ini(void *rule);
+int act_hipsave_main(void *rule, void *obj);
+int act_hipsave_fini(void *rule);
+/* the canvas the plugin entry points draw on (created at the first rule from rdata_get()) */
+smr_canvas_t *smr_hip_plugin_canvas(void);
+/* ends the chart: frees that canvas; the next _ini starts a new chart from rdata_get() (smrender
+ * itself renders one chart per process, src/smrender.c:852-1416, and never needs this) */
+int smr_hip_plugin_reset(void);
 
 #ifdef __cplusplus
 }

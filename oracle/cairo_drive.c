@@ -17,6 +17,7 @@
  *
  * libcairo is dlopen()ed so the file builds without cairo headers.
  */
+#define _GNU_SOURCE
 #include <dlfcn.h>
 #include <math.h>
 #include <stdint.h>
@@ -66,6 +67,16 @@ FN(void, cairo_set_operator, (cairo_t*, int))
 FN(int, cairo_status, (cairo_t*))
 FN(int, cairo_surface_status, (cairo_surface_t*))
 FN(const char*, cairo_version_string, (void))
+typedef struct { double x_bearing, y_bearing, width, height, x_advance, y_advance; } cairo_text_extents_t;
+typedef struct { double ascent, descent, height, max_x_advance, max_y_advance; } cairo_font_extents_t;
+FN(void*, cairo_font_options_create, (void))
+FN(void, cairo_font_options_set_hint_metrics, (void*, int))
+FN(void, cairo_set_font_options, (cairo_t*, const void*))
+FN(void, cairo_font_options_destroy, (void*))
+FN(void, cairo_select_font_face, (cairo_t*, const char*, int, int))
+FN(void, cairo_set_font_size, (cairo_t*, double))
+FN(void, cairo_font_extents, (cairo_t*, cairo_font_extents_t*))
+FN(void, cairo_text_extents, (cairo_t*, const char*, cairo_text_extents_t*))
 
 static void *lib_;
 #define LOAD(name) do { *(void**)(&p_##name) = dlsym(lib_, #name); if (!p_##name) { fprintf(stderr, "cairo_drive: missing %s\n", #name); return -2; } } while (0)
@@ -92,6 +103,9 @@ int cd_init(const char *path)
    LOAD(cairo_stroke); LOAD(cairo_fill); LOAD(cairo_scale); LOAD(cairo_translate);
    LOAD(cairo_rotate); LOAD(cairo_save); LOAD(cairo_restore); LOAD(cairo_set_operator);
    LOAD(cairo_status); LOAD(cairo_surface_status); LOAD(cairo_version_string);
+   LOAD(cairo_font_options_create); LOAD(cairo_font_options_set_hint_metrics); LOAD(cairo_set_font_options);
+   LOAD(cairo_font_options_destroy); LOAD(cairo_select_font_face); LOAD(cairo_set_font_size);
+   LOAD(cairo_font_extents); LOAD(cairo_text_extents);
    return 0;
 }
 
@@ -240,4 +254,67 @@ int cd_rot_paint(uint32_t *dstpix, int dw, int dh, const uint32_t *srcpix, int s
    p_cairo_surface_destroy(dst);
    p_cairo_surface_destroy(src);
    return e;
+}
+
+/* ---- caption geometry: the part of cap_coord before find_angle (src/smrules_cairo.c:2250-2279)
+ * with the font set-up of act_cap_ini (:1335-1357; fontconfig face when libcairo has it, like
+ * the reference's CAIRO_HAS_FC_FONT branch, else the toy face of its #else branch).
+ * out[0..2] = the int arguments (w, h, x in pt) cap_coord passes to cairo_smr_plane. ---- */
+int cd_caption_geometry(const char *font, double size_mm, const char *text, double xoff_pt, double yoff_pt, int ew_aligned,
+                        double w_pt, double h_pt, int *out)
+{
+   cairo_rectangle_t ext = { 0, 0, w_pt, h_pt };
+   cairo_surface_t *sfc = p_cairo_recording_surface_create(CAIRO_CONTENT_COLOR_ALPHA, &ext);
+   cairo_t *ctx = p_cairo_create(sfc);
+   void *fo = p_cairo_font_options_create();
+   p_cairo_font_options_set_hint_metrics(fo, 1);
+   p_cairo_set_font_options(ctx, fo);
+   p_cairo_font_options_destroy(fo);
+   void *(*fc_parse)(const unsigned char*) = (void *(*)(const unsigned char*)) dlsym(RTLD_DEFAULT, "FcNameParse");
+   void (*fc_destroy)(void*) = (void (*)(void*)) dlsym(RTLD_DEFAULT, "FcPatternDestroy");
+   void *(*ft_face)(void*) = (void *(*)(void*)) dlsym(lib_, "cairo_ft_font_face_create_for_pattern");
+   void (*set_face)(cairo_t*, void*) = (void (*)(cairo_t*, void*)) dlsym(lib_, "cairo_set_font_face");
+   void (*face_destroy)(void*) = (void (*)(void*)) dlsym(lib_, "cairo_font_face_destroy");
+   void *pat;
+   if (fc_parse && fc_destroy && ft_face && set_face && face_destroy && (pat = fc_parse((const unsigned char*) font)) != NULL)
+   {
+      void *cfc = ft_face(pat);
+      fc_destroy(pat);
+      set_face(ctx, cfc);
+      face_destroy(cfc);
+   }
+   else
+      p_cairo_select_font_face(ctx, font, 0, 0);
+   cairo_text_extents_t tx; cairo_font_extents_t fe;
+   p_cairo_set_font_size(ctx, size_mm * 72 / 25.4);
+   p_cairo_font_extents(ctx, &fe);
+   p_cairo_text_extents(ctx, text, &tx);
+   double width = tx.width + tx.x_bearing + xoff_pt, height = fe.ascent;
+   (void) yoff_pt;
+   if (ew_aligned) { out[0] = (int) (width * 2); out[1] = (int) height; out[2] = (int) width; }
+   else { out[0] = (int) width; out[1] = (int) height; out[2] = 0; }
+   p_cairo_destroy(ctx);
+   p_cairo_surface_destroy(sfc);
+   return 0;
+}
+
+/* cairo_smr_plane, src/smrules_cairo.c:1536-1558.  out must hold round(w*dpi/72) x round(h*dpi/72) pixels */
+int cd_plane(int w_pt, int h_pt, int x_pt, uint32_t col, int dpi, uint32_t *out)
+{
+   double s = (double) dpi / 72.0;
+   int W = (int) round(w_pt * s), H = (int) round(h_pt * s);
+   cairo_surface_t *img = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, W, H);
+   if (p_cairo_surface_status(img)) return -1;
+   cairo_t *c = p_cairo_create(img);
+   p_cairo_scale(c, s, s);
+   set_color(c, col);
+   p_cairo_rectangle(c, x_pt, 0, w_pt - x_pt, h_pt);
+   p_cairo_fill(c);
+   p_cairo_destroy(c);
+   p_cairo_surface_flush(img);
+   unsigned char *d = p_cairo_image_surface_get_data(img);
+   int stride = p_cairo_image_surface_get_stride(img);
+   for (int y = 0; y < H; y++) memcpy(out + (size_t) y * W, d + (size_t) y * stride, (size_t) W * 4);
+   p_cairo_surface_destroy(img);
+   return 0;
 }

@@ -1,0 +1,228 @@
+/* hostsim.c -- TEST INFRASTRUCTURE.  A miniature smrender host for exercising the plugin
+ * boundary of libsmr_hip.so (act_draw_ and act_cap_ entry points) without the smrender executable.
+ *
+ * It is OUR code, compiled against the reference's own headers where they lie
+ * (/root/reference/libsmrender/smrender.h, /root/reference/src/rdata.h: read at build time,
+ * never copied) and linked with oracle/_ref/libsmrender_ref.so, which oracle/Makefile builds
+ * from the reference's untouched libsmrender sources (bstring.c bxtree.c lists.c osm_func.c
+ * smlog.c smutil.c; no config.h needed: every use is behind #ifdef HAVE_CONFIG_H, so the
+ * library's own defaults apply -- bx_hash_t = uint32_t, BX_RES = 8: object ids must fit 32 bits).
+ * So get_param, get_object, put_object, match_attr, realloc_tags, malloc_node/way, log_msg
+ * are the REAL host functions and smrule_t/action_t/osm_*_t have the REAL layout; the
+ * _Static_asserts below pin smrender_amd/csrc/smr_abi.h to them.
+ *
+ * What lives in the smrender executable (not buildable here: it needs the autoconf-generated
+ * config.h and cairo headers) is restated minimally: rdata_get (src/rdata.c:41-47),
+ * parse_color ('#' forms + a few names; src/smrparse.c:222-258), parse_style (:270-283),
+ * the rule set-up of init_rule/parse_fparam (:365-467, :616-664) and the
+ * _ini / traverse / _main / _fini protocol of apply_smrules (src/smcore.c:424-491).
+ */
+#define _GNU_SOURCE
+#include <errno.h>
+#include <math.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "smrender.h"
+#include "rdata.h"
+#include "../smrender_amd/csrc/smr_abi.h"
+
+/* ---- ABI pin: our restated layouts vs the reference's headers ---- */
+#define SAME(T1, T2) _Static_assert(sizeof(T1) == sizeof(T2), "sizeof " #T1)
+#define SAMEF(T1, T2, f) _Static_assert(offsetof(T1, f) == offsetof(T2, f), "offsetof " #T1 "." #f)
+SAME(smr_osm_obj_t, osm_obj_t); SAMEF(smr_osm_obj_t, osm_obj_t, type); SAMEF(smr_osm_obj_t, osm_obj_t, vis);
+SAMEF(smr_osm_obj_t, osm_obj_t, tag_cnt); SAMEF(smr_osm_obj_t, osm_obj_t, ver); SAMEF(smr_osm_obj_t, osm_obj_t, id);
+SAMEF(smr_osm_obj_t, osm_obj_t, tim); SAMEF(smr_osm_obj_t, osm_obj_t, otag);
+SAME(smr_osm_node_t, osm_node_t); SAMEF(smr_osm_node_t, osm_node_t, lat); SAMEF(smr_osm_node_t, osm_node_t, lon);
+SAME(smr_osm_way_t, osm_way_t); SAMEF(smr_osm_way_t, osm_way_t, ref_cnt); SAMEF(smr_osm_way_t, osm_way_t, ref);
+SAME(smr_osm_rel_t, osm_rel_t); SAMEF(smr_osm_rel_t, osm_rel_t, mem_cnt); SAMEF(smr_osm_rel_t, osm_rel_t, mem);
+SAME(struct smr_rmember, struct rmember); SAMEF(struct smr_rmember, struct rmember, id); SAMEF(struct smr_rmember, struct rmember, role);
+SAME(struct smr_otag, struct otag); SAME(smr_bstring_t, bstring_t); SAMEF(smr_bstring_t, bstring_t, buf);
+SAME(smr_fparam_t, fparam_t); SAMEF(smr_fparam_t, fparam_t, val); SAMEF(smr_fparam_t, fparam_t, dval); SAMEF(smr_fparam_t, fparam_t, conv_error);
+SAME(smr_smrule_t, smrule_t); SAMEF(smr_smrule_t, smrule_t, data); SAMEF(smr_smrule_t, smrule_t, act);
+_Static_assert(sizeof(smr_action_t) == offsetof(action_t, stag), "action_t head");
+SAMEF(smr_action_t, action_t, fp); SAMEF(smr_action_t, action_t, flags); SAMEF(smr_action_t, action_t, tag_cnt);
+SAMEF(smr_action_t, action_t, libhandle); SAMEF(smr_action_t, action_t, parm);
+SAME(struct smr_rdata, struct rdata); SAMEF(struct smr_rdata, struct rdata, bb); SAMEF(struct smr_rdata, struct rdata, polygon_window);
+SAMEF(struct smr_rdata, struct rdata, wc); SAMEF(struct smr_rdata, struct rdata, lath); SAMEF(struct smr_rdata, struct rdata, lath_len);
+SAMEF(struct smr_rdata, struct rdata, w); SAMEF(struct smr_rdata, struct rdata, h); SAMEF(struct smr_rdata, struct rdata, dpi);
+SAMEF(struct smr_rdata, struct rdata, proj); SAMEF(struct smr_rdata, struct rdata, ds); SAMEF(struct smr_rdata, struct rdata, mean_lat);
+_Static_assert((int) SMR_OSM_NODE == (int) OSM_NODE && (int) SMR_OSM_WAY == (int) OSM_WAY && (int) SMR_OSM_REL == (int) OSM_REL, "object type enum");
+
+int hs_abi_check(void) { return 0; }      /* compiling this file is the check */
+
+/* ---- what the executable exports ---- */
+static struct rdata rd_;
+struct rdata *rdata_get(void) { return &rd_; }
+
+static unsigned bgcolor_ = 0xffffff;
+
+int parse_color(const char *s)
+{
+   static const struct { const char *n; int c; } names[] = {
+      { "black", 0x000000 }, { "white", 0xffffff }, { "red", 0xff0000 }, { "green", 0x00ff00 }, { "blue", 0x0000ff },
+      { "yellow", 0xffff00 }, { "grey", 0xbebebe }, { "gray", 0xbebebe }, { NULL, 0 } };
+   if (s == NULL) return -1;
+   if (*s == '#')
+   {
+      s++;
+      int l = (int) strlen(s);
+      if (l != 6 && l != 8) return 0;
+      errno = 0;
+      long long c = strtoll(s, NULL, 16);
+      if (errno) return 0;
+      return (int) (c & 0x7fffffff);
+   }
+   if (!strcmp(s, "bgcolor")) return (int) bgcolor_;
+   for (int i = 0; names[i].n != NULL; i++)
+      if (!strcmp(s, names[i].n)) return names[i].c;
+   log_msg(LOG_WARN, "unknown color %s, defaulting to black", s);
+   return 0;
+}
+
+int parse_style(const char *s)
+{
+   static const char *st[] = { "solid", "dashed", "dotted", "transparent", "pipe", "rounddot" };   /* enum order of src/smrender_dev.h */
+   if (s == NULL) return 0;
+   for (int i = 0; i < 6; i++) if (!strcmp(s, st[i])) return i;
+   return 0;
+}
+
+/* chart geometry: the fields init_rendering_window/init_bbox_mll leave in struct rdata */
+void hs_set_rdata(double lon0, double w, double h, double wc, double lath, double lath_len, double lat_ll, double lon_ru,
+                  double lat_ru, int dpi, unsigned bgcolor)
+{
+   memset(&rd_, 0, sizeof(rd_));
+   rd_.bb.ll.lon = lon0; rd_.bb.ll.lat = lat_ll; rd_.bb.ru.lon = lon_ru; rd_.bb.ru.lat = lat_ru;
+   rd_.w = rd_.pgw = w; rd_.h = rd_.pgh = h; rd_.wc = wc; rd_.hc = lat_ru - lat_ll;
+   rd_.lath = lath; rd_.lath_len = lath_len; rd_.dpi = dpi;
+   rd_.mean_lat = (lat_ll + lat_ru) / 2; rd_.mean_lon = (lon0 + lon_ru) / 2;
+   rd_.proj = PROJ_MERC; rd_.img_scale = 1;
+   bgcolor_ = bgcolor;
+}
+
+/* ---- rules: what init_rule + parse_fparam build ---- */
+static char *next_tok(char **p, const char *delim, char *found)
+{
+   char *s = *p;
+   if (s == NULL || *s == '\0') return NULL;
+   char *e = s + strcspn(s, delim);
+   *found = *e;
+   if (*e) { *e = '\0'; *p = e + 1; } else *p = e;
+   return s;
+}
+
+smrule_t *hs_rule_new(int type, const char *func, const char *params)
+{
+   smrule_t *r = calloc(1, sizeof(*r));
+   action_t *a = calloc(1, sizeof(*a));
+   osm_node_t *oo = calloc(1, sizeof(osm_storage_t));
+   oo->obj.type = (int8_t) type;
+   oo->obj.id = 0x7f000001;
+   r->oo = &oo->obj; r->act = a;
+   a->func_name = strdup(func);
+   a->parm = strdup(params ? params : "");
+   char *buf = strdup(a->parm), *p = buf, c, *s;
+   int n = 0;
+   fparam_t **fp = calloc(1, sizeof(*fp));
+   while ((s = next_tok(&p, "=;", &c)) != NULL)
+   {
+      fp = realloc(fp, sizeof(*fp) * (n + 2));
+      fp[n] = calloc(1, sizeof(**fp));
+      fp[n + 1] = NULL;
+      fp[n]->attr = s;
+      if (c == '=' && (fp[n]->val = next_tok(&p, ";", &c)) != NULL)
+      {
+         char *end;
+         errno = 0;
+         fp[n]->dval = strtod(fp[n]->val, &end);
+         fp[n]->conv_error = end == fp[n]->val ? EDOM : errno;
+      }
+      n++;
+   }
+   a->fp = fp;
+   return r;
+}
+
+/* ---- objects, stored in the real bxtree through the real put_object ---- */
+static void set_tags(osm_obj_t *o, const char *tags)
+{
+   char *buf = strdup(tags ? tags : ""), *p = buf, c, *k;
+   int n = 0;
+   while ((k = next_tok(&p, "=", &c)) != NULL && n < o->tag_cnt)
+   {
+      char *v = next_tok(&p, ";", &c);
+      o->otag[n].k.buf = k; o->otag[n].k.len = (int) strlen(k);
+      o->otag[n].v.buf = v ? v : ""; o->otag[n].v.len = v ? (int) strlen(v) : 0;
+      n++;
+   }
+   o->tag_cnt = (short) n;
+}
+
+static int count_tags(const char *tags)
+{
+   int n = 0;
+   if (tags == NULL || *tags == '\0') return 0;
+   for (n = 1; *tags; tags++) if (*tags == ';') n++;
+   return n;
+}
+
+int hs_node(int64_t id, double lat, double lon, const char *tags)
+{
+   osm_node_t *n = malloc_node((short) count_tags(tags));
+   osm_node_default(n);
+   n->obj.id = id; n->lat = lat; n->lon = lon;
+   set_tags(&n->obj, tags);
+   return put_object(&n->obj);
+}
+
+int hs_way(int64_t id, const int64_t *ref, int cnt, const char *tags)
+{
+   osm_way_t *w = malloc_way((short) count_tags(tags), cnt);
+   osm_way_default(w);
+   w->obj.id = id;
+   memcpy(w->ref, ref, sizeof(*ref) * cnt);
+   set_tags(&w->obj, tags);
+   return put_object(&w->obj);
+}
+
+int hs_rel_of_ways(int64_t id, const int64_t *way, int cnt)
+{
+   osm_rel_t *r = malloc_rel(0, (short) cnt);
+   r->obj.type = OSM_REL; r->obj.id = id; r->obj.vis = 1;
+   for (int i = 0; i < cnt; i++) { r->mem[i].type = OSM_WAY; r->mem[i].id = way[i]; r->mem[i].role = ROLE_EMPTY; }
+   return put_object(&r->obj);
+}
+
+/* call_ini -> apply to the listed objects in the given order -> call_fini (src/smcore.c:382-421,
+ * :248-312, :324-379): >0 from _ini disables the rule, non-zero from _main stops the traversal */
+int hs_apply(smrule_t *r, int (*ini)(smrule_t *), int (*mainf)(smrule_t *, osm_obj_t *), int (*fini)(smrule_t *),
+             int type, const int64_t *ids, int n)
+{
+   int e = ini ? ini(r) : 0;
+   if (e < 0) return 1000 + -e;
+   if (e > 0) return 2000 + e;
+   for (int i = 0; i < n; i++)
+   {
+      osm_obj_t *o = get_object(type, ids[i]);
+      if (o == NULL) return 3000;
+      if ((e = mainf(r, o)) != 0) break;
+   }
+   int f = fini ? fini(r) : 0;
+   return e ? 4000 + (e < 0 ? -e : e) : (f ? 5000 + (f < 0 ? -f : f) : 0);
+}
+
+/* value of a tag (for the autoangle / autoalign checks); NULL if absent */
+const char *hs_get_tag(int type, int64_t id, const char *key)
+{
+   static char buf[256];
+   osm_obj_t *o = get_object(type, id);
+   if (o == NULL) return NULL;
+   int n = match_attr(o, key, NULL);
+   if (n < 0 || n >= o->tag_cnt) return NULL;
+   int l = o->otag[n].v.len < 255 ? o->otag[n].v.len : 255;
+   memcpy(buf, o->otag[n].v.buf, l);
+   buf[l] = '\0';
+   return buf;
+}

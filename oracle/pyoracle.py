@@ -101,6 +101,9 @@ def cairo():
         L.cd_render.argtypes = [C.c_double] + [C.c_int] * 4 + [C.c_void_p]
         L.cd_direct_fill.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
         L.cd_rot_paint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]
+        L.cd_caption_geometry.argtypes = [C.c_char_p, C.c_double, C.c_char_p, C.c_double, C.c_double, C.c_int,
+                                          C.c_double, C.c_double, C.c_void_p]
+        L.cd_plane.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p]
         _cd = L
     return _cd or None
 
@@ -141,10 +144,13 @@ def oracle_scene(rules, dpi, W, H, bg, x0=0, y0=0):
     c = L.orc_canvas_new(x0, y0, W, H, dpi, bg)
     for st, ways in rules:
         L.orc_rule_begin(c)
-        for x, y, closed in ways:
+        for way in ways:
+            x, y, closed = way[:3]
+            fcol, bcol = (way[3], way[4]) if len(way) > 3 else (None, None)      # optional per-way colours (color=%key)
             x = np.ascontiguousarray(x, np.float64)
             y = np.ascontiguousarray(y, np.float64)
-            L.orc_draw_way(c, C.byref(st), P(x), P(y), len(x), int(closed), 0, 0, 0, 0)
+            L.orc_draw_way(c, C.byref(st), P(x), P(y), len(x), int(closed), fcol is not None, fcol or 0,
+                           bcol is not None, bcol or 0)
         L.orc_rule_end(c)
     out = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (H, W)).copy()
     L.orc_canvas_free(c)

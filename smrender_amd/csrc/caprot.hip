@@ -110,6 +110,7 @@ struct caprot_args_t
    int64_t n;
    int fg_w, fg_h, fg_x, r, num_steps;
    uint32_t fg_pix;
+   const uint32_t *fg;               /* optional explicit plane pixels */
    double weight;
    const smr_rotmat_t *mats;         /* [num_steps] */
    const double *ang, *wfac;         /* [num_steps] */
@@ -162,12 +163,21 @@ __global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
       const smr_rotmat_t M = A.mats[i];
       long long ksum = 0;
       int cnt = 0;
-      if (!fg_skip)
+      if (!fg_skip || A.fg)
       {
          for (int p = lane; p < npix; p += 64)
          {
             int line = p / A.fg_w, col = p - line * A.fg_w;
-            if (col < A.fg_x) continue;                       /* transparent part of the plane: never counted */
+            int psr = sr, psg = sg, psb = sb;
+            double plum = lum_s;
+            if (A.fg)
+            {
+               uint32_t fp = A.fg[p];
+               if (smr_alphad(fp) > 0.2) continue;            /* transparent plane pixel: never counted */
+               smr_bw_stretch(fp, psr, psg, psb);
+               plum = smr_lum(psr, psg, psb);
+            }
+            else if (col < A.fg_x) continue;                  /* transparent part of the plane */
             /* pixman: transform the scanline start (pixel centre), then step by the first matrix column */
             int32_t vx = M.xoff * 65536 + 0x8000, vy = (line + M.yoff) * 65536 + 0x8000;
             int64_t X = (int64_t) M.m[0][0] * (vx >> 16) + (int64_t) M.m[0][1] * (vy >> 16) + M.m[0][2] +
@@ -209,10 +219,10 @@ __global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
             if (smr_alphad(d) > 0.2) { dst[p] = SMR_TRANSPIX; continue; }
             int dr, dg, db;
             smr_bw_stretch(d, dr, dg, db);
-            long long k = 2125ll * (dr - sr) + 7154ll * (dg - sg) + 721ll * (db - sb);
+            long long k = 2125ll * (dr - psr) + 7154ll * (dg - psg) + 721ll * (db - psb);
             ksum += k < 0 ? -k : k;
             cnt++;
-            double dist = fabs(smr_lum(dr, dg, db) - lum_s);
+            double dist = fabs(smr_lum(dr, dg, db) - plum);
             if (dist > 1.0) dist = 1;
             if (dist < 0.0) dist = 0.0;
             uint32_t c = (uint32_t) (int) round(dist * 255.0);
@@ -329,7 +339,7 @@ extern "C" int smr_hip_caprot(smr_canvas_t *c, const smr_cap_batch_t *b, double 
    A.canvas = c->pix; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h;
    A.cx = b->d_cx; A.cy = b->d_cy; A.n = b->n;
    A.fg_w = b->fg_w; A.fg_h = b->fg_h; A.fg_x = b->fg_x; A.r = r; A.num_steps = n_steps;
-   A.fg_pix = cap_color_pixel(b->col); A.weight = b->weight;
+   A.fg_pix = cap_color_pixel(b->col); A.fg = b->d_fg; A.weight = b->weight;
    A.mats = d_m; A.ang = d_t; A.wfac = d_t + n_steps;
    A.out_angle = d_angle; A.out_dv = d_dv;
    smr_timer_t T(smr_g.profiling);

@@ -1,0 +1,847 @@
+/* plugin.cpp -- the drop-in boundary: smrender's action API on top of the C-ABI of libsmr_hip.
+ *
+ * smrender binds these symbols with dlsym() when a rule says
+ *    _action_ = draw@libsmr_hip.so:color=...      (src/smrparse.c:286-300, :408-448)
+ * and then drives them as  _ini (at rule-parse time, before any OSM data is loaded:
+ * src/smrparse.c:464), _main once per matching object in bxtree id order
+ * (src/smcore.c:248-312) and _fini (src/smcore.c:324-379).  This file mirrors, for the hot path,
+ *    act_draw_ini/_main/_fini   src/smrules_cairo.c:583-694, :1019-1073, :1076-1148
+ *    act_cap_ini/_main/_fini    src/smrules_cairo.c:1243-1383, :2447-2484, :2487-2509  (angle=auto)
+ *    cap_coord                  src/smrules_cairo.c:2202-2392  (extents, plane, flip, tags)
+ * with the same parameter names, return codes and logging.  _main only appends to SoA
+ * batches; _fini uploads, projects and launches.  Host functions (get_param, get_object,
+ * rdata_get, log_msg, ...) are looked up at run time in the global scope: the smrender
+ * executable is linked -rdynamic and libsmrender.so is a global library (configure.ac:98-101).
+ *
+ * Host Cairo is used for one thing only: text extents of the caption font (and the tiny
+ * caption-colour plane), exactly the calls of cap_coord :2250-2252 and cairo_smr_plane
+ * :1536-1558; libcairo is dlopen()ed for that.  No pixel of the chart is produced by it.
+ */
+#include <dlfcn.h>
+#include <errno.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <strings.h>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+#include "smr_abi.h"
+#include "../../include/smr_hip.h"
+
+/* ---------------------------------------------------------------------------------------- */
+/* host API                                                                                 */
+/* ---------------------------------------------------------------------------------------- */
+struct host_api_t
+{
+   bool resolved = false;
+   char *(*get_param)(const char *, double *, const smr_action_t *) = nullptr;
+   int (*get_param_bool)(const char *, const smr_action_t *) = nullptr;
+   void *(*get_object)(int, int64_t) = nullptr;
+   int (*match_attr)(const smr_osm_obj_t *, const char *, const char *) = nullptr;
+   int (*realloc_tags)(smr_osm_obj_t *, int) = nullptr;
+   int (*log_msg)(int, const char *, ...) = nullptr;
+   struct smr_rdata *(*rdata_get)(void) = nullptr;
+   int (*parse_color)(const char *) = nullptr;
+   int (*parse_style)(const char *) = nullptr;
+   int (*parse_alignment)(const smr_action_t *) = nullptr;
+   int (*poly_area)(const smr_osm_way_t *, struct smr_coord *, double *) = nullptr;
+   double (*rdata_square_mm)(void) = nullptr;
+   double (*rdata_square_nm)(void) = nullptr;
+};
+static host_api_t H;
+
+template <typename F> static void host_sym(F &f, const char *name) { f = (F) dlsym(RTLD_DEFAULT, name); }
+
+static void host_resolve(void)
+{
+   if (H.resolved) return;
+   host_sym(H.get_param, "get_param"); host_sym(H.get_param_bool, "get_param_bool");
+   host_sym(H.get_object, "get_object"); host_sym(H.match_attr, "match_attr");
+   host_sym(H.realloc_tags, "realloc_tags"); host_sym(H.log_msg, "log_msg");
+   host_sym(H.rdata_get, "rdata_get"); host_sym(H.parse_color, "parse_color");
+   host_sym(H.parse_style, "parse_style"); host_sym(H.parse_alignment, "parse_alignment");
+   host_sym(H.poly_area, "poly_area"); host_sym(H.rdata_square_mm, "rdata_square_mm");
+   host_sym(H.rdata_square_nm, "rdata_square_nm");
+   H.resolved = true;
+}
+
+static void plog(int level, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+static void plog(int level, const char *fmt, ...)
+{
+   char buf[1024];
+   va_list ap;
+   va_start(ap, fmt);
+   vsnprintf(buf, sizeof(buf), fmt, ap);
+   va_end(ap);
+   if (H.log_msg) H.log_msg(level, "libsmr_hip: %s", buf);
+   else fprintf(stderr, "libsmr_hip[%d]: %s\n", level, buf);
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* the chart: device, projection, canvas (one per process)                                  */
+/* ---------------------------------------------------------------------------------------- */
+struct plugin_t
+{
+   bool ready = false;
+   smr_canvas_t *canvas = nullptr;
+   smr_proj_t proj;
+   int W = 0, H = 0, dpi = 0, band_y0 = 0, band_h = 0;
+};
+static plugin_t P;
+
+extern "C" smr_canvas_t *smr_hip_plugin_canvas(void) { return P.canvas; }
+
+extern "C" int smr_hip_plugin_reset(void)
+{
+   if (P.canvas) smr_hip_canvas_destroy(P.canvas);
+   P = plugin_t();
+   return SMR_OK;
+}
+
+static int env_int(const char *name, int def)
+{
+   const char *s = getenv(name);
+   return s && *s ? atoi(s) : def;
+}
+
+/* called from every _ini.  rdata is complete at that time (init_rendering_window runs before
+ * the rules are parsed: src/smrender.c:1134 vs :1190). */
+static int plugin_setup(void)
+{
+   host_resolve();
+   if (P.ready) return 0;
+   if (!H.get_param || !H.get_param_bool || !H.get_object || !H.rdata_get)
+   {
+      plog(SMR_LOG_ERR, "host symbols get_param/get_param_bool/get_object/rdata_get not found: not running inside smrender?");
+      return -1;
+   }
+   const struct smr_rdata *rd = H.rdata_get();
+   if (rd->proj != 0 || rd->polygon_window)
+   {
+      plog(SMR_LOG_ERR, "only the Mercator projection without polygon window is implemented on the GPU path");
+      return -1;
+   }
+   if (smr_hip_init(env_int("SMR_HIP_DEVICE", 0)) != SMR_OK)
+   {
+      plog(SMR_LOG_ERR, "%s", smr_hip_last_error());
+      return -1;
+   }
+   memset(&P.proj, 0, sizeof(P.proj));
+   P.proj.lon0 = rd->bb.ll.lon; P.proj.w = rd->w; P.proj.h = rd->h; P.proj.wc = rd->wc;
+   P.proj.lath = rd->lath; P.proj.lath_len = rd->lath_len;
+   P.proj.lat_ll = rd->bb.ll.lat; P.proj.lon_ru = rd->bb.ru.lon; P.proj.lat_ru = rd->bb.ru.lat;
+   P.proj.dpi = rd->dpi;
+   if (smr_hip_set_projection(&P.proj) != SMR_OK)
+   {
+      plog(SMR_LOG_ERR, "%s", smr_hip_last_error());
+      return -1;
+   }
+   /* the pixel grid of cairo_smr_image_surface_from_bg, src/smrules_cairo.c:344 */
+   P.W = (int) round(rd->w); P.H = (int) round(rd->h); P.dpi = rd->dpi;
+   P.band_y0 = env_int("SMR_HIP_BAND_Y0", 0);
+   P.band_h = env_int("SMR_HIP_BAND_H", P.H - P.band_y0);
+   uint32_t bg = 0xffffff;
+   if (H.parse_color) bg = (uint32_t) H.parse_color("bgcolor");     /* src/smrules_cairo.c:324 */
+   if (smr_hip_canvas_create(P.W, P.H, P.dpi, bg, P.band_y0, P.band_h, &P.canvas) != SMR_OK)
+   {
+      plog(SMR_LOG_ERR, "%s", smr_hip_last_error());
+      return -1;
+   }
+   char name[256] = "";
+   smr_hip_device_name(name, sizeof(name));
+   plog(SMR_LOG_NOTICE, "device canvas %dx%d px @ %d dpi, rows %d..%d on %s", P.W, P.H, P.dpi, P.band_y0,
+        P.band_y0 + P.band_h - 1, name);
+   P.ready = true;
+   return 0;
+}
+
+/* device buffer with the life time of a scope */
+struct dbuf_t
+{
+   void *p = nullptr;
+   ~dbuf_t() { if (p) smr_hip_free(p); }
+   int put(const void *h, size_t bytes)
+   {
+      if (smr_hip_malloc(&p, bytes ? bytes : 16) != SMR_OK) return -1;
+      if (bytes && smr_hip_memcpy_h2d(p, h, bytes) != SMR_OK) return -1;
+      return 0;
+   }
+   int alloc(size_t bytes) { return smr_hip_malloc(&p, bytes ? bytes : 16) == SMR_OK ? 0 : -1; }
+};
+
+/* struct col_spec, src/smrender_dev.h:176-180 + parse_col_spec src/smrparse.c:261-267 */
+struct col_spec_t { uint32_t col = 0; const char *key = nullptr; };
+
+static void parse_col_spec(const char *s, col_spec_t *cs)
+{
+   if (*s == '%') cs->key = s + 1;
+   else cs->col = H.parse_color ? (uint32_t) H.parse_color(s) : 0;
+}
+
+/* color_by_cs, src/smrules_cairo.c:2042-2076 */
+static uint32_t color_by_cs(const smr_osm_obj_t *o, const col_spec_t *cs)
+{
+   char buf[32];
+   int n;
+   if (cs->key == nullptr || o == nullptr || !H.match_attr) return cs->col;
+   if ((n = H.match_attr(o, cs->key, nullptr)) == -1)
+   {
+      plog(SMR_LOG_WARN, "object %d/%lld has no color key '%s'", o->type, (long long) o->id, cs->key);
+      return 0;
+   }
+   if (o->otag[n].v.len > (int) sizeof(buf) - 1) return 0;
+   memcpy(buf, o->otag[n].v.buf, o->otag[n].v.len);
+   buf[o->otag[n].v.len] = '\0';
+   return H.parse_color ? (uint32_t) H.parse_color(buf) : 0;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* draw                                                                                     */
+/* ---------------------------------------------------------------------------------------- */
+struct draw_rule_t
+{
+   smr_draw_style_t st;
+   col_spec_t fill_cs, border_cs;
+   std::vector<double> lat, lon;          /* one entry per ref (the closing ref of a closed way shares the first) */
+   std::vector<int64_t> way_off;
+   std::vector<int32_t> ref;
+   std::vector<uint32_t> fill_col, border_col;
+};
+
+static int draw_ini(smr_smrule_t *r)
+{
+   int e;
+   host_resolve();
+   if (r->oo->type != SMR_OSM_WAY && r->oo->type != SMR_OSM_REL)
+   {
+      plog(SMR_LOG_WARN, "'draw' may be applied to ways or relations only");
+      return 1;
+   }
+   if ((e = plugin_setup()) != 0) return e;
+
+   draw_rule_t *d = new draw_rule_t();
+   memset(&d->st, 0, sizeof(d->st));
+   char *s;
+   if ((s = H.get_param("color", nullptr, r->act)) != nullptr) { parse_col_spec(s, &d->fill_cs); d->st.fill_used = 1; }
+   if (H.get_param("width", &d->st.fill_width_mm, r->act) == nullptr) d->st.fill_width_mm = 0;
+   d->st.fill_style = H.parse_style ? H.parse_style(H.get_param("style", nullptr, r->act)) : 0;
+   if ((s = H.get_param("bcolor", nullptr, r->act)) != nullptr) { parse_col_spec(s, &d->border_cs); d->st.border_used = 1; }
+   if (H.get_param("bwidth", &d->st.border_width_mm, r->act) == nullptr) d->st.border_width_mm = 0;
+   d->st.border_style = H.parse_style ? H.parse_style(H.get_param("bstyle", nullptr, r->act)) : 0;
+   d->st.fill_col = d->fill_cs.col; d->st.border_col = d->border_cs.col;
+   d->st.curve = H.get_param_bool("curve", r->act) ? 1 : H.get_param_bool("wavy", r->act) ? 2 : 0;
+   d->st.directional = H.get_param_bool("directional", r->act);
+   d->st.ignore_open = H.get_param_bool("ignore_open", r->act);
+   /* DRAW_TRANSPARENT parses but draws solid (cairo_smr_dash has no case for it) */
+   if (d->st.fill_style == 3) d->st.fill_style = 0;
+   if (d->st.border_style == 3) d->st.border_style = 0;
+
+   const char *why = nullptr;
+   if (d->st.fill_style || d->st.border_style || H.get_param("dash", nullptr, r->act) || H.get_param("bdash", nullptr, r->act))
+      why = "dashed/dotted/pipe/rounddot styles";
+   else if (d->st.curve) why = "curve/wavy";
+   else if (d->st.directional) why = "directional=1";
+   else if (H.get_param("file", nullptr, r->act)) why = "image pattern fill (file=)";
+   if (why)
+   {
+      plog(SMR_LOG_ERR, "draw: %s are not implemented on the GPU path yet; use the built-in draw for this rule", why);
+      delete d;
+      return 1;
+   }
+   d->way_off.push_back(0);
+   r->data = d;
+   return 0;
+}
+
+static int draw_way(draw_rule_t *d, const smr_osm_way_t *w)
+{
+   /* is_closed_poly, src/smcoast.c:115-125 */
+   const bool closed = w->ref_cnt >= 4 && w->ref[0] == w->ref[w->ref_cnt - 1];
+   if (!closed && d->st.ignore_open) return 0;
+   if (w->ref_cnt < 2)
+   {
+      plog(SMR_LOG_WARN, "ignoring short way %lld (len = %d)", (long long) w->obj.id, w->ref_cnt);
+      return 0;
+   }
+   const int32_t first = (int32_t) d->lat.size();
+   int emitted = 0;
+   for (int i = 0; i < w->ref_cnt; i++)
+   {
+      if (closed && i == w->ref_cnt - 1 && emitted) { d->ref.push_back(first); emitted++; break; }
+      const smr_osm_node_t *n = (const smr_osm_node_t *) H.get_object(SMR_OSM_NODE, w->ref[i]);
+      if (n == nullptr)      /* cairo_smr_poly_line skips missing nodes, src/smrules_cairo.c:853-857 */
+      {
+         plog(SMR_LOG_WARN, "node %lld of way %lld at pos %d does not exist", (long long) w->ref[i], (long long) w->obj.id, i);
+         continue;
+      }
+      d->ref.push_back((int32_t) d->lat.size());
+      d->lat.push_back(n->lat); d->lon.push_back(n->lon);
+      emitted++;
+   }
+   if (d->lat.size() > 0x7fffff00u) { plog(SMR_LOG_ERR, "draw: more than 2^31 nodes in one rule"); return -1; }
+   d->way_off.push_back((int64_t) d->ref.size());
+   if (d->fill_cs.key) d->fill_col.push_back(color_by_cs(&w->obj, &d->fill_cs));
+   if (d->border_cs.key) d->border_col.push_back(color_by_cs(&w->obj, &d->border_cs));
+   return 0;
+}
+
+static int draw_main(smr_smrule_t *r, smr_osm_obj_t *o)
+{
+   draw_rule_t *d = (draw_rule_t *) r->data;
+   if (d == nullptr) return -1;
+   if (o->type == SMR_OSM_WAY) return draw_way(d, (const smr_osm_way_t *) o);
+   if (o->type == SMR_OSM_REL)
+   {
+      const smr_osm_rel_t *rel = (const smr_osm_rel_t *) o;
+      for (int i = 0; i < rel->mem_cnt; i++)
+      {
+         if (rel->mem[i].type != SMR_OSM_WAY) continue;
+         const smr_osm_way_t *w = (const smr_osm_way_t *) H.get_object(SMR_OSM_WAY, rel->mem[i].id);
+         if (w == nullptr) continue;
+         int e = draw_way(d, w);
+         if (e < 0) return e;
+      }
+      return 0;
+   }
+   plog(SMR_LOG_WARN, "draw() may not be applied to object type %d", o->type);
+   return 1;
+}
+
+static int draw_fini(smr_smrule_t *r)
+{
+   draw_rule_t *d = (draw_rule_t *) r->data;
+   if (d == nullptr) return 0;
+   int ret = 0;
+   const int64_t n_ways = (int64_t) d->way_off.size() - 1, n_refs = (int64_t) d->ref.size();
+   if (n_ways > 0 && n_refs > 0)
+   {
+      size_t n = d->lat.size();
+      if (n & 1) { d->lat.push_back(d->lat.back()); d->lon.push_back(d->lon.back()); n++; }
+      dbuf_t lat, lon, x, y, off, ref, fc, bc;
+      bool ok = lat.put(d->lat.data(), n * 8) == 0 && lon.put(d->lon.data(), n * 8) == 0 && x.alloc(n * 8) == 0 &&
+                y.alloc(n * 8) == 0 && off.put(d->way_off.data(), d->way_off.size() * 8) == 0 &&
+                ref.put(d->ref.data(), d->ref.size() * 4) == 0;
+      if (ok && d->fill_cs.key) ok = fc.put(d->fill_col.data(), d->fill_col.size() * 4) == 0;
+      if (ok && d->border_cs.key) ok = bc.put(d->border_col.data(), d->border_col.size() * 4) == 0;
+      if (ok) ok = smr_hip_project((const double *) lat.p, (const double *) lon.p, (int64_t) n, (double *) x.p, (double *) y.p,
+                                   nullptr, nullptr, nullptr) == SMR_OK;
+      if (ok)
+      {
+         smr_draw_batch_t b;
+         memset(&b, 0, sizeof(b));
+         b.d_x = (const double *) x.p; b.d_y = (const double *) y.p; b.n_nodes = (int64_t) n;
+         b.d_way_off = (const int64_t *) off.p; b.d_ref = (const int32_t *) ref.p; b.n_ways = n_ways; b.n_refs = n_refs;
+         b.d_way_fill_col = d->fill_cs.key ? (const uint32_t *) fc.p : nullptr;
+         b.d_way_border_col = d->border_cs.key ? (const uint32_t *) bc.p : nullptr;
+         ok = smr_hip_draw(P.canvas, &d->st, &b) == SMR_OK;
+      }
+      if (ok) ok = smr_hip_sync() == SMR_OK;
+      if (!ok) { plog(SMR_LOG_ERR, "draw: %s", smr_hip_last_error()); ret = -1; }
+      else plog(SMR_LOG_INFO, "draw: %lld ways, %lld refs rendered on the GPU", (long long) n_ways, (long long) n_refs);
+   }
+   delete d;
+   r->data = nullptr;
+   return ret;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* host libcairo for text extents (glyph outlines stay on the host, BASELINE north_star)    */
+/* ---------------------------------------------------------------------------------------- */
+typedef struct { double x_bearing, y_bearing, width, height, x_advance, y_advance; } cr_text_extents_t;
+typedef struct { double ascent, descent, height, max_x_advance, max_y_advance; } cr_font_extents_t;
+typedef struct { double x, y, width, height; } cr_rectangle_t;
+
+struct cairo_api_t
+{
+   void *lib = nullptr, *fc = nullptr;
+   void *(*recording_surface_create)(int, const cr_rectangle_t *);
+   void *(*image_surface_create)(int, int, int);
+   void *(*create)(void *);
+   void (*destroy)(void *);
+   void (*surface_destroy)(void *);
+   void (*surface_flush)(void *);
+   unsigned char *(*image_surface_get_data)(void *);
+   int (*image_surface_get_stride)(void *);
+   void *(*font_options_create)(void);
+   void (*font_options_set_hint_metrics)(void *, int);
+   void (*set_font_options)(void *, const void *);
+   void (*font_options_destroy)(void *);
+   void (*select_font_face)(void *, const char *, int, int);
+   void (*set_font_size)(void *, double);
+   void (*font_extents)(void *, cr_font_extents_t *);
+   void (*text_extents)(void *, const char *, cr_text_extents_t *);
+   void (*scale)(void *, double, double);
+   void (*set_source_rgba)(void *, double, double, double, double);
+   void (*rectangle)(void *, double, double, double, double);
+   void (*fill)(void *);
+   /* optional: fontconfig face like the reference's CAIRO_HAS_FC_FONT branch (:1345-1354) */
+   void *(*ft_font_face_create_for_pattern)(void *);
+   void (*set_font_face)(void *, void *);
+   void (*font_face_destroy)(void *);
+   void *(*FcNameParse)(const unsigned char *);
+   void (*FcPatternDestroy)(void *);
+};
+static cairo_api_t CR;
+
+#define CR_LOAD(field, name) do { *(void **) (&CR.field) = dlsym(CR.lib, name); if (!CR.field) { plog(SMR_LOG_ERR, "libcairo lacks %s", name); return -1; } } while (0)
+
+static int cairo_load(void)
+{
+   if (CR.lib) return 0;
+   const char *cand[] = { getenv("SMR_HIP_LIBCAIRO"), "libcairo.so.2", "/opt/conda/lib/libcairo.so.2", nullptr };
+   for (int i = 0; i < 4 && !CR.lib; i++)
+      if (cand[i] && *cand[i]) CR.lib = dlopen(cand[i], RTLD_NOW | RTLD_GLOBAL);
+   if (!CR.lib)
+   {
+      plog(SMR_LOG_ERR, "cap: libcairo.so.2 (text extents) cannot be loaded: %s", dlerror());
+      return -1;
+   }
+   CR_LOAD(recording_surface_create, "cairo_recording_surface_create"); CR_LOAD(image_surface_create, "cairo_image_surface_create");
+   CR_LOAD(create, "cairo_create"); CR_LOAD(destroy, "cairo_destroy"); CR_LOAD(surface_destroy, "cairo_surface_destroy");
+   CR_LOAD(surface_flush, "cairo_surface_flush"); CR_LOAD(image_surface_get_data, "cairo_image_surface_get_data");
+   CR_LOAD(image_surface_get_stride, "cairo_image_surface_get_stride"); CR_LOAD(font_options_create, "cairo_font_options_create");
+   CR_LOAD(font_options_set_hint_metrics, "cairo_font_options_set_hint_metrics"); CR_LOAD(set_font_options, "cairo_set_font_options");
+   CR_LOAD(font_options_destroy, "cairo_font_options_destroy"); CR_LOAD(select_font_face, "cairo_select_font_face");
+   CR_LOAD(set_font_size, "cairo_set_font_size"); CR_LOAD(font_extents, "cairo_font_extents"); CR_LOAD(text_extents, "cairo_text_extents");
+   CR_LOAD(scale, "cairo_scale"); CR_LOAD(set_source_rgba, "cairo_set_source_rgba"); CR_LOAD(rectangle, "cairo_rectangle");
+   CR_LOAD(fill, "cairo_fill");
+   *(void **) (&CR.ft_font_face_create_for_pattern) = dlsym(CR.lib, "cairo_ft_font_face_create_for_pattern");
+   *(void **) (&CR.set_font_face) = dlsym(CR.lib, "cairo_set_font_face");
+   *(void **) (&CR.font_face_destroy) = dlsym(CR.lib, "cairo_font_face_destroy");
+   *(void **) (&CR.FcNameParse) = dlsym(RTLD_DEFAULT, "FcNameParse");
+   *(void **) (&CR.FcPatternDestroy) = dlsym(RTLD_DEFAULT, "FcPatternDestroy");
+   return 0;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* cap (angle=auto)                                                                         */
+/* ---------------------------------------------------------------------------------------- */
+struct cap_item_t
+{
+   smr_osm_obj_t *o;
+   double lat, lon;
+   int pw, ph, px;            /* plane size / first opaque column in pt, ints like cairo_smr_plane's arguments */
+   uint32_t col;
+   short pos;
+};
+
+struct cap_rule_t
+{
+   short pos = 0;
+   col_spec_t cs;
+   const char *font = "serif", *key = nullptr;
+   std::vector<std::string> klist;
+   double size = 0, xoff = 0, yoff = 0, phase = 0, weight = 1;
+   double min_auto_size = 0.5, max_auto_size = 12.0, min_area_size = 8.0, auto_scale = 0.2;   /* src/smrender_dev.h:107-110 */
+   const char *halignkey = nullptr, *valignkey = nullptr;
+   void *sfc = nullptr, *ctx = nullptr;
+   std::vector<cap_item_t> items;
+};
+
+static double mm2pt(double mm) { return mm * 72 / 25.4; }
+
+/* parse_alignment_str, src/smrparse.c:667-701 */
+static int alignment_str(const char *s)
+{
+   static const struct { const char *n; int p; } tab[] = {
+      { "east", SMR_POS_E }, { "west", SMR_POS_W }, { "north", SMR_POS_N }, { "south", SMR_POS_S },
+      { "northeast", SMR_POS_E | SMR_POS_N }, { "northwest", SMR_POS_W | SMR_POS_N }, { "southeast", SMR_POS_E | SMR_POS_S },
+      { "southwest", SMR_POS_W | SMR_POS_S }, { "center", 0 }, { "middle", 0 } };
+   if (s == nullptr || *s == '\0') return 0;
+   for (auto &t : tab) if (!strcasecmp(s, t.n)) return t.p;
+   plog(SMR_LOG_WARN, "unknown alignment '%s'", s);
+   return 0;
+}
+
+static int alignment(const smr_action_t *act)      /* parse_alignment, src/smrparse.c:704-720 */
+{
+   if (H.parse_alignment) return H.parse_alignment(act);
+   char *s; int pos = 0;
+   if ((s = H.get_param("align", nullptr, act)) != nullptr) return alignment_str(s);
+   if ((s = H.get_param("halign", nullptr, act)) != nullptr) pos |= alignment_str(s) & (SMR_POS_E | SMR_POS_W);
+   if ((s = H.get_param("valign", nullptr, act)) != nullptr) pos |= alignment_str(s) & (SMR_POS_N | SMR_POS_S);
+   return pos;
+}
+
+static int cap_ini(smr_smrule_t *r)
+{
+   int e;
+   host_resolve();
+   if ((e = plugin_setup()) != 0) return e;
+   char *s; double angle = 0;
+   /* parse_auto_rot, src/smrparse.c:1033-1074: only angle=auto runs on the GPU */
+   if ((s = H.get_param("angle", &angle, r->act)) == nullptr || strcasecmp(s, "auto") || H.get_param("anglekey", nullptr, r->act))
+   {
+      plog(SMR_LOG_ERR, "cap: only angle=auto (the auto-rotation scan) runs on the GPU path; use the built-in cap for fixed angles");
+      return 1;
+   }
+   if (!H.match_attr || !H.realloc_tags)
+   {
+      plog(SMR_LOG_ERR, "cap: host symbols match_attr/realloc_tags not found");
+      return -1;
+   }
+   if (cairo_load() != 0) return -1;
+
+   cap_rule_t *cap = new cap_rule_t();
+   if ((s = H.get_param("font", nullptr, r->act)) != nullptr) cap->font = s;
+   else plog(SMR_LOG_NOTICE, "parameter 'font' missing, defaulting to \"%s\"", cap->font);
+   if (H.get_param("size", &cap->size, r->act) == nullptr && r->oo->type == SMR_OSM_NODE)
+   {
+      cap->size = 4.0;      /* DEFAULT_CAP_SIZE */
+      plog(SMR_LOG_NOTICE, "parameter 'size' missing, defaulting to %.1f", cap->size);
+   }
+   cap->xoff = cap->yoff = mm2pt(cap->size) / 2;
+   if ((cap->key = H.get_param("key", nullptr, r->act)) == nullptr)
+   {
+      plog(SMR_LOG_WARN, "parameter 'key' missing");
+      delete cap;
+      return 1;
+   }
+   if ((s = H.get_param("color", nullptr, r->act)) != nullptr) parse_col_spec(s, &cap->cs);
+   (void) H.get_param("min_size", &cap->min_auto_size, r->act);
+   (void) H.get_param("max_size", &cap->max_auto_size, r->act);
+   (void) H.get_param("min_area", &cap->min_area_size, r->act);
+   (void) H.get_param("auto_scale", &cap->auto_scale, r->act);
+   (void) H.get_param("xoff", &cap->xoff, r->act);
+   (void) H.get_param("yoff", &cap->yoff, r->act);
+   if (H.get_param("weight", &cap->weight, r->act) == nullptr) cap->weight = 1.0;
+   if (cap->weight > 1.0) cap->weight = 1.0;
+   else if (cap->weight < -1.0) cap->weight = -1.0;
+   (void) H.get_param("phase", &cap->phase, r->act);
+   cap->pos = (short) alignment(r->act);
+   if ((cap->halignkey = H.get_param("alignkey", nullptr, r->act)) != nullptr)
+   {
+      cap->valignkey = cap->halignkey;
+      cap->pos &= ~(SMR_POS_N | SMR_POS_S | SMR_POS_E | SMR_POS_W);
+   }
+   else
+   {
+      if ((cap->halignkey = H.get_param("halignkey", nullptr, r->act)) != nullptr) cap->pos &= ~(SMR_POS_E | SMR_POS_W);
+      if ((cap->valignkey = H.get_param("valignkey", nullptr, r->act)) != nullptr) cap->pos &= ~(SMR_POS_N | SMR_POS_S);
+   }
+   if (*cap->key == '*') { cap->key++; cap->pos |= SMR_POS_UC; }
+   /* parse_keylist, src/smrparse.c:859-...: "(a|b|c)" is a list of alternatives */
+   {
+      std::string k(cap->key);
+      if (k.size() > 1 && k.front() == '(' && k.back() == ')')
+      {
+         size_t a = 1;
+         while (a < k.size())
+         {
+            size_t b = k.find('|', a);
+            if (b == std::string::npos) b = k.size() - 1;
+            cap->klist.push_back(k.substr(a, b - a));
+            a = b + 1;
+         }
+      }
+      else cap->klist.push_back(k);
+   }
+   /* the measuring context: like cap.ctx on the recording surface, hint metrics off (:1335-1357) */
+   cr_rectangle_t ext = { 0, 0, P.proj.w * 72 / P.dpi, P.proj.h * 72 / P.dpi };
+   cap->sfc = CR.recording_surface_create(0x3000, &ext);
+   cap->ctx = CR.create(cap->sfc);
+   void *fo = CR.font_options_create();
+   CR.font_options_set_hint_metrics(fo, 1 /* CAIRO_HINT_METRICS_OFF */);
+   CR.set_font_options(cap->ctx, fo);
+   CR.font_options_destroy(fo);
+   void *pat = nullptr;
+   if (CR.FcNameParse && CR.FcPatternDestroy && CR.ft_font_face_create_for_pattern && CR.set_font_face && CR.font_face_destroy &&
+       (pat = CR.FcNameParse((const unsigned char *) cap->font)) != nullptr)
+   {
+      void *cfc = CR.ft_font_face_create_for_pattern(pat);
+      CR.FcPatternDestroy(pat);
+      CR.set_font_face(cap->ctx, cfc);
+      CR.font_face_destroy(cfc);
+   }
+   else CR.select_font_face(cap->ctx, cap->font, 0, 0);
+   r->data = cap;
+   return 0;
+}
+
+static void strupper(char *s) { for (; *s; s++) if (*s >= 'a' && *s <= 'z') *s -= 32; }
+
+/* the part of cap_coord (:2202-2281) that runs before find_angle: extents -> plane geometry */
+static int cap_collect(cap_rule_t *cap, double size_mm, double lat, double lon, const smr_bstring_t *str, smr_osm_obj_t *o)
+{
+   if (size_mm == 0.0) return 0;
+   std::string buf(str->buf, (size_t) str->len);
+   if (cap->pos & SMR_POS_UC) strupper(&buf[0]);
+   cr_text_extents_t tx; cr_font_extents_t fe;
+   CR.set_font_size(cap->ctx, mm2pt(size_mm));
+   CR.font_extents(cap->ctx, &fe);
+   CR.text_extents(cap->ctx, buf.c_str(), &tx);
+   double width = tx.width + tx.x_bearing + cap->xoff, height = fe.ascent;
+   cap_item_t it;
+   it.o = o; it.lat = lat; it.lon = lon;
+   it.pos = (cap->pos & 0xc) ? (short) ((cap->pos & 0xfff0) | SMR_POS_E) : cap->pos;
+   it.col = color_by_cs(o, &cap->cs);
+   /* cairo_smr_plane(int w, int h, int x, int col): the double arguments are truncated to int pt (:1536, :2272, :2277) */
+   if (cap->pos & 0xc) { it.pw = (int) (width * 2); it.ph = (int) height; it.px = (int) width; }
+   else { it.pw = (int) width; it.ph = (int) height; it.px = 0; }
+   cap->items.push_back(it);
+   return 0;
+}
+
+static int cap_main(smr_smrule_t *r, smr_osm_obj_t *o)
+{
+   cap_rule_t *cap = (cap_rule_t *) r->data;
+   if (cap == nullptr) return -1;
+   int n = -1;
+   for (size_t i = 0; i < cap->klist.size(); i++)
+      if ((n = H.match_attr(o, cap->klist[i].c_str(), nullptr)) >= 0) break;
+   if (n == -1) return 0;
+   if (o->type == SMR_OSM_NODE)
+   {
+      const smr_osm_node_t *nd = (const smr_osm_node_t *) o;
+      return cap_collect(cap, cap->size, nd->lat, nd->lon, &o->otag[n].v, o);
+   }
+   if (o->type == SMR_OSM_WAY)
+   {
+      /* cap_way, :2395-2444: closed ways only, caption at the centroid, size from the area */
+      const smr_osm_way_t *w = (const smr_osm_way_t *) o;
+      if (!(w->ref_cnt >= 4 && w->ref[0] == w->ref[w->ref_cnt - 1])) return 0;
+      if (!H.poly_area) { plog(SMR_LOG_WARN, "cap: host symbol poly_area not found, way %lld skipped", (long long) o->id); return 0; }
+      struct smr_coord c; double ar;
+      if (H.poly_area(w, &c, &ar)) return 0;
+      double size = cap->size;
+      if (size == 0.0)
+      {
+         if (!H.rdata_square_mm || !H.rdata_square_nm) return 0;
+         double area_mm2 = fabs(ar) * H.rdata_square_mm() / H.rdata_square_nm();
+         size = cap->auto_scale * sqrt(area_mm2);
+         if (cap->max_auto_size != 0.0 && size > cap->max_auto_size) size = cap->max_auto_size;
+         if (cap->min_auto_size != 0.0 && size < cap->min_auto_size)
+            size = area_mm2 < cap->min_area_size ? 0.0 : cap->min_auto_size;
+      }
+      return cap_collect(cap, size, c.lat, c.lon, &o->otag[n].v, o);
+   }
+   return 1;
+}
+
+/* cairo_smr_plane, :1536-1558, with the real libcairo: a w x h pt image at dpi/72, the
+ * rectangle [x,w] x [0,h] filled in the caption colour */
+static int make_plane(int w_pt, int h_pt, int x_pt, uint32_t col, int dpi, std::vector<uint32_t> &pix, int *w_px, int *h_px)
+{
+   double s = (double) dpi / 72.0;
+   int W = (int) round(w_pt * s), Hh = (int) round(h_pt * s);
+   *w_px = W; *h_px = Hh;
+   if (W <= 0 || Hh <= 0) return -1;
+   void *sfc = CR.image_surface_create(0 /* ARGB32 */, W, Hh);
+   void *ctx = CR.create(sfc);
+   CR.scale(ctx, s, s);
+   CR.set_source_rgba(ctx, (double) ((col >> 16) & 0xff) / 255.0, (double) ((col >> 8) & 0xff) / 255.0, (double) (col & 0xff) / 255.0,
+                      1.0 - (double) (((col & 0x7f000000u) >> 23) & 0xff) / 255.0);
+   CR.rectangle(ctx, x_pt, 0, w_pt - x_pt, h_pt);
+   CR.fill(ctx);
+   CR.destroy(ctx);
+   CR.surface_flush(sfc);
+   const unsigned char *d = CR.image_surface_get_data(sfc);
+   int stride = CR.image_surface_get_stride(sfc);
+   pix.resize((size_t) W * Hh);
+   for (int y = 0; y < Hh; y++) memcpy(&pix[(size_t) y * W], d + (size_t) y * stride, (size_t) W * 4);
+   CR.surface_destroy(sfc);
+   return 0;
+}
+
+static void add_tag(smr_osm_obj_t *o, const char *key, const char *sub, const char *val)     /* :2299-2348 */
+{
+   if (H.realloc_tags(o, o->tag_cnt + 1) == -1) return;
+   smr_otag *t = &o->otag[o->tag_cnt - 1];
+   size_t kl = strlen(key) + strlen(sub) + 2, vl = strlen(val) + 1;
+   t->k.buf = (char *) malloc(kl); t->v.buf = (char *) malloc(vl < 8 ? 8 : vl);
+   if (!t->k.buf || !t->v.buf) { free(t->k.buf); free(t->v.buf); o->tag_cnt--; return; }
+   t->k.len = snprintf(t->k.buf, kl, "%s:%s", key, sub);
+   t->v.len = snprintf(t->v.buf, vl < 8 ? 8 : vl, "%s", val);
+}
+
+static int cap_fini(smr_smrule_t *r)
+{
+   cap_rule_t *cap = (cap_rule_t *) r->data;
+   if (cap == nullptr) return 0;
+   int ret = 0;
+   /* one GPU batch per distinct caption plane */
+   std::map<std::vector<int64_t>, std::vector<size_t>> groups;
+   for (size_t i = 0; i < cap->items.size(); i++)
+   {
+      const cap_item_t &it = cap->items[i];
+      groups[{ it.pw, it.ph, it.px, (int64_t) it.col }].push_back(i);
+   }
+   std::vector<double> angle(cap->items.size(), 0.0);
+   for (auto &g : groups)
+   {
+      const std::vector<size_t> &idx = g.second;
+      const cap_item_t &first = cap->items[idx[0]];
+      std::vector<uint32_t> plane; int w_px, h_px;
+      if (make_plane(first.pw, first.ph, first.px, first.col, P.dpi, plane, &w_px, &h_px) != 0) continue;   /* empty plane: angle 0 */
+      size_t n = idx.size(), np = (n + 1) & ~(size_t) 1;
+      std::vector<double> lat(np), lon(np), out(n);
+      for (size_t k = 0; k < n; k++) { lat[k] = cap->items[idx[k]].lat; lon[k] = cap->items[idx[k]].lon; }
+      if (np > n) { lat[n] = lat[n - 1]; lon[n] = lon[n - 1]; }
+      dbuf_t dlat, dlon, dx, dy, dfg, dang;
+      bool ok = dlat.put(lat.data(), np * 8) == 0 && dlon.put(lon.data(), np * 8) == 0 && dx.alloc(np * 8) == 0 && dy.alloc(np * 8) == 0 &&
+                dfg.put(plane.data(), plane.size() * 4) == 0 && dang.alloc(n * 8) == 0;
+      if (ok) ok = smr_hip_project((const double *) dlat.p, (const double *) dlon.p, (int64_t) np, (double *) dx.p, (double *) dy.p,
+                                   nullptr, nullptr, nullptr) == SMR_OK;
+      if (ok)
+      {
+         smr_cap_batch_t b;
+         memset(&b, 0, sizeof(b));
+         b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) n;
+         b.fg_w = w_px; b.fg_h = h_px; b.fg_x = 0; b.col = first.col; b.phase_deg = cap->phase; b.weight = cap->weight;
+         b.d_fg = (const uint32_t *) dfg.p;
+         ok = smr_hip_caprot(P.canvas, &b, (double *) dang.p, nullptr) == SMR_OK;
+      }
+      if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, n * 8) == SMR_OK;
+      if (!ok) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; break; }
+      for (size_t k = 0; k < n; k++) angle[idx[k]] = out[k];
+   }
+   if (ret == 0)
+      for (size_t i = 0; i < cap->items.size(); i++)
+      {
+         cap_item_t &it = cap->items[i];
+         double a = angle[i];
+         short pos = it.pos;
+         if (a > M_PI_2 && a < 3 * M_PI_2)       /* flip text if necessary, :2284-2292 */
+         {
+            a -= M_PI;
+            if (pos & SMR_POS_E) pos = (short) ((cap->pos & 0xfff0) | SMR_POS_W);
+         }
+         char val[32];
+         snprintf(val, sizeof(val), "%.1f", a * 180.0 / M_PI);
+         add_tag(it.o, cap->key, "autoangle", val);
+         add_tag(it.o, cap->key, "autoalign", (pos & SMR_POS_E) ? "east" : (pos & SMR_POS_W) ? "west" : "center");
+      }
+   plog(SMR_LOG_INFO, "cap: %zu captions scanned on the GPU in %zu plane group(s)", cap->items.size(), groups.size());
+   CR.destroy(cap->ctx);
+   CR.surface_destroy(cap->sfc);
+   delete cap;
+   r->data = nullptr;
+   return ret;
+}
+
+/* ---------------------------------------------------------------------------------------- */
+/* hipsave: the device canvas -> PNG (stands in for save_main_image, src/smrules_cairo.c:388-412)   */
+/* ---------------------------------------------------------------------------------------- */
+static uint32_t crc_table[256];
+static void crc_init(void)
+{
+   for (uint32_t n = 0; n < 256; n++)
+   {
+      uint32_t c = n;
+      for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+      crc_table[n] = c;
+   }
+}
+static uint32_t crc_update(uint32_t c, const unsigned char *b, size_t n) { for (size_t i = 0; i < n; i++) c = crc_table[(c ^ b[i]) & 0xff] ^ (c >> 8); return c; }
+
+static void png_chunk(FILE *f, const char *type, const unsigned char *data, uint32_t len)
+{
+   unsigned char h[8] = { (unsigned char) (len >> 24), (unsigned char) (len >> 16), (unsigned char) (len >> 8), (unsigned char) len,
+                          (unsigned char) type[0], (unsigned char) type[1], (unsigned char) type[2], (unsigned char) type[3] };
+   fwrite(h, 1, 8, f);
+   if (len) fwrite(data, 1, len, f);
+   uint32_t c = crc_update(0xffffffffu, h + 4, 4);
+   c = crc_update(c, data, len) ^ 0xffffffffu;
+   unsigned char t[4] = { (unsigned char) (c >> 24), (unsigned char) (c >> 16), (unsigned char) (c >> 8), (unsigned char) c };
+   fwrite(t, 1, 4, f);
+}
+
+/* RGBA8 PNG with stored (uncompressed) deflate blocks, one IDAT per row block; pixels are
+ * un-premultiplied the way cairo's PNG writer does */
+static int write_png(const char *path, int W, int Hh, int y0, int h)
+{
+   FILE *f = fopen(path, "wb");
+   if (!f) { plog(SMR_LOG_ERR, "hipsave: cannot open %s: %s", path, strerror(errno)); return -1; }
+   crc_init();
+   static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+   fwrite(sig, 1, 8, f);
+   unsigned char ihdr[13] = { (unsigned char) (W >> 24), (unsigned char) (W >> 16), (unsigned char) (W >> 8), (unsigned char) W,
+                              (unsigned char) (h >> 24), (unsigned char) (h >> 16), (unsigned char) (h >> 8), (unsigned char) h, 8, 6, 0, 0, 0 };
+   png_chunk(f, "IHDR", ihdr, 13);
+   const size_t rowb = (size_t) W * 4 + 1;
+   std::vector<uint32_t> px((size_t) W);
+   std::vector<unsigned char> blk;
+   uint32_t s1 = 1, s2 = 0;
+   for (int y = 0; y < h; y++)
+   {
+      if (smr_hip_canvas_read(P.canvas, 0, y0 + y, W, 1, px.data()) != SMR_OK) { fclose(f); return -1; }
+      blk.clear();
+      if (y == 0) { blk.push_back(0x78); blk.push_back(0x01); }
+      /* stored blocks of at most 65535 bytes */
+      std::vector<unsigned char> row(rowb);
+      row[0] = 0;
+      for (int x = 0; x < W; x++)
+      {
+         uint32_t p = px[x], a = p >> 24;
+         unsigned char *o = &row[1 + 4 * (size_t) x];
+         if (a == 0) { o[0] = o[1] = o[2] = o[3] = 0; }
+         else
+         {
+            o[0] = (unsigned char) ((((p >> 16) & 0xff) * 255 + a / 2) / a);
+            o[1] = (unsigned char) ((((p >> 8) & 0xff) * 255 + a / 2) / a);
+            o[2] = (unsigned char) (((p & 0xff) * 255 + a / 2) / a);
+            o[3] = (unsigned char) a;
+         }
+      }
+      for (size_t i = 0; i < rowb; i++) { s1 = (s1 + row[i]) % 65521u; s2 = (s2 + s1) % 65521u; }
+      for (size_t off = 0; off < rowb;)
+      {
+         size_t n = std::min<size_t>(65535, rowb - off);
+         bool final = y == h - 1 && off + n == rowb;
+         blk.push_back(final ? 1 : 0);
+         blk.push_back((unsigned char) (n & 0xff)); blk.push_back((unsigned char) (n >> 8));
+         blk.push_back((unsigned char) (~n & 0xff)); blk.push_back((unsigned char) ((~n >> 8) & 0xff));
+         blk.insert(blk.end(), row.begin() + off, row.begin() + off + n);
+         off += n;
+      }
+      if (y == h - 1)
+      {
+         uint32_t ad = (s2 << 16) | s1;
+         blk.push_back((unsigned char) (ad >> 24)); blk.push_back((unsigned char) (ad >> 16));
+         blk.push_back((unsigned char) (ad >> 8)); blk.push_back((unsigned char) ad);
+      }
+      png_chunk(f, "IDAT", blk.data(), (uint32_t) blk.size());
+   }
+   png_chunk(f, "IEND", nullptr, 0);
+   fclose(f);
+   return 0;
+}
+
+static int hipsave_ini(smr_smrule_t *r)
+{
+   int e;
+   host_resolve();
+   if ((e = plugin_setup()) != 0) return e;
+   if (H.get_param("file", nullptr, r->act) == nullptr)
+   {
+      plog(SMR_LOG_WARN, "hipsave: parameter 'file' missing");
+      return 1;
+   }
+   return 0;
+}
+
+static int hipsave_main(smr_smrule_t *, smr_osm_obj_t *) { return 0; }
+
+static int hipsave_fini(smr_smrule_t *r)
+{
+   const char *file = H.get_param("file", nullptr, r->act);
+   if (!file || !P.canvas) return -1;
+   if (smr_hip_sync() != SMR_OK) return -1;
+   int e = write_png(file, P.W, P.band_h, 0, P.band_h);
+   if (e == 0) plog(SMR_LOG_NOTICE, "hipsave: %dx%d px (rows %d..%d of the chart) written to %s", P.W, P.band_h, P.band_y0,
+                    P.band_y0 + P.band_h - 1, file);
+   return e;
+}
+
+/* ---- the exported symbols (include/smr_hip.h): void* in the public header, host types here ---- */
+#define SMR_ACTION(name) \
+   extern "C" int act_##name##_ini(void *r) { return name##_ini((smr_smrule_t *) r); } \
+   extern "C" int act_##name##_main(void *r, void *o) { return name##_main((smr_smrule_t *) r, (smr_osm_obj_t *) o); } \
+   extern "C" int act_##name##_fini(void *r) { return name##_fini((smr_smrule_t *) r); }
+SMR_ACTION(draw)
+SMR_ACTION(cap)
+SMR_ACTION(hipsave)

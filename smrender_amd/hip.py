@@ -42,7 +42,7 @@ class _DrawBatch(C.Structure):
 
 class _CapBatch(C.Structure):
     _fields_ = [("d_cx", C.c_void_p), ("d_cy", C.c_void_p), ("n", C.c_int64), ("fg_w", C.c_int32), ("fg_h", C.c_int32),
-                ("fg_x", C.c_int32), ("col", C.c_uint32), ("phase_deg", C.c_double), ("weight", C.c_double)]
+                ("fg_x", C.c_int32), ("col", C.c_uint32), ("phase_deg", C.c_double), ("weight", C.c_double), ("d_fg", C.c_void_p)]
 
 
 class Timings(C.Structure):
@@ -58,7 +58,9 @@ EXPORTS = [
     "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_read", "smr_hip_canvas_device",
     "smr_hip_draw", "smr_hip_caprot", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
-    "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h",
+    "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
+    "act_draw_ini", "act_draw_main", "act_draw_fini", "act_cap_ini", "act_cap_main", "act_cap_fini",
+    "act_hipsave_ini", "act_hipsave_main", "act_hipsave_fini",
 ]
 
 _lib = None
@@ -92,6 +94,7 @@ def lib():
         L.smr_hip_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.smr_hip_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.smr_hip_device_name.argtypes = [C.c_char_p, C.c_size_t]
+        L.smr_hip_plugin_canvas.restype = C.c_void_p
         _lib = L
     return _lib
 
@@ -204,8 +207,8 @@ class Canvas:
                        n_ways, n_refs, d_fill_col.ptr if d_fill_col else None, d_border_col.ptr if d_border_col else None)
         _chk(lib().smr_hip_draw(self.h, C.byref(style), C.byref(b)))
 
-    def caprot(self, d_cx, d_cy, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_angle, d_dv=None):
-        b = _CapBatch(d_cx.ptr, d_cy.ptr, n, fg_w, fg_h, fg_x, col, phase_deg, weight)
+    def caprot(self, d_cx, d_cy, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_angle, d_dv=None, d_fg=None):
+        b = _CapBatch(d_cx.ptr, d_cy.ptr, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_fg.ptr if d_fg else None)
         _chk(lib().smr_hip_caprot(self.h, C.byref(b), d_angle.ptr, d_dv.ptr if d_dv else None))
 
     def clear(self):

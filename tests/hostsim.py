@@ -1,0 +1,71 @@
+"""Python driver of the miniature smrender host (oracle/hostsim.c + the reference's own
+libsmrender built into oracle/_ref/).  TEST INFRASTRUCTURE: used by tests/test_plugin*.py only."""
+import ctypes as C
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_DIR = os.path.join(ROOT, "oracle", "_ref")
+OSM_NODE, OSM_WAY, OSM_REL = 1, 2, 3
+_hs = None
+
+
+def available():
+    return os.path.exists(os.path.join(REF_DIR, "libhostsim.so")) and os.path.exists(os.path.join(REF_DIR, "libsmrender_ref.so"))
+
+
+def host():
+    """libhostsim.so + libsmrender_ref.so loaded into the GLOBAL scope, the way the smrender executable
+    (-rdynamic) and libsmrender.so present their symbols to a dlopen()ed plugin."""
+    global _hs
+    if _hs is None:
+        C.CDLL(os.path.join(REF_DIR, "libsmrender_ref.so"), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(os.path.join(REF_DIR, "libhostsim.so"), mode=C.RTLD_GLOBAL)
+        L.hs_set_rdata.argtypes = [C.c_double] * 9 + [C.c_int, C.c_uint]
+        L.hs_rule_new.restype = C.c_void_p
+        L.hs_rule_new.argtypes = [C.c_int, C.c_char_p, C.c_char_p]
+        L.hs_node.argtypes = [C.c_int64, C.c_double, C.c_double, C.c_char_p]
+        L.hs_way.argtypes = [C.c_int64, C.c_void_p, C.c_int, C.c_char_p]
+        L.hs_rel_of_ways.argtypes = [C.c_int64, C.c_void_p, C.c_int]
+        L.hs_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.hs_get_tag.restype = C.c_char_p
+        L.hs_get_tag.argtypes = [C.c_int, C.c_int64, C.c_char_p]
+        _hs = L
+    return _hs
+
+
+def set_chart(proj, bgcolor=0xffffff):
+    """proj: a Projection / oracle Proj (same fields as struct rdata's, src/rdata.h:99-158)"""
+    host().hs_set_rdata(proj.lon0, proj.w, proj.h, proj.wc, proj.lath, proj.lath_len, proj.lat_ll, proj.lon_ru, proj.lat_ru,
+                        proj.dpi, bgcolor)
+
+
+def apply_rule(lib, func, obj_type, params, ids, rule_type=None):
+    """what smrender does with `_action_ = func@libsmr_hip.so:params`: dlsym the three entry points,
+    call _ini, _main per object (in the order given = bxtree id order), _fini.  Returns hs_apply's code."""
+    H = host()
+    r = H.hs_rule_new(rule_type or obj_type, func.encode(), params.encode())
+    f = [C.cast(getattr(lib, f"act_{func}_{s}"), C.c_void_p) for s in ("ini", "main", "fini")]
+    ids = np.ascontiguousarray(ids, np.int64)
+    return H.hs_apply(r, f[0], f[1], f[2], obj_type, ids.ctypes.data, len(ids))
+
+
+def add_nodes(ids, lat, lon, tags=None):
+    H = host()
+    for k, i in enumerate(ids):
+        assert H.hs_node(int(i), float(lat[k]), float(lon[k]), (tags[k] if tags else "").encode()) == 0
+
+
+def add_way(wid, refs, tags=""):
+    refs = np.ascontiguousarray(refs, np.int64)
+    assert host().hs_way(int(wid), refs.ctypes.data, len(refs), tags.encode()) == 0
+
+
+def add_rel(rid, ways):
+    ways = np.ascontiguousarray(ways, np.int64)
+    assert host().hs_rel_of_ways(int(rid), ways.ctypes.data, len(ways)) == 0
+
+
+def get_tag(obj_type, oid, key):
+    v = host().hs_get_tag(obj_type, int(oid), key.encode())
+    return None if v is None else v.decode()

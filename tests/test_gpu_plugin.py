@@ -1,0 +1,136 @@
+"""The drop-in boundary on the GPU: rules of the form `draw@libsmr_hip.so:...` / `cap@libsmr_hip.so:...`
+driven through the reference's own libsmrender (oracle/_ref) by the miniature host, compared with
+the oracle restatement of act_draw / cap_coord + find_angle on the same objects."""
+import ctypes as C
+import numpy as np
+import pytest
+from oracle import pyoracle as po
+import hostsim as hs
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not hs.available(), reason="oracle/_ref not built")]
+
+W, H, DPI = 384, 300, 300
+
+
+def plugin_canvas(sa):
+    L = sa.lib()
+    h = L.smr_hip_plugin_canvas()
+    assert h
+    out = np.empty((H, W), np.uint32)
+    assert L.smr_hip_canvas_read(h, 0, 0, W, H, out.ctypes.data) == 0
+    return out
+
+
+@pytest.fixture
+def chart(hip):
+    sa = hip
+    sa.lib().smr_hip_plugin_reset()
+    proj = sa.Projection.from_window(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    hs.set_chart(proj, 0xfff8e0)
+    yield sa, proj
+    sa.lib().smr_hip_plugin_reset()
+
+
+_next_id = [1000]
+
+
+def load_ways(sa, proj, arrs, tags=None):
+    """puts the synthetic ways into the host's object tree; returns (way ids, oracle way list)"""
+    from smrender_amd import synth
+    x, y, off, ref = arrs
+    lat, lon = synth.px_to_geo(proj, x, y)
+    base = _next_id[0]
+    _next_id[0] += len(x) + len(off) + 10
+    hs.add_nodes(base + np.arange(len(x)), lat, lon)
+    wids = []
+    for w in range(len(off) - 1):
+        wid = base + len(x) + w
+        hs.add_way(wid, base + ref[off[w]:off[w + 1]].astype(np.int64), tags[w] if tags else "")
+        wids.append(wid)
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    ox, oy, _, _, _ = po.project(op, lat, lon)
+    return wids, po.ways_from_arrays(ox, oy, off, ref)
+
+
+def test_draw_rule_through_the_action_api(chart):
+    sa, proj = chart
+    wids, oways = load_ways(sa, proj, po.synth_ways(60, W, H, seed=77))
+    rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", wids)
+    assert rc == 0, sa.lib().smr_hip_last_error()
+    want = po.oracle_scene([(po.Style(1, 1, 0x4080c0, 0, 0, 0.1, 0), oways)], DPI, W, H, 0xfff8e0)
+    got = plugin_canvas(sa)
+    assert np.array_equal(got, want)
+
+
+def test_draw_relation_members_and_key_colours(chart):
+    sa, proj = chart
+    cols = ["#c04020", "#3020a0c0", "green", "#102030"]
+    arrs = po.synth_ways(24, W, H, seed=78)
+    tags = [f"colour={cols[w % 4]};name=w{w}" for w in range(24)]
+    wids, oways = load_ways(sa, proj, arrs, tags)
+    rid = _next_id[0]; _next_id[0] += 1
+    hs.add_rel(rid, wids[:10])
+    # rule 1: a relation rule draws the member ways (src/smrules_cairo.c:1054-1068)
+    assert hs.apply_rule(sa.lib(), "draw", hs.OSM_REL, "bcolor=#204060;bwidth=0.3", [rid]) == 0
+    # rule 2: colour per way from a tag (color=%key, color_by_cs :2042-2076)
+    assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=%colour", wids[10:]) == 0
+    pc = {"#c04020": 0xc04020, "#3020a0c0": 0x3020a0c0, "green": 0x00ff00, "#102030": 0x102030}
+    r1 = (po.Style(0, 1, 0, 0x204060, 0, 0.3, 0), oways[:10])
+    r2 = (po.Style(1, 0, 0, 0, 0, 0, 0), [(x, y, c, pc[cols[(10 + k) % 4]], None) for k, (x, y, c) in enumerate(oways[10:])])
+    want = po.oracle_scene([r1, r2], DPI, W, H, 0xfff8e0)
+    assert np.array_equal(plugin_canvas(sa), want)
+
+
+def test_unsupported_draw_styles_are_refused_loudly(chart):
+    sa, proj = chart
+    for params in ("bcolor=black;bstyle=dashed", "color=red;curve=1", "color=red;directional=1"):
+        assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, []) == 2001      # "Rule will be ignored"
+
+
+def test_cap_autoangle_tags(chart):
+    sa, proj = chart
+    from smrender_amd import synth
+    cd = po.cairo()
+    if cd is None:
+        pytest.skip("libcairo (text extents) not loadable")
+    wids, oways = load_ways(sa, proj, po.synth_ways(90, W, H, seed=79))
+    assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", wids) == 0
+    img = plugin_canvas(sa)
+    rng = np.random.default_rng(5)
+    n = 12
+    cx, cy = rng.uniform(20, W - 20, n), rng.uniform(20, H - 20, n)
+    lat, lon = synth.px_to_geo(proj, cx, cy)
+    names = [f"Cap {k}" if k % 3 else "Longer Caption Text" for k in range(n)]
+    base = _next_id[0]; _next_id[0] += n + 1
+    nids = base + np.arange(n)
+    hs.add_nodes(nids, lat, lon, [f"name={t}" for t in names])
+    params = "key=name;size=2;angle=auto;color=black;halign=east;font=serif;weight=0.7"
+    assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, params, nids) == 0, sa.lib().smr_hip_last_error()
+
+    # oracle: cap_coord's geometry through the real libcairo, find_angle restated (oracle/caprot.c)
+    L = po.orc()
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    px, py, _, _, _ = po.project(op, lat, lon)
+    xoff = 2 * 72 / 25.4 / 2
+    for k in range(n):
+        geo = np.zeros(3, np.int32)
+        cd.cd_caption_geometry(b"serif", 2.0, names[k].encode(), xoff, xoff, 1, W * 72 / DPI, H * 72 / DPI, po.P(geo))
+        pw, ph, pxx = [int(v) for v in geo]
+        crnd = lambda v: int(np.sign(v) * np.floor(abs(v) + 0.5))
+        fw, fh = crnd(pw * DPI / 72), crnd(ph * DPI / 72)
+        fg = np.zeros((fh, fw), np.uint32)
+        assert cd.cd_plane(pw, ph, pxx, 0, DPI, po.P(fg)) == 0
+        r = C.c_int()
+        steps = L.orc_num_steps(fw, fh, DPI, C.byref(r)); r = r.value
+        ox, oy = crnd(px[k] - r / 2.0), crnd(py[k] - r / 2.0)
+        cut = np.zeros((r, r), np.uint32)
+        xs0, ys0, xs1, ys1 = max(ox, 0), max(oy, 0), min(ox + r, W), min(oy + r, H)
+        if xs1 > xs0 and ys1 > ys0:
+            cut[ys0 - oy:ys1 - oy, xs0 - ox:xs1 - ox] = img[ys0:ys1, xs0:xs1]
+        a = L.orc_find_angle(po.P(cut), r, po.P(fg), fw, fh, steps, 0.0, 0.7, None)
+        align = "east"
+        if np.pi / 2 < a < 3 * np.pi / 2:
+            a -= np.pi
+            align = "west"
+        assert hs.get_tag(hs.OSM_NODE, nids[k], "name:autoangle") == "%.1f" % np.degrees(a), k
+        assert hs.get_tag(hs.OSM_NODE, nids[k], "name:autoalign") == align, k
