@@ -149,7 +149,7 @@ smrule_t *hs_rule_new(int type, const char *func, const char *params)
 static void set_tags(osm_obj_t *o, const char *tags)
 {
    char *buf = strdup(tags ? tags : ""), *p = buf, c, *k;
-   int n = 0;
+   int n = 1;      /* tag 0 is "generator=smrender", set by osm_*_default (libsmrender/osm_func.c) */
    while ((k = next_tok(&p, "=", &c)) != NULL && n < o->tag_cnt)
    {
       char *v = next_tok(&p, ";", &c);
@@ -170,7 +170,7 @@ static int count_tags(const char *tags)
 
 int hs_node(int64_t id, double lat, double lon, const char *tags)
 {
-   osm_node_t *n = malloc_node((short) count_tags(tags));
+   osm_node_t *n = malloc_node((short) (count_tags(tags) + 1));
    osm_node_default(n);
    n->obj.id = id; n->lat = lat; n->lon = lon;
    set_tags(&n->obj, tags);
@@ -179,7 +179,7 @@ int hs_node(int64_t id, double lat, double lon, const char *tags)
 
 int hs_way(int64_t id, const int64_t *ref, int cnt, const char *tags)
 {
-   osm_way_t *w = malloc_way((short) count_tags(tags), cnt);
+   osm_way_t *w = malloc_way((short) (count_tags(tags) + 1), cnt);
    osm_way_default(w);
    w->obj.id = id;
    memcpy(w->ref, ref, sizeof(*ref) * cnt);
