@@ -140,7 +140,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    stage = {k: 0.0 for k in ("proj_ms", "setup_ms", "bin_ms", "sort_ms", "raster_ms")}
+    stage = {k: 0.0 for k in ("proj_ms", "edges_ms", "prims_ms", "bin_ms", "raster_ms")}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -140,7 +140,8 @@ void *smr_hip_stream(void);                    /* hipStream_t of the library */
  * the library stream; smr_hip_timings() returns the last call's per-stage ms (and syncs). */
 typedef struct
 {
-   float proj_ms, setup_ms, bin_ms, sort_ms, raster_ms, caprot_ms, total_ms;
+   float proj_ms, edges_ms, prims_ms, bin_ms, raster_ms, caprot_ms, total_ms;   /* draw: edge generation, primitive set-up,
+                                                                                 binning + sort, raster */
    uint64_t n_prims, n_edges, n_tile_refs, n_tiles;
 } smr_timings_t;
 int smr_hip_set_profiling(int on);

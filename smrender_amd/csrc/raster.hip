@@ -10,13 +10,26 @@
  */
 #include "smr_dev.h"
 #include "smr_host.h"
+#include <algorithm>
 
 /* ------------------------------------------------------------------------------------ */
 /* vertex setup: px (double) -> pt -> 24.8 -> replay scale (fixed * fixed(dpi/72) >> 8)   */
 /* ------------------------------------------------------------------------------------ */
+__device__ __forceinline__ int64_t smr_find_way(const int64_t *__restrict__ way_off, int64_t n_ways, int64_t g)
+{
+   int64_t lo = 0, hi = n_ways;       /* way_off[lo] <= g < way_off[hi] */
+   while (hi - lo > 1)
+   {
+      int64_t mid = (lo + hi) >> 1;
+      if (way_off[mid] <= g) lo = mid; else hi = mid;
+   }
+   return lo;
+}
+
 __global__ void k_dev_points(const double *__restrict__ x, const double *__restrict__ y,
                              const int32_t *__restrict__ ref, int64_t n_refs, int dpi, int32_t sfix,
-                             int2 *__restrict__ pts)
+                             const int64_t *__restrict__ way_off, int64_t n_ways,
+                             int2 *__restrict__ pts, int32_t *__restrict__ refway)
 {
    int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    int64_t stride = (int64_t) gridDim.x * blockDim.x;
@@ -29,6 +42,7 @@ __global__ void k_dev_points(const double *__restrict__ x, const double *__restr
       p.x = (int32_t) (((int64_t) fx * sfix) >> 8);
       p.y = (int32_t) (((int64_t) fy * sfix) >> 8);
       pts[g] = p;
+      refway[g] = (int32_t) smr_find_way(way_off, n_ways, g);
    }
 }
 
@@ -60,50 +74,21 @@ __global__ void k_way_info(const int64_t *__restrict__ way_off, const int32_t *_
    if (f & 8) atomicOr(any_open_fill, 1u);
 }
 
-__device__ __forceinline__ int64_t smr_find_way(const int64_t *__restrict__ way_off, int64_t n_ways, int64_t g)
-{
-   int64_t lo = 0, hi = n_ways;       /* way_off[lo] <= g < way_off[hi] */
-   while (hi - lo > 1)
-   {
-      int64_t mid = (lo + hi) >> 1;
-      if (way_off[mid] <= g) lo = mid; else hi = mid;
-   }
-   return lo;
-}
-
-__global__ void k_prim_init(smr_prim_t *prims, int64_t n_prims)
-{
-   int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-   if (i >= n_prims) return;
-   smr_prim_t p;
-   p.edge_off = 0; p.edge_cnt = 0; p.color = 0;
-   p.minx = INT32_MAX; p.miny = INT32_MAX; p.maxx = INT32_MIN; p.maxy = INT32_MIN;
-   p.flags = 0; p.pad_[0] = p.pad_[1] = p.pad_[2] = 0;
-   prims[i] = p;
-}
-
-__device__ __forceinline__ void smr_bbox_add(smr_prim_t *p, int32_t x, int32_t y)
-{
-   atomicMin(&p->minx, x); atomicMax(&p->maxx, x);
-   atomicMin(&p->miny, y); atomicMax(&p->maxy, y);
-}
-
 /* fill polygon: edge g = pts[g] -> pts[g+1]; the slot of the last ref closes the polygon
  * (cairo_fill closes sub-paths implicitly) */
-__global__ void k_fill_edges(const int2 *__restrict__ pts, const int64_t *__restrict__ way_off, int64_t n_ways,
-                             int64_t n_refs, const uint8_t *__restrict__ wayflags, smr_edge_t *__restrict__ edges,
-                             smr_prim_t *__restrict__ prims)
+__global__ void k_fill_edges(const int2 *__restrict__ pts, const int64_t *__restrict__ way_off,
+                             const int32_t *__restrict__ refway, int64_t n_refs,
+                             const uint8_t *__restrict__ wayflags, smr_edge_t *__restrict__ edges)
 {
    int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    if (g >= n_refs) return;
-   int64_t w = smr_find_way(way_off, n_ways, g);
+   int64_t w = refway[g];
    smr_edge_t e; e.x1 = e.y1 = e.x2 = e.y2 = 0;
    if (wayflags[w] & 4)
    {
       int64_t a = way_off[w], b = way_off[w + 1];
       int2 p = pts[g], q = pts[g + 1 < b ? g + 1 : a];
       e.x1 = p.x; e.y1 = p.y; e.x2 = q.x; e.y2 = q.y;
-      smr_bbox_add(&prims[2 * w + 1], p.x, p.y);
    }
    edges[g] = e;
 }
@@ -135,7 +120,7 @@ __device__ __forceinline__ smr_face_t smr_face(int2 p, int32_t ddx, int32_t ddy,
    return f;
 }
 
-__device__ __forceinline__ int smr_emit_poly(const int2 *p, int n, smr_edge_t *out, smr_prim_t *prim)
+__device__ __forceinline__ int smr_emit_poly(const int2 *p, int n, smr_edge_t *out)
 {
    int64_t a = 0;
    for (int i = 0; i < n; i++)
@@ -150,7 +135,6 @@ __device__ __forceinline__ int smr_emit_poly(const int2 *p, int n, smr_edge_t *o
       int2 s = a > 0 ? p[i] : p[j], e = a > 0 ? p[j] : p[i];
       smr_edge_t ed; ed.x1 = s.x; ed.y1 = s.y; ed.x2 = e.x; ed.y2 = e.y;
       out[i] = ed;
-      smr_bbox_add(prim, p[i].x, p[i].y);
    }
    return n;
 }
@@ -161,22 +145,23 @@ __device__ __forceinline__ int smr_sgn_cmp(double dx1, double dy1, double dx2, d
    return c > 0 ? 1 : c < 0 ? -1 : 0;
 }
 
-/* mode 0: border strokes (prim 2w), widths per cairo_smr_border_width; mode 1: fill of open
- * ways drawn as a stroke of the fill width (prim 2w+1, src/smrules_cairo.c:1003-1008) */
-__global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__restrict__ way_off, int64_t n_ways,
-                               int64_t n_refs, const uint8_t *__restrict__ wayflags, int mode, int dpi,
+/* mode 0: border strokes, widths per cairo_smr_border_width; mode 1: fill of open ways drawn
+ * as a stroke of the fill width (src/smrules_cairo.c:1003-1008) */
+__global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__restrict__ way_off,
+                               const int32_t *__restrict__ refway, int64_t n_refs,
+                               const uint8_t *__restrict__ wayflags, int mode, int dpi,
                                double hw_nofill_pt, double hw_open_pt, double hw_closed_pt, double hw_fill_pt,
-                               int fill_used, smr_edge_t *__restrict__ edges, smr_prim_t *__restrict__ prims)
+                               int fill_used, smr_edge_t *__restrict__ edges)
 {
    int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    if (g >= n_refs) return;
-   int64_t w = smr_find_way(way_off, n_ways, g);
-   smr_edge_t *out = edges + (size_t) SMR_SLOTS * g;
-   smr_edge_t z; z.x1 = z.y1 = z.x2 = z.y2 = 0;
+   int64_t w = refway[g];
    /* slots 0..3: join wedge at the segment's start point, slots 4..7: the segment's quad;
     * every 4 aligned slots hold one closed convex piece (or nothing) */
+   smr_edge_t loc[SMR_SLOTS];
+   smr_edge_t z; z.x1 = z.y1 = z.x2 = z.y2 = 0;
 #pragma unroll
-   for (int i = 0; i < SMR_SLOTS; i++) out[i] = z;
+   for (int i = 0; i < SMR_SLOTS; i++) loc[i] = z;
    uint8_t wf = wayflags[w];
    int64_t a = way_off[w], b = way_off[w + 1];
    bool on = mode == 0 ? (wf & 2) != 0 : (wf & 8) != 0;
@@ -187,7 +172,6 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
       {
          double hw = mode == 1 ? hw_fill_pt : (!fill_used ? hw_nofill_pt : ((wf & 1) ? hw_closed_pt : hw_open_pt));
          double s = (double) dpi / 72;
-         smr_prim_t *prim = &prims[2 * w + mode];
          int32_t ddx = p2.x - p1.x, ddy = p2.y - p1.y;
          smr_face_t start = smr_face(p1, ddx, ddy, hw, s);
          /* previous non-degenerate segment of the same way ends at p1 */
@@ -224,51 +208,25 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
                   if (smr_sgn_cmp(fdx1, fdy1, mdx, mdy) != smr_sgn_cmp(fdx2, fdy2, mdx, mdy))
                   {
                      int2 q[4] = { p1, inpt, make_int2((int32_t) rint(mx * 256.0), (int32_t) rint(my * 256.0)), outpt };
-                     smr_emit_poly(q, 4, out, prim);
+                     smr_emit_poly(q, 4, loc);
                      mitered = true;
                   }
                }
                if (!mitered)
                {
                   int2 q[3] = { p1, inpt, outpt };
-                  smr_emit_poly(q, 3, out, prim);
+                  smr_emit_poly(q, 3, loc);
                }
             }
          }
          int2 q[4] = { start.ccw, make_int2(start.ccw.x + ddx, start.ccw.y + ddy),
                        make_int2(start.cw.x + ddx, start.cw.y + ddy), start.cw };
-         smr_emit_poly(q, 4, out + 4, prim);
+         smr_emit_poly(q, 4, loc + 4);
       }
    }
-}
-
-/* finalise the primitive table: edge ranges, colours, validity against the full chart, and
- * the index of the first primitive that draws at all (it meets a still-clear group layer,
- * which libcairo composites with SOURCE semantics) */
-__global__ void k_prim_finish(smr_prim_t *__restrict__ prims, int64_t n_ways, const int64_t *__restrict__ way_off,
-                              const uint8_t *__restrict__ wayflags, uint64_t off_border, uint64_t off_fill,
-                              uint64_t off_openfill, uint32_t border_pix, uint32_t fill_pix,
-                              const uint32_t *__restrict__ way_border_pix, const uint32_t *__restrict__ way_fill_pix,
-                              int W, int H, uint32_t *__restrict__ first_prim)
-{
-   int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-   if (w >= n_ways) return;
-   uint8_t wf = wayflags[w];
-   int64_t a = way_off[w], n = way_off[w + 1] - a;
-   for (int k = 0; k < 2; k++)
-   {
-      smr_prim_t *p = &prims[2 * w + k];
-      bool on = k == 0 ? (wf & 2) != 0 : (wf & 12) != 0;
-      if (!on || p->minx > p->maxx) { p->flags = 0; continue; }
-      if (k == 0) { p->edge_off = off_border + (uint64_t) SMR_SLOTS * a; p->edge_cnt = (uint32_t) (SMR_SLOTS * n); }
-      else if (wf & 4) { p->edge_off = off_fill + (uint64_t) a; p->edge_cnt = (uint32_t) n; }
-      else { p->edge_off = off_openfill + (uint64_t) SMR_SLOTS * a; p->edge_cnt = (uint32_t) (SMR_SLOTS * n); }
-      p->color = k == 0 ? (way_border_pix ? way_border_pix[w] : border_pix) : (way_fill_pix ? way_fill_pix[w] : fill_pix);
-      int c0 = p->minx >> 8, c1 = p->maxx >> 8, r0 = p->miny >> 8, r1 = p->maxy >> 8;
-      if (c1 < 0 || r1 < 0 || c0 >= W || r0 >= H) { p->flags = 0; continue; }
-      p->flags = SMR_PF_VALID | ((k == 0 || (wf & 8)) ? SMR_PF_PIECES : 0u);
-      atomicMin(first_prim, (uint32_t) (2 * w + k));
-   }
+   smr_edge_t *out = edges + (size_t) SMR_SLOTS * g;
+#pragma unroll
+   for (int i = 0; i < SMR_SLOTS; i++) out[i] = loc[i];
 }
 
 /* 0xTTRRGGBB -> premultiplied source pixel, per way (color=%key rules) */
@@ -284,12 +242,307 @@ __global__ void k_color_pixels(const uint32_t *__restrict__ col, int64_t n, uint
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* binning: primitive bbox -> 64x4 tiles of this band                                      */
+/* primitive setup: ONE WAVEFRONT per primitive.  Reads the primitive's edge slots once
+ * (coalesced), and leaves
+ *   - its items (64-slot chunks) with their binning boxes,
+ *   - its bbox, validity against the full chart, colour,
+ *   - its ROW MASK: one bit per chart row, set when libcairo's tor converter sub-samples the
+ *     row (an edge starts or ends inside it, or active edges cross inside it), clear when it
+ *     takes the exact full-row path.  The decision is global per (primitive, row), so it is
+ *     made here once instead of by every tile.
+ * Item ids are a closed form of (way, kind, chunk): base_w = (way_off[w] >> 3) + w is strictly
+ * increasing in w and leaves room for ceil(n/8) chunks per kind, so no scan is needed and ids
+ * ascend in drawing order (way, border before fill, chunk).                               */
 /* ------------------------------------------------------------------------------------ */
-__device__ __forceinline__ bool smr_prim_tiles(const smr_prim_t &p, int W, int band_y0, int band_h,
+#define SMR_LONGCAP 128      /* edges spanning a whole pixel row, kept in LDS per primitive */
+#define SMR_ACTCAP 16        /* active edges per vertex-free row in the lane-per-row analysis */
+
+struct setup_args_t
+{
+   const smr_edge_t *edges;
+   const int64_t *way_off;
+   const uint8_t *wayflags;
+   int64_t n_ways;
+   uint64_t off_border, off_fill, off_open;
+   uint32_t border_pix, fill_pix;
+   const uint32_t *way_border_pix, *way_fill_pix;
+   int W, H;
+   smr_prim_t *prims;
+   smr_item_t *items;
+   uint32_t *mask;
+   uint32_t mask_cap;         /* words */
+   uint32_t *small;           /* [1] first_prim [2] status [4] mask words demanded */
+};
+
+struct setup_lds_t
+{
+   int l_p1x[SMR_LONGCAP], l_p1y[SMR_LONGCAP], l_dxs[SMR_LONGCAP], l_D[SMR_LONGCAP], l_ytop[SMR_LONGCAP], l_ybot[SMR_LONGCAP];
+   int act0[64][SMR_ACTCAP + 1], act1[64][SMR_ACTCAP + 1];
+   uint32_t nlong;
+};
+
+__device__ __forceinline__ int smr_wave_min(int v) { for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d)); return v; }
+__device__ __forceinline__ int smr_wave_max(int v) { for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d)); return v; }
+
+/* mark the rows in which edge o starts or ends, and remember o if it spans a whole row */
+__device__ __forceinline__ void smr_setup_edge(const smr_oedge_t &o, int row0, int nrows, uint32_t *lmask, setup_lds_t &L)
+{
+   if (o.dir == 0) return;
+   if (o.ytop % SMR_GRID_Y != 0)
+   {
+      int r = o.ytop / SMR_GRID_Y - row0;             /* ytop >= 0 whenever the row is on the chart */
+      if (o.ytop >= 0 && r >= 0 && r < nrows) atomicOr(&lmask[r >> 5], 1u << (r & 31));
+   }
+   if (o.ybot % SMR_GRID_Y != 0)
+   {
+      int r = (o.ybot > 0 ? (o.ybot - 1) / SMR_GRID_Y : -1) - row0;
+      if (o.ybot > 0 && r >= 0 && r < nrows) atomicOr(&lmask[r >> 5], 1u << (r & 31));
+   }
+   int first_full = o.ytop >= 0 ? (o.ytop + SMR_GRID_Y - 1) / SMR_GRID_Y : -((-o.ytop) / SMR_GRID_Y);   /* ceil(ytop/15) */
+   if ((first_full + 1) * SMR_GRID_Y <= o.ybot)
+   {
+      uint32_t k = atomicAdd(&L.nlong, 1u);
+      if (k < SMR_LONGCAP)
+      {
+         L.l_p1x[k] = o.p1x; L.l_p1y[k] = o.p1y; L.l_dxs[k] = o.dxs; L.l_D[k] = o.D; L.l_ytop[k] = o.ytop; L.l_ybot[k] = o.ybot;
+      }
+   }
+}
+
+__global__ __launch_bounds__(64) void k_prim_setup(setup_args_t A)
+{
+   extern __shared__ uint32_t lmask[];             /* [(H + 31) / 32 + 1] */
+   __shared__ setup_lds_t L;
+   const int64_t p = blockIdx.x;
+   const int64_t w = p >> 1;
+   const int kind = (int) (p & 1);
+   const int lane = threadIdx.x;
+   const uint8_t wf = A.wayflags[w];
+   const int64_t a = A.way_off[w], b = A.way_off[w + 1], n = b - a;
+   const int64_t base = (a >> 3) + w, span = (b >> 3) + (w + 1) - base;
+   const int64_t item0 = 2 * base + (kind ? span : 0);
+   const bool on = kind == 0 ? (wf & 2) != 0 : (wf & 12) != 0;
+   const bool pieces = kind == 0 || (wf & 8);
+   smr_prim_t P;
+   P.edge_off = 0; P.edge_cnt = 0; P.color = 0; P.minx = P.miny = INT32_MAX; P.maxx = P.maxy = INT32_MIN;
+   P.flags = 0; P.mask_off = 0; P.row0 = 0; P.nrows = 0;
+   int64_t nitems = 0;
+   if (on)
+   {
+      if (kind == 0) { P.edge_off = A.off_border + (uint64_t) SMR_SLOTS * a; P.edge_cnt = (uint32_t) (SMR_SLOTS * n); }
+      else if (wf & 4) { P.edge_off = A.off_fill + (uint64_t) a; P.edge_cnt = (uint32_t) n; }
+      else { P.edge_off = A.off_open + (uint64_t) SMR_SLOTS * a; P.edge_cnt = (uint32_t) (SMR_SLOTS * n); }
+      P.color = kind == 0 ? (A.way_border_pix ? A.way_border_pix[w] : A.border_pix) : (A.way_fill_pix ? A.way_fill_pix[w] : A.fill_pix);
+      nitems = ((int64_t) P.edge_cnt + 63) >> 6;
+   }
+   /* every slot of this kind's id range is written: unused ones as invalid */
+   for (int64_t i = nitems + lane; i < span; i += 64)
+   {
+      smr_item_t z; z.edge_off = 0; z.prim = (uint32_t) p; z.cnt_flags = 0; z.color = 0; z.minx = z.miny = z.maxx = z.maxy = 0;
+      A.items[item0 + i] = z;
+   }
+   if (!on) { if (lane == 0) A.prims[p] = P; return; }
+   const smr_edge_t *E = A.edges + P.edge_off;
+   const uint32_t item_flags = SMR_PF_VALID | (pieces ? SMR_PF_PIECES : 0u) | (nitems > 1 ? SMR_PF_MULTI : 0u);
+
+   /* ---- pass A: items + bbox ---- */
+   smr_edge_t e0; e0.x1 = e0.y1 = e0.x2 = e0.y2 = 0;
+   for (int64_t k = 0; k < nitems; k++)
+   {
+      uint32_t idx = (uint32_t) (k * 64) + lane;
+      smr_edge_t e; e.x1 = e.y1 = e.x2 = e.y2 = 0;
+      if (idx < P.edge_cnt) e = E[idx];
+      if (k == 0) e0 = e;
+      bool has = idx < P.edge_cnt && (e.x1 != e.x2 || e.y1 != e.y2 || !pieces);
+      /* fill polygons: every vertex counts (one per slot); pieces: empty slots are all zero */
+      if (pieces && e.x1 == 0 && e.y1 == 0 && e.x2 == 0 && e.y2 == 0) has = false;
+      int mnx = has ? min(e.x1, e.x2) : INT32_MAX, mxx = has ? max(e.x1, e.x2) : INT32_MIN;
+      int mny = has ? min(e.y1, e.y2) : INT32_MAX, mxy = has ? max(e.y1, e.y2) : INT32_MIN;
+      /* the exact full-row path evaluates an edge at the row boundaries, up to half a sub-row beyond
+       * its end points: the BINNING box of an edge that can span a whole row grows by that reach
+       * (the primitive's own box, which clips the coverage like libcairo's extents, does not) */
+      int ext = 0;
+      if (has && mxy - mny >= 239) ext = (int) (((int64_t) (mxx - mnx) * 9) / (mxy - mny)) + 2;
+      int bmn = smr_wave_min(has ? mnx - ext : INT32_MAX), bmx = smr_wave_max(has ? mxx + ext : INT32_MIN);
+      mnx = smr_wave_min(mnx); mny = smr_wave_min(mny); mxx = smr_wave_max(mxx); mxy = smr_wave_max(mxy);
+      P.minx = min(P.minx, mnx); P.miny = min(P.miny, mny); P.maxx = max(P.maxx, mxx); P.maxy = max(P.maxy, mxy);
+      if (lane == 0)
+      {
+         smr_item_t it;
+         it.edge_off = (uint32_t) (P.edge_off + (uint64_t) k * 64);
+         it.prim = (uint32_t) p;
+         uint32_t cnt = min(64u, P.edge_cnt - (uint32_t) (k * 64));
+         it.cnt_flags = mnx <= mxx ? (cnt | (item_flags << 8)) : 0;
+         it.color = P.color;
+         it.minx = bmn; it.miny = mny; it.maxx = bmx; it.maxy = mxy;
+         A.items[item0 + k] = it;
+      }
+   }
+   bool valid = P.minx <= P.maxx;
+   if (valid)
+   {
+      int c0 = P.minx >> 8, c1 = P.maxx >> 8, r0 = P.miny >> 8, r1 = P.maxy >> 8;
+      if (c1 < 0 || r1 < 0 || c0 >= A.W || r0 >= A.H) valid = false;
+   }
+   /* a primitive off the chart needs no flag in its items: their boxes are off the chart too */
+   if (!valid) { if (lane == 0) A.prims[p] = P; return; }
+   P.flags = item_flags;
+   P.row0 = max(0, P.miny >> 8);
+   P.nrows = min(A.H - 1, P.maxy >> 8) - P.row0 + 1;
+   const uint32_t nwords = ((uint32_t) P.nrows + 31u) >> 5;
+   /* fill chunks are binned up to the primitive's right edge: edges left of a tile carry winding into it */
+   if (!pieces && nitems > 1)
+      for (int64_t i = lane; i < nitems; i += 64) A.items[item0 + i].maxx = P.maxx;
+
+   /* ---- pass B: row mask ---- */
+   for (uint32_t i = lane; i < nwords; i += 64) lmask[i] = 0;
+   if (lane == 0) L.nlong = 0;
+   __syncthreads();
+   if (nitems == 1)
+   {
+      if ((uint32_t) lane < P.edge_cnt) smr_setup_edge(smr_orient(e0), P.row0, P.nrows, lmask, L);
+   }
+   else
+   {
+      for (uint32_t idx = lane; idx < P.edge_cnt; idx += 64) smr_setup_edge(smr_orient(E[idx]), P.row0, P.nrows, lmask, L);
+   }
+   __syncthreads();
+   const uint32_t nlong = L.nlong;
+   /* one vertex-free row decided by the whole wavefront: lanes walk the candidate edges (the LDS list
+    * of row-spanning edges, or every edge slot when that list overflowed), the active ones' cells at
+    * the top and the bottom of the row go to LDS, then every pair is compared */
+   auto row_by_wave = [&](int r)
+   {
+      const int rs0 = (P.row0 + r) * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
+      int *f0 = &L.act0[0][0], *f1 = &L.act1[0][0];
+      uint32_t cnt = 0;
+      const uint32_t ncand = nlong <= SMR_LONGCAP ? nlong : P.edge_cnt;
+      __syncthreads();
+      for (uint32_t base_i = 0; base_i < ncand; base_i += 64)
+      {
+         uint32_t idx = base_i + lane;
+         int32_t p1x = 0, p1y = 0, dxs = 0, D = 1, ytop = 0, ybot = 0;
+         bool have = false;
+         if (idx < ncand)
+         {
+            if (nlong <= SMR_LONGCAP)
+            {
+               p1x = L.l_p1x[idx]; p1y = L.l_p1y[idx]; dxs = L.l_dxs[idx]; D = L.l_D[idx]; ytop = L.l_ytop[idx]; ybot = L.l_ybot[idx];
+               have = true;
+            }
+            else
+            {
+               smr_oedge_t o = smr_orient(E[idx]);
+               p1x = o.p1x; p1y = o.p1y; dxs = o.dxs; D = o.D; ytop = o.ytop; ybot = o.ybot;
+               have = o.dir != 0;
+            }
+         }
+         bool act = have && ytop <= rs0 && ybot >= rs1;
+         unsigned long long am = __ballot(act);
+         if (!am) continue;
+         uint32_t pos = cnt + __popcll(am & ((1ull << lane) - 1ull));
+         if (act && pos < SMR_ROWCAP)
+         {
+            int64_t q; int32_t rem;
+            smr_edge_x(p1x, p1y, dxs, D, rs0, q, rem);
+            f0[pos] = smr_cell(q, rem, D, dxs);
+            smr_edge_x(p1x, p1y, dxs, D, rs1, q, rem);
+            f1[pos] = smr_cell(q, rem, D, dxs);
+         }
+         cnt += __popcll(am);
+      }
+      __syncthreads();
+      bool viol = false;
+      if (cnt > SMR_ROWCAP) { if (lane == 0) atomicOr(&A.small[2], SMR_ST_ROWCAP); viol = true; }
+      else if ((uint32_t) lane < cnt)
+      {
+         int a0 = f0[lane], a1 = f1[lane];
+         for (uint32_t j = 0; j < cnt; j++) if (a0 < f0[j] && a1 > f1[j]) viol = true;
+      }
+      if (__ballot(viol) && lane == 0) lmask[r >> 5] |= 1u << (r & 31);
+      __syncthreads();
+   };
+   if (nlong > SMR_LONGCAP)
+   {
+      /* more row-spanning edges than the LDS list holds (rare: such primitives have a vertex in
+       * almost every row) */
+      for (int r = 0; r < P.nrows; r++)
+         if (!((lmask[r >> 5] >> (r & 31)) & 1u)) row_by_wave(r);
+   }
+   else if (nlong > 0)
+   {
+      /* lane = row: every vertex-free row collects the edges spanning it and checks that their order
+       * at the top of the row is their order at the bottom; rows with more than SMR_ACTCAP active
+       * edges are left to row_by_wave */
+      for (int rb = 0; rb < P.nrows; rb += 64)
+      {
+         const int r = rb + lane;
+         const bool mine = r < P.nrows && !((lmask[r >> 5] >> (r & 31)) & 1u);
+         const int rs0 = (P.row0 + r) * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
+         int cnt = 0;
+         bool over = false;
+         if (!__ballot(mine)) continue;
+         for (uint32_t i = 0; i < nlong; i++)
+         {
+            const int ytop = L.l_ytop[i], ybot = L.l_ybot[i];
+            if (mine && !over && ytop <= rs0 && ybot >= rs1)
+            {
+               if (cnt < SMR_ACTCAP)
+               {
+                  int64_t q; int32_t rem;
+                  const int32_t p1x = L.l_p1x[i], p1y = L.l_p1y[i], dxs = L.l_dxs[i], D = L.l_D[i];
+                  smr_edge_x(p1x, p1y, dxs, D, rs0, q, rem);
+                  L.act0[lane][cnt] = smr_cell(q, rem, D, dxs);
+                  smr_edge_x(p1x, p1y, dxs, D, rs1, q, rem);
+                  L.act1[lane][cnt] = smr_cell(q, rem, D, dxs);
+                  cnt++;
+               }
+               else over = true;
+            }
+         }
+         bool viol = false;
+         if (!over)
+            for (int i = 0; i < cnt; i++)
+            {
+               int a0 = L.act0[lane][i], a1 = L.act1[lane][i];
+               for (int j = 0; j < cnt; j++) if (a0 < L.act0[lane][j] && a1 > L.act1[lane][j]) viol = true;
+            }
+         if (mine && viol) atomicOr(&lmask[r >> 5], 1u << (r & 31));
+         unsigned long long om = __ballot(over);
+         while (om)
+         {
+            int j = __ffsll((long long) om) - 1;
+            om &= om - 1;
+            row_by_wave(rb + j);
+         }
+      }
+   }
+   __syncthreads();
+   uint32_t moff = 0;
+   if (lane == 0) moff = atomicAdd(&A.small[4], nwords);
+   moff = __shfl(moff, 0);
+   if (moff + nwords > A.mask_cap)
+   {
+      /* the host sees the demand in small[4], enlarges the arena and runs the set-up again */
+      if (lane == 0) { atomicOr(&A.small[2], SMR_ST_MASK_ARENA); P.flags = 0; A.prims[p] = P; }
+      return;
+   }
+   for (uint32_t i = lane; i < nwords; i += 64) A.mask[moff + i] = lmask[i];
+   P.mask_off = moff;
+   if (lane == 0)
+   {
+      A.prims[p] = P;
+      atomicMin(&A.small[1], (uint32_t) p);
+   }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* binning: item box -> 64x4 tiles of this band                                            */
+/* ------------------------------------------------------------------------------------ */
+__device__ __forceinline__ bool smr_item_tiles(const smr_item_t &p, int W, int band_y0, int band_h,
                                                int &tx0, int &tx1, int &ty0, int &ty1)
 {
-   if (!(p.flags & SMR_PF_VALID)) return false;
+   if (!((p.cnt_flags >> 8) & SMR_PF_VALID)) return false;
    int c0 = p.minx >> 8, c1 = p.maxx >> 8, r0 = (p.miny >> 8) - band_y0, r1 = (p.maxy >> 8) - band_y0;
    if (c1 < 0 || r1 < 0 || c0 >= W || r0 >= band_h) return false;
    if (c0 < 0) c0 = 0;
@@ -301,14 +554,14 @@ __device__ __forceinline__ bool smr_prim_tiles(const smr_prim_t &p, int W, int b
 }
 
 template <bool SCATTER>
-__global__ void k_bin(const smr_prim_t *__restrict__ prims, int64_t n_prims, int W, int band_y0, int band_h, int TX,
+__global__ void k_bin(const smr_item_t *__restrict__ items, int64_t n_items, int W, int band_y0, int band_h, int TX,
                       uint32_t *__restrict__ counts, const uint32_t *__restrict__ tile_off, uint32_t *__restrict__ entries)
 {
    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-   if (i >= n_prims) return;
-   smr_prim_t p = prims[i];
+   if (i >= n_items) return;
+   smr_item_t p = items[i];
    int tx0, tx1, ty0, ty1;
-   if (!smr_prim_tiles(p, W, band_y0, band_h, tx0, tx1, ty0, ty1)) return;
+   if (!smr_item_tiles(p, W, band_y0, band_h, tx0, tx1, ty0, ty1)) return;
    for (int ty = ty0; ty <= ty1; ty++)
       for (int tx = tx0; tx <= tx1; tx++)
       {
@@ -451,7 +704,9 @@ __global__ __launch_bounds__(64) void k_tile_sort(const uint32_t *__restrict__ t
 struct raster_args_t
 {
    const smr_prim_t *prims;
+   const smr_item_t *items;
    const smr_edge_t *edges;
+   const uint32_t *mask;
    const uint32_t *tile_off;
    const uint32_t *entries;
    const uint32_t *first_prim;
@@ -560,125 +815,253 @@ __global__ __launch_bounds__(64) void k_raster(raster_args_t A)
    uint32_t layer[SMR_TH] = { 0, 0, 0, 0 };
    const int my_row = lane / SMR_GRID_Y;               /* sub-row lane -> pixel row (lanes 60..63 idle) */
    const int my_ys = ysbase + lane;
+   uint16_t *bk = L.bucket[lane < SMR_NSUB ? lane : 0];
 
-   for (uint32_t ei = beg; ei < end; ei++)
-   {
-      const uint32_t pi = A.entries[ei];
-      const smr_prim_t P = A.prims[pi];
-      const smr_edge_t *E = A.edges + P.edge_off;
-      const uint32_t mask = (P.flags & SMR_PF_EVENODD) ? 1u : ~0u;
+   /* state of the primitive being accumulated */
+   uint32_t cur = 0xffffffffu, cur_flags = 0, cur_color = 0;
+   uint32_t partial = 0, rowcnt[SMR_TH] = { 0, 0, 0, 0 };
+   int cnt = 0, lw = 0;
+   bool ovf = false, touched = false;
 
 #pragma unroll
-      for (int r = 0; r < SMR_TH; r++) { L.cover[r][lane] = 0; L.uarea[r][lane] = 0; }
-      if (lane < SMR_TH) L.left[lane] = 0;
+   for (int r = 0; r < SMR_TH; r++) { L.cover[r][lane] = 0; L.uarea[r][lane] = 0; }
+   if (lane < SMR_TH) L.left[lane] = 0;
+   __syncthreads();
 
-      /* ---- pass 1: per pixel row, who is active and does any edge start/end inside it ---- */
-      uint32_t partial = 0, rowcnt[SMR_TH] = { 0, 0, 0, 0 };
-      bool any = false;
-      for (uint32_t base = 0; base < P.edge_cnt; base += 64)
+   for (uint32_t ei = beg; ei <= end; ei++)
+   {
+      smr_item_t it;
+      it.prim = 0xffffffffu; it.cnt_flags = 0; it.edge_off = 0; it.color = 0;
+      if (ei < end) it = A.items[A.entries[ei]];
+
+      /* ================= flush: the previous primitive is complete ================= */
+      if (it.prim != cur && cur != 0xffffffffu && touched)
       {
-         uint32_t idx = base + lane;
-         smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0;
-         if (idx < P.edge_cnt) o = smr_orient(E[idx]);
+         const bool pieces = (cur_flags & SMR_PF_PIECES) != 0;
+         const uint32_t mask = (cur_flags & SMR_PF_EVENODD) ? 1u : ~0u;
+         const smr_prim_t P = A.prims[cur];
+         const smr_edge_t *E = A.edges;
+
+         /* ---- sub-sampled rows: crossings -> spans -> cells ---- */
+         if (__ballot(ovf) && lane == 0) atomicOr(A.status, SMR_ST_BUCKET_OVERFLOW);
+         const bool mine = lane < SMR_NSUB && ((partial >> my_row) & 1u);
+         auto add_span = [&](int x1, int x2)
+         {
+            if (x1 == x2) return;
+            int ix1 = x1 >> 8, ix2 = x2 >> 8, fx1 = x1 & 255, fx2 = x2 & 255;
+            if (ix1 != ix2)
+            {
+               smr_cell_add(L, my_row, ix1, 1, 2 * fx1);
+               smr_cell_add(L, my_row, ix2, -1, -2 * fx2);
+            }
+            else smr_cell_add(L, my_row, ix1, 0, 2 * (fx1 - fx2));
+         };
+         if (mine && pieces)
+         {
+            for (int i = 0; i < cnt; i++) add_span(bk[2 * i], bk[2 * i + 1]);
+         }
+         else if (mine)
+         {
+            for (int i = 1; i < cnt; i++)
+            {
+               uint16_t v = bk[i];
+               int k = i - 1;
+               while (k >= 0 && (bk[k] >> 1) > (v >> 1)) { bk[k + 1] = bk[k]; k--; }
+               bk[k + 1] = v;
+            }
+            int winding = lw;
+            int xstart = (((uint32_t) winding & mask) != 0) ? 0 : -1;
+            for (int i = 0; i < cnt; i++)
+            {
+               int xend = bk[i] >> 1;
+               winding += (bk[i] & 1) ? 1 : -1;
+               if (((uint32_t) winding & mask) == 0)
+               {
+                  if (i + 1 < cnt && (bk[i + 1] >> 1) == xend) continue;
+                  if (xstart >= 0) add_span(xstart, xend);
+                  xstart = -1;
+               }
+               else if (xstart < 0) xstart = xend;
+            }
+            if (xstart >= 0) add_span(xstart, SMR_TW * 256);
+         }
+
+         /* ---- rows that take libcairo's exact full-row path ---- */
+         uint32_t fullrows = 0;
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++) if (!((partial >> r) & 1u) && rowcnt[r] > 0) fullrows |= 1u << r;
+         if (fullrows && pieces && (cur_flags & SMR_PF_MULTI))
+         {
+            /* a stroke's pieces left of this tile carry winding into it and were not binned here:
+             * collect the row's active edges from the whole primitive (rare: rows free of vertices
+             * in a multi-item stroke) */
+#pragma unroll
+            for (int r = 0; r < SMR_TH; r++) rowcnt[r] = 0;
+            for (uint32_t base = 0; base < P.edge_cnt; base += 64)
+            {
+               uint32_t idx = base + lane;
+               smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0;
+               if (idx < P.edge_cnt) o = smr_orient(E[P.edge_off + idx]);
+#pragma unroll
+               for (int r = 0; r < SMR_TH; r++)
+               {
+                  if (!((fullrows >> r) & 1u)) continue;
+                  int rs0 = ysbase + r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
+                  bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs1;
+                  unsigned long long am = __ballot(act);
+                  if (am)
+                  {
+                     uint32_t pos = rowcnt[r] + __popcll(am & lt_mask);
+                     if (act && pos < SMR_ROWCAP) L.rowlist[r][pos] = (uint32_t) (P.edge_off + idx);
+                     rowcnt[r] += __popcll(am);
+                  }
+               }
+            }
+         }
+         __syncthreads();
+         for (int r = 0; r < SMR_TH; r++)
+         {
+            if (!((fullrows >> r) & 1u)) continue;
+            uint32_t n = rowcnt[r];
+            if (n > SMR_ROWCAP) { if (lane == 0) atomicOr(A.status, SMR_ST_ROWCAP); continue; }
+            const int rs0 = ysbase + r * SMR_GRID_Y;
+            int64_t q0 = 0, q1 = 0; int32_t r0 = 0, r1 = 0, c0 = 0, c1 = 0, dxs = 0, D = 1, dir = 0;
+            const bool on = (uint32_t) lane < n;
+            if (on)
+            {
+               smr_oedge_t o = smr_orient(E[L.rowlist[r][lane]]);
+               dxs = o.dxs; D = o.D; dir = o.dir;
+               smr_edge_x(o.p1x, o.p1y, o.dxs, o.D, rs0, q0, r0);
+               smr_edge_x(o.p1x, o.p1y, o.dxs, o.D, rs0 + SMR_GRID_Y, q1, r1);
+               c0 = smr_cell(q0, r0, D, dxs); c1 = smr_cell(q1, r1, D, dxs);
+            }
+            /* rank sort by (cell, next cell) */
+            unsigned long long key = ((unsigned long long) (uint32_t) (c0 + 0x40000000) << 32) | (uint32_t) (c1 + 0x40000000);
+            L.key[lane] = key;
+            __syncthreads();
+            int rank = 0;
+            for (uint32_t j = 0; j < n; j++)
+            {
+               unsigned long long kj = L.key[j];
+               rank += (kj < key || (kj == key && j < (uint32_t) lane)) ? 1 : 0;
+            }
+            if (on) L.perm[rank] = lane;
+            __syncthreads();
+            int src = on ? L.perm[lane] : lane;
+            q0 = __shfl(q0, src); q1 = __shfl(q1, src);
+            r0 = __shfl(r0, src); r1 = __shfl(r1, src); c0 = __shfl(c0, src); c1 = __shfl(c1, src);
+            dxs = __shfl(dxs, src); D = __shfl(D, src); dir = __shfl(dir, src);
+            int c0n = __shfl_down(c0, 1);
+            /* winding prefix */
+            int wsum = on ? dir : 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(wsum, d); if (lane >= d) wsum += t; }
+            bool last = (uint32_t) lane + 1 == n;
+            bool is_end = on && ((((uint32_t) wsum & mask) == 0 && (last || c0n != c0)) || last);
+            int prev_end = __shfl_up((int) is_end, 1);
+            bool is_start = on && (lane == 0 || prev_end);
+            if (is_start) smr_render_edge(L, r, X0, dxs, D, q0, r0, q1, r1, +1);
+            else if (is_end) smr_render_edge(L, r, X0, dxs, D, q0, r0, q1, r1, -1);
+            __syncthreads();
+         }
+         __syncthreads();
+
+         /* ---- cells -> alpha -> ordered blend into the group layer; lane = column ---- */
+         const uint32_t spix = cur_color;
+         const bool lerp = (spix >> 24) == 255u || cur == first_prim;
+         /* libcairo composites inside the primitive's pixel extents only */
+         const int pxc = tx * SMR_TW + lane;
+         const bool col_in = pxc >= (P.minx >> 8) && pxc <= (P.maxx >> 8);
 #pragma unroll
          for (int r = 0; r < SMR_TH; r++)
          {
+            int c = L.cover[r][lane];
+            int ua = L.uarea[r][lane];
+            L.cover[r][lane] = 0; L.uarea[r][lane] = 0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(c, d); if (lane >= d) c += t; }
+            c += L.left[r];
+            int area = c * 512 - ua;
+            int a = (area + (area << 4) + 256) >> 9;
+            a = a < 0 ? 0 : a > 255 ? 255 : a;
+            if (!col_in || row0 + r < (P.miny >> 8) || row0 + r > (P.maxy >> 8)) a = 0;
+            if (a) layer[r] = lerp ? smr_blend_lerp(spix, (uint32_t) a, layer[r]) : smr_blend_over_mask(spix, (uint32_t) a, layer[r]);
+         }
+         __syncthreads();
+         if (lane < SMR_TH) L.left[lane] = 0;
+         __syncthreads();
+      }
+      if (ei >= end) break;
+
+      /* ================= a new primitive begins ================= */
+      if (it.prim != cur)
+      {
+         cur = it.prim; cur_flags = it.cnt_flags >> 8; cur_color = it.color;
+         cnt = 0; lw = 0; ovf = false; touched = false;
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++) rowcnt[r] = 0;
+         /* the tile's 4 bits of the primitive's row mask; rows outside the mask hold no edge */
+         const smr_prim_t *Pp = &A.prims[cur];
+         const uint32_t moff = Pp->mask_off;
+         const int prow0 = Pp->row0, pn = Pp->nrows;
+         partial = 0;
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++)
+         {
+            int rr = row0 + r - prow0;
+            uint32_t bit = 1;
+            if (rr >= 0 && rr < pn) bit = (A.mask[moff + ((uint32_t) rr >> 5)] >> (rr & 31)) & 1u;
+            partial |= bit << r;
+         }
+      }
+
+      /* ================= one item: up to 64 edge slots, one per lane ================= */
+      const uint32_t icnt = it.cnt_flags & 0xffu;
+      const bool pieces = (cur_flags & SMR_PF_PIECES) != 0;
+      smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0; o.p1x = o.p1y = o.dxs = 0; o.D = 1;
+      if ((uint32_t) lane < icnt) o = smr_orient(A.edges[(size_t) it.edge_off + lane]);
+      const int32_t eminx = o.p1x + (o.dxs < 0 ? o.dxs : 0), emaxx = o.p1x + (o.dxs > 0 ? o.dxs : 0);
+      const bool inband = o.dir != 0 && o.ytop < ysbase + SMR_NSUB && o.ybot > ysbase && eminx < X1;
+
+      /* full rows: remember who spans them */
+      if (~partial & 0xfu)
+      {
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++)
+         {
+            if ((partial >> r) & 1u) continue;
             int rs0 = ysbase + r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
-            bool act = o.dir != 0 && o.ytop < rs1 && o.ybot > rs0;
-            bool part = act && (o.ytop > rs0 || o.ybot < rs1);
-            unsigned long long am = __ballot(act), pm = __ballot(part);
-            if (pm) partial |= 1u << r;
+            bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs1;
+            unsigned long long am = __ballot(act);
             if (am)
             {
-               any = true;
+               touched = true;
                uint32_t pos = rowcnt[r] + __popcll(am & lt_mask);
-               if (act && pos < SMR_ROWCAP) L.rowlist[r][pos] = idx;
+               if (act && pos < SMR_ROWCAP) L.rowlist[r][pos] = it.edge_off + lane;
                rowcnt[r] += __popcll(am);
             }
          }
       }
-      if (!any) continue;
-      __syncthreads();
 
-      /* ---- pass 1b: rows that may take libcairo's exact full-row path ---- */
-      for (int r = 0; r < SMR_TH; r++)
-      {
-         if ((partial >> r) & 1u) continue;
-         uint32_t cnt = rowcnt[r];
-         if (cnt == 0) continue;
-         if (cnt > SMR_ROWCAP) { partial |= 1u << r; if (lane == 0) atomicOr(A.status, SMR_ST_ROWCAP); continue; }
-         const int rs0 = ysbase + r * SMR_GRID_Y;
-         int64_t q0 = 0, q1 = 0; int32_t r0 = 0, r1 = 0, c0 = 0, c1 = 0, dxs = 0, D = 1, dir = 0;
-         const bool on = (uint32_t) lane < cnt;
-         if (on)
-         {
-            smr_oedge_t o = smr_orient(E[L.rowlist[r][lane]]);
-            dxs = o.dxs; D = o.D; dir = o.dir;
-            smr_edge_x(o.p1x, o.p1y, o.dxs, o.D, rs0, q0, r0);
-            smr_edge_x(o.p1x, o.p1y, o.dxs, o.D, rs0 + SMR_GRID_Y, q1, r1);
-            c0 = smr_cell(q0, r0, D, dxs); c1 = smr_cell(q1, r1, D, dxs);
-         }
-         /* rank sort by (cell, next cell) */
-         unsigned long long key = ((unsigned long long) (uint32_t) (c0 + 0x40000000) << 32) | (uint32_t) (c1 + 0x40000000);
-         L.key[lane] = key;
-         __syncthreads();
-         int rank = 0;
-         for (uint32_t j = 0; j < cnt; j++)
-         {
-            unsigned long long kj = L.key[j];
-            rank += (kj < key || (kj == key && j < (uint32_t) lane)) ? 1 : 0;
-         }
-         if (on) L.perm[rank] = lane;
-         __syncthreads();
-         int src = on ? L.perm[lane] : lane;
-         /* gather the sorted order */
-         q0 = __shfl(q0, src); q1 = __shfl(q1, src);
-         r0 = __shfl(r0, src); r1 = __shfl(r1, src); c0 = __shfl(c0, src); c1 = __shfl(c1, src);
-         dxs = __shfl(dxs, src); D = __shfl(D, src); dir = __shfl(dir, src);
-         int c1n = __shfl_down(c1, 1), c0n = __shfl_down(c0, 1);
-         bool viol = on && (uint32_t) (lane + 1) < cnt && c1n < c1;
-         if (__ballot(viol)) { partial |= 1u << r; __syncthreads(); continue; }
-         /* winding prefix */
-         int wsum = on ? dir : 0;
-#pragma unroll
-         for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(wsum, d); if (lane >= d) wsum += t; }
-         bool last = (uint32_t) lane + 1 == cnt;
-         bool is_end = on && ((((uint32_t) wsum & mask) == 0 && (last || c0n != c0)) || last);
-         int prev_end = __shfl_up((int) is_end, 1);
-         bool is_start = on && (lane == 0 || prev_end);
-         if (is_start) smr_render_edge(L, r, X0, dxs, D, q0, r0, q1, r1, +1);
-         else if (is_end) smr_render_edge(L, r, X0, dxs, D, q0, r0, q1, r1, -1);
-         __syncthreads();
-      }
-
-      /* ---- pass 2: sub-sampled rows; lane = sub-row ---- */
+      /* sub-sampled rows; lane = sub-row */
       if (partial)
       {
          const bool mine = lane < SMR_NSUB && ((partial >> my_row) & 1u);
-         const bool pieces = (P.flags & SMR_PF_PIECES) != 0;
-         int cnt = 0, lw = 0;
-         bool ovf = false;
-         uint16_t *bk = L.bucket[lane];
-         for (uint32_t base = 0; base < P.edge_cnt; base += 64)
+         unsigned long long om = __ballot(inband);
+         if (pieces)
          {
-            uint32_t idx = base + lane;
-            smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0; o.p1x = o.p1y = o.dxs = 0; o.D = 1;
-            if (idx < P.edge_cnt) o = smr_orient(E[idx]);
-            const int32_t eminx = o.p1x + (o.dxs < 0 ? o.dxs : 0), emaxx = o.p1x + (o.dxs > 0 ? o.dxs : 0);
-            bool ov = o.dir != 0 && o.ytop < ysbase + SMR_NSUB && o.ybot > ysbase && eminx < X1;
-            unsigned long long om = __ballot(ov);
-            if (pieces)
-            {
-               /* a piece (4 aligned lanes) is needed when any of its edges meets the strip and
-                * its x-extent meets the tile */
-               int32_t pmax = o.dir != 0 ? emaxx : INT32_MIN;
-               pmax = max(pmax, __shfl_xor(pmax, 1)); pmax = max(pmax, __shfl_xor(pmax, 2));
-               unsigned long long right = __ballot(pmax > X0);
-               om = om & right;
-               om |= om >> 1; om |= om >> 2;            /* gather the piece's bits into its first lane */
-               om &= 0x1111111111111111ull;
-            }
-            if (!om) continue;
+            /* a piece (4 aligned lanes) is needed when any of its edges meets the strip and
+             * its x-extent meets the tile */
+            int32_t pmax = o.dir != 0 ? emaxx : INT32_MIN;
+            pmax = max(pmax, __shfl_xor(pmax, 1)); pmax = max(pmax, __shfl_xor(pmax, 2));
+            unsigned long long right = __ballot(pmax > X0);
+            om = om & right;
+            om |= om >> 1; om |= om >> 2;            /* gather the piece's bits into its first lane */
+            om &= 0x1111111111111111ull;
+         }
+         if (om)
+         {
+            touched = true;
             __syncthreads();
             L.e_p1x[lane] = o.p1x; L.e_p1y[lane] = o.p1y; L.e_dxs[lane] = o.dxs; L.e_D[lane] = o.D;
             L.e_ytop[lane] = o.ytop; L.e_ybot[lane] = o.ybot; L.e_dir[lane] = o.dir;
@@ -745,66 +1128,7 @@ __global__ __launch_bounds__(64) void k_raster(raster_args_t A)
                }
             }
          }
-         if (__ballot(ovf) && lane == 0) atomicOr(A.status, SMR_ST_BUCKET_OVERFLOW);
-         auto add_span = [&](int x1, int x2)
-         {
-            if (x1 == x2) return;
-            int ix1 = x1 >> 8, ix2 = x2 >> 8, fx1 = x1 & 255, fx2 = x2 & 255;
-            if (ix1 != ix2)
-            {
-               smr_cell_add(L, my_row, ix1, 1, 2 * fx1);
-               smr_cell_add(L, my_row, ix2, -1, -2 * fx2);
-            }
-            else smr_cell_add(L, my_row, ix1, 0, 2 * (fx1 - fx2));
-         };
-         if (mine && pieces)
-         {
-            for (int i = 0; i < cnt; i++) add_span(bk[2 * i], bk[2 * i + 1]);
-         }
-         else if (mine)
-         {
-            for (int i = 1; i < cnt; i++)
-            {
-               uint16_t v = bk[i];
-               int k = i - 1;
-               while (k >= 0 && (bk[k] >> 1) > (v >> 1)) { bk[k + 1] = bk[k]; k--; }
-               bk[k + 1] = v;
-            }
-            int winding = lw;
-            int xstart = (((uint32_t) winding & mask) != 0) ? 0 : -1;
-            for (int i = 0; i < cnt; i++)
-            {
-               int xend = bk[i] >> 1;
-               winding += (bk[i] & 1) ? 1 : -1;
-               if (((uint32_t) winding & mask) == 0)
-               {
-                  if (i + 1 < cnt && (bk[i + 1] >> 1) == xend) continue;
-                  if (xstart >= 0) add_span(xstart, xend);
-                  xstart = -1;
-               }
-               else if (xstart < 0) xstart = xend;
-            }
-            if (xstart >= 0) add_span(xstart, SMR_TW * 256);
-         }
       }
-      __syncthreads();
-
-      /* ---- pass 3: cells -> alpha -> ordered blend into the group layer; lane = column ---- */
-      const uint32_t spix = P.color;
-      const bool lerp = (spix >> 24) == 255u || pi == first_prim;
-#pragma unroll
-      for (int r = 0; r < SMR_TH; r++)
-      {
-         int c = L.cover[r][lane];
-#pragma unroll
-         for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(c, d); if (lane >= d) c += t; }
-         c += L.left[r];
-         int area = c * 512 - L.uarea[r][lane];
-         int a = (area + (area << 4) + 256) >> 9;
-         a = a < 0 ? 0 : a > 255 ? 255 : a;
-         if (a) layer[r] = lerp ? smr_blend_lerp(spix, (uint32_t) a, layer[r]) : smr_blend_over_mask(spix, (uint32_t) a, layer[r]);
-      }
-      __syncthreads();
    }
 
    /* pop_group_to_source + paint: layer OVER canvas */
@@ -911,17 +1235,20 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
 
    hipStream_t s = smr_g.stream;
    const int64_t n_ways = b->n_ways, n_refs = b->n_refs, n_prims = 2 * n_ways;
+   const int64_t n_items = 2 * ((n_refs >> 3) + n_ways);           /* id space of k_prim_setup, sparse */
    const int TX = (c->W + SMR_TW - 1) / SMR_TW, TY = (c->band_h + SMR_TH - 1) / SMR_TH;
    const uint32_t n_tiles = (uint32_t) TX * TY;
    smr_timer_t T(smr_g.profiling);
    T.mark(s);                                                   /* 0 */
 
-   int2 *pts; uint8_t *wayflags; uint32_t *small; smr_prim_t *prims; uint32_t *way_pix = nullptr;
+   int2 *pts; int32_t *refway; uint8_t *wayflags; uint32_t *small; smr_prim_t *prims; smr_item_t *items; uint32_t *way_pix = nullptr;
    SMR_TRY(c->ensure(SMR_BUF_PTS, (size_t) n_refs * sizeof(int2), (void **) &pts));
+   SMR_TRY(c->ensure(SMR_BUF_REFWAY, (size_t) n_refs * 4, (void **) &refway));
    SMR_TRY(c->ensure(SMR_BUF_WAYFLAGS, (size_t) n_ways, (void **) &wayflags));
-   SMR_TRY(c->ensure(SMR_BUF_SMALL, 64, (void **) &small));     /* [0] any_open_fill [1] first_prim [2] status [3] total */
+   SMR_TRY(c->ensure(SMR_BUF_SMALL, 64, (void **) &small));     /* [0] any_open_fill [1] first_prim [2] status [3] entries [4] mask words */
    SMR_TRY(c->ensure(SMR_BUF_PRIMS, (size_t) n_prims * sizeof(smr_prim_t), (void **) &prims));
-   uint32_t init_small[4] = { 0, 0xffffffffu, 0, 0 };
+   SMR_TRY(c->ensure(SMR_BUF_ITEMS, (size_t) n_items * sizeof(smr_item_t), (void **) &items));
+   uint32_t init_small[8] = { 0, 0xffffffffu, 0, 0, 0, 0, 0, 0 };
    SMR_HIP(hipMemcpyAsync(small, init_small, sizeof(init_small), hipMemcpyHostToDevice, s));
 
    const int TB = 256;
@@ -929,12 +1256,11 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    int32_t sfix = (int32_t) nearbyint((double) c->dpi / 72 * 256.0);
    {
       unsigned nb = blocks(n_refs, TB); if (nb > 65536u * 4) nb = 65536u * 4;
-      k_dev_points<<<nb, TB, 0, s>>>(b->d_x, b->d_y, b->d_ref, n_refs, c->dpi, sfix, pts);
+      k_dev_points<<<nb, TB, 0, s>>>(b->d_x, b->d_y, b->d_ref, n_refs, c->dpi, sfix, b->d_way_off, n_ways, pts, refway);
    }
    k_way_info<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, b->d_ref, n_ways, st->border_used, st->fill_used,
                                                 st->ignore_open, wayflags, &small[0]);
-   k_prim_init<<<blocks(n_prims, TB), TB, 0, s>>>(prims, n_prims);
-   uint32_t h_small[4];
+   uint32_t h_small[8];
    SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
    const bool open_fill = h_small[0] != 0;
@@ -943,6 +1269,7 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    uint64_t off_border = 0, off_fill = st->border_used ? (uint64_t) SMR_SLOTS * n_refs : 0;
    uint64_t off_open = off_fill + (st->fill_used ? (uint64_t) n_refs : 0);
    uint64_t n_edges = off_open + (open_fill ? (uint64_t) SMR_SLOTS * n_refs : 0);
+   if (n_edges >= 0xffffff00ull) return smr_fail(SMR_E_CAPACITY, "draw: %llu edge slots in one rule (limit 2^32)", (unsigned long long) n_edges);
    smr_edge_t *edges;
    SMR_TRY(c->ensure(SMR_BUF_EDGES, (size_t) n_edges * sizeof(smr_edge_t), (void **) &edges));
 
@@ -951,13 +1278,13 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    double hw_closed = mm2wu(2 * st->border_width_mm, c->dpi) / 2;
    double hw_fill = mm2wu(st->fill_width_mm, c->dpi) / 2;
    if (st->border_used)
-      k_stroke_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, n_ways, n_refs, wayflags, 0, c->dpi, hw_nofill,
-                                                       hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border, prims);
+      k_stroke_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill,
+                                                       hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border);
    if (st->fill_used)
-      k_fill_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, n_ways, n_refs, wayflags, edges + off_fill, prims);
+      k_fill_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, refway, n_refs, wayflags, edges + off_fill);
    if (open_fill)
-      k_stroke_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, n_ways, n_refs, wayflags, 1, c->dpi, hw_nofill,
-                                                       hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open, prims);
+      k_stroke_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill,
+                                                       hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open);
    uint32_t *wb_pix = nullptr, *wf_pix = nullptr;
    if (b->d_way_border_col || b->d_way_fill_col)
    {
@@ -965,11 +1292,37 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
       if (b->d_way_border_col) { wb_pix = way_pix; k_color_pixels<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_border_col, n_ways, wb_pix); }
       if (b->d_way_fill_col) { wf_pix = way_pix + n_ways; k_color_pixels<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_fill_col, n_ways, wf_pix); }
    }
-   k_prim_finish<<<blocks(n_ways, TB), TB, 0, s>>>(prims, n_ways, b->d_way_off, wayflags, off_border, off_fill, off_open,
-                                                   host_color_pixel(st->border_col), host_color_pixel(st->fill_col),
-                                                   wb_pix, wf_pix, c->W, c->H, &small[1]);
    SMR_HIP(hipGetLastError());
-   T.mark(s);                                                   /* 1: setup done */
+   T.mark(s);                                                   /* 1: edges done */
+
+   /* primitive set-up (items, boxes, row masks); the mask arena grows on demand */
+   uint32_t *maskbuf;
+   size_t mask_cap = c->buf[SMR_BUF_MASK].cap / 4;
+   if (mask_cap < (size_t) n_prims * 2 + 65536) mask_cap = (size_t) n_prims * 2 + 65536;
+   for (int attempt = 0;; attempt++)
+   {
+      SMR_TRY(c->ensure(SMR_BUF_MASK, mask_cap * 4, (void **) &maskbuf));
+      setup_args_t SA;
+      SA.edges = edges; SA.way_off = b->d_way_off; SA.wayflags = wayflags; SA.n_ways = n_ways;
+      SA.off_border = off_border; SA.off_fill = off_fill; SA.off_open = off_open;
+      SA.border_pix = host_color_pixel(st->border_col); SA.fill_pix = host_color_pixel(st->fill_col);
+      SA.way_border_pix = wb_pix; SA.way_fill_pix = wf_pix; SA.W = c->W; SA.H = c->H;
+      SA.prims = prims; SA.items = items; SA.mask = maskbuf; SA.mask_cap = (uint32_t) std::min<size_t>(mask_cap, 0xffffffffu);
+      SA.small = small;
+      size_t lds = ((size_t) (c->H + 31) / 32 + 1) * 4;
+      k_prim_setup<<<(unsigned) n_prims, 64, lds, s>>>(SA);
+      SMR_HIP(hipGetLastError());
+      SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
+      SMR_HIP(hipStreamSynchronize(s));
+      if (!(h_small[2] & SMR_ST_MASK_ARENA)) break;
+      if (attempt) return smr_fail(SMR_E_CAPACITY, "draw: row-mask arena of %zu words still too small", mask_cap);
+      mask_cap = (size_t) h_small[4] + 1024;
+      init_small[0] = h_small[0];
+      SMR_HIP(hipMemcpyAsync(small, init_small, sizeof(init_small), hipMemcpyHostToDevice, s));
+   }
+   if (h_small[2] & SMR_ST_ROWCAP)
+      return smr_fail(SMR_E_CAPACITY, "draw: more than %d edges of one primitive span a vertex-free pixel row", SMR_ROWCAP);
+   T.mark(s);                                                   /* 2: primitives set up */
 
    /* binning */
    uint32_t *counts, *tile_off, *sums;
@@ -978,7 +1331,7 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    SMR_TRY(c->ensure(SMR_BUF_TILEOFF, ((size_t) n_tiles + 1) * 4, (void **) &tile_off));
    SMR_TRY(c->ensure(SMR_BUF_SUMS, (size_t) nb_scan * 4, (void **) &sums));
    SMR_HIP(hipMemsetAsync(counts, 0, (size_t) n_tiles * 4, s));
-   k_bin<false><<<blocks(n_prims, TB), TB, 0, s>>>(prims, n_prims, c->W, c->band_y0, c->band_h, TX, counts, nullptr, nullptr);
+   k_bin<false><<<blocks(n_items, TB), TB, 0, s>>>(items, n_items, c->W, c->band_y0, c->band_h, TX, counts, nullptr, nullptr);
    k_scan_block<<<nb_scan, 256, 0, s>>>(counts, tile_off, sums, n_tiles);
    k_scan_sums<<<1, 1024, 0, s>>>(sums, nb_scan, &small[3]);
    k_scan_add<<<nb_scan, 256, 0, s>>>(tile_off, sums, n_tiles);
@@ -989,15 +1342,15 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    uint32_t *entries;
    SMR_TRY(c->ensure(SMR_BUF_ENTRIES, ((size_t) n_entries + 1) * 4, (void **) &entries));
    SMR_HIP(hipMemsetAsync(counts, 0, (size_t) n_tiles * 4, s));
-   k_bin<true><<<blocks(n_prims, TB), TB, 0, s>>>(prims, n_prims, c->W, c->band_y0, c->band_h, TX, counts, tile_off, entries);
+   k_bin<true><<<blocks(n_items, TB), TB, 0, s>>>(items, n_items, c->W, c->band_y0, c->band_h, TX, counts, tile_off, entries);
    SMR_HIP(hipGetLastError());
-   T.mark(s);                                                   /* 2: binned */
    k_tile_sort<<<n_tiles, 64, 0, s>>>(tile_off, entries, n_tiles);
    SMR_HIP(hipGetLastError());
-   T.mark(s);                                                   /* 3: sorted */
+   T.mark(s);                                                   /* 3: binned + sorted */
 
    raster_args_t A;
-   A.prims = prims; A.edges = edges; A.tile_off = tile_off; A.entries = entries; A.first_prim = &small[1];
+   A.prims = prims; A.items = items; A.edges = edges; A.mask = maskbuf; A.tile_off = tile_off; A.entries = entries;
+   A.first_prim = &small[1];
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
    k_raster<<<n_tiles, 64, 0, s>>>(A);
@@ -1008,9 +1361,11 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    if (smr_g.profiling)
    {
       smr_timings_t &t = smr_g.last;
-      t.setup_ms = T.ms(0, 1); t.bin_ms = T.ms(1, 2); t.sort_ms = T.ms(2, 3); t.raster_ms = T.ms(3, 4); t.total_ms = T.ms(0, 4);
+      t.edges_ms = T.ms(0, 1); t.prims_ms = T.ms(1, 2); t.bin_ms = T.ms(2, 3); t.raster_ms = T.ms(3, 4); t.total_ms = T.ms(0, 4);
       t.n_prims = (uint64_t) n_prims; t.n_edges = n_edges; t.n_tile_refs = n_entries; t.n_tiles = n_tiles;
    }
+   if (h_small[2] & SMR_ST_ROWCAP)
+      return smr_fail(SMR_E_CAPACITY, "draw: more than %d edges of one primitive span a vertex-free pixel row inside one tile", SMR_ROWCAP);
    if (h_small[2] & SMR_ST_BUCKET_OVERFLOW)
       return smr_fail(SMR_E_CAPACITY, "draw: more than %d edge crossings on one sub-scanline inside a 64-px tile", SMR_BK);
    return SMR_OK;

@@ -19,7 +19,7 @@
 struct __attribute__((aligned(16))) smr_edge_t { int32_t x1, y1, x2, y2; };
 
 /* one primitive = one cairo_stroke()/cairo_fill() of the reference (render_poly_line,
- * src/smrules_cairo.c:953-1016): an edge range + a solid source pixel */
+ * src/smrules_cairo.c:953-1016): an edge range + a solid source pixel + the row mask */
 struct __attribute__((aligned(16))) smr_prim_t
 {
    uint64_t edge_off;        /* first edge slot in the edge arena */
@@ -27,15 +27,31 @@ struct __attribute__((aligned(16))) smr_prim_t
    uint32_t color;           /* premultiplied ARGB32 source pixel */
    int32_t minx, miny, maxx, maxy;   /* bbox of the emitted vertices, 24.8 */
    uint32_t flags;           /* SMR_PF_* */
-   uint32_t pad_[3];
+   uint32_t mask_off;        /* first word of the row mask in the mask arena */
+   int32_t row0, nrows;      /* chart rows the mask covers; bit set = the row is sub-sampled (an edge starts or
+                                ends inside it, or edges cross in it), clear = libcairo's exact full-row path */
 };
 #define SMR_PF_VALID 1u
 #define SMR_PF_EVENODD 2u
 #define SMR_PF_PIECES 4u     /* every 4 aligned edge slots form one closed convex piece, all wound alike (strokes) */
+#define SMR_PF_MULTI 8u      /* the primitive has more than one item */
+
+/* one item = up to 64 consecutive edge slots of one primitive: the unit that is binned to
+ * tiles and that one wavefront loads with one 16-byte access per lane */
+struct __attribute__((aligned(16))) smr_item_t
+{
+   uint32_t edge_off;        /* first slot (arena index) */
+   uint32_t prim;            /* 2 * way + (0 border | 1 fill) */
+   uint32_t cnt_flags;       /* slots in bits 0..7, SMR_PF_* << 8 */
+   uint32_t color;
+   int32_t minx, miny, maxx, maxy;   /* binning box, 24.8: maxx is the PRIMITIVE's for fill chunks (edges left of a
+                                        tile carry winding into it) */
+};
 
 /* status word bits reported back to the host */
 #define SMR_ST_BUCKET_OVERFLOW 1u
 #define SMR_ST_ROWCAP 2u
+#define SMR_ST_MASK_ARENA 4u
 
 __device__ __forceinline__ int smr_to_grid_y(int32_t y) { return (int) ((15ll * y + 128) >> 8); }
 

@@ -46,7 +46,7 @@ class _CapBatch(C.Structure):
 
 
 class Timings(C.Structure):
-    _fields_ = [("proj_ms", C.c_float), ("setup_ms", C.c_float), ("bin_ms", C.c_float), ("sort_ms", C.c_float),
+    _fields_ = [("proj_ms", C.c_float), ("edges_ms", C.c_float), ("prims_ms", C.c_float), ("bin_ms", C.c_float),
                 ("raster_ms", C.c_float), ("caprot_ms", C.c_float), ("total_ms", C.c_float),
                 ("n_prims", C.c_uint64), ("n_edges", C.c_uint64), ("n_tile_refs", C.c_uint64), ("n_tiles", C.c_uint64)]
 
