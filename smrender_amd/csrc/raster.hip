@@ -254,8 +254,8 @@ __global__ void k_color_pixels(const uint32_t *__restrict__ col, int64_t n, uint
  * increasing in w and leaves room for ceil(n/8) chunks per kind, so no scan is needed and ids
  * ascend in drawing order (way, border before fill, chunk).                               */
 /* ------------------------------------------------------------------------------------ */
-#define SMR_LONGCAP 128      /* edges spanning a whole pixel row, kept in LDS per primitive */
-#define SMR_ACTCAP 16        /* active edges per vertex-free row in the lane-per-row analysis */
+#define SMR_LONGCAP 64       /* edges spanning a whole pixel row, kept in LDS per primitive */
+#define SMR_ACTCAP 8         /* active edges per vertex-free row in the lane-per-row analysis */
 
 struct setup_args_t
 {
@@ -309,14 +309,13 @@ __device__ __forceinline__ void smr_setup_edge(const smr_oedge_t &o, int row0, i
    }
 }
 
-__global__ __launch_bounds__(64) void k_prim_setup(setup_args_t A)
+#define SMR_MASK_BLOCK 2048u   /* words a wavefront takes from the mask arena with one atomic */
+
+__device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const int64_t p, const int lane, setup_lds_t &L, uint32_t *lmask,
+                                                   uint32_t &arena_pos, uint32_t &arena_left, uint32_t &first_valid)
 {
-   extern __shared__ uint32_t lmask[];             /* [(H + 31) / 32 + 1] */
-   __shared__ setup_lds_t L;
-   const int64_t p = blockIdx.x;
    const int64_t w = p >> 1;
    const int kind = (int) (p & 1);
-   const int lane = threadIdx.x;
    const uint8_t wf = A.wayflags[w];
    const int64_t a = A.way_off[w], b = A.way_off[w + 1], n = b - a;
    const int64_t base = (a >> 3) + w, span = (b >> 3) + (w + 1) - base;
@@ -397,7 +396,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(setup_args_t A)
    /* ---- pass B: row mask ---- */
    for (uint32_t i = lane; i < nwords; i += 64) lmask[i] = 0;
    if (lane == 0) L.nlong = 0;
-   __syncthreads();
+   SMR_WAVE_SYNC();
    if (nitems == 1)
    {
       if ((uint32_t) lane < P.edge_cnt) smr_setup_edge(smr_orient(e0), P.row0, P.nrows, lmask, L);
@@ -406,7 +405,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(setup_args_t A)
    {
       for (uint32_t idx = lane; idx < P.edge_cnt; idx += 64) smr_setup_edge(smr_orient(E[idx]), P.row0, P.nrows, lmask, L);
    }
-   __syncthreads();
+   SMR_WAVE_SYNC();
    const uint32_t nlong = L.nlong;
    /* one vertex-free row decided by the whole wavefront: lanes walk the candidate edges (the LDS list
     * of row-spanning edges, or every edge slot when that list overflowed), the active ones' cells at
@@ -417,7 +416,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(setup_args_t A)
       int *f0 = &L.act0[0][0], *f1 = &L.act1[0][0];
       uint32_t cnt = 0;
       const uint32_t ncand = nlong <= SMR_LONGCAP ? nlong : P.edge_cnt;
-      __syncthreads();
+      SMR_WAVE_SYNC();
       for (uint32_t base_i = 0; base_i < ncand; base_i += 64)
       {
          uint32_t idx = base_i + lane;
@@ -451,7 +450,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(setup_args_t A)
          }
          cnt += __popcll(am);
       }
-      __syncthreads();
+      SMR_WAVE_SYNC();
       bool viol = false;
       if (cnt > SMR_ROWCAP) { if (lane == 0) atomicOr(&A.small[2], SMR_ST_ROWCAP); viol = true; }
       else if ((uint32_t) lane < cnt)
@@ -460,7 +459,7 @@ __global__ __launch_bounds__(64) void k_prim_setup(setup_args_t A)
          for (uint32_t j = 0; j < cnt; j++) if (a0 < f0[j] && a1 > f1[j]) viol = true;
       }
       if (__ballot(viol) && lane == 0) lmask[r >> 5] |= 1u << (r & 31);
-      __syncthreads();
+      SMR_WAVE_SYNC();
    };
    if (nlong > SMR_LONGCAP)
    {
@@ -517,11 +516,21 @@ __global__ __launch_bounds__(64) void k_prim_setup(setup_args_t A)
          }
       }
    }
-   __syncthreads();
-   uint32_t moff = 0;
-   if (lane == 0) moff = atomicAdd(&A.small[4], nwords);
-   moff = __shfl(moff, 0);
-   if (moff + nwords > A.mask_cap)
+   SMR_WAVE_SYNC();
+   /* mask words come from a block this wavefront owns: one global atomic per SMR_MASK_BLOCK words
+    * instead of one per primitive (2 M atomics on one address would take longer than the set-up) */
+   uint32_t moff;
+   if (nwords > arena_left)
+   {
+      const uint32_t take = nwords > SMR_MASK_BLOCK / 4 ? nwords : SMR_MASK_BLOCK;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(&A.small[4], take);
+      base = __shfl(base, 0);
+      if (take == nwords) moff = base;                  /* a tall primitive gets its words directly */
+      else { arena_pos = base; arena_left = take; moff = arena_pos; arena_pos += nwords; arena_left -= nwords; }
+   }
+   else { moff = arena_pos; arena_pos += nwords; arena_left -= nwords; }
+   if ((uint64_t) moff + nwords > A.mask_cap)
    {
       /* the host sees the demand in small[4], enlarges the arena and runs the set-up again */
       if (lane == 0) { atomicOr(&A.small[2], SMR_ST_MASK_ARENA); P.flags = 0; A.prims[p] = P; }
@@ -529,11 +538,27 @@ __global__ __launch_bounds__(64) void k_prim_setup(setup_args_t A)
    }
    for (uint32_t i = lane; i < nwords; i += 64) A.mask[moff + i] = lmask[i];
    P.mask_off = moff;
-   if (lane == 0)
+   if (lane == 0) A.prims[p] = P;
+   first_valid = min(first_valid, (uint32_t) p);
+}
+
+#define SMR_SETUP_WAVES 4
+
+/* persistent wavefronts, each sets up primitive gwave, gwave + nwaves, ... (2 M one-wave workgroups
+ * would be bound by the workgroup dispatch rate, not by the work) */
+__global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_t A, int mask_words)
+{
+   extern __shared__ uint32_t lmask_all[];         /* [SMR_SETUP_WAVES][mask_words] */
+   __shared__ setup_lds_t LL[SMR_SETUP_WAVES];
+   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   const int64_t gwave = (int64_t) blockIdx.x * SMR_SETUP_WAVES + wv, nwaves = (int64_t) gridDim.x * SMR_SETUP_WAVES;
+   uint32_t arena_pos = 0, arena_left = 0, first_valid = 0xffffffffu;
+   for (int64_t p = gwave; p < 2 * A.n_ways; p += nwaves)
    {
-      A.prims[p] = P;
-      atomicMin(&A.small[1], (uint32_t) p);
+      smr_prim_setup_one(A, p, lane, LL[wv], lmask_all + (size_t) wv * mask_words, arena_pos, arena_left, first_valid);
+      SMR_WAVE_SYNC();
    }
+   if (lane == 0 && first_valid != 0xffffffffu) atomicMin(&A.small[1], first_valid);
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -634,21 +659,36 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t *__restrict__ out, co
 
 __global__ void k_set_u32(uint32_t *p, const uint32_t *v) { *p = *v; }
 
-/* per-tile sort of the scattered primitive indices (ascending = drawing order) */
+/* per-tile sort of the scattered item indices (ascending = drawing order), then the tile's
+ * work stream: one smr_thdr_t per entry with the item header, the tile's bits of the
+ * primitive's row mask and the primitive's pixel extents relative to the tile */
 #define SORT_LDS 4096
-__global__ __launch_bounds__(64) void k_tile_sort(const uint32_t *__restrict__ tile_off, uint32_t *__restrict__ entries,
-                                                  uint32_t n_tiles)
+struct sort_args_t
+{
+   const uint32_t *tile_off;
+   uint32_t *entries;
+   const smr_item_t *items;
+   const smr_prim_t *prims;
+   const uint32_t *mask;
+   const uint32_t *first_prim;
+   smr_thdr_t *hdrs;
+   uint32_t n_tiles;
+   int TX, band_y0;
+};
+
+__global__ __launch_bounds__(64) void k_tile_sort(sort_args_t A)
 {
    __shared__ uint32_t s[SORT_LDS];
-   uint32_t tile = smr_xcd_remap(blockIdx.x, n_tiles);
-   uint32_t beg = tile_off[tile], n = tile_off[tile + 1] - beg;
-   if (n < 2) return;
-   uint32_t lane = threadIdx.x;
+   const uint32_t tile = smr_xcd_remap(blockIdx.x, A.n_tiles);
+   const uint32_t beg = A.tile_off[tile], n = A.tile_off[tile + 1] - beg;
+   if (n == 0) return;
+   const uint32_t lane = threadIdx.x;
    uint32_t N = 2;
    while (N < n) N <<= 1;
-   if (N <= SORT_LDS)
+   const bool in_lds = N <= SORT_LDS;
+   if (n >= 2 && in_lds)
    {
-      for (uint32_t i = lane; i < N; i += 64) s[i] = i < n ? entries[beg + i] : 0xffffffffu;
+      for (uint32_t i = lane; i < N; i += 64) s[i] = i < n ? A.entries[beg + i] : 0xffffffffu;
       __syncthreads();
       for (uint32_t k = 2; k <= N; k <<= 1)
       {
@@ -666,13 +706,12 @@ __global__ __launch_bounds__(64) void k_tile_sort(const uint32_t *__restrict__ t
             __syncthreads();
          }
       }
-      for (uint32_t i = lane; i < n; i += 64) entries[beg + i] = s[i];
    }
-   else
+   else if (n >= 2)
    {
-      /* rare: more primitives on one 64x4 tile than fit in LDS -- same network in global
+      /* rare: more items on one 64x4 tile than fit in LDS -- same network in global
        * memory through L1-bypassing (agent-scope) accesses */
-      uint32_t *e = entries + beg;
+      uint32_t *e = A.entries + beg;
       for (uint32_t k = 2; k <= N; k <<= 1)
       {
          for (uint32_t j = k >> 1; j > 0; j >>= 1)
@@ -696,6 +735,37 @@ __global__ __launch_bounds__(64) void k_tile_sort(const uint32_t *__restrict__ t
          }
       }
    }
+   /* the work stream */
+   const int tx = tile % A.TX, ty = tile / A.TX;
+   const int row0 = A.band_y0 + ty * SMR_TH, col0 = tx * SMR_TW;
+   const uint32_t first_prim = *A.first_prim;
+   for (uint32_t i = lane; i < n; i += 64)
+   {
+      uint32_t idx;
+      if (n < 2) idx = A.entries[beg + i];
+      else if (in_lds) idx = s[i];
+      else idx = __hip_atomic_load(&A.entries[beg + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const smr_item_t it = A.items[idx];
+      const smr_prim_t P = A.prims[it.prim];
+      smr_thdr_t h;
+      h.edge_off = it.edge_off; h.prim = it.prim; h.color = it.color;
+      h.cnt_flags = it.cnt_flags | (it.prim == first_prim ? 1u << 16 : 0u);
+      uint32_t bits = 0;
+#pragma unroll
+      for (int r = 0; r < SMR_TH; r++)
+      {
+         int rr = row0 + r - P.row0;
+         uint32_t bit = 1;      /* rows outside the mask hold no edge of the primitive */
+         if (rr >= 0 && rr < P.nrows) bit = (A.mask[P.mask_off + ((uint32_t) rr >> 5)] >> (rr & 31)) & 1u;
+         bits |= bit << r;
+         if (row0 + r >= (P.miny >> 8) && row0 + r <= (P.maxy >> 8)) bits |= 16u << r;
+      }
+      h.rowbits = bits;
+      h.colmin = (P.minx >> 8) - col0; h.colmax = (P.maxx >> 8) - col0;
+      h.pad_ = 0;
+      A.hdrs[beg + i] = h;
+      if (in_lds && n >= 2) A.entries[beg + i] = idx;
+   }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -704,16 +774,14 @@ __global__ __launch_bounds__(64) void k_tile_sort(const uint32_t *__restrict__ t
 struct raster_args_t
 {
    const smr_prim_t *prims;
-   const smr_item_t *items;
+   const smr_thdr_t *hdrs;    /* per-tile sorted work stream (k_tile_sort) */
    const smr_edge_t *edges;
-   const uint32_t *mask;
    const uint32_t *tile_off;
-   const uint32_t *entries;
-   const uint32_t *first_prim;
    uint32_t *canvas;          /* band pixels, stride W */
    uint32_t *status;
    int W, band_y0, band_h, TX;
    uint32_t n_tiles;
+   int exp;
 };
 
 struct raster_lds_t
@@ -721,8 +789,8 @@ struct raster_lds_t
    int cover[SMR_TH][SMR_TW];
    int uarea[SMR_TH][SMR_TW];
    int left[SMR_TH];
-   int e_p1x[64], e_p1y[64], e_dxs[64], e_D[64], e_ytop[64], e_ybot[64], e_dir[64];
    uint32_t rowlist[SMR_TH][SMR_ROWCAP];
+   int redge[SMR_TH][16][5];  /* p1x, p1y, dxs, D, dir of the first 16 edges spanning each full row */
    unsigned long long key[64];
    int perm[64];
    uint16_t bucket[SMR_NSUB][SMR_BKS];
@@ -799,350 +867,557 @@ __device__ void smr_render_edge(raster_lds_t &L, int row, int32_t X0, int32_t dx
    }
 }
 
-__global__ __launch_bounds__(64) void k_raster(raster_args_t A)
-{
-   __shared__ raster_lds_t L;
-   const uint32_t tile = smr_xcd_remap(blockIdx.x, A.n_tiles);
-   const uint32_t beg = A.tile_off[tile], end = A.tile_off[tile + 1];
-   if (beg == end) return;
-   const int lane = threadIdx.x;
-   const int tx = tile % A.TX, ty = tile / A.TX;
-   const int32_t X0 = tx * SMR_TW * 256, X1 = X0 + SMR_TW * 256;
-   const int row0 = A.band_y0 + ty * SMR_TH;          /* absolute pixel row of the tile */
-   const int ysbase = row0 * SMR_GRID_Y;
-   const uint32_t first_prim = *A.first_prim;
-   const unsigned long long lt_mask = (1ull << lane) - 1ull;
-   uint32_t layer[SMR_TH] = { 0, 0, 0, 0 };
-   const int my_row = lane / SMR_GRID_Y;               /* sub-row lane -> pixel row (lanes 60..63 idle) */
-   const int my_ys = ysbase + lane;
-   uint16_t *bk = L.bucket[lane < SMR_NSUB ? lane : 0];
+#define SMR_RASTER_WAVES 4      /* independent wavefronts per workgroup, one tile at a time each */
 
-   /* state of the primitive being accumulated */
-   uint32_t cur = 0xffffffffu, cur_flags = 0, cur_color = 0;
-   uint32_t partial = 0, rowcnt[SMR_TH] = { 0, 0, 0, 0 };
-   int cnt = 0, lw = 0;
-   bool ovf = false, touched = false;
+__global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t A)
+{
+   __shared__ raster_lds_t LL[SMR_RASTER_WAVES];
+   raster_lds_t &L = LL[threadIdx.x >> 6];
+   const int lane = threadIdx.x & 63;
+   const uint32_t gwave = blockIdx.x * SMR_RASTER_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * SMR_RASTER_WAVES;
+   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+   const int my_row = lane / SMR_GRID_Y;               /* sub-row lane -> pixel row (lanes 60..63 idle) */
+   uint16_t *bk = L.bucket[lane < SMR_NSUB ? lane : 0];
 
 #pragma unroll
    for (int r = 0; r < SMR_TH; r++) { L.cover[r][lane] = 0; L.uarea[r][lane] = 0; }
    if (lane < SMR_TH) L.left[lane] = 0;
-   __syncthreads();
+   SMR_WAVE_SYNC();
 
-   for (uint32_t ei = beg; ei <= end; ei++)
+   /* persistent wavefronts: tile = gwave, gwave + nwaves, ... (1 M workgroup launches would cost more
+    * than the work of the many empty or light tiles) */
+   for (uint32_t tile = gwave; tile < A.n_tiles; tile += nwaves)
    {
-      smr_item_t it;
-      it.prim = 0xffffffffu; it.cnt_flags = 0; it.edge_off = 0; it.color = 0;
-      if (ei < end) it = A.items[A.entries[ei]];
+      const uint32_t beg = A.tile_off[tile], end = A.tile_off[tile + 1];
+      if (beg == end) continue;
+      const int tx = tile % A.TX, ty = tile / A.TX;
+      const int32_t X0 = tx * SMR_TW * 256, X1 = X0 + SMR_TW * 256;
+      const int row0 = A.band_y0 + ty * SMR_TH;          /* absolute pixel row of the tile */
+      const int ysbase = row0 * SMR_GRID_Y;
+      const int my_ys = ysbase + lane;
+      uint32_t layer[SMR_TH] = { 0, 0, 0, 0 };
 
-      /* ================= flush: the previous primitive is complete ================= */
-      if (it.prim != cur && cur != 0xffffffffu && touched)
+      /* state of the primitive being accumulated */
+      uint32_t cur = 0xffffffffu, cur_flags = 0, cur_color = 0;
+      uint32_t partial = 0, rowcnt[SMR_TH] = { 0, 0, 0, 0 };
+      int cnt = 0, lw = 0;
+      int cl = 1, cr = 0;            /* stroke pieces: the interval being grown (empty while cl > cr), tile-relative 24.8 */
+      bool ovf = false, touched = false;
+      /* merge [l, r] into the lane's list of disjoint covered intervals (LDS bucket) */
+      auto push_interval = [&](int l, int r)
       {
-         const bool pieces = (cur_flags & SMR_PF_PIECES) != 0;
-         const uint32_t mask = (cur_flags & SMR_PF_EVENODD) ? 1u : ~0u;
-         const smr_prim_t P = A.prims[cur];
-         const smr_edge_t *E = A.edges;
-
-         /* ---- sub-sampled rows: crossings -> spans -> cells ---- */
-         if (__ballot(ovf) && lane == 0) atomicOr(A.status, SMR_ST_BUCKET_OVERFLOW);
-         const bool mine = lane < SMR_NSUB && ((partial >> my_row) & 1u);
-         auto add_span = [&](int x1, int x2)
+         for (int i = 0; i < cnt;)
          {
-            if (x1 == x2) return;
-            int ix1 = x1 >> 8, ix2 = x2 >> 8, fx1 = x1 & 255, fx2 = x2 & 255;
-            if (ix1 != ix2)
+            int ia = bk[2 * i], ib = bk[2 * i + 1];
+            if (ia <= r && l <= ib)
             {
-               smr_cell_add(L, my_row, ix1, 1, 2 * fx1);
-               smr_cell_add(L, my_row, ix2, -1, -2 * fx2);
+               l = min(l, ia); r = max(r, ib);
+               cnt--;
+               bk[2 * i] = bk[2 * cnt]; bk[2 * i + 1] = bk[2 * cnt + 1];
+               i = 0;
             }
-            else smr_cell_add(L, my_row, ix1, 0, 2 * (fx1 - fx2));
-         };
-         if (mine && pieces)
-         {
-            for (int i = 0; i < cnt; i++) add_span(bk[2 * i], bk[2 * i + 1]);
+            else i++;
          }
-         else if (mine)
+         if (2 * cnt + 2 <= SMR_BK) { bk[2 * cnt] = (uint16_t) l; bk[2 * cnt + 1] = (uint16_t) r; cnt++; }
+         else ovf = true;
+      };
+
+      /* the tile's work stream is read 64 headers at a time (one coalesced 32-byte access per lane) and
+       * handed out by v_readlane; the edge slots of entry k+1 are in flight while entry k is processed */
+      uint4 hb0 = make_uint4(0u, 0xffffffffu, 0u, 0u), hb1 = make_uint4(0u, 0u, 0u, 0u);
+      uint32_t bbase = beg;
+      auto load_batch = [&]()
+      {
+         const uint32_t k = bbase + lane;
+         if (k < end)
          {
-            for (int i = 1; i < cnt; i++)
+            const uint4 *hp = reinterpret_cast<const uint4 *>(&A.hdrs[k]);
+            hb0 = hp[0]; hb1 = hp[1];
+         }
+      };
+      auto load_edge = [&](uint32_t k) -> smr_edge_t
+      {
+         smr_edge_t e; e.x1 = e.y1 = e.x2 = e.y2 = 0;
+         if (k < end)
+         {
+            const int j = (int) (k - bbase);
+            const uint32_t eo = __builtin_amdgcn_readlane(hb0.x, j), cf = __builtin_amdgcn_readlane(hb0.z, j);
+            if ((uint32_t) lane < (cf & 0xffu)) e = A.edges[(size_t) eo + lane];
+         }
+         return e;
+      };
+      load_batch();
+      smr_edge_t edge1 = load_edge(beg);
+      uint32_t cur_rowin = 0; int cur_colmin = 0, cur_colmax = -1; bool cur_first = false;
+
+      for (uint32_t ei = beg; ei <= end; ei++)
+      {
+         const smr_edge_t my_edge = edge1;
+         smr_item_t it;
+         it.prim = 0xffffffffu; it.cnt_flags = 0; it.edge_off = 0; it.color = 0;
+         uint32_t it_rowbits = 0; int it_colmin = 0, it_colmax = -1;
+         if (ei < end)
+         {
+            const int j = (int) (ei - bbase);
+            it.edge_off = __builtin_amdgcn_readlane(hb0.x, j); it.prim = __builtin_amdgcn_readlane(hb0.y, j);
+            it.cnt_flags = __builtin_amdgcn_readlane(hb0.z, j); it.color = __builtin_amdgcn_readlane(hb0.w, j);
+            it_rowbits = __builtin_amdgcn_readlane(hb1.x, j);
+            it_colmin = (int) __builtin_amdgcn_readlane(hb1.y, j); it_colmax = (int) __builtin_amdgcn_readlane(hb1.z, j);
+            if (ei + 1 == bbase + 64) { bbase += 64; load_batch(); }
+            edge1 = load_edge(ei + 1);
+         }
+
+         /* ================= flush: the previous primitive is complete ================= */
+         if (it.prim != cur && cur != 0xffffffffu && touched)
+         {
+            const bool pieces = (cur_flags & SMR_PF_PIECES) != 0;
+            const uint32_t mask = (cur_flags & SMR_PF_EVENODD) ? 1u : ~0u;
+            const smr_edge_t *E = A.edges;
+
+            /* ---- sub-sampled rows: crossings -> spans -> cells ---- */
+            if (__ballot(ovf) && lane == 0) atomicOr(A.status, SMR_ST_BUCKET_OVERFLOW);
+            const bool mine = lane < SMR_NSUB && ((partial >> my_row) & 1u);
+            auto add_span = [&](int x1, int x2)
             {
-               uint16_t v = bk[i];
-               int k = i - 1;
-               while (k >= 0 && (bk[k] >> 1) > (v >> 1)) { bk[k + 1] = bk[k]; k--; }
-               bk[k + 1] = v;
-            }
-            int winding = lw;
-            int xstart = (((uint32_t) winding & mask) != 0) ? 0 : -1;
-            for (int i = 0; i < cnt; i++)
-            {
-               int xend = bk[i] >> 1;
-               winding += (bk[i] & 1) ? 1 : -1;
-               if (((uint32_t) winding & mask) == 0)
+               if (x1 == x2) return;
+               int ix1 = x1 >> 8, ix2 = x2 >> 8, fx1 = x1 & 255, fx2 = x2 & 255;
+               if (ix1 != ix2)
                {
-                  if (i + 1 < cnt && (bk[i + 1] >> 1) == xend) continue;
-                  if (xstart >= 0) add_span(xstart, xend);
-                  xstart = -1;
+                  smr_cell_add(L, my_row, ix1, 1, 2 * fx1);
+                  smr_cell_add(L, my_row, ix2, -1, -2 * fx2);
                }
-               else if (xstart < 0) xstart = xend;
+               else smr_cell_add(L, my_row, ix1, 0, 2 * (fx1 - fx2));
+            };
+            if (A.exp & 8) {} else if (mine && pieces)
+            {
+               if (cl <= cr) push_interval(cl, cr);
+               for (int i = 0; i < cnt; i++) add_span(bk[2 * i], bk[2 * i + 1]);
             }
-            if (xstart >= 0) add_span(xstart, SMR_TW * 256);
-         }
+            else if (mine)
+            {
+               for (int i = 1; i < cnt; i++)
+               {
+                  uint16_t v = bk[i];
+                  int k = i - 1;
+                  while (k >= 0 && (bk[k] >> 1) > (v >> 1)) { bk[k + 1] = bk[k]; k--; }
+                  bk[k + 1] = v;
+               }
+               int winding = lw;
+               int xstart = (((uint32_t) winding & mask) != 0) ? 0 : -1;
+               for (int i = 0; i < cnt; i++)
+               {
+                  int xend = bk[i] >> 1;
+                  winding += (bk[i] & 1) ? 1 : -1;
+                  if (((uint32_t) winding & mask) == 0)
+                  {
+                     if (i + 1 < cnt && (bk[i + 1] >> 1) == xend) continue;
+                     if (xstart >= 0) add_span(xstart, xend);
+                     xstart = -1;
+                  }
+                  else if (xstart < 0) xstart = xend;
+               }
+               if (xstart >= 0) add_span(xstart, SMR_TW * 256);
+            }
 
-         /* ---- rows that take libcairo's exact full-row path ---- */
-         uint32_t fullrows = 0;
+            /* ---- rows that take libcairo's exact full-row path ---- */
+            uint32_t fullrows = 0;
 #pragma unroll
-         for (int r = 0; r < SMR_TH; r++) if (!((partial >> r) & 1u) && rowcnt[r] > 0) fullrows |= 1u << r;
-         if (fullrows && pieces && (cur_flags & SMR_PF_MULTI))
+            for (int r = 0; r < SMR_TH; r++) if (!((partial >> r) & 1u) && rowcnt[r] > 0) fullrows |= 1u << r;
+            if (fullrows && pieces && (cur_flags & SMR_PF_MULTI))
+            {
+               const smr_prim_t P = A.prims[cur];
+               /* a stroke's pieces left of this tile carry winding into it and were not binned here:
+                * collect the row's active edges from the whole primitive (rare: rows free of vertices
+                * in a multi-item stroke) */
+#pragma unroll
+               for (int r = 0; r < SMR_TH; r++) rowcnt[r] = 0;
+               for (uint32_t base = 0; base < P.edge_cnt; base += 64)
+               {
+                  uint32_t idx = base + lane;
+                  smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0;
+                  if (idx < P.edge_cnt) o = smr_orient(E[P.edge_off + idx]);
+#pragma unroll
+                  for (int r = 0; r < SMR_TH; r++)
+                  {
+                     if (!((fullrows >> r) & 1u)) continue;
+                     int rs0 = ysbase + r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
+                     bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs1;
+                     unsigned long long am = __ballot(act);
+                     if (am)
+                     {
+                        uint32_t pos = rowcnt[r] + __popcll(am & lt_mask);
+                        if (act && pos < SMR_ROWCAP) L.rowlist[r][pos] = (uint32_t) (P.edge_off + idx);
+                        if (act && pos < 16) { int *re = L.redge[r][pos]; re[0] = o.p1x; re[1] = o.p1y; re[2] = o.dxs; re[3] = o.D; re[4] = o.dir; }
+                        rowcnt[r] += __popcll(am);
+                     }
+                  }
+               }
+            }
+            SMR_WAVE_SYNC();
+            uint32_t nmax = 0;
+#pragma unroll
+            for (int r = 0; r < SMR_TH; r++) if ((fullrows >> r) & 1u) nmax = max(nmax, rowcnt[r]);
+            if (fullrows && nmax <= 16)
+            {
+               /* ---- fast form: lane = (row, edge slot), 16 slots per row, all full rows at once ---- */
+               const int grp = lane >> 4, es = lane & 15;
+               const uint32_t my_n = grp == 0 ? rowcnt[0] : grp == 1 ? rowcnt[1] : grp == 2 ? rowcnt[2] : rowcnt[3];
+               const bool onr = ((fullrows >> grp) & 1u) && (uint32_t) es < my_n;
+               const int rs0 = ysbase + grp * SMR_GRID_Y;
+               int32_t c0 = 0, c1 = 0, dir = 0, D = 1, q1 = 0, r1 = 0, q2 = 0, r2 = 0, dxs = 0;
+               if (onr)
+               {
+                  smr_oedge_t o;
+                  { const int *re = L.redge[grp][es]; o.p1x = re[0]; o.p1y = re[1]; o.dxs = re[2]; o.D = re[3]; o.dir = re[4]; }
+                  const int64_t ec = 256 - 30ll * o.p1y;
+                  const double inv = 1.0 / (double) o.D;
+                  D = o.D; dir = o.dir; dxs = o.dxs;
+                  smr_edge_qr(ec, 2 * o.dxs, o.D, inv, rs0, q1, r1);
+                  smr_edge_qr(ec, 2 * o.dxs, o.D, inv, rs0 + SMR_GRID_Y, q2, r2);
+                  q1 += o.p1x; q2 += o.p1x;
+                  c0 = q1 + (r1 >= (D >> 1) ? 1 : 0); c1 = q2 + (r2 >= (D >> 1) ? 1 : 0);
+                  /* step back from the sample location (half a sub-row) to the row boundary */
+                  const int64_t nn = (int64_t) dxs * 1024;
+                  int64_t dq = (int64_t) trunc((double) nn * inv);
+                  int64_t dr = nn - dq * D;
+                  if (nn >= 0) { if (dr < 0) { dq--; dr += D; } else if (dr >= D) { dq++; dr -= D; } }
+                  else { if (dr > 0) { dq++; dr -= D; } else if (dr <= -(int64_t) D) { dq--; dr += D; } }
+                  const int32_t hq = (int32_t) (dq / 2), hr = (int32_t) (dr / 2);
+                  q1 -= hq; r1 -= hr;
+                  if (r1 < 0) { --q1; r1 += D; } else if (r1 >= D) { ++q1; r1 -= D; }
+                  q2 -= hq; r2 -= hr;
+                  if (r2 < 0) { --q2; r2 += D; } else if (r2 >= D) { ++q2; r2 -= D; }
+                  q1 -= X0; q2 -= X0;
+               }
+               /* position in the row's (cell, next cell) order, winding before me, neighbours' cells */
+               int wsum = 0, pred_c0 = INT32_MIN, succ_c0 = INT32_MAX;
+               bool has_pred = false, has_succ = false;
+               for (uint32_t j = 0; j < nmax; j++)
+               {
+                  const int src = (lane & 48) + (int) j;
+                  const int kc0 = __shfl(c0, src), kc1 = __shfl(c1, src), kdir = __shfl(dir, src);
+                  if (j < my_n && (int) j != es)
+                  {
+                     const bool before = kc0 < c0 || (kc0 == c0 && (kc1 < c1 || (kc1 == c1 && (int) j < es)));
+                     if (before) { wsum += kdir; pred_c0 = max(pred_c0, kc0); has_pred = true; }
+                     else { succ_c0 = min(succ_c0, kc0); has_succ = true; }
+                  }
+               }
+               const int wincl = wsum + dir;
+               const bool is_end = onr && ((((uint32_t) wincl & mask) == 0 && (!has_succ || succ_c0 != c0)) || !has_succ);
+               const bool is_start = onr && (!has_pred || (((uint32_t) wsum & mask) == 0 && pred_c0 != c0));
+               /* per boundary edge: everything the columns need, computed once by the edge's lane */
+               int b_ix1 = (int) (q1 >> 8), b_ix2 = (int) (q2 >> 8), b_fx1 = q1 & 255, b_fx2 = q2 & 255;
+               int64_t b_tmp0 = 0, b_dx = 1;
+               if (b_ix1 != b_ix2)
+               {
+                  int32_t qa = q1, ra = r1, qb = q2, rb = r2;
+                  if (b_ix2 < b_ix1)
+                  {
+                     int t = b_ix1; b_ix1 = b_ix2; b_ix2 = t;
+                     t = b_fx1; b_fx1 = b_fx2; b_fx2 = t;
+                     qa = q2; ra = r2; qb = q1; rb = r1;
+                  }
+                  b_dx = (int64_t) (qb - qa) * D + (rb - ra);
+                  b_tmp0 = ((int64_t) (256 - b_fx1) * D - ra) * SMR_GRID_Y;
+               }
+               const double b_inv = 1.0 / smr_i64_to_f64(b_dx);
+               const int b_fx = b_fx1 | (b_fx2 << 16);
+               const int b_sign = is_start ? 1 : -1;
+               unsigned long long bm = __ballot(is_start || is_end);
+               while (bm)
+               {
+                  const int j = __ffsll((long long) bm) - 1;
+                  bm &= bm - 1;
+                  const int r = j >> 4;
+                  const int sgn = __builtin_amdgcn_readlane(b_sign, j);
+                  const int ix1 = __builtin_amdgcn_readlane(b_ix1, j), ix2 = __builtin_amdgcn_readlane(b_ix2, j);
+                  const int fxp = __builtin_amdgcn_readlane(b_fx, j);
+                  const int fx1 = fxp & 0xffff, fx2 = fxp >> 16;
+                  int cov = 0, ua = 0, lf = 0;
+                  if (ix1 == ix2)
+                  {
+                     if (lane == ix1) { cov = SMR_GRID_Y; ua = (fx1 + fx2) * SMR_GRID_Y; }
+                     if (ix1 < 0) lf = SMR_GRID_Y;
+                  }
+                  else if (ix2 < 0) lf = SMR_GRID_Y;
+                  else if (ix1 < SMR_TW)
+                  {
+                     const int64_t tmp0 = ((int64_t) __builtin_amdgcn_readlane((int) (b_tmp0 >> 32), j) << 32) |
+                                          (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) b_tmp0, j);
+                     const int64_t dx = ((int64_t) __builtin_amdgcn_readlane((int) (b_dx >> 32), j) << 32) |
+                                        (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) b_dx, j);
+                     const double inv = __longlong_as_double(((long long) __builtin_amdgcn_readlane((int) (__double_as_longlong(b_inv) >> 32), j) << 32) |
+                                                             (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) __double_as_longlong(b_inv), j));
+                     const int64_t step = (int64_t) (SMR_GRID_Y * 256) * __builtin_amdgcn_readlane(D, j);
+                     /* y (in sub-rows) at which the edge crosses the right boundary of cell `cell` */
+                     auto Y = [&](int cell) -> int
+                     {
+                        const int64_t n = tmp0 + (int64_t) (cell - ix1) * step;
+                        int y = (int) (smr_i64_to_f64(n) * inv);
+                        int64_t rem = n - (int64_t) y * dx;
+                        if (rem < 0) y--; else if (rem >= dx) y++;
+                        return y;
+                     };
+                     int yhi = lane >= ix2 ? SMR_GRID_Y : (lane < ix1 ? 0 : Y(lane));
+                     int ylo = __shfl_up(yhi, 1);
+                     const int yleft = ix1 >= 0 ? 0 : Y(-1);
+                     if (lane == 0) ylo = yleft;
+                     cov = yhi - ylo;
+                     ua = cov * (lane == ix1 ? 256 + fx1 : lane == ix2 ? fx2 : 256);
+                     lf = yleft;
+                  }
+                  if (cov) atomicAdd(&L.cover[r][lane], sgn * cov);
+                  if (ua) atomicAdd(&L.uarea[r][lane], sgn * ua);
+                  if (lf && lane == 0) atomicAdd(&L.left[r], sgn * lf);
+               }
+               fullrows = 0;
+            }
+            for (int r = 0; r < SMR_TH; r++)
+            {
+               if (!((fullrows >> r) & 1u)) continue;
+               if (A.exp & 1) continue;
+               uint32_t n = rowcnt[r];
+               if (n > SMR_ROWCAP) { if (lane == 0) atomicOr(A.status, SMR_ST_ROWCAP); continue; }
+               const int rs0 = ysbase + r * SMR_GRID_Y;
+               int64_t q0 = 0, q1 = 0; int32_t r0 = 0, r1 = 0, c0 = 0, c1 = 0, dxs = 0, D = 1, dir = 0;
+               const bool on = (uint32_t) lane < n;
+               if (on)
+               {
+                  smr_oedge_t o = smr_orient(E[L.rowlist[r][lane]]);
+                  dxs = o.dxs; D = o.D; dir = o.dir;
+                  smr_edge_x(o.p1x, o.p1y, o.dxs, o.D, rs0, q0, r0);
+                  smr_edge_x(o.p1x, o.p1y, o.dxs, o.D, rs0 + SMR_GRID_Y, q1, r1);
+                  c0 = smr_cell(q0, r0, D, dxs); c1 = smr_cell(q1, r1, D, dxs);
+               }
+               /* rank sort by (cell, next cell) */
+               unsigned long long key = ((unsigned long long) (uint32_t) (c0 + 0x40000000) << 32) | (uint32_t) (c1 + 0x40000000);
+               L.key[lane] = key;
+               SMR_WAVE_SYNC();
+               int rank = 0;
+               for (uint32_t j = 0; j < n; j++)
+               {
+                  unsigned long long kj = L.key[j];
+                  rank += (kj < key || (kj == key && j < (uint32_t) lane)) ? 1 : 0;
+               }
+               if (on) L.perm[rank] = lane;
+               SMR_WAVE_SYNC();
+               int src = on ? L.perm[lane] : lane;
+               q0 = __shfl(q0, src); q1 = __shfl(q1, src);
+               r0 = __shfl(r0, src); r1 = __shfl(r1, src); c0 = __shfl(c0, src); c1 = __shfl(c1, src);
+               dxs = __shfl(dxs, src); D = __shfl(D, src); dir = __shfl(dir, src);
+               int c0n = __shfl_down(c0, 1);
+               /* winding prefix */
+               int wsum = on ? dir : 0;
+#pragma unroll
+               for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(wsum, d); if (lane >= d) wsum += t; }
+               bool last = (uint32_t) lane + 1 == n;
+               bool is_end = on && ((((uint32_t) wsum & mask) == 0 && (last || c0n != c0)) || last);
+               int prev_end = __shfl_up((int) is_end, 1);
+               bool is_start = on && (lane == 0 || prev_end);
+               if (is_start) smr_render_edge(L, r, X0, dxs, D, q0, r0, q1, r1, +1);
+               else if (is_end) smr_render_edge(L, r, X0, dxs, D, q0, r0, q1, r1, -1);
+               SMR_WAVE_SYNC();
+            }
+            SMR_WAVE_SYNC();
+
+            /* ---- cells -> alpha -> ordered blend into the group layer; lane = column ---- */
+            const uint32_t spix = cur_color;
+            const bool lerp = (spix >> 24) == 255u || cur_first;
+            /* libcairo composites inside the primitive's pixel extents only */
+            const bool col_in = lane >= cur_colmin && lane <= cur_colmax;
+#pragma unroll
+            for (int r = 0; r < SMR_TH; r++)
+            {
+               if (A.exp & 4) continue;
+               int c = L.cover[r][lane];
+               int ua = L.uarea[r][lane];
+               const int lf = L.left[r];
+               if (!__ballot((c | ua) != 0) && lf == 0) continue;        /* nothing of this primitive on the row */
+               L.cover[r][lane] = 0; L.uarea[r][lane] = 0;
+               c = smr_wave_scan(c) + lf;
+               int area = c * 512 - ua;
+               int a = (area + (area << 4) + 256) >> 9;
+               a = a < 0 ? 0 : a > 255 ? 255 : a;
+               if (!col_in || !((cur_rowin >> r) & 1u)) a = 0;
+               if (a) layer[r] = lerp ? smr_blend_lerp(spix, (uint32_t) a, layer[r]) : smr_blend_over_mask(spix, (uint32_t) a, layer[r]);
+            }
+            SMR_WAVE_SYNC();
+            if (lane < SMR_TH) L.left[lane] = 0;
+            SMR_WAVE_SYNC();
+         }
+         if (ei >= end) break;
+
+         /* ================= a new primitive begins ================= */
+         if (it.prim != cur)
          {
-            /* a stroke's pieces left of this tile carry winding into it and were not binned here:
-             * collect the row's active edges from the whole primitive (rare: rows free of vertices
-             * in a multi-item stroke) */
+            cur = it.prim; cur_flags = (it.cnt_flags >> 8) & 0xffu; cur_color = it.color;
+            cnt = 0; lw = 0; cl = 1; cr = 0; ovf = false; touched = false;
 #pragma unroll
             for (int r = 0; r < SMR_TH; r++) rowcnt[r] = 0;
-            for (uint32_t base = 0; base < P.edge_cnt; base += 64)
-            {
-               uint32_t idx = base + lane;
-               smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0;
-               if (idx < P.edge_cnt) o = smr_orient(E[P.edge_off + idx]);
+            partial = it_rowbits & 0xfu; cur_rowin = (it_rowbits >> 4) & 0xfu;
+            cur_colmin = it_colmin; cur_colmax = it_colmax; cur_first = (it.cnt_flags >> 16) & 1u;
+         }
+
+         /* ================= one item: up to 64 edge slots, one per lane ================= */
+         const uint32_t icnt = it.cnt_flags & 0xffu;
+         const bool pieces = (cur_flags & SMR_PF_PIECES) != 0;
+         smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0; o.p1x = o.p1y = o.dxs = 0; o.D = 1;
+         if ((uint32_t) lane < icnt) o = smr_orient(my_edge);
+         const int32_t eminx = o.p1x + (o.dxs < 0 ? o.dxs : 0), emaxx = o.p1x + (o.dxs > 0 ? o.dxs : 0);
+         const bool inband = o.dir != 0 && o.ytop < ysbase + SMR_NSUB && o.ybot > ysbase && eminx < X1;
+
+         /* full rows: remember who spans them */
+         if (~partial & 0xfu)
+         {
 #pragma unroll
-               for (int r = 0; r < SMR_TH; r++)
+            for (int r = 0; r < SMR_TH; r++)
+            {
+               if ((partial >> r) & 1u) continue;
+               int rs0 = ysbase + r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
+               bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs1;
+               unsigned long long am = __ballot(act);
+               if (am)
                {
-                  if (!((fullrows >> r) & 1u)) continue;
-                  int rs0 = ysbase + r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
-                  bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs1;
-                  unsigned long long am = __ballot(act);
-                  if (am)
-                  {
-                     uint32_t pos = rowcnt[r] + __popcll(am & lt_mask);
-                     if (act && pos < SMR_ROWCAP) L.rowlist[r][pos] = (uint32_t) (P.edge_off + idx);
-                     rowcnt[r] += __popcll(am);
-                  }
+                  touched = true;
+                  uint32_t pos = rowcnt[r] + __popcll(am & lt_mask);
+                  if (act && pos < SMR_ROWCAP) L.rowlist[r][pos] = it.edge_off + lane;
+                  if (act && pos < 16) { int *re = L.redge[r][pos]; re[0] = o.p1x; re[1] = o.p1y; re[2] = o.dxs; re[3] = o.D; re[4] = o.dir; }
+                  rowcnt[r] += __popcll(am);
                }
             }
          }
-         __syncthreads();
-         for (int r = 0; r < SMR_TH; r++)
+
+         /* sub-sampled rows; lane = sub-row */
+         if (partial)
          {
-            if (!((fullrows >> r) & 1u)) continue;
-            uint32_t n = rowcnt[r];
-            if (n > SMR_ROWCAP) { if (lane == 0) atomicOr(A.status, SMR_ST_ROWCAP); continue; }
-            const int rs0 = ysbase + r * SMR_GRID_Y;
-            int64_t q0 = 0, q1 = 0; int32_t r0 = 0, r1 = 0, c0 = 0, c1 = 0, dxs = 0, D = 1, dir = 0;
-            const bool on = (uint32_t) lane < n;
-            if (on)
+            const bool mine = lane < SMR_NSUB && ((partial >> my_row) & 1u);
+            unsigned long long om = __ballot(inband);
+            if (pieces)
             {
-               smr_oedge_t o = smr_orient(E[L.rowlist[r][lane]]);
-               dxs = o.dxs; D = o.D; dir = o.dir;
-               smr_edge_x(o.p1x, o.p1y, o.dxs, o.D, rs0, q0, r0);
-               smr_edge_x(o.p1x, o.p1y, o.dxs, o.D, rs0 + SMR_GRID_Y, q1, r1);
-               c0 = smr_cell(q0, r0, D, dxs); c1 = smr_cell(q1, r1, D, dxs);
+               /* a piece (4 aligned lanes) is needed when any of its edges meets the strip and
+                * its x-extent meets the tile */
+               int32_t pmax = o.dir != 0 ? emaxx : INT32_MIN;
+               pmax = max(pmax, __shfl_xor(pmax, 1)); pmax = max(pmax, __shfl_xor(pmax, 2));
+               unsigned long long right = __ballot(pmax > X0);
+               om = om & right;
+               om |= om >> 1; om |= om >> 2;            /* gather the piece's bits into its first lane */
+               om &= 0x1111111111111111ull;
             }
-            /* rank sort by (cell, next cell) */
-            unsigned long long key = ((unsigned long long) (uint32_t) (c0 + 0x40000000) << 32) | (uint32_t) (c1 + 0x40000000);
-            L.key[lane] = key;
-            __syncthreads();
-            int rank = 0;
-            for (uint32_t j = 0; j < n; j++)
-            {
-               unsigned long long kj = L.key[j];
-               rank += (kj < key || (kj == key && j < (uint32_t) lane)) ? 1 : 0;
-            }
-            if (on) L.perm[rank] = lane;
-            __syncthreads();
-            int src = on ? L.perm[lane] : lane;
-            q0 = __shfl(q0, src); q1 = __shfl(q1, src);
-            r0 = __shfl(r0, src); r1 = __shfl(r1, src); c0 = __shfl(c0, src); c1 = __shfl(c1, src);
-            dxs = __shfl(dxs, src); D = __shfl(D, src); dir = __shfl(dir, src);
-            int c0n = __shfl_down(c0, 1);
-            /* winding prefix */
-            int wsum = on ? dir : 0;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(wsum, d); if (lane >= d) wsum += t; }
-            bool last = (uint32_t) lane + 1 == n;
-            bool is_end = on && ((((uint32_t) wsum & mask) == 0 && (last || c0n != c0)) || last);
-            int prev_end = __shfl_up((int) is_end, 1);
-            bool is_start = on && (lane == 0 || prev_end);
-            if (is_start) smr_render_edge(L, r, X0, dxs, D, q0, r0, q1, r1, +1);
-            else if (is_end) smr_render_edge(L, r, X0, dxs, D, q0, r0, q1, r1, -1);
-            __syncthreads();
-         }
-         __syncthreads();
-
-         /* ---- cells -> alpha -> ordered blend into the group layer; lane = column ---- */
-         const uint32_t spix = cur_color;
-         const bool lerp = (spix >> 24) == 255u || cur == first_prim;
-         /* libcairo composites inside the primitive's pixel extents only */
-         const int pxc = tx * SMR_TW + lane;
-         const bool col_in = pxc >= (P.minx >> 8) && pxc <= (P.maxx >> 8);
-#pragma unroll
-         for (int r = 0; r < SMR_TH; r++)
-         {
-            int c = L.cover[r][lane];
-            int ua = L.uarea[r][lane];
-            L.cover[r][lane] = 0; L.uarea[r][lane] = 0;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(c, d); if (lane >= d) c += t; }
-            c += L.left[r];
-            int area = c * 512 - ua;
-            int a = (area + (area << 4) + 256) >> 9;
-            a = a < 0 ? 0 : a > 255 ? 255 : a;
-            if (!col_in || row0 + r < (P.miny >> 8) || row0 + r > (P.maxy >> 8)) a = 0;
-            if (a) layer[r] = lerp ? smr_blend_lerp(spix, (uint32_t) a, layer[r]) : smr_blend_over_mask(spix, (uint32_t) a, layer[r]);
-         }
-         __syncthreads();
-         if (lane < SMR_TH) L.left[lane] = 0;
-         __syncthreads();
-      }
-      if (ei >= end) break;
-
-      /* ================= a new primitive begins ================= */
-      if (it.prim != cur)
-      {
-         cur = it.prim; cur_flags = it.cnt_flags >> 8; cur_color = it.color;
-         cnt = 0; lw = 0; ovf = false; touched = false;
-#pragma unroll
-         for (int r = 0; r < SMR_TH; r++) rowcnt[r] = 0;
-         /* the tile's 4 bits of the primitive's row mask; rows outside the mask hold no edge */
-         const smr_prim_t *Pp = &A.prims[cur];
-         const uint32_t moff = Pp->mask_off;
-         const int prow0 = Pp->row0, pn = Pp->nrows;
-         partial = 0;
-#pragma unroll
-         for (int r = 0; r < SMR_TH; r++)
-         {
-            int rr = row0 + r - prow0;
-            uint32_t bit = 1;
-            if (rr >= 0 && rr < pn) bit = (A.mask[moff + ((uint32_t) rr >> 5)] >> (rr & 31)) & 1u;
-            partial |= bit << r;
-         }
-      }
-
-      /* ================= one item: up to 64 edge slots, one per lane ================= */
-      const uint32_t icnt = it.cnt_flags & 0xffu;
-      const bool pieces = (cur_flags & SMR_PF_PIECES) != 0;
-      smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0; o.p1x = o.p1y = o.dxs = 0; o.D = 1;
-      if ((uint32_t) lane < icnt) o = smr_orient(A.edges[(size_t) it.edge_off + lane]);
-      const int32_t eminx = o.p1x + (o.dxs < 0 ? o.dxs : 0), emaxx = o.p1x + (o.dxs > 0 ? o.dxs : 0);
-      const bool inband = o.dir != 0 && o.ytop < ysbase + SMR_NSUB && o.ybot > ysbase && eminx < X1;
-
-      /* full rows: remember who spans them */
-      if (~partial & 0xfu)
-      {
-#pragma unroll
-         for (int r = 0; r < SMR_TH; r++)
-         {
-            if ((partial >> r) & 1u) continue;
-            int rs0 = ysbase + r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
-            bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs1;
-            unsigned long long am = __ballot(act);
-            if (am)
+            if (om && !(A.exp & 2))
             {
                touched = true;
-               uint32_t pos = rowcnt[r] + __popcll(am & lt_mask);
-               if (act && pos < SMR_ROWCAP) L.rowlist[r][pos] = it.edge_off + lane;
-               rowcnt[r] += __popcll(am);
-            }
-         }
-      }
-
-      /* sub-sampled rows; lane = sub-row */
-      if (partial)
-      {
-         const bool mine = lane < SMR_NSUB && ((partial >> my_row) & 1u);
-         unsigned long long om = __ballot(inband);
-         if (pieces)
-         {
-            /* a piece (4 aligned lanes) is needed when any of its edges meets the strip and
-             * its x-extent meets the tile */
-            int32_t pmax = o.dir != 0 ? emaxx : INT32_MIN;
-            pmax = max(pmax, __shfl_xor(pmax, 1)); pmax = max(pmax, __shfl_xor(pmax, 2));
-            unsigned long long right = __ballot(pmax > X0);
-            om = om & right;
-            om |= om >> 1; om |= om >> 2;            /* gather the piece's bits into its first lane */
-            om &= 0x1111111111111111ull;
-         }
-         if (om)
-         {
-            touched = true;
-            __syncthreads();
-            L.e_p1x[lane] = o.p1x; L.e_p1y[lane] = o.p1y; L.e_dxs[lane] = o.dxs; L.e_D[lane] = o.D;
-            L.e_ytop[lane] = o.ytop; L.e_ybot[lane] = o.ybot; L.e_dir[lane] = o.dir;
-            __syncthreads();
-            while (om)
-            {
-               int j = __ffsll((long long) om) - 1;
-               om &= om - 1;
-               if (!pieces)
+               /* per-edge constants of the fast exact evaluation, broadcast by v_readlane */
+               const int64_t e_c = 256 - 30ll * o.p1y;
+               const int e_clo = (int) (uint32_t) e_c, e_chi = (int) (e_c >> 32);
+               const int e_dxs2 = 2 * o.dxs;
+               const double e_inv = 1.0 / (double) o.D;
+               const int e_ilo = (int) (uint32_t) __double_as_longlong(e_inv), e_ihi = (int) (__double_as_longlong(e_inv) >> 32);
+               /* sub-row window of the edge relative to the tile, [0, 60]; empty for empty slots */
+               const int e_t0 = o.dir == 0 ? 64 : min(max(o.ytop - ysbase, 0), 64), e_t1 = o.dir == 0 ? 0 : min(max(o.ybot - ysbase, 0), 64);
+               const int e_win = e_t0 | (e_t1 << 8) | ((o.dir > 0 ? 1 : 0) << 16);
+               const int e_rcpf = __float_as_int((float) e_inv);
+               /* a piece takes the 32-bit path when each of its edges is empty or short in x and y */
+               int e_small = (o.dir == 0 || (abs(o.dxs) < 4096 && o.D <= 60 * 4096)) ? 1 : 0;
+               e_small &= __shfl_xor(e_small, 1); e_small &= __shfl_xor(e_small, 2);      /* no short-circuit: every lane shuffles */
+               const unsigned long long smallmask = (pieces && !(A.exp & 16)) ? __ballot(e_small != 0) : 0ull;
+               while (om)
                {
-                  int ytop = L.e_ytop[j], ybot = L.e_ybot[j];
-                  if (mine && my_ys >= ytop && my_ys < ybot)
+                  const int j = __ffsll((long long) om) - 1;
+                  om &= om - 1;
+                  if (!pieces)
                   {
-                     int64_t q; int32_t rem;
-                     int32_t dxs = L.e_dxs[j], D = L.e_D[j];
-                     smr_edge_x(L.e_p1x[j], L.e_p1y[j], dxs, D, my_ys, q, rem);
-                     int32_t cell = smr_cell(q, rem, D, dxs);
-                     int dir = L.e_dir[j];
-                     if (cell < X0) lw += dir;
-                     else if (cell < X1)
+                     const int win = __builtin_amdgcn_readlane(e_win, j);
+                     if (__builtin_amdgcn_readlane(emaxx, j) < X0)
                      {
-                        if (cnt < SMR_BK) bk[cnt++] = (uint16_t) (((cell - X0) << 1) | (dir > 0 ? 1 : 0));
-                        else ovf = true;
+                        /* the edge lies left of the tile: every crossing is, so only its winding counts */
+                        if (mine && lane >= (win & 0xff) && lane < ((win >> 8) & 0xff)) lw += (win >> 16) ? 1 : -1;
                      }
-                  }
-               }
-               else if (mine)
-               {
-                  /* convex piece: its two crossings bound one covered interval; the stroke is
-                   * the union of the intervals of all pieces (every piece winds the same way) */
-                  int32_t lo = INT32_MAX, hi = INT32_MIN;
-#pragma unroll
-                  for (int k = 0; k < 4; k++)
-                  {
-                     int jj = j + k;
-                     if (L.e_dir[jj] != 0 && my_ys >= L.e_ytop[jj] && my_ys < L.e_ybot[jj])
+                     else if (mine && lane >= (win & 0xff) && lane < ((win >> 8) & 0xff))
                      {
-                        int64_t q; int32_t rem;
-                        int32_t dxs = L.e_dxs[jj], D = L.e_D[jj];
-                        smr_edge_x(L.e_p1x[jj], L.e_p1y[jj], dxs, D, my_ys, q, rem);
-                        int32_t cell = smr_cell(q, rem, D, dxs);
-                        lo = min(lo, cell); hi = max(hi, cell);
-                     }
-                  }
-                  if (lo < hi && hi > X0 && lo < X1)
-                  {
-                     int l = (lo < X0 ? X0 : lo) - X0, r = (hi > X1 ? X1 : hi) - X0;
-                     /* merge with every stored interval it overlaps or touches */
-                     for (int i = 0; i < cnt;)
-                     {
-                        int ia = bk[2 * i], ib = bk[2 * i + 1];
-                        if (ia <= r && l <= ib)
+                        const int64_t c = ((int64_t) __builtin_amdgcn_readlane(e_chi, j) << 32) | (uint32_t) __builtin_amdgcn_readlane(e_clo, j);
+                        const double inv = __longlong_as_double(((long long) __builtin_amdgcn_readlane(e_ihi, j) << 32) |
+                                                                (uint32_t) __builtin_amdgcn_readlane(e_ilo, j));
+                        int32_t cell = smr_edge_cell(c, __builtin_amdgcn_readlane(e_dxs2, j), __builtin_amdgcn_readlane(o.D, j), inv,
+                                                     __builtin_amdgcn_readlane(o.p1x, j), my_ys);
+                        if (cell < X0) lw += (win >> 16) ? 1 : -1;
+                        else if (cell < X1)
                         {
-                           l = min(l, ia); r = max(r, ib);
-                           cnt--;
-                           bk[2 * i] = bk[2 * cnt]; bk[2 * i + 1] = bk[2 * cnt + 1];
-                           i = 0;
+                           if (cnt < SMR_BK) bk[cnt++] = (uint16_t) (((cell - X0) << 1) | (win >> 16));
+                           else ovf = true;
                         }
-                        else i++;
                      }
-                     if (2 * cnt + 2 <= SMR_BK) { bk[2 * cnt] = (uint16_t) l; bk[2 * cnt + 1] = (uint16_t) r; cnt++; }
-                     else ovf = true;
+                  }
+                  else
+                  {
+                     /* convex piece: its two crossings bound one covered interval; the stroke is
+                      * the union of the intervals of all pieces (every piece winds the same way) */
+                     int32_t lo = INT32_MAX, hi = INT32_MIN;
+                     if ((smallmask >> j) & 1ull)
+                     {
+                        /* all four edges are short (|dx|, dy < 16 px): the numerator fits 32 bits, the quotient
+                         * 13, so 24-bit multiplies and one fp32 estimate give the exact floor; branch-free */
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                        {
+                           const int jj = j + k;
+                           const int win = __builtin_amdgcn_readlane(e_win, jj);
+                           const int D = __builtin_amdgcn_readlane(o.D, jj);
+                           const int t = my_ys * 512 + __builtin_amdgcn_readlane(e_clo, jj);
+                           const int n = __mul24(__builtin_amdgcn_readlane(e_dxs2, jj), t);
+                           int q = (int) floorf((float) n * __int_as_float(__builtin_amdgcn_readlane(e_rcpf, jj)));
+                           int rem = n - __mul24(q, D);
+                           if (rem < 0) { q--; rem += D; } else if (rem >= D) { q++; rem -= D; }
+                           const int cell = __builtin_amdgcn_readlane(o.p1x, jj) + q + (rem >= (D >> 1) ? 1 : 0);
+                           const bool in = lane >= (win & 0xff) && lane < ((win >> 8) & 0xff);
+                           lo = in ? min(lo, cell) : lo; hi = in ? max(hi, cell) : hi;
+                        }
+                     }
+                     else
+                     {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                        {
+                           const int jj = j + k;
+                           const int win = __builtin_amdgcn_readlane(e_win, jj);
+                           if (mine && lane >= (win & 0xff) && lane < ((win >> 8) & 0xff))
+                           {
+                              const int64_t c = ((int64_t) __builtin_amdgcn_readlane(e_chi, jj) << 32) | (uint32_t) __builtin_amdgcn_readlane(e_clo, jj);
+                              const double inv = __longlong_as_double(((long long) __builtin_amdgcn_readlane(e_ihi, jj) << 32) |
+                                                                      (uint32_t) __builtin_amdgcn_readlane(e_ilo, jj));
+                              int32_t cell = smr_edge_cell(c, __builtin_amdgcn_readlane(e_dxs2, jj), __builtin_amdgcn_readlane(o.D, jj), inv,
+                                                           __builtin_amdgcn_readlane(o.p1x, jj), my_ys);
+                              lo = min(lo, cell); hi = max(hi, cell);
+                           }
+                        }
+                     }
+                     if (mine && lo < hi && hi > X0 && lo < X1)
+                     {
+                        const int l = (lo < X0 ? X0 : lo) - X0, r = (hi > X1 ? X1 : hi) - X0;
+                        if (A.exp & 32) push_interval(l, r);
+                        else if (cl > cr) { cl = l; cr = r; }
+                        else if (l <= cr && cl <= r) { cl = min(cl, l); cr = max(cr, r); }
+                        else { push_interval(cl, cr); cl = l; cr = r; }
+                     }
                   }
                }
             }
          }
       }
-   }
 
-   /* pop_group_to_source + paint: layer OVER canvas */
-   const int px = tx * SMR_TW + lane;
-   if (px < A.W)
-   {
-#pragma unroll
-      for (int r = 0; r < SMR_TH; r++)
+      /* pop_group_to_source + paint: layer OVER canvas */
+      const int px = tx * SMR_TW + lane;
+      if (px < A.W)
       {
-         int row = ty * SMR_TH + r;
-         if (row < A.band_h && layer[r])
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++)
          {
-            uint32_t *d = A.canvas + (size_t) row * A.W + px;
-            *d = smr_blend_over(layer[r], *d);
+            int row = ty * SMR_TH + r;
+            if (row < A.band_h && layer[r])
+            {
+               uint32_t *d = A.canvas + (size_t) row * A.W + px;
+               *d = smr_blend_over(layer[r], *d);
+            }
          }
       }
    }
@@ -1297,8 +1572,12 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
 
    /* primitive set-up (items, boxes, row masks); the mask arena grows on demand */
    uint32_t *maskbuf;
+   const unsigned setup_wg = (unsigned) std::min<int64_t>((n_prims + SMR_SETUP_WAVES - 1) / SMR_SETUP_WAVES, 256 * 6);
    size_t mask_cap = c->buf[SMR_BUF_MASK].cap / 4;
-   if (mask_cap < (size_t) n_prims * 2 + 65536) mask_cap = (size_t) n_prims * 2 + 65536;
+   {
+      size_t want = (size_t) n_prims * 2 + (size_t) setup_wg * SMR_SETUP_WAVES * SMR_MASK_BLOCK + 65536;
+      if (mask_cap < want) mask_cap = want;
+   }
    for (int attempt = 0;; attempt++)
    {
       SMR_TRY(c->ensure(SMR_BUF_MASK, mask_cap * 4, (void **) &maskbuf));
@@ -1309,14 +1588,14 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
       SA.way_border_pix = wb_pix; SA.way_fill_pix = wf_pix; SA.W = c->W; SA.H = c->H;
       SA.prims = prims; SA.items = items; SA.mask = maskbuf; SA.mask_cap = (uint32_t) std::min<size_t>(mask_cap, 0xffffffffu);
       SA.small = small;
-      size_t lds = ((size_t) (c->H + 31) / 32 + 1) * 4;
-      k_prim_setup<<<(unsigned) n_prims, 64, lds, s>>>(SA);
+      int mask_words = (c->H + 31) / 32 + 1;
+      k_prim_setup<<<setup_wg, 64 * SMR_SETUP_WAVES, (size_t) mask_words * 4 * SMR_SETUP_WAVES, s>>>(SA, mask_words);
       SMR_HIP(hipGetLastError());
       SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
       SMR_HIP(hipStreamSynchronize(s));
       if (!(h_small[2] & SMR_ST_MASK_ARENA)) break;
       if (attempt) return smr_fail(SMR_E_CAPACITY, "draw: row-mask arena of %zu words still too small", mask_cap);
-      mask_cap = (size_t) h_small[4] + 1024;
+      mask_cap = (size_t) h_small[4] + 65536;
       init_small[0] = h_small[0];
       SMR_HIP(hipMemcpyAsync(small, init_small, sizeof(init_small), hipMemcpyHostToDevice, s));
    }
@@ -1344,16 +1623,27 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    SMR_HIP(hipMemsetAsync(counts, 0, (size_t) n_tiles * 4, s));
    k_bin<true><<<blocks(n_items, TB), TB, 0, s>>>(items, n_items, c->W, c->band_y0, c->band_h, TX, counts, tile_off, entries);
    SMR_HIP(hipGetLastError());
-   k_tile_sort<<<n_tiles, 64, 0, s>>>(tile_off, entries, n_tiles);
+   smr_thdr_t *hdrs;
+   SMR_TRY(c->ensure(SMR_BUF_HDRS, ((size_t) n_entries + 1) * sizeof(smr_thdr_t), (void **) &hdrs));
+   {
+      sort_args_t SO;
+      SO.tile_off = tile_off; SO.entries = entries; SO.items = items; SO.prims = prims; SO.mask = maskbuf; SO.first_prim = &small[1];
+      SO.hdrs = hdrs; SO.n_tiles = n_tiles; SO.TX = TX; SO.band_y0 = c->band_y0;
+      k_tile_sort<<<n_tiles, 64, 0, s>>>(SO);
+   }
    SMR_HIP(hipGetLastError());
    T.mark(s);                                                   /* 3: binned + sorted */
 
    raster_args_t A;
-   A.prims = prims; A.items = items; A.edges = edges; A.mask = maskbuf; A.tile_off = tile_off; A.entries = entries;
-   A.first_prim = &small[1];
+   A.prims = prims; A.hdrs = hdrs; A.edges = edges; A.tile_off = tile_off;
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
-   k_raster<<<n_tiles, 64, 0, s>>>(A);
+   A.exp = getenv("SMR_EXP") ? atoi(getenv("SMR_EXP")) : 0;
+   {
+      /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
+      unsigned nwg = std::min<unsigned>((n_tiles + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES, 256u * 8u);
+      k_raster<<<nwg, 64 * SMR_RASTER_WAVES, 0, s>>>(A);
+   }
    SMR_HIP(hipGetLastError());
    T.mark(s);                                                   /* 4: rastered */
    SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));

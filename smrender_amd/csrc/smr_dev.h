@@ -48,6 +48,20 @@ struct __attribute__((aligned(16))) smr_item_t
                                         tile carry winding into it) */
 };
 
+/* one entry of a tile's sorted work stream: everything the rasterizer needs about (item, tile) in
+ * one sequential 32-byte record, so that the wave that rasterizes the tile never chases pointers */
+struct __attribute__((aligned(16))) smr_thdr_t
+{
+   uint32_t edge_off;        /* first edge slot of the item */
+   uint32_t prim;
+   uint32_t cnt_flags;       /* slots in bits 0..7, SMR_PF_* << 8, bit 16: first primitive of the layer */
+   uint32_t color;
+   uint32_t rowbits;         /* bits 0..3: the tile's rows that are sub-sampled for this primitive (row mask);
+                                bits 4..7: the tile's rows inside the primitive's pixel extents */
+   int32_t colmin, colmax;   /* tile columns inside the primitive's pixel extents (may be outside 0..63) */
+   uint32_t pad_;
+};
+
 /* status word bits reported back to the host */
 #define SMR_ST_BUCKET_OVERFLOW 1u
 #define SMR_ST_ROWCAP 2u
@@ -102,6 +116,59 @@ __device__ __forceinline__ int32_t smr_cell(int64_t quo, int32_t rem, int32_t D,
 {
    return (int32_t) quo + ((dxs != 0 && rem >= (D >> 1)) ? 1 : 0);
 }
+
+/* Fast exact form of smr_edge_x + smr_cell for a lane that evaluates many sub-rows of one edge.
+ * Per edge (computed once by the lane that owns the edge): c = 256 - 30*p1y, dxs2 = 2*dxs,
+ * invD = 1/D.  x(ys) = p1x + floor(dxs2 * (512*ys + c) / D); the quotient fits 32 bits
+ * (|q| <= |dxs|), so one fp64 multiply estimates it to +-1 and one exact integer remainder
+ * corrects it.  Valid while |coordinates| < 2^20 px (the numerator stays below 2^63). */
+__device__ __forceinline__ int32_t smr_edge_cell(int64_t c, int32_t dxs2, int32_t D, double invD, int32_t p1x, int ys)
+{
+   const int64_t t = (int64_t) ys * 512 + c;
+   const int64_t n = t * (int64_t) dxs2;
+   const double nd = fma((double) (int32_t) (n >> 32), 4294967296.0, (double) (uint32_t) n);
+   int32_t q = (int32_t) floor(nd * invD);
+   int64_t rem = n - (int64_t) q * D;
+   if (rem < 0) { q--; rem += D; }
+   else if (rem >= D) { q++; rem -= D; }
+   return p1x + q + (rem >= (int64_t) (D >> 1) ? 1 : 0);
+}
+
+/* same evaluation, returning the quotient (without p1x) and the remainder: x = p1x + q + rem / D */
+__device__ __forceinline__ void smr_edge_qr(int64_t c, int32_t dxs2, int32_t D, double invD, int ys, int32_t &q, int32_t &rem)
+{
+   const int64_t t = (int64_t) ys * 512 + c;
+   const int64_t n = t * (int64_t) dxs2;
+   const double nd = fma((double) (int32_t) (n >> 32), 4294967296.0, (double) (uint32_t) n);
+   int32_t qq = (int32_t) floor(nd * invD);
+   int64_t r = n - (int64_t) qq * D;
+   if (r < 0) { qq--; r += D; }
+   else if (r >= D) { qq++; r -= D; }
+   q = qq; rem = (int32_t) r;
+}
+
+__device__ __forceinline__ double smr_i64_to_f64(int64_t n)
+{
+   return fma((double) (int32_t) (n >> 32), 4294967296.0, (double) (uint32_t) n);
+}
+
+/* inclusive prefix sum over the 64 lanes with DPP row shifts / broadcasts (VALU latency only; the
+ * ds_bpermute form of __shfl_up costs an LDS round trip per step) */
+__device__ __forceinline__ int smr_wave_scan(int v)
+{
+   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      /* row_shr:1 */
+   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      /* row_shr:2 */
+   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      /* row_shr:4 */
+   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      /* row_shr:8 */
+   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      /* row_bcast:15 -> rows 1, 3 */
+   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      /* row_bcast:31 -> rows 2, 3 */
+   return v;
+}
+
+/* wave-local ordering of LDS traffic: a wavefront's DS operations execute in program order, so
+ * only the compiler has to be held back; no s_barrier (waves of one workgroup are independent) */
+#define SMR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 /* ---- 8-bit compositing arithmetic (libcairo image spans / pixman 0.40) ---- */
 __device__ __forceinline__ uint32_t smr_mul7f(uint32_t a, uint32_t b) { uint32_t t = a * b + 0x7f; return (t + (t >> 8)) >> 8; }
