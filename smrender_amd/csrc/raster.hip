@@ -254,7 +254,7 @@ __global__ void k_color_pixels(const uint32_t *__restrict__ col, int64_t n, uint
  * increasing in w and leaves room for ceil(n/8) chunks per kind, so no scan is needed and ids
  * ascend in drawing order (way, border before fill, chunk).                               */
 /* ------------------------------------------------------------------------------------ */
-#define SMR_LONGCAP 64       /* edges spanning a whole pixel row, kept in LDS per primitive */
+#define SMR_LONGCAP 256      /* edges spanning a whole pixel row, kept in LDS per primitive */
 #define SMR_ACTCAP 8         /* active edges per vertex-free row in the lane-per-row analysis */
 
 struct setup_args_t
@@ -276,7 +276,7 @@ struct setup_args_t
 
 struct setup_lds_t
 {
-   int l_p1x[SMR_LONGCAP], l_p1y[SMR_LONGCAP], l_dxs[SMR_LONGCAP], l_D[SMR_LONGCAP], l_ytop[SMR_LONGCAP], l_ybot[SMR_LONGCAP];
+   int4 l_edge[SMR_LONGCAP];       /* p1x, p1y, dxs, dy of the oriented edge */
    int act0[64][SMR_ACTCAP + 1], act1[64][SMR_ACTCAP + 1];
    uint32_t nlong;
 };
@@ -304,7 +304,7 @@ __device__ __forceinline__ void smr_setup_edge(const smr_oedge_t &o, int row0, i
       uint32_t k = atomicAdd(&L.nlong, 1u);
       if (k < SMR_LONGCAP)
       {
-         L.l_p1x[k] = o.p1x; L.l_p1y[k] = o.p1y; L.l_dxs[k] = o.dxs; L.l_D[k] = o.D; L.l_ytop[k] = o.ytop; L.l_ybot[k] = o.ybot;
+         L.l_edge[k] = make_int4(o.p1x, o.p1y, o.dxs, o.D / 60);
       }
    }
 }
@@ -426,7 +426,8 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          {
             if (nlong <= SMR_LONGCAP)
             {
-               p1x = L.l_p1x[idx]; p1y = L.l_p1y[idx]; dxs = L.l_dxs[idx]; D = L.l_D[idx]; ytop = L.l_ytop[idx]; ybot = L.l_ybot[idx];
+               const int4 le = L.l_edge[idx];
+               p1x = le.x; p1y = le.y; dxs = le.z; D = 60 * le.w; ytop = smr_to_grid_y(le.y); ybot = smr_to_grid_y(le.y + le.w);
                have = true;
             }
             else
@@ -481,19 +482,33 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          int cnt = 0;
          bool over = false;
          if (!__ballot(mine)) continue;
+         /* few vertex-free rows in this batch: one wavefront pass over the candidates per row is cheaper
+          * than every lane walking the whole list */
+         const unsigned long long rows = __ballot(mine);
+         if (__popcll(rows) * 8 <= (int) nlong)
+         {
+            unsigned long long rm = rows;
+            while (rm)
+            {
+               int j = __ffsll((long long) rm) - 1;
+               rm &= rm - 1;
+               row_by_wave(rb + j);
+            }
+            continue;
+         }
          for (uint32_t i = 0; i < nlong; i++)
          {
-            const int ytop = L.l_ytop[i], ybot = L.l_ybot[i];
+            const int4 le = L.l_edge[i];
+            const int ytop = smr_to_grid_y(le.y), ybot = smr_to_grid_y(le.y + le.w);
             if (mine && !over && ytop <= rs0 && ybot >= rs1)
             {
                if (cnt < SMR_ACTCAP)
                {
-                  int64_t q; int32_t rem;
-                  const int32_t p1x = L.l_p1x[i], p1y = L.l_p1y[i], dxs = L.l_dxs[i], D = L.l_D[i];
-                  smr_edge_x(p1x, p1y, dxs, D, rs0, q, rem);
-                  L.act0[lane][cnt] = smr_cell(q, rem, D, dxs);
-                  smr_edge_x(p1x, p1y, dxs, D, rs1, q, rem);
-                  L.act1[lane][cnt] = smr_cell(q, rem, D, dxs);
+                  const int32_t D = 60 * le.w;
+                  const int64_t ec = 256 - 30ll * le.y;
+                  const double inv = 1.0 / (double) D;
+                  L.act0[lane][cnt] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs0);
+                  L.act1[lane][cnt] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs1);
                   cnt++;
                }
                else over = true;
@@ -781,7 +796,6 @@ struct raster_args_t
    uint32_t *status;
    int W, band_y0, band_h, TX;
    uint32_t n_tiles;
-   int exp;
 };
 
 struct raster_lds_t
@@ -869,6 +883,14 @@ __device__ void smr_render_edge(raster_lds_t &L, int row, int32_t X0, int32_t dx
 
 #define SMR_RASTER_WAVES 4      /* independent wavefronts per workgroup, one tile at a time each */
 
+/* -DSMR_SECTION_PROFILE: s_memtime stamps around the sections of k_raster, summed per section into
+ * status[14..] (diagnostic build only; the stamps cost ~10 % and no output depends on them) */
+#ifdef SMR_SECTION_PROFILE
+#define TICK(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); prof[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define TICK(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t A)
 {
    __shared__ raster_lds_t LL[SMR_RASTER_WAVES];
@@ -886,6 +908,9 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
 
    /* persistent wavefronts: tile = gwave, gwave + nwaves, ... (1 M workgroup launches would cost more
     * than the work of the many empty or light tiles) */
+#ifdef SMR_SECTION_PROFILE
+   unsigned long long prof[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memtime();
+#endif
    for (uint32_t tile = gwave; tile < A.n_tiles; tile += nwaves)
    {
       const uint32_t beg = A.tile_off[tile], end = A.tile_off[tile + 1];
@@ -966,6 +991,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             if (ei + 1 == bbase + 64) { bbase += 64; load_batch(); }
             edge1 = load_edge(ei + 1);
          }
+         TICK(0);      /* header hand-out + the previous entry's crossing loop */
 
          /* ================= flush: the previous primitive is complete ================= */
          if (it.prim != cur && cur != 0xffffffffu && touched)
@@ -988,7 +1014,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                }
                else smr_cell_add(L, my_row, ix1, 0, 2 * (fx1 - fx2));
             };
-            if (A.exp & 8) {} else if (mine && pieces)
+            if (mine && pieces)
             {
                if (cl <= cr) push_interval(cl, cr);
                for (int i = 0; i < cnt; i++) add_span(bk[2 * i], bk[2 * i + 1]);
@@ -1019,6 +1045,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                if (xstart >= 0) add_span(xstart, SMR_TW * 256);
             }
 
+            TICK(1);      /* flush: spans of the sub-sampled rows */
             /* ---- rows that take libcairo's exact full-row path ---- */
             uint32_t fullrows = 0;
 #pragma unroll
@@ -1106,77 +1133,62 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                const int wincl = wsum + dir;
                const bool is_end = onr && ((((uint32_t) wincl & mask) == 0 && (!has_succ || succ_c0 != c0)) || !has_succ);
                const bool is_start = onr && (!has_pred || (((uint32_t) wsum & mask) == 0 && pred_c0 != c0));
-               /* per boundary edge: everything the columns need, computed once by the edge's lane */
-               int b_ix1 = (int) (q1 >> 8), b_ix2 = (int) (q2 >> 8), b_fx1 = q1 & 255, b_fx2 = q2 & 255;
-               int64_t b_tmp0 = 0, b_dx = 1;
-               if (b_ix1 != b_ix2)
+               /* every span-boundary edge adds its exact trapezoid coverage to the cells it crosses inside
+                * the tile (libcairo's cell_list_render_edge; the per-cell y steps are floors of one
+                * 64-bit quotient each, estimated with one fp64 multiply and corrected exactly) */
+               if (is_start || is_end)
                {
-                  int32_t qa = q1, ra = r1, qb = q2, rb = r2;
-                  if (b_ix2 < b_ix1)
-                  {
-                     int t = b_ix1; b_ix1 = b_ix2; b_ix2 = t;
-                     t = b_fx1; b_fx1 = b_fx2; b_fx2 = t;
-                     qa = q2; ra = r2; qb = q1; rb = r1;
-                  }
-                  b_dx = (int64_t) (qb - qa) * D + (rb - ra);
-                  b_tmp0 = ((int64_t) (256 - b_fx1) * D - ra) * SMR_GRID_Y;
-               }
-               const double b_inv = 1.0 / smr_i64_to_f64(b_dx);
-               const int b_fx = b_fx1 | (b_fx2 << 16);
-               const int b_sign = is_start ? 1 : -1;
-               unsigned long long bm = __ballot(is_start || is_end);
-               while (bm)
-               {
-                  const int j = __ffsll((long long) bm) - 1;
-                  bm &= bm - 1;
-                  const int r = j >> 4;
-                  const int sgn = __builtin_amdgcn_readlane(b_sign, j);
-                  const int ix1 = __builtin_amdgcn_readlane(b_ix1, j), ix2 = __builtin_amdgcn_readlane(b_ix2, j);
-                  const int fxp = __builtin_amdgcn_readlane(b_fx, j);
-                  const int fx1 = fxp & 0xffff, fx2 = fxp >> 16;
-                  int cov = 0, ua = 0, lf = 0;
+                  const int sgn = is_start ? 1 : -1;
+                  int ix1 = (int) (q1 >> 8), ix2 = (int) (q2 >> 8), fx1 = q1 & 255, fx2 = q2 & 255;
                   if (ix1 == ix2)
                   {
-                     if (lane == ix1) { cov = SMR_GRID_Y; ua = (fx1 + fx2) * SMR_GRID_Y; }
-                     if (ix1 < 0) lf = SMR_GRID_Y;
+                     const int ix = ix1 < -1 ? -1 : ix1 > SMR_TW ? SMR_TW : ix1;
+                     smr_cell_add(L, grp, ix, sgn * SMR_GRID_Y, sgn * (fx1 + fx2) * SMR_GRID_Y);
                   }
-                  else if (ix2 < 0) lf = SMR_GRID_Y;
-                  else if (ix1 < SMR_TW)
+                  else
                   {
-                     const int64_t tmp0 = ((int64_t) __builtin_amdgcn_readlane((int) (b_tmp0 >> 32), j) << 32) |
-                                          (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) b_tmp0, j);
-                     const int64_t dx = ((int64_t) __builtin_amdgcn_readlane((int) (b_dx >> 32), j) << 32) |
-                                        (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) b_dx, j);
-                     const double inv = __longlong_as_double(((long long) __builtin_amdgcn_readlane((int) (__double_as_longlong(b_inv) >> 32), j) << 32) |
-                                                             (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) __double_as_longlong(b_inv), j));
-                     const int64_t step = (int64_t) (SMR_GRID_Y * 256) * __builtin_amdgcn_readlane(D, j);
-                     /* y (in sub-rows) at which the edge crosses the right boundary of cell `cell` */
-                     auto Y = [&](int cell) -> int
+                     int32_t qa = q1, ra = r1, qb = q2, rb = r2;
+                     if (ix2 < ix1)
                      {
-                        const int64_t n = tmp0 + (int64_t) (cell - ix1) * step;
-                        int y = (int) (smr_i64_to_f64(n) * inv);
-                        int64_t rem = n - (int64_t) y * dx;
-                        if (rem < 0) y--; else if (rem >= dx) y++;
-                        return y;
-                     };
-                     int yhi = lane >= ix2 ? SMR_GRID_Y : (lane < ix1 ? 0 : Y(lane));
-                     int ylo = __shfl_up(yhi, 1);
-                     const int yleft = ix1 >= 0 ? 0 : Y(-1);
-                     if (lane == 0) ylo = yleft;
-                     cov = yhi - ylo;
-                     ua = cov * (lane == ix1 ? 256 + fx1 : lane == ix2 ? fx2 : 256);
-                     lf = yleft;
+                        int t = ix1; ix1 = ix2; ix2 = t;
+                        t = fx1; fx1 = fx2; fx2 = t;
+                        qa = q2; ra = r2; qb = q1; rb = r1;
+                     }
+                     if (ix2 < 0) atomicAdd(&L.left[grp], sgn * SMR_GRID_Y);
+                     else if (ix1 < SMR_TW)
+                     {
+                        const int64_t dx = (int64_t) (qb - qa) * D + (rb - ra);
+                        const int64_t tmp0 = ((int64_t) (256 - fx1) * D - ra) * SMR_GRID_Y;
+                        const int64_t step = (int64_t) (SMR_GRID_Y * 256) * D;
+                        const double inv = 1.0 / smr_i64_to_f64(dx);
+                        /* y (in sub-rows) at which the edge crosses the right boundary of cell `cell` */
+                        auto Y = [&](int cell) -> int
+                        {
+                           const int64_t n = tmp0 + (int64_t) (cell - ix1) * step;
+                           int y = (int) (smr_i64_to_f64(n) * inv);
+                           int64_t rem = n - (int64_t) y * dx;
+                           if (rem < 0) y--; else if (rem >= dx) y++;
+                           return y;
+                        };
+                        int k = ix1, ylast = 0;
+                        if (ix1 < 0) { ylast = Y(-1); atomicAdd(&L.left[grp], sgn * ylast); k = 0; }
+                        const int kend = min(ix2, SMR_TW - 1);
+                        for (; k <= kend; k++)
+                        {
+                           const int yhi = k == ix2 ? SMR_GRID_Y : Y(k);
+                           const int cov = yhi - ylast;
+                           const int fac = k == ix1 ? 256 + fx1 : k == ix2 ? fx2 : 256;
+                           if (cov) { atomicAdd(&L.cover[grp][k], sgn * cov); atomicAdd(&L.uarea[grp][k], sgn * cov * fac); }
+                           ylast = yhi;
+                        }
+                     }
                   }
-                  if (cov) atomicAdd(&L.cover[r][lane], sgn * cov);
-                  if (ua) atomicAdd(&L.uarea[r][lane], sgn * ua);
-                  if (lf && lane == 0) atomicAdd(&L.left[r], sgn * lf);
                }
                fullrows = 0;
             }
             for (int r = 0; r < SMR_TH; r++)
             {
                if (!((fullrows >> r) & 1u)) continue;
-               if (A.exp & 1) continue;
                uint32_t n = rowcnt[r];
                if (n > SMR_ROWCAP) { if (lane == 0) atomicOr(A.status, SMR_ST_ROWCAP); continue; }
                const int rs0 = ysbase + r * SMR_GRID_Y;
@@ -1221,6 +1233,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             }
             SMR_WAVE_SYNC();
 
+            TICK(2);      /* flush: full rows */
             /* ---- cells -> alpha -> ordered blend into the group layer; lane = column ---- */
             const uint32_t spix = cur_color;
             const bool lerp = (spix >> 24) == 255u || cur_first;
@@ -1229,23 +1242,25 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
 #pragma unroll
             for (int r = 0; r < SMR_TH; r++)
             {
-               if (A.exp & 4) continue;
                int c = L.cover[r][lane];
                int ua = L.uarea[r][lane];
                const int lf = L.left[r];
                if (!__ballot((c | ua) != 0) && lf == 0) continue;        /* nothing of this primitive on the row */
                L.cover[r][lane] = 0; L.uarea[r][lane] = 0;
-               c = smr_wave_scan(c) + lf;
+               /* interior rows carry no cover change at all: the prefix sum is the left cover */
+               c = __ballot(c != 0) ? smr_wave_scan(c) + lf : lf;
                int area = c * 512 - ua;
                int a = (area + (area << 4) + 256) >> 9;
                a = a < 0 ? 0 : a > 255 ? 255 : a;
                if (!col_in || !((cur_rowin >> r) & 1u)) a = 0;
-               if (a) layer[r] = lerp ? smr_blend_lerp(spix, (uint32_t) a, layer[r]) : smr_blend_over_mask(spix, (uint32_t) a, layer[r]);
+               if (lerp && !__ballot(a != 0 && a != 255)) layer[r] = a ? spix : layer[r];      /* no edge pixel on the row */
+               else if (a) layer[r] = lerp ? smr_blend_lerp(spix, (uint32_t) a, layer[r]) : smr_blend_over_mask(spix, (uint32_t) a, layer[r]);
             }
             SMR_WAVE_SYNC();
             if (lane < SMR_TH) L.left[lane] = 0;
             SMR_WAVE_SYNC();
          }
+         TICK(3);         /* flush: cells -> alpha -> blend */
          if (ei >= end) break;
 
          /* ================= a new primitive begins ================= */
@@ -1288,6 +1303,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             }
          }
 
+         TICK(4);         /* orient + full-row bookkeeping */
          /* sub-sampled rows; lane = sub-row */
          if (partial)
          {
@@ -1304,7 +1320,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                om |= om >> 1; om |= om >> 2;            /* gather the piece's bits into its first lane */
                om &= 0x1111111111111111ull;
             }
-            if (om && !(A.exp & 2))
+            if (om)
             {
                touched = true;
                /* per-edge constants of the fast exact evaluation, broadcast by v_readlane */
@@ -1320,7 +1336,8 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                /* a piece takes the 32-bit path when each of its edges is empty or short in x and y */
                int e_small = (o.dir == 0 || (abs(o.dxs) < 4096 && o.D <= 60 * 4096)) ? 1 : 0;
                e_small &= __shfl_xor(e_small, 1); e_small &= __shfl_xor(e_small, 2);      /* no short-circuit: every lane shuffles */
-               const unsigned long long smallmask = (pieces && !(A.exp & 16)) ? __ballot(e_small != 0) : 0ull;
+               const unsigned long long smallmask = pieces ? __ballot(e_small != 0) : 0ull;
+               TICK(5);   /* per-edge constants */
                while (om)
                {
                   const int j = __ffsll((long long) om) - 1;
@@ -1394,17 +1411,18 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                      if (mine && lo < hi && hi > X0 && lo < X1)
                      {
                         const int l = (lo < X0 ? X0 : lo) - X0, r = (hi > X1 ? X1 : hi) - X0;
-                        if (A.exp & 32) push_interval(l, r);
-                        else if (cl > cr) { cl = l; cr = r; }
+                        if (cl > cr) { cl = l; cr = r; }
                         else if (l <= cr && cl <= r) { cl = min(cl, l); cr = max(cr, r); }
                         else { push_interval(cl, cr); cl = l; cr = r; }
                      }
                   }
                }
+               TICK(6);   /* crossing loop */
             }
          }
       }
 
+      TICK(7);
       /* pop_group_to_source + paint: layer OVER canvas */
       const int px = tx * SMR_TW + lane;
       if (px < A.W)
@@ -1420,7 +1438,11 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             }
          }
       }
+      TICK(8);            /* layer OVER canvas */
    }
+#ifdef SMR_SECTION_PROFILE
+   if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd((unsigned long long *) (A.status + 14) + i, prof[i]);
+#endif
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1520,10 +1542,13 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    SMR_TRY(c->ensure(SMR_BUF_PTS, (size_t) n_refs * sizeof(int2), (void **) &pts));
    SMR_TRY(c->ensure(SMR_BUF_REFWAY, (size_t) n_refs * 4, (void **) &refway));
    SMR_TRY(c->ensure(SMR_BUF_WAYFLAGS, (size_t) n_ways, (void **) &wayflags));
-   SMR_TRY(c->ensure(SMR_BUF_SMALL, 64, (void **) &small));     /* [0] any_open_fill [1] first_prim [2] status [3] entries [4] mask words */
+   SMR_TRY(c->ensure(SMR_BUF_SMALL, 512, (void **) &small));     /* [0] any_open_fill [1] first_prim [2] status [3] entries [4] mask words */
    SMR_TRY(c->ensure(SMR_BUF_PRIMS, (size_t) n_prims * sizeof(smr_prim_t), (void **) &prims));
    SMR_TRY(c->ensure(SMR_BUF_ITEMS, (size_t) n_items * sizeof(smr_item_t), (void **) &items));
    uint32_t init_small[8] = { 0, 0xffffffffu, 0, 0, 0, 0, 0, 0 };
+#ifdef SMR_SECTION_PROFILE
+   SMR_HIP(hipMemsetAsync(small, 0, 512, s));
+#endif
    SMR_HIP(hipMemcpyAsync(small, init_small, sizeof(init_small), hipMemcpyHostToDevice, s));
 
    const int TB = 256;
@@ -1638,7 +1663,6 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    A.prims = prims; A.hdrs = hdrs; A.edges = edges; A.tile_off = tile_off;
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
-   A.exp = getenv("SMR_EXP") ? atoi(getenv("SMR_EXP")) : 0;
    {
       /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
       unsigned nwg = std::min<unsigned>((n_tiles + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES, 256u * 8u);
@@ -1648,6 +1672,16 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    T.mark(s);                                                   /* 4: rastered */
    SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
+#ifdef SMR_SECTION_PROFILE
+   {
+      unsigned long long pr[12]; double tot = 0;
+      hipMemcpy(pr, small + 16, sizeof(pr), hipMemcpyDeviceToHost);
+      for (int i = 0; i < 12; i++) tot += (double) pr[i];
+      fprintf(stderr, "k_raster sections:");
+      for (int i = 0; i < 9; i++) fprintf(stderr, " %d:%.1f%%", i, 100.0 * (double) pr[i] / tot);
+      fprintf(stderr, "\n");
+   }
+#endif
    if (smr_g.profiling)
    {
       smr_timings_t &t = smr_g.last;
