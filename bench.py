@@ -51,6 +51,22 @@ def make_band(args, band, n_bands):
     return xs, ys, offs, refs
 
 
+def measured_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/<round>_hbm_traffic.json,
+    collected by tools/profile_round.sh in separate rocprofv3 --pmc runs of this same command and
+    corrected as MI355X_MICROARCH.md prescribes); None when the workload differs from the profiled one."""
+    if (args.ways, args.size, args.dpi) != (1000000, 16384, 300):
+        return None
+    best = None
+    for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+        if f.endswith("_hbm_traffic.json"):
+            best = os.path.join(ROOT, "profiles", f)
+    if best is None:
+        return None
+    k = json.load(open(best)).get("kernels", {}).get(kernel)
+    return None if k is None else round(k["hbm_bytes"])
+
+
 def cpu_baseline(args):
     """The reference's CPU path on a bounded sample of the same workload: our restatement of
     smrender's Cairo call sequence over the real libcairo (oracle/cairo_drive.c), else the
@@ -179,7 +195,7 @@ def main():
             "stage_ms": {k: round(v, 3) for k, v in stage.items()},
             "counts": {"prims": tm["n_prims"], "edge_slots": tm["n_edges"], "tile_refs": tm["n_tile_refs"], "tiles": tm["n_tiles"]},
             "roofline": {"kernel": "k_raster", "bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5), "traffic": measured_traffic("k_raster", args),
                          "algorithmic_bytes": alg_bytes},
             "roofline_proj": {"kernel": "k_project", "bound": "hbm",
                               "achieved": round(32.0 * len(lat) / (stage["proj_ms"] * 1e-3) / 1e9, 2) if stage["proj_ms"] > 0 else None,

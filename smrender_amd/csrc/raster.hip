@@ -896,7 +896,6 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
    __shared__ raster_lds_t LL[SMR_RASTER_WAVES];
    raster_lds_t &L = LL[threadIdx.x >> 6];
    const int lane = threadIdx.x & 63;
-   const uint32_t gwave = blockIdx.x * SMR_RASTER_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * SMR_RASTER_WAVES;
    const unsigned long long lt_mask = (1ull << lane) - 1ull;
    const int my_row = lane / SMR_GRID_Y;               /* sub-row lane -> pixel row (lanes 60..63 idle) */
    uint16_t *bk = L.bucket[lane < SMR_NSUB ? lane : 0];
@@ -911,11 +910,20 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
 #ifdef SMR_SECTION_PROFILE
    unsigned long long prof[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memtime();
 #endif
-   for (uint32_t tile = gwave; tile < A.n_tiles; tile += nwaves)
+   /* XCD-aware tile order: workgroups b and b+8 share an XCD and its L2, so XCD x rasterizes the tile
+    * columns tx = x, x+8, ... and walks each column top to bottom: the waves resident on one XCD work on
+    * vertically adjacent tiles at the same time, and an item's 1 KB of edge slots, needed by every tile
+    * the item spans, comes from HBM once and from that L2 afterwards */
+   const uint32_t xcd = blockIdx.x & 7u;
+   const uint32_t jw = (blockIdx.x >> 3) * SMR_RASTER_WAVES + (threadIdx.x >> 6), nwx = (gridDim.x >> 3) * SMR_RASTER_WAVES;
+   const uint32_t TYt = A.n_tiles / A.TX;
+   const uint32_t ncol = ((uint32_t) A.TX + 7u - xcd) >> 3;
+   for (uint32_t kt = jw; kt < ncol * TYt; kt += nwx)
    {
+      const int tx = (int) (xcd + 8u * (kt / TYt)), ty = (int) (kt % TYt);
+      const uint32_t tile = (uint32_t) ty * A.TX + tx;
       const uint32_t beg = A.tile_off[tile], end = A.tile_off[tile + 1];
       if (beg == end) continue;
-      const int tx = tile % A.TX, ty = tile / A.TX;
       const int32_t X0 = tx * SMR_TW * 256, X1 = X0 + SMR_TW * 256;
       const int row0 = A.band_y0 + ty * SMR_TH;          /* absolute pixel row of the tile */
       const int ysbase = row0 * SMR_GRID_Y;
@@ -1666,6 +1674,7 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    {
       /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
       unsigned nwg = std::min<unsigned>((n_tiles + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES, 256u * 8u);
+      nwg = (nwg + 7u) & ~7u;            /* a multiple of the 8 XCDs (k_raster's tile order) */
       k_raster<<<nwg, 64 * SMR_RASTER_WAVES, 0, s>>>(A);
    }
    SMR_HIP(hipGetLastError());
