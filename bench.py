@@ -109,20 +109,15 @@ def main():
     ap.add_argument("--ways", type=int, default=1000000)
     ap.add_argument("--size", type=int, default=16384)
     ap.add_argument("--dpi", type=int, default=300)
+    ap.add_argument("--captions", type=int, default=20000, help="C4 captions scanned after the timed region (0 = skip)")
     ap.add_argument("--cpu-window", type=int, default=3072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    sa.init(local)
+    from smrender_amd import dist as smrdist
+    grp = smrdist.Group()
+    rank, world = grp.rank, grp.world
+    sa.init(grp.local)
 
     W, H = args.size, args.size
     n_bands = world
@@ -148,10 +143,7 @@ def main():
 
     def barrier():
         sa.sync()
-        if dist is not None:
-            import torch
-            torch.cuda.synchronize()
-            dist.barrier()
+        grp.barrier()
 
     for _ in range(args.warmup):
         step()
@@ -164,14 +156,38 @@ def main():
         for k in stage:
             stage[k] += t[k]
     barrier()
-    dt = time.perf_counter() - t0
+    dt = grp.max(time.perf_counter() - t0)
     tm = sa.timings()
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
     checksum = int(cv.read(0, 0, W, min(64, H)).astype(np.uint64).sum())
+
+    # ---- C4, outside the timed region: caption auto-rotation scan over the rendered band ----
+    cap = None
+    if args.captions > 0:
+        fg_w, fg_h, fg_x = 270, 20, 135            # E-aligned 2 mm caption at 300 dpi -> 72 angles, 271 px cut-out
+        n_steps, r_px = sa.caprot_steps(fg_w, fg_h, args.dpi)
+        if world > 1:
+            halo = r_px // 2 + 2
+            above, below = grp.exchange_halo(cv.read(0, 0, W, halo), cv.read(0, H - halo, W, halo), halo)
+            cv.set_halo(above, below)
+        rng = np.random.default_rng(4321 + rank)
+        side = int(np.ceil(np.sqrt(args.captions)))
+        gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+        cx = ((gx.ravel()[:args.captions] + rng.uniform(0.2, 0.8, args.captions)) * W / side)
+        cy = ((gy.ravel()[:args.captions] + rng.uniform(0.2, 0.8, args.captions)) * H / side) + rank * H
+        d_cx, d_cy = sa.DeviceArray.from_numpy(cx), sa.DeviceArray.from_numpy(cy)
+        d_ang = sa.DeviceArray((args.captions,), np.float64)
+        cv.caprot(d_cx, d_cy, args.captions, fg_w, fg_h, fg_x, 0x000000, 0.0, 1.0, d_ang)      # warm-up
+        barrier()
+        cv.caprot(d_cx, d_cy, args.captions, fg_w, fg_h, fg_x, 0x000000, 0.0, 1.0, d_ang)
+        barrier()
+        cap_ms = grp.max(sa.timings()["caprot_ms"])
+        ang = d_ang.numpy()
+        cap_bytes = (4.0 * r_px * r_px + 4.0 * fg_w * fg_h + 32.0) * args.captions          # SURVEY 8d per candidate
+        cap = {"captions": args.captions * world, "angles": n_steps, "cutout_px": r_px, "plane_px": [fg_w, fg_h],
+               "caprot_ms": round(cap_ms, 3), "captions_per_s": round(args.captions * world / (cap_ms * 1e-3), 1),
+               "roofline": {"kernel": "k_caprot", "bound": "hbm", "achieved": round(cap_bytes / (cap_ms * 1e-3) / 1e9, 2),
+                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(cap_bytes / (cap_ms * 1e-3) / HBM_PEAK, 5)},
+               "distinct_angles": int(len(np.unique(ang)))}
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -204,12 +220,13 @@ def main():
         }
         if res["roofline_proj"]["achieved"]:
             res["roofline_proj"]["frac"] = round(res["roofline_proj"]["achieved"] * 1e9 / HBM_PEAK, 4)
+        if cap is not None:
+            res["caption_scan"] = cap
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(res), flush=True)
     cv.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

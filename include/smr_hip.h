@@ -77,6 +77,12 @@ int smr_hip_canvas_destroy(smr_canvas_t *c);
 int smr_hip_canvas_clear(smr_canvas_t *c);
 /* copy a rectangle (band-local rows) of premultiplied ARGB32 to host memory */
 int smr_hip_canvas_read(smr_canvas_t *c, int x, int y, int w, int h, uint32_t *host_dst);
+/* Multi-GPU caption scan: rows of the neighbouring bands the scan may read (cut-outs of
+ * radius r_px around captions near a band boundary).  `above` = n_above rows ending at row band_y0-1,
+ * `below` = n_below rows starting at row band_y0+band_h; host pointers, W pixels per row; the library
+ * keeps device copies until the next call (n = 0 drops them).  The exchange itself is the caller's
+ * (smrender_amd/dist.py: send/recv over RCCL). */
+int smr_hip_canvas_set_halo(smr_canvas_t *c, const uint32_t *above, int n_above, const uint32_t *below, int n_below);
 /* device pointer + row stride (pixels) of the band, for zero-copy consumers */
 int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *stride_px);
 

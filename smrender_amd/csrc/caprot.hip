@@ -105,7 +105,9 @@ static void rot_matrix(int dw, int dh, int sw, int sh, double a, smr_rotmat_t *o
 struct caprot_args_t
 {
    const uint32_t *canvas;           /* band pixels */
-   int W, band_y0, band_h;
+   const uint32_t *halo_above, *halo_below;   /* neighbour bands' rows (multi-GPU), may be NULL */
+   int n_above, n_below;
+   int W, H, band_y0, band_h;
    const double *cx, *cy;
    int64_t n;
    int fg_w, fg_h, fg_x, r, num_steps;
@@ -137,8 +139,12 @@ __device__ __forceinline__ uint32_t smr_cut_fetch(const caprot_args_t &A, int ox
 {
    if (x < 0 || y < 0 || x >= A.r || y >= A.r) return 0;      /* REPEAT_NONE on the r x r cut-out */
    int gx = ox + x, gy = oy + y - A.band_y0;
-   if (gx < 0 || gx >= A.W || gy < 0 || gy >= A.band_h) return 0;
-   return A.canvas[(size_t) gy * A.W + gx];
+   if (gx < 0 || gx >= A.W) return 0;
+   if (gy >= 0 && gy < A.band_h) return A.canvas[(size_t) gy * A.W + gx];
+   /* outside the band: the neighbour's rows if they were handed over, clear beyond the chart */
+   if (gy < 0 && gy >= -A.n_above) return A.halo_above[(size_t) (A.n_above + gy) * A.W + gx];
+   if (gy >= A.band_h && gy < A.band_h + A.n_below) return A.halo_below[(size_t) (gy - A.band_h) * A.W + gx];
+   return 0;
 }
 
 __global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
@@ -336,7 +342,17 @@ extern "C" int smr_hip_caprot(smr_canvas_t *c, const smr_cap_batch_t *b, double 
    SMR_HIP(hipStreamSynchronize(s));      /* the host vectors go out of scope below */
 
    caprot_args_t A;
-   A.canvas = c->pix; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h;
+   A.canvas = c->pix; A.W = c->W; A.H = c->H; A.band_y0 = c->band_y0; A.band_h = c->band_h;
+   A.halo_above = c->halo_above; A.halo_below = c->halo_below; A.n_above = c->n_above; A.n_below = c->n_below;
+   /* a caption owned by this band (centre inside it) reads at most r/2 + 1 rows beyond it */
+   {
+      const int need = r / 2 + 2;
+      const int need_above = need < c->band_y0 ? need : c->band_y0;
+      const int rest = c->H - c->band_y0 - c->band_h, need_below = need < rest ? need : rest;
+      if (c->n_above < need_above || c->n_below < need_below)
+         return smr_fail(SMR_E_INVAL, "caprot: this band needs %d halo rows above and %d below for a cut-out of %d px "
+                         "(smr_hip_canvas_set_halo)", need_above, need_below, r);
+   }
    A.cx = b->d_cx; A.cy = b->d_cy; A.n = b->n;
    A.fg_w = b->fg_w; A.fg_h = b->fg_h; A.fg_x = b->fg_x; A.r = r; A.num_steps = n_steps;
    A.fg_pix = cap_color_pixel(b->col); A.fg = b->d_fg; A.weight = b->weight;

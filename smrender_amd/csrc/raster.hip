@@ -1500,6 +1500,8 @@ extern "C" int smr_hip_canvas_destroy(smr_canvas_t *c)
    if (!c) return SMR_OK;
    hipStreamSynchronize(smr_g.stream);
    if (c->pix) hipFree(c->pix);
+   if (c->halo_above) hipFree(c->halo_above);
+   if (c->halo_below) hipFree(c->halo_below);
    for (auto &b : c->buf) if (b.p) hipFree(b.p);
    delete c;
    return SMR_OK;
@@ -1513,6 +1515,33 @@ extern "C" int smr_hip_canvas_read(smr_canvas_t *c, int x, int y, int w, int h, 
    SMR_HIP(hipMemcpy2DAsync(host_dst, (size_t) w * 4, c->pix + (size_t) y * c->W + x, (size_t) c->W * 4,
                             (size_t) w * 4, h, hipMemcpyDeviceToHost, smr_g.stream));
    SMR_HIP(hipStreamSynchronize(smr_g.stream));
+   return SMR_OK;
+}
+
+extern "C" int smr_hip_canvas_set_halo(smr_canvas_t *c, const uint32_t *above, int n_above, const uint32_t *below, int n_below)
+{
+   SMR_NEED_INIT();
+   if (!c || n_above < 0 || n_below < 0 || (n_above && !above) || (n_below && !below) || n_above > c->band_y0 ||
+       n_below > c->H - c->band_y0 - c->band_h)
+      return smr_fail(SMR_E_INVAL, "canvas_set_halo: bad strip (above %d, below %d rows)", n_above, n_below);
+   SMR_HIP(hipStreamSynchronize(smr_g.stream));
+   if (c->halo_above) { hipFree(c->halo_above); c->halo_above = nullptr; }
+   if (c->halo_below) { hipFree(c->halo_below); c->halo_below = nullptr; }
+   c->n_above = c->n_below = 0;
+   if (n_above)
+   {
+      size_t bytes = (size_t) n_above * c->W * 4;
+      if (hipMalloc(&c->halo_above, bytes) != hipSuccess) return smr_fail(SMR_E_NOMEM, "canvas_set_halo: hipMalloc %zu bytes", bytes);
+      SMR_HIP(hipMemcpy(c->halo_above, above, bytes, hipMemcpyHostToDevice));
+      c->n_above = n_above;
+   }
+   if (n_below)
+   {
+      size_t bytes = (size_t) n_below * c->W * 4;
+      if (hipMalloc(&c->halo_below, bytes) != hipSuccess) return smr_fail(SMR_E_NOMEM, "canvas_set_halo: hipMalloc %zu bytes", bytes);
+      SMR_HIP(hipMemcpy(c->halo_below, below, bytes, hipMemcpyHostToDevice));
+      c->n_below = n_below;
+   }
    return SMR_OK;
 }
 

@@ -37,6 +37,8 @@ struct smr_canvas
    int W = 0, H = 0, dpi = 0, band_y0 = 0, band_h = 0;
    uint32_t bg = 0;
    uint32_t *pix = nullptr;
+   uint32_t *halo_above = nullptr, *halo_below = nullptr;     /* neighbour rows for the caption scan */
+   int n_above = 0, n_below = 0;
    smr_devbuf_t buf[SMR_BUF_MAX];      /* grow-only work buffers, reused across draw calls */
 
    int ensure(int id, size_t bytes, void **out)

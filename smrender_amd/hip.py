@@ -56,6 +56,7 @@ EXPORTS = [
     "smr_hip_init", "smr_hip_shutdown", "smr_hip_last_error", "smr_hip_device_name",
     "smr_hip_proj_from_window", "smr_hip_set_projection", "smr_hip_project", "smr_hip_unproject",
     "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_read", "smr_hip_canvas_device",
+    "smr_hip_canvas_set_halo",
     "smr_hip_draw", "smr_hip_caprot", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
     "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
@@ -84,6 +85,7 @@ def lib():
         L.smr_hip_canvas_destroy.argtypes = [C.c_void_p]
         L.smr_hip_canvas_clear.argtypes = [C.c_void_p]
         L.smr_hip_canvas_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.smr_hip_canvas_set_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.smr_hip_canvas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.smr_hip_draw.argtypes = [C.c_void_p, C.POINTER(DrawStyle), C.POINTER(_DrawBatch)]
         L.smr_hip_caprot.argtypes = [C.c_void_p, C.POINTER(_CapBatch), C.c_void_p, C.c_void_p]
@@ -210,6 +212,13 @@ class Canvas:
     def caprot(self, d_cx, d_cy, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_angle, d_dv=None, d_fg=None):
         b = _CapBatch(d_cx.ptr, d_cy.ptr, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_fg.ptr if d_fg else None)
         _chk(lib().smr_hip_caprot(self.h, C.byref(b), d_angle.ptr, d_dv.ptr if d_dv else None))
+
+    def set_halo(self, above=None, below=None):
+        """neighbour bands' rows for the caption scan (uint32 [n, W] arrays or None)"""
+        a = None if above is None else np.ascontiguousarray(above, np.uint32)
+        b = None if below is None else np.ascontiguousarray(below, np.uint32)
+        _chk(lib().smr_hip_canvas_set_halo(self.h, a.ctypes.data if a is not None else None, 0 if a is None else a.shape[0],
+                                           b.ctypes.data if b is not None else None, 0 if b is None else b.shape[0]))
 
     def clear(self):
         _chk(lib().smr_hip_canvas_clear(self.h))

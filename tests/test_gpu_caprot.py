@@ -95,3 +95,45 @@ def test_caprot_rejects_oversized_plane(hip):
         cv.caprot(d, d, 1, 400, 80, 0, 0, 0.0, 1.0, d)
     assert e.value.code == -6
     cv.close()
+
+
+def test_bands_with_halo_match_full_canvas(hip):
+    """multi-GPU layout: a rank scans the captions whose centre lies in its band and reads the
+    neighbours' rows from the halo strips; the angles equal the single-canvas ones bit for bit"""
+    sa = hip
+    W, H = 300, 240
+    st = sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0, 0, 0, 0, 0, 0)
+    arrs = po.synth_ways(int(W * H / 900), W, H, seed=7)
+    x, y, off, ref = arrs
+    dev = [sa.DeviceArray.from_numpy(a) for a in (x, y, off, ref)]
+    full = sa.Canvas(W, H, 300, 0xffffff)
+    full.draw(st, dev[0], dev[1], dev[2], dev[3], len(off) - 1, len(ref))
+    img = full.read()
+    rng = np.random.default_rng(3)
+    n_cap = 60
+    cx, cy = rng.uniform(0, W, n_cap), rng.uniform(0, H - 0.01, n_cap)
+    fg_w, fg_h, fg_x = 70, 12, 35
+    n, r = sa.caprot_steps(fg_w, fg_h, 300)
+    d_all = sa.DeviceArray((n_cap,), np.float64)
+    full.caprot(sa.DeviceArray.from_numpy(cx), sa.DeviceArray.from_numpy(cy), n_cap, fg_w, fg_h, fg_x, 0, 0.0, 1.0, d_all)
+    sa.sync()
+    want = d_all.numpy()
+    from smrender_amd import dist
+    halo = r // 2 + 2
+    got = np.full(n_cap, np.nan)
+    for y0, h in dist.bands(H, 3):
+        cv = sa.Canvas(W, H, 300, 0xffffff, y0, h)
+        cv.draw(st, dev[0], dev[1], dev[2], dev[3], len(off) - 1, len(ref))
+        mine = np.nonzero((np.floor(cy) >= y0) & (np.floor(cy) < y0 + h))[0]
+        d = sa.DeviceArray((max(len(mine), 1),), np.float64)
+        if y0 > 0 or y0 + h < H:
+            with pytest.raises(sa.SmrHipError):          # no halo handed over: refused, not guessed
+                cv.caprot(sa.DeviceArray.from_numpy(cx[mine]), sa.DeviceArray.from_numpy(cy[mine]), len(mine), fg_w, fg_h, fg_x, 0, 0.0, 1.0, d)
+        a0, b1 = max(0, y0 - halo), min(H, y0 + h + halo)
+        cv.set_halo(img[a0:y0] if y0 > a0 else None, img[y0 + h:b1] if b1 > y0 + h else None)
+        cv.caprot(sa.DeviceArray.from_numpy(cx[mine]), sa.DeviceArray.from_numpy(cy[mine]), len(mine), fg_w, fg_h, fg_x, 0, 0.0, 1.0, d)
+        sa.sync()
+        got[mine] = d.numpy()[:len(mine)]
+        cv.close()
+    full.close()
+    assert np.array_equal(got, want)
