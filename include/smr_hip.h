@@ -73,6 +73,9 @@ typedef struct smr_canvas smr_canvas_t;
  * bgcolor uses the reference's colour ints 0xTTRRGGBB (src/smrparse.c:222-258). */
 int smr_hip_canvas_create(int W, int H, int dpi, uint32_t bgcolor, int band_y0, int band_h, smr_canvas_t **out);
 int smr_hip_canvas_destroy(smr_canvas_t *c);
+/* a second canvas with the same geometry and pixels: the device counterpart of
+ * cairo_smr_recording_surface_from_bg() (src/smrules_cairo.c:359-373), act_cap's auto_sfc (:2455-2460) */
+int smr_hip_canvas_clone(smr_canvas_t *c, smr_canvas_t **out);
 /* repaint the background (what cairo_smr_init_main_image does once per chart, :320-326) */
 int smr_hip_canvas_clear(smr_canvas_t *c);
 /* copy a rectangle (band-local rows) of premultiplied ARGB32 to host memory */
@@ -99,7 +102,8 @@ typedef struct
    int32_t fill_style, border_style;        /* DRAW_SOLID=0; anything else -> SMR_E_UNSUPPORTED */
    int32_t curve;                           /* curve=/wavy= -> SMR_E_UNSUPPORTED */
    int32_t directional;                     /* directional=1 -> SMR_E_UNSUPPORTED */
-   int32_t pad_;
+   int32_t direct;                          /* 1: draw straight onto the canvas, no group layer -- what a context without
+                                               push_group does, i.e. act_cap's auto_ctx rectangles (src/smrules_cairo.c:2376-2382) */
 } smr_draw_style_t;
 
 typedef struct

@@ -260,6 +260,9 @@ int cd_rot_paint(uint32_t *dstpix, int dw, int dh, const uint32_t *srcpix, int s
  * with the font set-up of act_cap_ini (:1335-1357; fontconfig face when libcairo has it, like
  * the reference's CAIRO_HAS_FC_FONT branch, else the toy face of its #else branch).
  * out[0..2] = the int arguments (w, h, x in pt) cap_coord passes to cairo_smr_plane. ---- */
+static double metrics_[4];
+void cd_last_metrics(double *out) { memcpy(out, metrics_, sizeof(metrics_)); }
+
 int cd_caption_geometry(const char *font, double size_mm, const char *text, double xoff_pt, double yoff_pt, int ew_aligned,
                         double w_pt, double h_pt, int *out)
 {
@@ -293,6 +296,8 @@ int cd_caption_geometry(const char *font, double size_mm, const char *text, doub
    (void) yoff_pt;
    if (ew_aligned) { out[0] = (int) (width * 2); out[1] = (int) height; out[2] = (int) width; }
    else { out[0] = (int) width; out[1] = (int) height; out[2] = 0; }
+   /* the extents cap_coord uses for the auto_ctx rectangle (:2364-2379) */
+   metrics_[0] = tx.width + tx.x_bearing; metrics_[1] = fe.ascent; metrics_[2] = fe.descent; metrics_[3] = tx.height;
    p_cairo_destroy(ctx);
    p_cairo_surface_destroy(sfc);
    return 0;

@@ -63,6 +63,9 @@ def orc():
         L.orc_rule_begin.argtypes = [C.c_void_p]
         L.orc_rule_end.argtypes = [C.c_void_p]
         L.orc_layer_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]
+        L.orc_direct_fill_pt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32]
+        L.orc_canvas_pixels_rw.restype = C.c_void_p
+        L.orc_canvas_pixels_rw.argtypes = [C.c_void_p]
         L.orc_draw_way.argtypes = [C.c_void_p, C.POINTER(Style), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_int, C.c_uint32, C.c_int, C.c_uint32]
         L.tor_coverage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
@@ -103,6 +106,7 @@ def cairo():
         L.cd_rot_paint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]
         L.cd_caption_geometry.argtypes = [C.c_char_p, C.c_double, C.c_char_p, C.c_double, C.c_double, C.c_int,
                                           C.c_double, C.c_double, C.c_void_p]
+        L.cd_last_metrics.argtypes = [C.c_void_p]
         L.cd_plane.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p]
         _cd = L
     return _cd or None

@@ -374,6 +374,53 @@ void orc_layer_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, u
    c->layer_clear = 0;
 }
 
+/* a fill issued on a context WITHOUT push_group (act_cap's auto_ctx, src/smrules_cairo.c:2376-2382):
+ * the spans composite straight onto the surface -- lerp for an opaque source, (s IN m) OVER d else */
+void orc_direct_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, uint32_t smr_col)
+{
+   uint32_t s = orc_color_pixel(smr_col);
+   int lerp = (s >> 24) == 255;
+   int32_t minx = INT32_MAX, miny = INT32_MAX, maxx = INT32_MIN, maxy = INT32_MIN;
+   for (int i = 0; i < n; i++)
+   {
+      int32_t lx = e[i].x1 < e[i].x2 ? e[i].x1 : e[i].x2, hx = e[i].x1 < e[i].x2 ? e[i].x2 : e[i].x1;
+      int32_t ly = e[i].y1 < e[i].y2 ? e[i].y1 : e[i].y2, hy = e[i].y1 < e[i].y2 ? e[i].y2 : e[i].y1;
+      if (lx < minx) minx = lx;
+      if (hx > maxx) maxx = hx;
+      if (ly < miny) miny = ly;
+      if (hy > maxy) maxy = hy;
+   }
+   if (minx > maxx) return;
+   int bx0 = (minx >> 8) - c->x0, bx1 = (maxx >> 8) - c->x0 + 1, by0 = (miny >> 8) - c->y0, by1 = (maxy >> 8) - c->y0 + 1;
+   if (bx0 < 0) bx0 = 0;
+   if (by0 < 0) by0 = 0;
+   if (bx1 > c->W) bx1 = c->W;
+   if (by1 > c->H) by1 = c->H;
+   if (bx0 >= bx1 || by0 >= by1) return;
+   int bw = bx1 - bx0, bh = by1 - by0;
+   tor_coverage(e, n, nonzero, c->x0 + bx0, c->y0 + by0, bw, bh, c->cov);
+   for (int y = 0; y < bh; y++)
+      for (int x = 0; x < bw; x++)
+      {
+         uint32_t m = c->cov[(size_t) y * bw + x];
+         if (!m) continue;
+         uint32_t *d = &c->pix[(size_t) (y + by0) * c->W + x + bx0];
+         *d = lerp ? blend_lerp(s, m, *d) : blend_over_mask(s, m, *d);
+      }
+}
+
+/* closed polygon given in pt on the recording surface (cairo_rectangle under translate+rotate) */
+void orc_direct_fill_pt(orc_canvas_t *c, const double *xy_pt, int n, uint32_t smr_col)
+{
+   int32_t *dev = malloc(sizeof(int32_t) * 2 * n);
+   tor_edge_t *e = malloc(sizeof(tor_edge_t) * n);
+   orc_pt_to_dev(xy_pt, n, c->dpi, dev);
+   orc_direct_edges(c, e, orc_fill_edges(dev, n, e), 1, smr_col);
+   free(dev); free(e);
+}
+
+uint32_t *orc_canvas_pixels_rw(orc_canvas_t *c) { return c->pix; }
+
 /* mm -> pt; width 0 -> 1 device pixel (THINLINE): src/smrules_cairo.c:67-69, src/rdata.c:50-53 */
 static double mm2wu(double mm, int dpi) { return mm == 0.0 ? 1.0 * 72 / dpi : mm * 72 / 25.4; }
 

@@ -54,6 +54,10 @@ void orc_rule_begin(orc_canvas_t *c);
 void orc_rule_end(orc_canvas_t *c);
 void orc_layer_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, uint32_t smr_col);
 
+void orc_direct_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, uint32_t smr_col);
+void orc_direct_fill_pt(orc_canvas_t *c, const double *xy_pt, int n, uint32_t smr_col);
+uint32_t *orc_canvas_pixels_rw(orc_canvas_t *c);
+
 /* style of one draw rule: struct actDraw subset (src/smrender_dev.h:216-224, :252-268) */
 typedef struct
 {

@@ -427,6 +427,7 @@ struct cap_item_t
    int pw, ph, px;            /* plane size / first opaque column in pt, ints like cairo_smr_plane's arguments */
    uint32_t col;
    short pos;
+   double tw, hgt, ascent;    /* tx.width + tx.x_bearing, max(tx.height, ascent + descent), fe.ascent: the auto_ctx rectangle */
 };
 
 struct cap_rule_t
@@ -579,6 +580,7 @@ static int cap_collect(cap_rule_t *cap, double size_mm, double lat, double lon, 
    it.o = o; it.lat = lat; it.lon = lon;
    it.pos = (cap->pos & 0xc) ? (short) ((cap->pos & 0xfff0) | SMR_POS_E) : cap->pos;
    it.col = color_by_cs(o, &cap->cs);
+   it.tw = tx.width + tx.x_bearing; it.hgt = fmax(tx.height, fe.ascent + fe.descent); it.ascent = fe.ascent;
    /* cairo_smr_plane(int w, int h, int x, int col): the double arguments are truncated to int pt (:1536, :2272, :2277) */
    if (cap->pos & 0xc) { it.pw = (int) (width * 2); it.ph = (int) height; it.px = (int) width; }
    else { it.pw = (int) width; it.ph = (int) height; it.px = 0; }
@@ -658,64 +660,196 @@ static void add_tag(smr_osm_obj_t *o, const char *key, const char *sub, const ch
    t->v.len = snprintf(t->v.buf, vl < 8 ? 8 : vl, "%s", val);
 }
 
+/* pos_offset, src/smrules_cairo.c:1478-1508 */
+static void pos_offset(int pos, double width, double height, double xoff, double yoff, double *ox, double *oy)
+{
+   switch (pos & 0x3)
+   {
+      case SMR_POS_N: *oy = 0 - yoff; break;
+      case SMR_POS_S: *oy = height + yoff; break;
+      default: *oy = height / 2;
+   }
+   switch (pos & 0xc)
+   {
+      case SMR_POS_E: *ox = 0 + xoff; break;
+      case SMR_POS_W: *ox = -width - xoff; break;
+      default: *ox = -width / 2;
+   }
+}
+
+/* The reference scans the captions of one rule one after the other, and each finished caption
+ * leaves a filled rectangle on the rule's private background copy (auto_sfc, :2376-2382) that later
+ * captions of the same rule see.  Captions whose cut-outs cannot reach each other's rectangles are
+ * independent: they get the same LEVEL and are scanned in one GPU batch; levels run in order. */
+static void cap_levels(const std::vector<double> &cx, const std::vector<double> &cy, const std::vector<double> &reach,
+                       std::vector<int> &level, int &n_levels)
+{
+   const size_t n = cx.size();
+   level.assign(n, 0);
+   n_levels = n ? 1 : 0;
+   double rmax = 1;
+   for (size_t i = 0; i < n; i++) rmax = std::max(rmax, reach[i]);
+   const double cell = 2 * rmax;
+   std::map<std::pair<long, long>, std::vector<size_t>> grid;
+   for (size_t i = 0; i < n; i++)
+   {
+      const long gx = (long) floor(cx[i] / cell), gy = (long) floor(cy[i] / cell);
+      int lv = 0;
+      for (long dy = -1; dy <= 1; dy++)
+         for (long dx = -1; dx <= 1; dx++)
+         {
+            auto f = grid.find({ gx + dx, gy + dy });
+            if (f == grid.end()) continue;
+            for (size_t j : f->second)
+               if (hypot(cx[i] - cx[j], cy[i] - cy[j]) <= reach[i] + reach[j]) lv = std::max(lv, level[j] + 1);
+         }
+      level[i] = lv;
+      n_levels = std::max(n_levels, lv + 1);
+      grid[{ gx, gy }].push_back(i);
+   }
+}
+
 static int cap_fini(smr_smrule_t *r)
 {
    cap_rule_t *cap = (cap_rule_t *) r->data;
    if (cap == nullptr) return 0;
    int ret = 0;
-   /* one GPU batch per distinct caption plane */
-   std::map<std::vector<int64_t>, std::vector<size_t>> groups;
-   for (size_t i = 0; i < cap->items.size(); i++)
+   const size_t n_all = cap->items.size();
+   std::vector<double> angle(n_all, 0.0), cx(n_all), cy(n_all), reach(n_all, 1.0);
+   std::vector<int> fw(n_all), fh(n_all), level;
+   std::vector<short> final_pos(n_all);
+   int n_levels = 0;
+   smr_canvas_t *autoc = nullptr;
+   size_t n_groups = 0;
+   const double sc = (double) P.dpi / 72.0;
+   if (n_all)
    {
-      const cap_item_t &it = cap->items[i];
-      groups[{ it.pw, it.ph, it.px, (int64_t) it.col }].push_back(i);
-   }
-   std::vector<double> angle(cap->items.size(), 0.0);
-   for (auto &g : groups)
-   {
-      const std::vector<size_t> &idx = g.second;
-      const cap_item_t &first = cap->items[idx[0]];
-      std::vector<uint32_t> plane; int w_px, h_px;
-      if (make_plane(first.pw, first.ph, first.px, first.col, P.dpi, plane, &w_px, &h_px) != 0) continue;   /* empty plane: angle 0 */
-      size_t n = idx.size(), np = (n + 1) & ~(size_t) 1;
-      std::vector<double> lat(np), lon(np), out(n);
-      for (size_t k = 0; k < n; k++) { lat[k] = cap->items[idx[k]].lat; lon[k] = cap->items[idx[k]].lon; }
-      if (np > n) { lat[n] = lat[n - 1]; lon[n] = lon[n - 1]; }
-      dbuf_t dlat, dlon, dx, dy, dfg, dang;
-      bool ok = dlat.put(lat.data(), np * 8) == 0 && dlon.put(lon.data(), np * 8) == 0 && dx.alloc(np * 8) == 0 && dy.alloc(np * 8) == 0 &&
-                dfg.put(plane.data(), plane.size() * 4) == 0 && dang.alloc(n * 8) == 0;
+      /* all anchors -> px in one projection call */
+      const size_t np = (n_all + 1) & ~(size_t) 1;
+      std::vector<double> lat(np), lon(np);
+      for (size_t k = 0; k < n_all; k++) { lat[k] = cap->items[k].lat; lon[k] = cap->items[k].lon; }
+      if (np > n_all) { lat[n_all] = lat[n_all - 1]; lon[n_all] = lon[n_all - 1]; }
+      dbuf_t dlat, dlon, dx, dy;
+      bool ok = dlat.put(lat.data(), np * 8) == 0 && dlon.put(lon.data(), np * 8) == 0 && dx.alloc(np * 8) == 0 && dy.alloc(np * 8) == 0;
       if (ok) ok = smr_hip_project((const double *) dlat.p, (const double *) dlon.p, (int64_t) np, (double *) dx.p, (double *) dy.p,
                                    nullptr, nullptr, nullptr) == SMR_OK;
-      if (ok)
+      std::vector<double> hx(np), hy(np);
+      if (ok) ok = smr_hip_memcpy_d2h(hx.data(), dx.p, np * 8) == SMR_OK && smr_hip_memcpy_d2h(hy.data(), dy.p, np * 8) == SMR_OK;
+      if (!ok) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
+      for (size_t k = 0; k < n_all && ok; k++)
       {
-         smr_cap_batch_t b;
-         memset(&b, 0, sizeof(b));
-         b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) n;
-         b.fg_w = w_px; b.fg_h = h_px; b.fg_x = 0; b.col = first.col; b.phase_deg = cap->phase; b.weight = cap->weight;
-         b.d_fg = (const uint32_t *) dfg.p;
-         ok = smr_hip_caprot(P.canvas, &b, (double *) dang.p, nullptr) == SMR_OK;
+         const cap_item_t &it = cap->items[k];
+         cx[k] = hx[k]; cy[k] = hy[k];
+         fw[k] = (int) round(it.pw * sc); fh[k] = (int) round(it.ph * sc);
+         int steps = 0, rpx = 0;
+         if (fw[k] > 0 && fh[k] > 0) smr_hip_caprot_steps(fw[k], fh[k], P.dpi, &steps, &rpx);
+         /* what a caption can see (half the cut-out's diagonal) or paint (its rectangle): both within r_px */
+         reach[k] = std::max(1.0, (double) rpx);
       }
-      if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, n * 8) == SMR_OK;
-      if (!ok) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; break; }
-      for (size_t k = 0; k < n; k++) angle[idx[k]] = out[k];
+      if (ret == 0) cap_levels(cx, cy, reach, level, n_levels);
+      if (ret == 0 && smr_hip_canvas_clone(P.canvas, &autoc) != SMR_OK) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
    }
-   if (ret == 0)
-      for (size_t i = 0; i < cap->items.size(); i++)
+   for (int lv = 0; lv < n_levels && ret == 0; lv++)
+   {
+      /* one GPU batch per distinct caption plane of this level */
+      std::map<std::vector<int64_t>, std::vector<size_t>> groups;
+      for (size_t i = 0; i < n_all; i++)
       {
-         cap_item_t &it = cap->items[i];
+         if (level[i] != lv) continue;
+         const cap_item_t &it = cap->items[i];
+         groups[{ it.pw, it.ph, it.px, (int64_t) it.col }].push_back(i);
+      }
+      n_groups += groups.size();
+      for (auto &g : groups)
+      {
+         const std::vector<size_t> &idx = g.second;
+         const cap_item_t &first = cap->items[idx[0]];
+         std::vector<uint32_t> plane; int w_px, h_px;
+         if (make_plane(first.pw, first.ph, first.px, first.col, P.dpi, plane, &w_px, &h_px) != 0) continue;   /* empty plane: angle 0 */
+         const size_t n = idx.size();
+         std::vector<double> gx(n), gy(n), out(n);
+         for (size_t k = 0; k < n; k++) { gx[k] = cx[idx[k]]; gy[k] = cy[idx[k]]; }
+         dbuf_t dx, dy, dfg, dang;
+         bool ok = dx.put(gx.data(), n * 8) == 0 && dy.put(gy.data(), n * 8) == 0 && dfg.put(plane.data(), plane.size() * 4) == 0 &&
+                   dang.alloc(n * 8) == 0;
+         if (ok)
+         {
+            smr_cap_batch_t b;
+            memset(&b, 0, sizeof(b));
+            b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) n;
+            b.fg_w = w_px; b.fg_h = h_px; b.fg_x = 0; b.col = first.col; b.phase_deg = cap->phase; b.weight = cap->weight;
+            b.d_fg = (const uint32_t *) dfg.p;
+            ok = smr_hip_caprot(autoc, &b, (double *) dang.p, nullptr) == SMR_OK;
+         }
+         if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, n * 8) == SMR_OK;
+         if (!ok) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; break; }
+         for (size_t k = 0; k < n; k++) angle[idx[k]] = out[k];
+      }
+      if (ret != 0) break;
+      /* flip (:2284-2292), then this level's rectangles onto the private background (:2376-2382) */
+      std::vector<double> rx, ry;
+      std::vector<int64_t> roff(1, 0);
+      std::vector<int32_t> rref;
+      for (size_t i = 0; i < n_all; i++)
+      {
+         if (level[i] != lv) continue;
+         const cap_item_t &it = cap->items[i];
          double a = angle[i];
          short pos = it.pos;
-         if (a > M_PI_2 && a < 3 * M_PI_2)       /* flip text if necessary, :2284-2292 */
+         if (a > M_PI_2 && a < 3 * M_PI_2)
          {
             a -= M_PI;
             if (pos & SMR_POS_E) pos = (short) ((cap->pos & 0xfff0) | SMR_POS_W);
          }
-         char val[32];
-         snprintf(val, sizeof(val), "%.1f", a * 180.0 / M_PI);
-         add_tag(it.o, cap->key, "autoangle", val);
-         add_tag(it.o, cap->key, "autoalign", (pos & SMR_POS_E) ? "east" : (pos & SMR_POS_W) ? "west" : "center");
+         angle[i] = a; final_pos[i] = pos;
+         if (lv + 1 == n_levels) continue;                   /* nobody is left to see the last level's rectangles */
+         double ox, oy;
+         pos_offset(pos, it.tw, it.hgt, cap->xoff, cap->yoff, &ox, &oy);
+         const double wr = it.tw + cap->xoff, hr = -it.ascent, ca = cos(a), sa = sin(a);
+         const double xpt = cx[i] * 72 / P.dpi, ypt = cy[i] * 72 / P.dpi;
+         const double ux[4] = { ox, ox + wr, ox + wr, ox }, uy[4] = { oy, oy, oy + hr, oy + hr };
+         const int32_t base = (int32_t) rx.size();
+         for (int k = 0; k < 4; k++)
+         {
+            const double X = (ca * ux[k] + -sa * uy[k]) + xpt, Y = (sa * ux[k] + ca * uy[k]) + ypt;
+            rx.push_back(X * P.dpi / 72); ry.push_back(Y * P.dpi / 72);
+            rref.push_back(base + k);
+         }
+         rref.push_back(base);
+         roff.push_back((int64_t) rref.size());
       }
-   plog(SMR_LOG_INFO, "cap: %zu captions scanned on the GPU in %zu plane group(s)", cap->items.size(), groups.size());
+      if (!rref.empty())
+      {
+         if (rx.size() & 1) { rx.push_back(0); ry.push_back(0); }
+         dbuf_t dx, dy, doff, dref;
+         bool ok = dx.put(rx.data(), rx.size() * 8) == 0 && dy.put(ry.data(), ry.size() * 8) == 0 &&
+                   doff.put(roff.data(), roff.size() * 8) == 0 && dref.put(rref.data(), rref.size() * 4) == 0;
+         if (ok)
+         {
+            smr_draw_style_t st;
+            memset(&st, 0, sizeof(st));
+            st.fill_used = 1; st.fill_col = cap->items[0].col; st.direct = 1;     /* auto_ctx's source: the first object's colour (:2459) */
+            smr_draw_batch_t b;
+            memset(&b, 0, sizeof(b));
+            b.d_x = (const double *) dx.p; b.d_y = (const double *) dy.p; b.n_nodes = (int64_t) rx.size();
+            b.d_way_off = (const int64_t *) doff.p; b.d_ref = (const int32_t *) dref.p;
+            b.n_ways = (int64_t) roff.size() - 1; b.n_refs = (int64_t) rref.size();
+            ok = smr_hip_draw(autoc, &st, &b) == SMR_OK && smr_hip_sync() == SMR_OK;
+         }
+         if (!ok) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
+      }
+   }
+   if (autoc) smr_hip_canvas_destroy(autoc);
+   if (ret == 0)
+      for (size_t i = 0; i < n_all; i++)
+      {
+         cap_item_t &it = cap->items[i];
+         char val[32];
+         snprintf(val, sizeof(val), "%.1f", angle[i] * 180.0 / M_PI);
+         add_tag(it.o, cap->key, "autoangle", val);
+         add_tag(it.o, cap->key, "autoalign", (final_pos[i] & SMR_POS_E) ? "east" : (final_pos[i] & SMR_POS_W) ? "west" : "center");
+      }
+   plog(SMR_LOG_INFO, "cap: %zu captions scanned on the GPU in %d dependency level(s), %zu batch(es)", n_all, n_levels, n_groups);
    CR.destroy(cap->ctx);
    CR.surface_destroy(cap->sfc);
    delete cap;

@@ -796,6 +796,7 @@ struct raster_args_t
    uint32_t *status;
    int W, band_y0, band_h, TX;
    uint32_t n_tiles;
+   int direct;                /* no group layer: primitives composite straight onto the canvas */
 };
 
 struct raster_lds_t
@@ -929,6 +930,13 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
       const int ysbase = row0 * SMR_GRID_Y;
       const int my_ys = ysbase + lane;
       uint32_t layer[SMR_TH] = { 0, 0, 0, 0 };
+      if (A.direct)
+      {
+         const int pxd = tx * SMR_TW + lane;
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++)
+            if (pxd < A.W && ty * SMR_TH + r < A.band_h) layer[r] = A.canvas[(size_t) (ty * SMR_TH + r) * A.W + pxd];
+      }
 
       /* state of the primitive being accumulated */
       uint32_t cur = 0xffffffffu, cur_flags = 0, cur_color = 0;
@@ -1244,7 +1252,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             TICK(2);      /* flush: full rows */
             /* ---- cells -> alpha -> ordered blend into the group layer; lane = column ---- */
             const uint32_t spix = cur_color;
-            const bool lerp = (spix >> 24) == 255u || cur_first;
+            const bool lerp = (spix >> 24) == 255u || (cur_first && !A.direct);
             /* libcairo composites inside the primitive's pixel extents only */
             const bool col_in = lane >= cur_colmin && lane <= cur_colmax;
 #pragma unroll
@@ -1439,10 +1447,10 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
          for (int r = 0; r < SMR_TH; r++)
          {
             int row = ty * SMR_TH + r;
-            if (row < A.band_h && layer[r])
+            if (row < A.band_h && (layer[r] || A.direct))
             {
                uint32_t *d = A.canvas + (size_t) row * A.W + px;
-               *d = smr_blend_over(layer[r], *d);
+               *d = A.direct ? layer[r] : smr_blend_over(layer[r], *d);
             }
          }
       }
@@ -1483,6 +1491,19 @@ extern "C" int smr_hip_canvas_create(int W, int H, int dpi, uint32_t bgcolor, in
    k_fill_u32<<<2048, 256, 0, smr_g.stream>>>(c->pix, n, host_color_pixel(bgcolor));
    SMR_HIP(hipGetLastError());
    *out = c;
+   return SMR_OK;
+}
+
+extern "C" int smr_hip_canvas_clone(smr_canvas_t *c, smr_canvas_t **out)
+{
+   SMR_NEED_INIT();
+   if (!c || !out) return smr_fail(SMR_E_INVAL, "canvas_clone: NULL");
+   smr_canvas_t *n = new smr_canvas_t();
+   n->W = c->W; n->H = c->H; n->dpi = c->dpi; n->band_y0 = c->band_y0; n->band_h = c->band_h; n->bg = c->bg;
+   size_t bytes = (size_t) c->W * c->band_h * 4;
+   if (hipMalloc(&n->pix, bytes) != hipSuccess) { delete n; return smr_fail(SMR_E_NOMEM, "canvas_clone: hipMalloc %zu bytes", bytes); }
+   SMR_HIP(hipMemcpyAsync(n->pix, c->pix, bytes, hipMemcpyDeviceToDevice, smr_g.stream));
+   *out = n;
    return SMR_OK;
 }
 
@@ -1700,6 +1721,7 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    A.prims = prims; A.hdrs = hdrs; A.edges = edges; A.tile_off = tile_off;
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
+   A.direct = st->direct != 0;
    {
       /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
       unsigned nwg = std::min<unsigned>((n_tiles + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES, 256u * 8u);

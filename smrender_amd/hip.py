@@ -31,7 +31,7 @@ class DrawStyle(C.Structure):
     _fields_ = [("fill_used", C.c_int32), ("border_used", C.c_int32), ("fill_col", C.c_uint32),
                 ("border_col", C.c_uint32), ("fill_width_mm", C.c_double), ("border_width_mm", C.c_double),
                 ("ignore_open", C.c_int32), ("fill_style", C.c_int32), ("border_style", C.c_int32),
-                ("curve", C.c_int32), ("directional", C.c_int32), ("pad_", C.c_int32)]
+                ("curve", C.c_int32), ("directional", C.c_int32), ("direct", C.c_int32)]
 
 
 class _DrawBatch(C.Structure):
@@ -56,7 +56,7 @@ EXPORTS = [
     "smr_hip_init", "smr_hip_shutdown", "smr_hip_last_error", "smr_hip_device_name",
     "smr_hip_proj_from_window", "smr_hip_set_projection", "smr_hip_project", "smr_hip_unproject",
     "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_read", "smr_hip_canvas_device",
-    "smr_hip_canvas_set_halo",
+    "smr_hip_canvas_set_halo", "smr_hip_canvas_clone",
     "smr_hip_draw", "smr_hip_caprot", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
     "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
@@ -85,6 +85,7 @@ def lib():
         L.smr_hip_canvas_destroy.argtypes = [C.c_void_p]
         L.smr_hip_canvas_clear.argtypes = [C.c_void_p]
         L.smr_hip_canvas_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.smr_hip_canvas_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.smr_hip_canvas_set_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.smr_hip_canvas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.smr_hip_draw.argtypes = [C.c_void_p, C.POINTER(DrawStyle), C.POINTER(_DrawBatch)]
@@ -212,6 +213,14 @@ class Canvas:
     def caprot(self, d_cx, d_cy, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_angle, d_dv=None, d_fg=None):
         b = _CapBatch(d_cx.ptr, d_cy.ptr, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_fg.ptr if d_fg else None)
         _chk(lib().smr_hip_caprot(self.h, C.byref(b), d_angle.ptr, d_dv.ptr if d_dv else None))
+
+    def clone(self):
+        """device copy (act_cap's auto_sfc)"""
+        h = C.c_void_p()
+        _chk(lib().smr_hip_canvas_clone(self.h, C.byref(h)))
+        o = Canvas.__new__(Canvas)
+        o.W, o.H, o.dpi, o.band_y0, o.band_h, o.h = self.W, self.H, self.dpi, self.band_y0, self.band_h, h.value
+        return o
 
     def set_halo(self, above=None, below=None):
         """neighbour bands' rows for the caption scan (uint32 [n, W] arrays or None)"""

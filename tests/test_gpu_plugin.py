@@ -87,50 +87,99 @@ def test_unsupported_draw_styles_are_refused_loudly(chart):
         assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, []) == 2001      # "Rule will be ignored"
 
 
-def test_cap_autoangle_tags(chart):
+def oracle_caption_tags(img, names, px, py, size_mm, col, weight):
+    """cap_coord for every caption of one rule in object order (src/smrules_cairo.c:2202-2392): geometry through
+    the real libcairo, find_angle restated (oracle/caprot.c), and the rule's private background copy that
+    collects one filled rectangle per finished caption (auto_ctx, :2376-2382).  Returns [(angle tag, align tag)]
+    and the number of captions whose angle the earlier rectangles changed."""
+    cd, L = po.cairo(), po.orc()
+    oc = L.orc_canvas_new(0, 0, W, H, DPI, 0xffffff)
+    bgpix = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels_rw(oc), C.POINTER(C.c_uint32)), (H, W))
+    bgpix[:] = img
+    xoff = size_mm * 72 / 25.4 / 2
+    crnd = lambda v: int(np.sign(v) * np.floor(abs(v) + 0.5))
+    out, changed = [], 0
+    for k in range(len(names)):
+        geo = np.zeros(3, np.int32)
+        cd.cd_caption_geometry(b"serif", size_mm, names[k].encode(), xoff, xoff, 1, W * 72 / DPI, H * 72 / DPI, po.P(geo))
+        met = np.zeros(4)
+        cd.cd_last_metrics(po.P(met))
+        pw, ph, pxx = [int(v) for v in geo]
+        fw, fh = crnd(pw * DPI / 72), crnd(ph * DPI / 72)
+        fg = np.zeros((fh, fw), np.uint32)
+        assert cd.cd_plane(pw, ph, pxx, col, DPI, po.P(fg)) == 0
+        r = C.c_int()
+        steps = L.orc_num_steps(fw, fh, DPI, C.byref(r)); r = r.value
+
+        def find(bg):
+            ox, oy = crnd(px[k] - r / 2.0), crnd(py[k] - r / 2.0)
+            cut = np.zeros((r, r), np.uint32)
+            xs0, ys0, xs1, ys1 = max(ox, 0), max(oy, 0), min(ox + r, W), min(oy + r, H)
+            if xs1 > xs0 and ys1 > ys0:
+                cut[ys0 - oy:ys1 - oy, xs0 - ox:xs1 - ox] = bg[ys0:ys1, xs0:xs1]
+            return L.orc_find_angle(po.P(cut), r, po.P(fg), fw, fh, steps, 0.0, weight, None)
+
+        a = find(bgpix)
+        changed += a != find(img)
+        pos_e = True
+        if np.pi / 2 < a < 3 * np.pi / 2:
+            a -= np.pi
+            pos_e = False
+        out.append(("%.1f" % np.degrees(a), "east" if pos_e else "west"))
+        # the rectangle: translate(x, y) rotate(a) rectangle(ox, oy, tw + xoff, -ascent); colour of the rule's first object
+        tw, asc, desc, th = met
+        hgt = max(th, asc + desc)
+        ox_, oy_ = (xoff if pos_e else -tw - xoff), hgt / 2
+        wr, hr = tw + xoff, -asc
+        ca, sn = np.cos(a), np.sin(a)
+        xpt, ypt = px[k] * 72 / DPI, py[k] * 72 / DPI
+        pts = []
+        for ux, uy in ((ox_, oy_), (ox_ + wr, oy_), (ox_ + wr, oy_ + hr), (ox_, oy_ + hr)):
+            pts += [(ca * ux + -sn * uy) + xpt, (sn * ux + ca * uy) + ypt]
+        L.orc_direct_fill_pt(oc, po.P(np.array(pts)), 4, col)
+    L.orc_canvas_free(oc)
+    return out, changed
+
+
+def run_caption_rule(chart, seed, cx, cy, names, size_mm, colname, col, weight):
     sa, proj = chart
     from smrender_amd import synth
-    cd = po.cairo()
-    if cd is None:
+    if po.cairo() is None:
         pytest.skip("libcairo (text extents) not loadable")
-    wids, oways = load_ways(sa, proj, po.synth_ways(90, W, H, seed=79))
+    wids, oways = load_ways(sa, proj, po.synth_ways(90, W, H, seed=seed))
     assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", wids) == 0
     img = plugin_canvas(sa)
-    rng = np.random.default_rng(5)
-    n = 12
-    cx, cy = rng.uniform(20, W - 20, n), rng.uniform(20, H - 20, n)
     lat, lon = synth.px_to_geo(proj, cx, cy)
-    names = [f"Cap {k}" if k % 3 else "Longer Caption Text" for k in range(n)]
+    n = len(names)
     base = _next_id[0]; _next_id[0] += n + 1
     nids = base + np.arange(n)
     hs.add_nodes(nids, lat, lon, [f"name={t}" for t in names])
-    params = "key=name;size=2;angle=auto;color=black;halign=east;font=serif;weight=0.7"
+    params = f"key=name;size={size_mm};angle=auto;color={colname};halign=east;font=serif;weight={weight}"
     assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, params, nids) == 0, sa.lib().smr_hip_last_error()
-
-    # oracle: cap_coord's geometry through the real libcairo, find_angle restated (oracle/caprot.c)
-    L = po.orc()
     op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
     px, py, _, _, _ = po.project(op, lat, lon)
-    xoff = 2 * 72 / 25.4 / 2
+    want, changed = oracle_caption_tags(img, names, px, py, size_mm, col, weight)
     for k in range(n):
-        geo = np.zeros(3, np.int32)
-        cd.cd_caption_geometry(b"serif", 2.0, names[k].encode(), xoff, xoff, 1, W * 72 / DPI, H * 72 / DPI, po.P(geo))
-        pw, ph, pxx = [int(v) for v in geo]
-        crnd = lambda v: int(np.sign(v) * np.floor(abs(v) + 0.5))
-        fw, fh = crnd(pw * DPI / 72), crnd(ph * DPI / 72)
-        fg = np.zeros((fh, fw), np.uint32)
-        assert cd.cd_plane(pw, ph, pxx, 0, DPI, po.P(fg)) == 0
-        r = C.c_int()
-        steps = L.orc_num_steps(fw, fh, DPI, C.byref(r)); r = r.value
-        ox, oy = crnd(px[k] - r / 2.0), crnd(py[k] - r / 2.0)
-        cut = np.zeros((r, r), np.uint32)
-        xs0, ys0, xs1, ys1 = max(ox, 0), max(oy, 0), min(ox + r, W), min(oy + r, H)
-        if xs1 > xs0 and ys1 > ys0:
-            cut[ys0 - oy:ys1 - oy, xs0 - ox:xs1 - ox] = img[ys0:ys1, xs0:xs1]
-        a = L.orc_find_angle(po.P(cut), r, po.P(fg), fw, fh, steps, 0.0, 0.7, None)
-        align = "east"
-        if np.pi / 2 < a < 3 * np.pi / 2:
-            a -= np.pi
-            align = "west"
-        assert hs.get_tag(hs.OSM_NODE, nids[k], "name:autoangle") == "%.1f" % np.degrees(a), k
-        assert hs.get_tag(hs.OSM_NODE, nids[k], "name:autoalign") == align, k
+        assert hs.get_tag(hs.OSM_NODE, nids[k], "name:autoangle") == want[k][0], k
+        assert hs.get_tag(hs.OSM_NODE, nids[k], "name:autoalign") == want[k][1], k
+    return changed
+
+
+def test_cap_autoangle_tags(chart):
+    rng = np.random.default_rng(5)
+    n = 12
+    cx, cy = rng.uniform(20, W - 20, n), rng.uniform(20, H - 20, n)
+    names = [f"Cap {k}" if k % 3 else "Longer Caption Text" for k in range(n)]
+    run_caption_rule(chart, 79, cx, cy, names, 2.0, "black", 0x000000, 0.7)
+
+
+def test_cap_same_rule_captions_see_earlier_rectangles(chart):
+    """the reference scans a rule's captions one after the other; each leaves a filled rectangle on the
+    rule's private background copy (auto_ctx, src/smrules_cairo.c:2376-2382) that later ones see.
+    The plugin runs independent captions as one batch and dependent ones level by level."""
+    rng = np.random.default_rng(9)
+    # two clusters of mutually overlapping captions + a few isolated ones
+    cx = np.concatenate([rng.uniform(60, 100, 5), rng.uniform(250, 290, 5), rng.uniform(20, W - 20, 4)])
+    cy = np.concatenate([rng.uniform(60, 90, 5), rng.uniform(180, 210, 5), rng.uniform(20, H - 20, 4)])
+    changed = run_caption_rule(chart, 91, cx, cy, [f"Name {k}" for k in range(14)], 1.6, "#203040", 0x203040, 1.0)
+    assert changed >= 2          # the dependency really changed some angles in this scene
