@@ -102,6 +102,32 @@ void hs_set_rdata(double lon0, double w, double h, double wc, double lath, doubl
    bgcolor_ = bgcolor;
 }
 
+/* page_way(), src/smcoast.c:105-108: the way init_corner_brg (:804-841) builds from the corners of the
+ * bounding box, refs = NW, SW, SE, NE, NW (counterclockwise on the chart) */
+static osm_way_t *page_way_;
+const osm_way_t *page_way(void) { return page_way_; }
+
+int hs_make_page_way(void)
+{
+   const double n = rd_.bb.ru.lat, s = rd_.bb.ll.lat, e = rd_.bb.ru.lon, w = rd_.bb.ll.lon;
+   const double lat[4] = { n, s, s, n }, lon[4] = { w, w, e, e };       /* NW, SW, SE, NE */
+   osm_way_t *pw = malloc_way(2, 5);
+   osm_way_default(pw);
+   for (int k = 3; k >= 0; k--)           /* the reference creates the nodes NE first; ids only matter for uniqueness */
+   {
+      osm_node_t *nd = malloc_node(2);
+      osm_node_default(nd);
+      nd->lat = lat[k]; nd->lon = lon[k];
+      put_object(&nd->obj);
+      pw->ref[k] = nd->obj.id;
+   }
+   pw->ref[4] = pw->ref[0];
+   pw->ref_cnt = 5;
+   put_object(&pw->obj);
+   page_way_ = pw;
+   return 0;
+}
+
 /* ---- rules: what init_rule + parse_fparam build ---- */
 static char *next_tok(char **p, const char *delim, char *found)
 {

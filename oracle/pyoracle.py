@@ -161,6 +161,61 @@ def oracle_scene(rules, dpi, W, H, bg, x0=0, y0=0):
     return out
 
 
+def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0):
+    """One directional draw rule (act_draw_main :1039-1052, act_draw_fini :1084-1140): group 1 = the open ways,
+    group 2 = ALL closed ways as one path with one non-zero fill (a page rectangle, if the reference adds
+    one, is just another closed way of `ways`).  The border is off in directional mode (:674-680)."""
+    L = orc()
+    c = L.orc_canvas_new(x0, y0, W, H, dpi, bg)
+    s1 = Style(st.fill_used, 0, st.fill_col, 0, st.fill_width_mm, st.border_width_mm, st.ignore_open)
+    L.orc_rule_begin(c)
+    for x, y, closed in ways:
+        if not closed:
+            x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+            L.orc_draw_way(c, C.byref(s1), P(x), P(y), len(x), 0, 0, 0, 0, 0)
+    L.orc_rule_end(c)
+    edges = []
+    for x, y, closed in ways:
+        if closed:
+            x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+            dev = np.zeros(2 * len(x), np.int32)
+            L.orc_px_to_dev(P(x), P(y), len(x), dpi, P(dev))
+            e = np.zeros((len(x), 4), np.int32)
+            L.orc_fill_edges(P(dev), len(x), P(e))
+            edges.append(e)
+    L.orc_rule_begin(c)
+    if edges:
+        e = np.ascontiguousarray(np.concatenate(edges))
+        L.orc_layer_edges(c, P(e), len(e), 1, st.fill_col)
+    L.orc_rule_end(c)
+    out = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (H, W)).copy()
+    L.orc_canvas_free(c)
+    return out
+
+
+def cairo_directional(st, ways, dpi, W, H, bg):
+    """the same rule through the real libcairo: sub-paths of all closed ways, then ONE cairo_fill"""
+    L = cairo()
+    L.cd_begin(W * 72 / dpi, H * 72 / dpi, bg)
+    L.cd_rule_begin()
+    for x, y, closed in ways:
+        if not closed and len(x) >= 2 and not st.ignore_open:
+            xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
+            L.cd_poly_line(P(xy), len(xy))
+            L.cd_stroke(st.fill_col, mm2wu(st.fill_width_mm, dpi))
+    L.cd_rule_end()
+    L.cd_rule_begin()
+    for x, y, closed in ways:
+        if closed:
+            xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
+            L.cd_poly_line(P(xy), len(xy))
+    L.cd_fill(st.fill_col)
+    L.cd_rule_end()
+    out = np.zeros((H, W), np.uint32)
+    assert L.cd_render(float(dpi), 0, 0, W, H, P(out)) == 0
+    return out
+
+
 def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None):
     """Same scene through the real libcairo with the reference's call sequence."""
     L = cairo()

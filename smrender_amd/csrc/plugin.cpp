@@ -51,6 +51,7 @@ struct host_api_t
    int (*poly_area)(const smr_osm_way_t *, struct smr_coord *, double *) = nullptr;
    double (*rdata_square_mm)(void) = nullptr;
    double (*rdata_square_nm)(void) = nullptr;
+   const smr_osm_way_t *(*page_way)(void) = nullptr;
 };
 static host_api_t H;
 
@@ -65,7 +66,7 @@ static void host_resolve(void)
    host_sym(H.rdata_get, "rdata_get"); host_sym(H.parse_color, "parse_color");
    host_sym(H.parse_style, "parse_style"); host_sym(H.parse_alignment, "parse_alignment");
    host_sym(H.poly_area, "poly_area"); host_sym(H.rdata_square_mm, "rdata_square_mm");
-   host_sym(H.rdata_square_nm, "rdata_square_nm");
+   host_sym(H.rdata_square_nm, "rdata_square_nm"); host_sym(H.page_way, "page_way");
    H.resolved = true;
 }
 
@@ -210,6 +211,8 @@ struct draw_rule_t
    std::vector<int64_t> way_off;
    std::vector<int32_t> ref;
    std::vector<uint32_t> fill_col, border_col;
+   /* directional=1: the closed way with the largest |area| decides about the page rectangle (:1091-1109) */
+   double max_area = -1; bool max_cw = false; uint32_t max_col = 0;
 };
 
 static int draw_ini(smr_smrule_t *r)
@@ -244,13 +247,26 @@ static int draw_ini(smr_smrule_t *r)
    if (d->st.fill_style || d->st.border_style || H.get_param("dash", nullptr, r->act) || H.get_param("bdash", nullptr, r->act))
       why = "dashed/dotted/pipe/rounddot styles";
    else if (d->st.curve) why = "curve/wavy";
-   else if (d->st.directional) why = "directional=1";
    else if (H.get_param("file", nullptr, r->act)) why = "image pattern fill (file=)";
    if (why)
    {
       plog(SMR_LOG_ERR, "draw: %s are not implemented on the GPU path yet; use the built-in draw for this rule", why);
       delete d;
       return 1;
+   }
+   /* check if parameter combination makes sense (:673-686) */
+   if (d->st.directional)
+   {
+      if (d->st.fill_used && d->st.border_used)
+      {
+         plog(SMR_LOG_WARN, "in directional mode, filling and border drawing is not supported at the same time -> disabling border");
+         d->st.border_used = 0;
+      }
+      if (!d->st.fill_used && d->st.border_used)
+      {
+         plog(SMR_LOG_NOTICE, "directional mode makes only sense with a fill operation -> disabling directional mode");
+         d->st.directional = 0;
+      }
    }
    d->way_off.push_back(0);
    r->data = d;
@@ -269,15 +285,23 @@ static int draw_way(draw_rule_t *d, const smr_osm_way_t *w)
    }
    const int32_t first = (int32_t) d->lat.size();
    int emitted = 0;
+   double ar = 0, plat = 0, plon = 0;       /* poly_area's shoelace sum in lon * cos(lat), src/smfunc.c:377-432 */
    for (int i = 0; i < w->ref_cnt; i++)
    {
-      if (closed && i == w->ref_cnt - 1 && emitted) { d->ref.push_back(first); emitted++; break; }
+      if (closed && i == w->ref_cnt - 1 && emitted)
+      {
+         ar += plon * cos(plat * M_PI / 180.0) * d->lat[first] - d->lon[first] * cos(d->lat[first] * M_PI / 180.0) * plat;
+         d->ref.push_back(first); emitted++;
+         break;
+      }
       const smr_osm_node_t *n = (const smr_osm_node_t *) H.get_object(SMR_OSM_NODE, w->ref[i]);
       if (n == nullptr)      /* cairo_smr_poly_line skips missing nodes, src/smrules_cairo.c:853-857 */
       {
          plog(SMR_LOG_WARN, "node %lld of way %lld at pos %d does not exist", (long long) w->ref[i], (long long) w->obj.id, i);
          continue;
       }
+      if (emitted) ar += plon * cos(plat * M_PI / 180.0) * n->lat - n->lon * cos(n->lat * M_PI / 180.0) * plat;
+      plat = n->lat; plon = n->lon;
       d->ref.push_back((int32_t) d->lat.size());
       d->lat.push_back(n->lat); d->lon.push_back(n->lon);
       emitted++;
@@ -286,6 +310,11 @@ static int draw_way(draw_rule_t *d, const smr_osm_way_t *w)
    d->way_off.push_back((int64_t) d->ref.size());
    if (d->fill_cs.key) d->fill_col.push_back(color_by_cs(&w->obj, &d->fill_cs));
    if (d->border_cs.key) d->border_col.push_back(color_by_cs(&w->obj, &d->border_cs));
+   if (closed && d->st.directional && fabs(ar) > d->max_area)
+   {
+      d->max_area = fabs(ar); d->max_cw = ar < 0;
+      d->max_col = d->fill_cs.key ? d->fill_col.back() : d->fill_cs.col;
+   }
    return 0;
 }
 
@@ -316,6 +345,19 @@ static int draw_fini(smr_smrule_t *r)
    draw_rule_t *d = (draw_rule_t *) r->data;
    if (d == nullptr) return 0;
    int ret = 0;
+   if (d->st.directional && d->max_area >= 0)
+   {
+      /* the largest polygon is clockwise: a page-sized polygon goes first, so that it becomes a hole
+       * (:1103-1109); the fill colour is the one of that first way unless it is the hole (:1116-1129) */
+      if (d->max_cw)
+      {
+         const smr_osm_way_t *pw = H.page_way ? H.page_way() : nullptr;
+         if (pw == nullptr) plog(SMR_LOG_ERR, "NULL pointer to caught");      /* render_poly_line's message for page_way() == NULL */
+         else { const char *k1 = d->fill_cs.key, *k2 = d->border_cs.key; d->fill_cs.key = d->border_cs.key = nullptr;
+                draw_way(d, pw); d->fill_cs.key = k1; d->border_cs.key = k2; if (k1) d->fill_col.push_back(0); }
+      }
+      d->st.fill_col = d->max_cw ? (d->fill_cs.key ? 0u : d->fill_cs.col) : d->max_col;
+   }
    const int64_t n_ways = (int64_t) d->way_off.size() - 1, n_refs = (int64_t) d->ref.size();
    if (n_ways > 0 && n_refs > 0)
    {

@@ -46,12 +46,14 @@ __global__ void k_dev_points(const double *__restrict__ x, const double *__restr
    }
 }
 
+enum { SMR_PASS_NORMAL = 0, SMR_PASS_OPEN = 1, SMR_PASS_COMPOUND = 2 };
+
 /* per-way classification: is_closed_poly (src/smcoast.c:115-125), short-way skip
  * (src/smrules_cairo.c:962-966), ignore_open (:1030-1033); decides which of the two
  * primitives of the way exist.  wayflags: bit0 closed, bit1 border prim, bit2 fill polygon,
  * bit3 fill-as-stroke (open way) */
 __global__ void k_way_info(const int64_t *__restrict__ way_off, const int32_t *__restrict__ ref, int64_t n_ways,
-                           int border_used, int fill_used, int ignore_open, uint8_t *__restrict__ wayflags,
+                           int border_used, int fill_used, int ignore_open, int mode, uint8_t *__restrict__ wayflags,
                            uint32_t *__restrict__ any_open_fill)
 {
    int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,6 +72,10 @@ __global__ void k_way_info(const int64_t *__restrict__ way_off, const int32_t *_
       if (border_used) f |= 2;
       if (fill_used) f |= closed ? 4 : 8;
    }
+   /* directional rules (act_draw_main :1039-1052, act_draw_fini :1084-1140): pass 1 draws the open ways only,
+    * pass 2 the closed ones as ONE compound fill */
+   if (mode == SMR_PASS_OPEN && closed) f = 1;
+   if (mode == SMR_PASS_COMPOUND) f = closed ? (f & (1 | 4)) : 0;
    wayflags[w] = f;
    if (f & 8) atomicOr(any_open_fill, 1u);
 }
@@ -272,6 +278,7 @@ struct setup_args_t
    uint32_t *mask;
    uint32_t mask_cap;         /* words */
    uint32_t *small;           /* [1] first_prim [2] status [4] mask words demanded */
+   uint32_t compound;         /* primitive id all items belong to (directional compound fill), 0xffffffff: their own */
 };
 
 struct setup_lds_t
@@ -345,6 +352,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    const uint32_t item_flags = SMR_PF_VALID | (pieces ? SMR_PF_PIECES : 0u) | (nitems > 1 ? SMR_PF_MULTI : 0u);
 
    /* ---- pass A: items + bbox ---- */
+   int bin_maxx = INT32_MIN;
    smr_edge_t e0; e0.x1 = e0.y1 = e0.x2 = e0.y2 = 0;
    for (int64_t k = 0; k < nitems; k++)
    {
@@ -365,11 +373,12 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
       int bmn = smr_wave_min(has ? mnx - ext : INT32_MAX), bmx = smr_wave_max(has ? mxx + ext : INT32_MIN);
       mnx = smr_wave_min(mnx); mny = smr_wave_min(mny); mxx = smr_wave_max(mxx); mxy = smr_wave_max(mxy);
       P.minx = min(P.minx, mnx); P.miny = min(P.miny, mny); P.maxx = max(P.maxx, mxx); P.maxy = max(P.maxy, mxy);
+      bin_maxx = max(bin_maxx, bmx);
       if (lane == 0)
       {
          smr_item_t it;
          it.edge_off = (uint32_t) (P.edge_off + (uint64_t) k * 64);
-         it.prim = (uint32_t) p;
+         it.prim = A.compound != 0xffffffffu ? A.compound : (uint32_t) p;
          uint32_t cnt = min(64u, P.edge_cnt - (uint32_t) (k * 64));
          it.cnt_flags = mnx <= mxx ? (cnt | (item_flags << 8)) : 0;
          it.color = P.color;
@@ -391,7 +400,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    const uint32_t nwords = ((uint32_t) P.nrows + 31u) >> 5;
    /* fill chunks are binned up to the primitive's right edge: edges left of a tile carry winding into it */
    if (!pieces && nitems > 1)
-      for (int64_t i = lane; i < nitems; i += 64) A.items[item0 + i].maxx = P.maxx;
+      for (int64_t i = lane; i < nitems; i += 64) A.items[item0 + i].maxx = bin_maxx;
 
    /* ---- pass B: row mask ---- */
    for (uint32_t i = lane; i < nwords; i += 64) lmask[i] = 0;
@@ -554,7 +563,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    for (uint32_t i = lane; i < nwords; i += 64) A.mask[moff + i] = lmask[i];
    P.mask_off = moff;
    if (lane == 0) A.prims[p] = P;
-   first_valid = min(first_valid, (uint32_t) p);
+   first_valid = min(first_valid, A.compound != 0xffffffffu ? A.compound : (uint32_t) p);
 }
 
 #define SMR_SETUP_WAVES 4
@@ -574,6 +583,90 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_
       SMR_WAVE_SYNC();
    }
    if (lane == 0 && first_valid != 0xffffffffu) atomicMin(&A.small[1], first_valid);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* directional rules: all closed ways of the rule are ONE path with ONE non-zero fill
+ * (act_draw_fini, src/smrules_cairo.c:1084-1140).  Every way was set up like a fill of its
+ * own (items, box, row mask over ITS edges); the compound primitive is their union:
+ * box = union, row mask = OR of the members' masks, and rows in which no member has a vertex
+ * are decided over the edges of ALL members.                                              */
+/* ------------------------------------------------------------------------------------ */
+__global__ void k_compound_merge(smr_prim_t *prims, int64_t n_ways, uint32_t compound, uint32_t *mask, uint32_t *covered)
+{
+   int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (w >= n_ways) return;
+   const smr_prim_t P = prims[2 * w + 1];
+   if (!(P.flags & SMR_PF_VALID)) return;
+   smr_prim_t *C = &prims[compound];
+   atomicMin(&C->minx, P.minx); atomicMin(&C->miny, P.miny); atomicMax(&C->maxx, P.maxx); atomicMax(&C->maxy, P.maxy);
+   const uint32_t nwords = ((uint32_t) P.nrows + 31u) >> 5;
+   const uint32_t sh = (uint32_t) P.row0 & 31u, base = (uint32_t) P.row0 >> 5;
+   for (uint32_t i = 0; i < nwords; i++)
+   {
+      const uint32_t m = mask[P.mask_off + i];
+      const uint32_t nb = min(32u, (uint32_t) P.nrows - 32u * i);
+      const uint32_t cv = nb == 32u ? 0xffffffffu : ((1u << nb) - 1u);
+      if (m << sh) atomicOr(&mask[base + i], m << sh);
+      atomicOr(&covered[base + i], cv << sh);
+      if (sh)
+      {
+         if (m >> (32u - sh)) atomicOr(&mask[base + i + 1], m >> (32u - sh));
+         if (cv >> (32u - sh)) atomicOr(&covered[base + i + 1], cv >> (32u - sh));
+      }
+   }
+}
+
+/* one wavefront per chart row that some member covers and in which no member has a vertex: collect the
+ * edges of all members spanning the row, compare every pair (order at the top = order at the bottom?).
+ * More than SMR_ROWCAP such edges: the row is sub-sampled instead (status SMR_ST_DEGRADED: the one place
+ * where the result may leave libcairo's arithmetic, by the difference between 15 samples and the exact
+ * trapezoid on that row's edge pixels). */
+__global__ __launch_bounds__(64) void k_compound_rows(const smr_edge_t *__restrict__ E, int64_t n_edges, uint32_t *mask,
+                                                      const uint32_t *__restrict__ covered, int H, uint32_t *status)
+{
+   __shared__ int f0[SMR_ROWCAP], f1[SMR_ROWCAP];
+   const int r = blockIdx.x, lane = threadIdx.x;
+   if (r >= H) return;
+   if (!((covered[r >> 5] >> (r & 31)) & 1u) || ((mask[r >> 5] >> (r & 31)) & 1u)) return;
+   const int rs0 = r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
+   uint32_t cnt = 0;
+   for (int64_t base = 0; base < n_edges; base += 64)
+   {
+      const int64_t idx = base + lane;
+      smr_oedge_t o; o.dir = 0; o.ytop = o.ybot = 0;
+      if (idx < n_edges) o = smr_orient(E[idx]);
+      const bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs1;
+      const unsigned long long am = __ballot(act);
+      if (!am) continue;
+      const uint32_t pos = cnt + __popcll(am & ((1ull << lane) - 1ull));
+      if (act && pos < SMR_ROWCAP)
+      {
+         const int64_t ec = 256 - 30ll * o.p1y;
+         const double inv = 1.0 / (double) o.D;
+         f0[pos] = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs0);
+         f1[pos] = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs1);
+      }
+      cnt += __popcll(am);
+   }
+   __syncthreads();
+   bool viol = false;
+   if (cnt > SMR_ROWCAP) { viol = true; if (lane == 0) atomicOr(status, SMR_ST_DEGRADED); }
+   else if ((uint32_t) lane < cnt)
+   {
+      const int a0 = f0[lane], a1 = f1[lane];
+      for (uint32_t j = 0; j < cnt; j++) if (a0 < f0[j] && a1 > f1[j]) viol = true;
+   }
+   if (__ballot(viol) && lane == 0) atomicOr(&mask[r >> 5], 1u << (r & 31));
+}
+
+__global__ void k_compound_init(smr_prim_t *prims, uint32_t compound, uint64_t edge_off, uint32_t edge_cnt, uint32_t color, int H)
+{
+   smr_prim_t P;
+   P.edge_off = edge_off; P.edge_cnt = edge_cnt; P.color = color;
+   P.minx = P.miny = INT32_MAX; P.maxx = P.maxy = INT32_MIN;
+   P.flags = SMR_PF_VALID | SMR_PF_MULTI; P.mask_off = 0; P.row0 = 0; P.nrows = H;
+   prims[compound] = P;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1575,6 +1668,8 @@ extern "C" int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *str
 
 static double mm2wu(double mm, int dpi) { return mm == 0.0 ? 1.0 * 72 / dpi : mm * 72 / 25.4; }
 
+static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, int mode);
+
 extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b)
 {
    SMR_NEED_INIT();
@@ -1582,7 +1677,21 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    if (st->fill_style != 0 || st->border_style != 0)
       return smr_fail(SMR_E_UNSUPPORTED, "draw: only style=solid is implemented on the GPU path (dashed/dotted/pipe pending)");
    if (st->curve) return smr_fail(SMR_E_UNSUPPORTED, "draw: curve/wavy not implemented on the GPU path");
-   if (st->directional) return smr_fail(SMR_E_UNSUPPORTED, "draw: directional=1 not implemented on the GPU path");
+   if (st->directional && st->fill_used)
+   {
+      /* act_draw_ini disables the border in directional mode (:674-680); open ways are drawn at once into the
+       * rule's group (act_draw_main :1030-1036), the closed ones as one compound fill in a second group
+       * (act_draw_fini :1084-1140) */
+      smr_draw_style_t s2 = *st;
+      s2.border_used = 0; s2.directional = 0;
+      SMR_TRY(draw_pass(c, &s2, b, SMR_PASS_OPEN));
+      return draw_pass(c, &s2, b, SMR_PASS_COMPOUND);
+   }
+   return draw_pass(c, st, b, SMR_PASS_NORMAL);      /* directional without a fill is not directional (:681-685) */
+}
+
+static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, int mode)
+{
    if (b->n_ways < 0 || b->n_refs < 0 || b->n_ways > 0x7ffffff0ll / 2 || b->n_refs > 0x7fffffffll)
       return smr_fail(SMR_E_INVAL, "draw: batch too large (n_ways %lld, n_refs %lld)", (long long) b->n_ways, (long long) b->n_refs);
    if (b->n_ways == 0 || b->n_refs == 0 || (!st->fill_used && !st->border_used)) return SMR_OK;
@@ -1601,7 +1710,9 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    SMR_TRY(c->ensure(SMR_BUF_REFWAY, (size_t) n_refs * 4, (void **) &refway));
    SMR_TRY(c->ensure(SMR_BUF_WAYFLAGS, (size_t) n_ways, (void **) &wayflags));
    SMR_TRY(c->ensure(SMR_BUF_SMALL, 512, (void **) &small));     /* [0] any_open_fill [1] first_prim [2] status [3] entries [4] mask words */
-   SMR_TRY(c->ensure(SMR_BUF_PRIMS, (size_t) n_prims * sizeof(smr_prim_t), (void **) &prims));
+   SMR_TRY(c->ensure(SMR_BUF_PRIMS, ((size_t) n_prims + 1) * sizeof(smr_prim_t), (void **) &prims));
+   const uint32_t compound = mode == SMR_PASS_COMPOUND ? (uint32_t) n_prims : 0xffffffffu;
+   const uint32_t cwords = mode == SMR_PASS_COMPOUND ? (uint32_t) (c->H + 31) / 32 + 1 : 0;
    SMR_TRY(c->ensure(SMR_BUF_ITEMS, (size_t) n_items * sizeof(smr_item_t), (void **) &items));
    uint32_t init_small[8] = { 0, 0xffffffffu, 0, 0, 0, 0, 0, 0 };
 #ifdef SMR_SECTION_PROFILE
@@ -1617,7 +1728,7 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
       k_dev_points<<<nb, TB, 0, s>>>(b->d_x, b->d_y, b->d_ref, n_refs, c->dpi, sfix, b->d_way_off, n_ways, pts, refway);
    }
    k_way_info<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, b->d_ref, n_ways, st->border_used, st->fill_used,
-                                                st->ignore_open, wayflags, &small[0]);
+                                                st->ignore_open, mode, wayflags, &small[0]);
    uint32_t h_small[8];
    SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
@@ -1658,7 +1769,7 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    const unsigned setup_wg = (unsigned) std::min<int64_t>((n_prims + SMR_SETUP_WAVES - 1) / SMR_SETUP_WAVES, 256 * 6);
    size_t mask_cap = c->buf[SMR_BUF_MASK].cap / 4;
    {
-      size_t want = (size_t) n_prims * 2 + (size_t) setup_wg * SMR_SETUP_WAVES * SMR_MASK_BLOCK + 65536;
+      size_t want = (size_t) n_prims * 2 + (size_t) setup_wg * SMR_SETUP_WAVES * SMR_MASK_BLOCK + 65536 + cwords;
       if (mask_cap < want) mask_cap = want;
    }
    for (int attempt = 0;; attempt++)
@@ -1670,13 +1781,33 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
       SA.border_pix = host_color_pixel(st->border_col); SA.fill_pix = host_color_pixel(st->fill_col);
       SA.way_border_pix = wb_pix; SA.way_fill_pix = wf_pix; SA.W = c->W; SA.H = c->H;
       SA.prims = prims; SA.items = items; SA.mask = maskbuf; SA.mask_cap = (uint32_t) std::min<size_t>(mask_cap, 0xffffffffu);
-      SA.small = small;
+      SA.small = small; SA.compound = compound;
+      if (mode == SMR_PASS_COMPOUND)
+      {
+         /* the compound's own row mask sits at the start of the arena; the members' words follow */
+         uint32_t *covered;
+         SMR_TRY(c->ensure(SMR_BUF_COVERED, (size_t) cwords * 4, (void **) &covered));
+         SMR_HIP(hipMemsetAsync(maskbuf, 0, (size_t) cwords * 4, s));
+         SMR_HIP(hipMemsetAsync(covered, 0, (size_t) cwords * 4, s));
+         SMR_HIP(hipMemcpyAsync(&small[4], &cwords, 4, hipMemcpyHostToDevice, s));
+         k_compound_init<<<1, 1, 0, s>>>(prims, compound, off_fill, (uint32_t) n_refs, host_color_pixel(st->fill_col), c->H);
+      }
       int mask_words = (c->H + 31) / 32 + 1;
       k_prim_setup<<<setup_wg, 64 * SMR_SETUP_WAVES, (size_t) mask_words * 4 * SMR_SETUP_WAVES, s>>>(SA, mask_words);
       SMR_HIP(hipGetLastError());
       SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
       SMR_HIP(hipStreamSynchronize(s));
-      if (!(h_small[2] & SMR_ST_MASK_ARENA)) break;
+      if (!(h_small[2] & SMR_ST_MASK_ARENA))
+      {
+         if (mode == SMR_PASS_COMPOUND)
+         {
+            uint32_t *covered = (uint32_t *) c->buf[SMR_BUF_COVERED].p;
+            k_compound_merge<<<blocks(n_ways, TB), TB, 0, s>>>(prims, n_ways, compound, maskbuf, covered);
+            k_compound_rows<<<(unsigned) c->H, 64, 0, s>>>(edges + off_fill, n_refs, maskbuf, covered, c->H, &small[2]);
+            SMR_HIP(hipGetLastError());
+         }
+         break;
+      }
       if (attempt) return smr_fail(SMR_E_CAPACITY, "draw: row-mask arena of %zu words still too small", mask_cap);
       mask_cap = (size_t) h_small[4] + 65536;
       init_small[0] = h_small[0];

@@ -66,6 +66,7 @@ struct __attribute__((aligned(16))) smr_thdr_t
 #define SMR_ST_BUCKET_OVERFLOW 1u
 #define SMR_ST_ROWCAP 2u
 #define SMR_ST_MASK_ARENA 4u
+#define SMR_ST_DEGRADED 8u      /* a compound row with more than SMR_ROWCAP spanning edges was sub-sampled */
 
 __device__ __forceinline__ int smr_to_grid_y(int32_t y) { return (int) ((15ll * y + 128) >> 8); }
 

@@ -38,6 +38,7 @@ def set_chart(proj, bgcolor=0xffffff):
     """proj: a Projection / oracle Proj (same fields as struct rdata's, src/rdata.h:99-158)"""
     host().hs_set_rdata(proj.lon0, proj.w, proj.h, proj.wc, proj.lath, proj.lath_len, proj.lat_ll, proj.lon_ru, proj.lat_ru,
                         proj.dpi, bgcolor)
+    host().hs_make_page_way()
 
 
 def apply_rule(lib, func, obj_type, params, ids, rule_type=None):

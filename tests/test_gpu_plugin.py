@@ -83,8 +83,40 @@ def test_draw_relation_members_and_key_colours(chart):
 
 def test_unsupported_draw_styles_are_refused_loudly(chart):
     sa, proj = chart
-    for params in ("bcolor=black;bstyle=dashed", "color=red;curve=1", "color=red;directional=1"):
+    for params in ("bcolor=black;bstyle=dashed", "color=red;curve=1"):
         assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, []) == 2001      # "Rule will be ignored"
+
+
+@pytest.mark.parametrize("sea_first", [True, False])
+def test_directional_rule_with_page_rectangle(chart, sea_first):
+    """directional=1 through the action API (act_draw_ini :673-686, _main :1039-1052, _fini :1084-1140): the way
+    with the largest area decides; if it runs clockwise the page rectangle of page_way() becomes the outer ring"""
+    from test_oracle_cairo import _nested_scene
+    from test_gpu_raster import _ways_to_arrays
+    sa, proj = chart
+    ways = _nested_scene(W, H, 11)[0 if not sea_first else 1:]     # with / without the outer frame
+
+    def area_on_chart(x, y):            # > 0: counterclockwise with north up (pixel y points down)
+        return -0.5 * np.sum(x[:-1] * y[1:] - x[1:] * y[:-1])
+    big = max((w for w in ways if w[2]), key=lambda w: abs(area_on_chart(w[0], w[1])))
+    if (area_on_chart(big[0], big[1]) < 0) != sea_first:
+        # make the largest way clockwise (page rectangle expected) / counterclockwise (none) as the case wants
+        ways = [(x[::-1].copy(), y[::-1].copy(), c) if c else (x, y, c) for x, y, c in ways]
+    arrs = _ways_to_arrays(ways)
+    wids, oways = load_ways(sa, proj, arrs)
+    rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.2;width=0.3;directional=1", wids)
+    assert rc == 0, sa.lib().smr_hip_last_error()
+    if sea_first:
+        op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+        plat = np.array([proj.lat_ru, proj.lat_ll, proj.lat_ll, proj.lat_ru, proj.lat_ru])
+        plon = np.array([proj.lon0, proj.lon0, proj.lon_ru, proj.lon_ru, proj.lon0])
+        px, py, _, _, _ = po.project(op, plat, plon)
+        oways = oways + [(px, py, True)]
+    want = po.oracle_directional(po.Style(1, 0, 0x4080c0, 0, 0.3, 0, 0), oways, DPI, W, H, 0xfff8e0)
+    got = plugin_canvas(sa)
+    assert np.array_equal(got, want)
+    # with the page rectangle the chart's corner is painted; without, it is outside every ring
+    assert (got[0, 0] != 0xfff8e0) == sea_first
 
 
 def oracle_caption_tags(img, names, px, py, size_mm, col, weight):

@@ -105,7 +105,7 @@ def test_edge_cases(hip):
     d = sa.DeviceArray((4,), np.float64)
     cv.draw(gs, d, d, sa.DeviceArray.from_numpy(np.zeros(1, np.int64)), None, 0, 0)      # nothing to draw
     assert np.all(cv.read() == 0xffffffff)
-    for bad in ("fill_style", "curve", "directional"):
+    for bad in ("fill_style", "curve"):
         gs2 = sa.DrawStyle(1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
         setattr(gs2, bad, 1)
         with pytest.raises(sa.SmrHipError) as e:       # unsupported styles fail loudly
@@ -132,3 +132,37 @@ def test_dense_scene_vs_oracle(hip):
     g = gpu_scene(hip, rules, 300, 512, 512, 0xffffff)
     o = oracle_of(rules, 300, 512, 512, 0xffffff)
     assert np.array_equal(g, o), report(g, o)
+
+
+def _ways_to_arrays(ways):
+    xs, ys, off, ref = [], [], [0], []
+    n = 0
+    for x, y, closed in ways:
+        k = len(x) - 1 if closed else len(x)
+        xs.append(np.asarray(x[:k], np.float64)); ys.append(np.asarray(y[:k], np.float64))
+        ref.extend(range(n, n + k))
+        if closed:
+            ref.append(n)
+        n += k
+        off.append(len(ref))
+    return np.concatenate(xs), np.concatenate(ys), np.array(off, np.int64), np.array(ref, np.int32)
+
+
+@pytest.mark.parametrize("col,size", [(0xc0d8f0, (200, 160)), (0x30c0d8f0, (200, 160)), (0x4080c0, (700, 333))])
+def test_directional_compound_fill(hip, col, size):
+    """directional=1 (act_draw_fini :1084-1140): all closed ways of the rule are one non-zero fill, open ways
+    are drawn first; holes and islands follow from the orientation of the ways"""
+    from test_oracle_cairo import _nested_scene
+    sa = hip
+    W, H = size
+    ways = _nested_scene(W, H, 3 + W, n_small=40 if W < 300 else 400)
+    st = po.Style(1, 0, col, 0, 0.3, 0, 0)
+    want = po.oracle_directional(st, ways, 300, W, H, 0xffffff)
+    x, y, off, ref = _ways_to_arrays(ways)
+    cv = sa.Canvas(W, H, 300, 0xffffff)
+    gs = sa.DrawStyle(1, 1, col, 0x000000, 0.3, 0.2, 0, 0, 0, 0, 1, 0)       # the border is ignored in directional mode (:674-680)
+    cv.draw(gs, sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off),
+            sa.DeviceArray.from_numpy(ref), len(off) - 1, len(ref))
+    got = cv.read()
+    cv.close()
+    assert np.array_equal(got, want), report(got, want)

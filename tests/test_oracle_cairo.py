@@ -70,3 +70,30 @@ def test_rot_paint_exact():
         assert cd.cd_rot_paint(po.P(a1), dw, dh, po.P(src), r, r, k * 2 * np.pi / n) == 0
         po.orc().orc_rot_paint(po.P(a2), dw, dh, po.P(src), r, r, k * 2 * np.pi / n)
         assert np.array_equal(a1, a2), t
+
+
+def _nested_scene(W, H, seed, n_small=40):
+    """an outer rectangle, a big clockwise 'sea' inside it, islands of both orientations, a few open ways"""
+    rng = np.random.default_rng(seed)
+    ways = [(np.array([2.0, 2.0, W - 2.0, W - 2.0, 2.0]), np.array([2.0, H - 2.0, H - 2.0, 2.0, 2.0]), True)]
+    t = np.linspace(0, 2 * np.pi, 41)[:-1][::-1]
+    bx, by = W / 2 + 0.42 * W * np.cos(t) * rng.uniform(0.85, 1, 40), H / 2 + 0.42 * H * np.sin(t) * rng.uniform(0.85, 1, 40)
+    ways.append((np.append(bx, bx[0]), np.append(by, by[0]), True))
+    x, y, off, ref = po.synth_ways(n_small, W, H, seed=seed, rmin=3.0, rmax=0.12 * W)
+    ways += po.ways_from_arrays(x, y, off, ref)
+    for k in range(4):
+        n = int(rng.integers(2, 7))
+        ways.append((rng.uniform(0, W, n), rng.uniform(0, H, n), False))
+    return ways
+
+
+@pytest.mark.parametrize("col", [0xc0d8f0, 0x30c0d8f0])
+def test_directional_compound_fill(col):
+    """directional=1: ONE non-zero fill over all closed ways; holes come from orientation"""
+    ways = _nested_scene(200, 160, 3)
+    st = po.Style(1, 0, col, 0, 0.3, 0, 0)
+    a = po.oracle_directional(st, ways, 300, 200, 160, 0xffffff)
+    b = po.cairo_directional(st, ways, 300, 200, 160, 0xffffff)
+    d = po.chan_diff(a, b)
+    assert (d <= 2).mean() >= 0.995 and (d == 0).mean() >= 0.98, ((d > 2).sum(), d.max())
+    assert len(np.unique(a)) > 10
