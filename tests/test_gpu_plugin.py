@@ -116,7 +116,7 @@ def test_directional_rule_with_page_rectangle(chart, sea_first):
     got = plugin_canvas(sa)
     assert np.array_equal(got, want)
     # with the page rectangle the chart's corner is painted; without, it is outside every ring
-    assert (got[0, 0] != 0xfff8e0) == sea_first
+    assert ((got[0, 0] & 0xffffff) != 0xfff8e0) == sea_first
 
 
 def oracle_caption_tags(img, names, px, py, size_mm, col, weight):
