@@ -101,7 +101,9 @@ typedef struct
    int32_t ignore_open;                     /* ignore_open=1 */
    int32_t fill_style, border_style;        /* DRAW_SOLID=0; anything else -> SMR_E_UNSUPPORTED */
    int32_t curve;                           /* curve=/wavy= -> SMR_E_UNSUPPORTED */
-   int32_t directional;                     /* directional=1 -> SMR_E_UNSUPPORTED */
+   int32_t directional;                     /* directional=1 with a fill: open ways first, then ALL closed ways of the batch as one
+                                               non-zero fill in fill_col (act_draw_fini, src/smrules_cairo.c:1084-1140); the caller
+                                               appends the page rectangle (:1103-1109) as one more closed way when it is due */
    int32_t direct;                          /* 1: draw straight onto the canvas, no group layer -- what a context without
                                                push_group does, i.e. act_cap's auto_ctx rectangles (src/smrules_cairo.c:2376-2382) */
 } smr_draw_style_t;
@@ -120,6 +122,12 @@ typedef struct
 } smr_draw_batch_t;
 
 int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b);
+/* Flags about the last smr_hip_draw of this process.  SMR_DRAW_DEGRADED_ROWS: some pixel row of a polygon held no
+ * vertex but more spanning edges than the exact whole-row coverage path keeps (64); such rows were sub-sampled on the
+ * 15-row grid instead, so their anti-aliasing may differ from libcairo's by a few levels.  No counterpart in the
+ * reference (libcairo has no such limit); the plugin logs a warning. */
+#define SMR_DRAW_DEGRADED_ROWS 1u
+uint32_t smr_hip_draw_status(void);
 
 /* ---- caption auto-rotation: replaces find_angle ----------------------------------------
  * src/smrules_cairo.c:1959-2019 (find_angle), :1828-1861 (dv_sample), :1746-1759

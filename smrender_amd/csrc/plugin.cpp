@@ -383,6 +383,8 @@ static int draw_fini(smr_smrule_t *r)
       }
       if (ok) ok = smr_hip_sync() == SMR_OK;
       if (!ok) { plog(SMR_LOG_ERR, "draw: %s", smr_hip_last_error()); ret = -1; }
+      else if (smr_hip_draw_status() & SMR_DRAW_DEGRADED_ROWS)
+         plog(SMR_LOG_WARN, "draw: some pixel rows with more than 64 crossing edges were sub-sampled (anti-aliasing may differ slightly)");
       else plog(SMR_LOG_INFO, "draw: %lld ways, %lld refs rendered on the GPU", (long long) n_ways, (long long) n_refs);
    }
    delete d;

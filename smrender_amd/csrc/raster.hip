@@ -462,7 +462,8 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
       }
       SMR_WAVE_SYNC();
       bool viol = false;
-      if (cnt > SMR_ROWCAP) { if (lane == 0) atomicOr(&A.small[2], SMR_ST_ROWCAP); viol = true; }
+      /* more spanning edges than the exact full-row path holds: the row is sub-sampled instead (reported) */
+      if (cnt > SMR_ROWCAP) { if (lane == 0) atomicOr(&A.small[2], SMR_ST_DEGRADED); viol = true; }
       else if ((uint32_t) lane < cnt)
       {
          int a0 = f0[lane], a1 = f1[lane];
@@ -1670,8 +1671,11 @@ static double mm2wu(double mm, int dpi) { return mm == 0.0 ? 1.0 * 72 / dpi : mm
 
 static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, int mode);
 
+extern "C" uint32_t smr_hip_draw_status(void) { return smr_g.draw_status; }
+
 extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b)
 {
+   smr_g.draw_status = 0;
    SMR_NEED_INIT();
    if (!c || !st || !b) return smr_fail(SMR_E_INVAL, "draw: NULL argument");
    if (st->fill_style != 0 || st->border_style != 0)
@@ -1879,6 +1883,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       t.edges_ms = T.ms(0, 1); t.prims_ms = T.ms(1, 2); t.bin_ms = T.ms(2, 3); t.raster_ms = T.ms(3, 4); t.total_ms = T.ms(0, 4);
       t.n_prims = (uint64_t) n_prims; t.n_edges = n_edges; t.n_tile_refs = n_entries; t.n_tiles = n_tiles;
    }
+   if (h_small[2] & SMR_ST_DEGRADED) smr_g.draw_status |= SMR_DRAW_DEGRADED_ROWS;
    if (h_small[2] & SMR_ST_ROWCAP)
       return smr_fail(SMR_E_CAPACITY, "draw: more than %d edges of one primitive span a vertex-free pixel row inside one tile", SMR_ROWCAP);
    if (h_small[2] & SMR_ST_BUCKET_OVERFLOW)

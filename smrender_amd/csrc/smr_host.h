@@ -17,6 +17,7 @@ struct smr_global_t
    bool have_proj = false;
    bool profiling = false;
    smr_timings_t last;
+   uint32_t draw_status = 0;
    char err[512] = "";
 };
 extern smr_global_t smr_g;

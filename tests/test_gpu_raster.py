@@ -166,3 +166,29 @@ def test_directional_compound_fill(hip, col, size):
     got = cv.read()
     cv.close()
     assert np.array_equal(got, want), report(got, want)
+
+
+def test_rows_beyond_the_exact_path_are_subsampled_and_reported(hip):
+    """A comb with 45 slanted teeth: 90 edges span vertex-free pixel rows, more than the exact whole-row path
+    keeps.  The library sub-samples such rows (libcairo has no such limit), says so through
+    smr_hip_draw_status(), and stays within a few levels of the oracle; rows with vertices are exact."""
+    sa = hip
+    W, H = 420, 90
+    xs, ys = [], []
+    for k in range(45):
+        x0 = 10.3 + k * 8.8
+        xs += [x0, x0 + 6.1, x0 + 9.3, x0 + 5.7]; ys += [70.2, 12.4, 12.4, 70.2]
+    xs += [W - 8.0, 10.3]; ys += [80.5, 80.5]
+    x, y = np.array(xs), np.array(ys)
+    n = len(x)
+    off, ref = np.array([0, n + 1], np.int64), np.append(np.arange(n), 0).astype(np.int32)
+    st = po.Style(1, 0, 0x204060, 0, 0, 0, 0)
+    want = oracle_of([(st, (x, y, off, ref))], 300, W, H, 0xffffff)
+    got = gpu_scene(sa, [(st, (x, y, off, ref))], 300, W, H, 0xffffff)
+    assert sa.lib().smr_hip_draw_status() & 1
+    d = po.chan_diff(got, want)
+    assert 0 < d.max() <= 4 and (d > 0).mean() < 0.2, report(got, want)
+    assert d[:13].max() == 0 and d[70:].max() == 0        # rows with vertices / with two spanning edges only
+    # an ordinary scene afterwards clears the flag
+    gpu_scene(sa, [(st, po.synth_ways(5, 64, 64, seed=1))], 300, 64, 64, 0xffffff)
+    assert sa.lib().smr_hip_draw_status() == 0
