@@ -30,7 +30,23 @@ class Proj(C.Structure):
 
 class Style(C.Structure):
     _fields_ = [("fill_used", C.c_int), ("border_used", C.c_int), ("fill_col", C.c_uint32), ("border_col", C.c_uint32),
-                ("fill_width_mm", C.c_double), ("border_width_mm", C.c_double), ("ignore_open", C.c_int)]
+                ("fill_width_mm", C.c_double), ("border_width_mm", C.c_double), ("ignore_open", C.c_int),
+                ("border_style", C.c_int), ("fill_style", C.c_int), ("border_ndash", C.c_int), ("fill_ndash", C.c_int),
+                ("border_dash", C.c_double * 4), ("fill_dash", C.c_double * 4)]
+
+    SOLID, DASHED, DOTTED, TRANSPARENT, PIPE, ROUNDDOT = range(6)
+    DEFAULT_DASH = {1: (7.0, 3.0), 4: (7.0, 3.0), 2: (1.0,), 5: (0.0, 2.0)}      # parse_dash_style, src/smrparse.c:1077-1102
+
+    def with_dash(self, border_style=0, fill_style=0, border_dash=None, fill_dash=None):
+        """copy with dash styles; None = the style's default array"""
+        s = Style.from_buffer_copy(bytes(self))
+        s.border_style, s.fill_style = border_style, fill_style
+        bd = tuple(border_dash) if border_dash else Style.DEFAULT_DASH.get(border_style, ())
+        fd = tuple(fill_dash) if fill_dash else Style.DEFAULT_DASH.get(fill_style, ())
+        s.border_ndash, s.fill_ndash = len(bd), len(fd)
+        for i, v in enumerate(bd): s.border_dash[i] = v
+        for i, v in enumerate(fd): s.fill_dash[i] = v
+        return s
 
 
 def P(a):
@@ -216,6 +232,15 @@ def cairo_directional(st, ways, dpi, W, H, bg):
     return out
 
 
+def _cd_dash(L, style, bwidth_mm, ds, n, dpi):
+    dash = [mm2wu(bwidth_mm, dpi) * ds[i] for i in range(n)]
+    rnd = style in (4, 5)
+    if style == 4:
+        dash = [0.0, sum(dash)]
+    arr = (C.c_double * max(len(dash), 1))(*dash)
+    L.cd_set_dash(arr, len(dash), int(rnd))
+
+
 def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None):
     """Same scene through the real libcairo with the reference's call sequence."""
     L = cairo()
@@ -235,11 +260,18 @@ def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None):
                     bw = mm2wu(2 * st.border_width_mm, dpi) + mm2wu(st.fill_width_mm, dpi)
                 else:
                     bw = mm2wu(2 * st.border_width_mm, dpi)
+                # cairo_smr_dash (:898-923) before every stroke; the pipe is a dashed stroke + dots (:974-986)
+                _cd_dash(L, 1 if st.border_style == 4 else st.border_style, st.border_width_mm, st.border_dash, st.border_ndash, dpi)
                 L.cd_poly_line(P(xy), len(xy))
                 L.cd_stroke(st.border_col, bw)
+                if st.border_style == 4:
+                    _cd_dash(L, 4, st.border_width_mm, st.border_dash, st.border_ndash, dpi)
+                    L.cd_poly_line(P(xy), len(xy))
+                    L.cd_stroke(st.border_col, bw * 2.5)
             if st.fill_used:
                 L.cd_poly_line(P(xy), len(xy))
                 if not closed:
+                    _cd_dash(L, st.fill_style, st.border_width_mm, st.fill_dash, st.fill_ndash, dpi)
                     L.cd_stroke(st.fill_col, mm2wu(st.fill_width_mm, dpi))
                 else:
                     L.cd_fill(st.fill_col)

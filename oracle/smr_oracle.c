@@ -180,63 +180,337 @@ static int sgn_cmp(double dx1, double dy1, double dx2, double dy2)
    return c > 0 ? 1 : c < 0 ? -1 : 0;
 }
 
+/* join of two faces at one vertex (outer_join / inner_join of cairo-path-stroke-polygon.c): which side is
+ * the outer one and, for a miter inside the limit, the miter point.  That stroker REPLACES the incoming
+ * face's outer corner by the miter point and never adds the outgoing one: the outer contour runs from miter
+ * point to miter point, the inner one through the incoming corner, the vertex itself and the outgoing corner. */
+typedef struct { int kind; int clockwise; pt_t m; } join_t;     /* kind 0: faces coincide, 1: miter, 2: bevel */
+
+static join_t stroke_join(const face_t *in, const face_t *out)
+{
+   join_t j; j.kind = 0; j.clockwise = 0; j.m = in->point;
+   if (in->cw.x == out->cw.x && in->cw.y == out->cw.y && in->ccw.x == out->ccw.x && in->ccw.y == out->ccw.y) return j;
+   /* _cairo_slope_compare(in, out) < 0  <=>  in.dy*out.dx < out.dy*in.dx */
+   int64_t l = (int64_t) in->ddy * out->ddx, r = (int64_t) out->ddy * in->ddx;
+   if (l != r) j.clockwise = l < r;
+   else j.clockwise = (in->ddx > 0 || (in->ddx == 0 && in->ddy > 0));   /* anti-parallel */
+   pt_t inpt = j.clockwise ? in->cw : in->ccw, outpt = j.clockwise ? out->cw : out->ccw;
+   double in_dot_out = in->sx * out->sx + in->sy * out->sy;
+   double ml = 10.0;
+   j.kind = 2;
+   if (2 <= ml * ml * (1 + in_dot_out))
+   {
+      double x1 = inpt.x / 256.0, y1 = inpt.y / 256.0, dx1 = in->sx, dy1 = in->sy;
+      double x2 = outpt.x / 256.0, y2 = outpt.y / 256.0, dx2 = out->sx, dy2 = out->sy;
+      double my = (((x2 - x1) * dy1 * dy2 - y2 * dx2 * dy1 + y1 * dx1 * dy2) / (dx1 * dy2 - dx2 * dy1));
+      double mx;
+      if (fabs(dy1) >= fabs(dy2)) mx = (my - y1) * dx1 / dy1 + x1;
+      else mx = (my - y2) * dx2 / dy2 + x2;
+      double ix = in->point.x / 256.0, iy = in->point.y / 256.0;
+      double fdx1 = x1 - ix, fdy1 = y1 - iy, fdx2 = x2 - ix, fdy2 = y2 - iy, mdx = mx - ix, mdy = my - iy;
+      if (sgn_cmp(fdx1, fdy1, mdx, mdy) != sgn_cmp(fdx2, fdy2, mdx, mdy))
+      {
+         j.kind = 1;
+         j.m.x = orc_fixed_from_double(mx); j.m.y = orc_fixed_from_double(my);
+      }
+   }
+   return j;
+}
+
+/* The polygon of that stroker is cut into closed convex pieces whose outer edges are exactly its edges and
+ * whose other edges join vertices it has too, so that the scan converter makes the same decision per row:
+ *   body of a segment  = quad over its four face corners, an outer corner replaced by the miter point
+ *   join, miter        = triangle (vertex, incoming inner corner, outgoing inner corner)
+ *   join, bevel        = quad (vertex, incoming outer, outgoing outer, incoming inner corner)            */
 int orc_stroke_edges(const int32_t *xy, int n, double hw_pt, int dpi, tor_edge_t *out)
 {
    double s = (double) dpi / 72;
-   int cnt = 0, have = 0;
-   face_t cur;          /* face at the END of the previous segment (at the join point) */
+   int cnt = 0;
+   /* drop the degenerate segments first: every segment then knows its neighbours */
+   pt_t *p = malloc(sizeof(pt_t) * (n > 0 ? n : 1));
+   int m = 0;
+   for (int i = 0; i < n; i++)
+   {
+      pt_t q = { xy[2 * i], xy[2 * i + 1] };
+      if (m == 0 || p[m - 1].x != q.x || p[m - 1].y != q.y) p[m++] = q;
+   }
+   face_t prev_end;
+   for (int i = 0; i + 1 < m; i++)
+   {
+      int32_t ddx = p[i + 1].x - p[i].x, ddy = p[i + 1].y - p[i].y;
+      face_t start, end;
+      compute_face(p[i], ddx, ddy, hw_pt, s, &start);
+      end = start;
+      end.point = p[i + 1];
+      end.ccw.x += ddx; end.ccw.y += ddy; end.cw.x += ddx; end.cw.y += ddy;
+      pt_t c_ccw0 = start.ccw, c_cw0 = start.cw, c_ccw1 = end.ccw, c_cw1 = end.cw;
+      if (i > 0)
+      {
+         join_t j = stroke_join(&prev_end, &start);
+         pt_t in_inner = j.clockwise ? prev_end.ccw : prev_end.cw, out_inner = j.clockwise ? start.ccw : start.cw;
+         pt_t in_outer = j.clockwise ? prev_end.cw : prev_end.ccw, out_outer = j.clockwise ? start.cw : start.ccw;
+         if (j.kind == 1)
+         {
+            if (j.clockwise) c_cw0 = j.m; else c_ccw0 = j.m;
+            pt_t q[3] = { p[i], in_inner, out_inner };
+            cnt += emit_poly(q, 3, out + cnt);
+         }
+         else if (j.kind == 2)
+         {
+            pt_t q[4] = { p[i], in_outer, out_outer, in_inner };
+            cnt += emit_poly(q, 4, out + cnt);
+         }
+      }
+      if (i + 2 < m)
+      {
+         face_t nstart;
+         compute_face(p[i + 1], p[i + 2].x - p[i + 1].x, p[i + 2].y - p[i + 1].y, hw_pt, s, &nstart);
+         join_t j = stroke_join(&end, &nstart);
+         if (j.kind == 1) { if (j.clockwise) c_cw1 = j.m; else c_ccw1 = j.m; }
+      }
+      pt_t q[4] = { c_ccw0, c_ccw1, c_cw1, c_cw0 };
+      cnt += emit_poly(q, 4, out + cnt);
+      prev_end = end;
+   }
+   free(p);
+   return cnt;
+}
+
+/* ---------------- dashed strokes ----------------
+ * libcairo 1.16 sends a stroke with a dash array through the older stroker (cairo-path-stroke.c,
+ * _cairo_path_fixed_stroke_dashed_to_polygon): every "on" stretch of a segment is one sub-edge
+ * with faces of its own, consecutive sub-edges across a vertex are joined (miter, limit 10), all
+ * other ends are capped (butt: the end edge; round: a fan over the pen's vertices).  The edges it
+ * collects bound exactly the union of the closed convex pieces emitted here (quad per sub-edge,
+ * wedge per join, half disc per round cap, cut into pieces of at most four edges), which is the
+ * form the tor restatement and the GPU path take them in.                                     */
+
+typedef struct { int32_t dx, dy; } slope_t;
+
+static int slope_cmp(slope_t a, slope_t b)          /* _cairo_slope_compare */
+{
+   int64_t l = (int64_t) a.dy * b.dx, r = (int64_t) b.dy * a.dx;
+   if (l != r) return l < r ? -1 : 1;
+   if (a.dx == 0 && a.dy == 0 && b.dx == 0 && b.dy == 0) return 0;
+   if (a.dx == 0 && a.dy == 0) return 1;
+   if (b.dx == 0 && b.dy == 0) return -1;
+   if ((a.dx ^ b.dx) < 0 || (a.dy ^ b.dy) < 0)
+      return (a.dx > 0 || (a.dx == 0 && a.dy > 0)) ? -1 : 1;
+   return 0;
+}
+
+/* the stroker's pen: a polygon of an even number of vertices around the half line width */
+int orc_pen(double hw_pt, int dpi, int32_t *vx, int32_t *vy, int cap)
+{
+   const double s = (double) dpi / 72, tol = 0.1;
+   double major = hw_pt * sqrt(s * s);
+   int n;
+   if (tol >= 4 * major) n = 1;
+   else if (tol >= major) n = 4;
+   else
+   {
+      n = (int) ceil(2 * M_PI / acos(1 - tol / major));
+      if (n % 2) n++;
+      if (n < 4) n = 4;
+   }
+   if (n > cap) return -n;
+   for (int i = 0; i < n; i++)
+   {
+      double th = 2 * M_PI * i / (double) n;
+      vx[i] = orc_fixed_from_double(hw_pt * cos(th) * s);
+      vy[i] = orc_fixed_from_double(hw_pt * sin(th) * s);
+   }
+   return n;
+}
+
+typedef struct
+{
+   double s, hw;
+   int round_cap, npen;
+   int32_t pvx[ORC_PEN_MAX], pvy[ORC_PEN_MAX];
+   slope_t pcw[ORC_PEN_MAX], pccw[ORC_PEN_MAX];
+   tor_edge_t *out; int cnt;                       /* out == NULL: count only */
+} dasher_t;
+
+typedef struct { pt_t ccw, cw, point; double ux, uy; slope_t dev; } dface_t;
+
+static void d_emit(dasher_t *d, const pt_t *q, int n)
+{
+   tor_edge_t tmp[4];
+   int k = emit_poly(q, n, tmp);
+   if (d->out) memcpy(d->out + d->cnt, tmp, sizeof(tor_edge_t) * k);
+   d->cnt += k;
+}
+
+static void d_face(const dasher_t *d, pt_t p, slope_t dev, double ux, double uy, dface_t *f)
+{
+   double fx = -uy * d->hw, fy = ux * d->hw;
+   fx *= d->s; fy *= d->s;
+   int32_t ox = orc_fixed_from_double(fx), oy = orc_fixed_from_double(fy);
+   f->point = p; f->ux = ux; f->uy = uy; f->dev = dev;
+   f->ccw.x = p.x + ox; f->ccw.y = p.y + oy; f->cw.x = p.x - ox; f->cw.y = p.y - oy;
+}
+
+static int pen_active_ccw(const dasher_t *d, slope_t sl)       /* _cairo_pen_find_active_ccw_vertex_index */
+{
+   slope_t rev = { -sl.dx, -sl.dy };
+   int i;
+   for (i = d->npen - 1; i >= 0; i--)
+      if (slope_cmp(d->pccw[i], rev) >= 0 && slope_cmp(d->pcw[i], rev) < 0) break;
+   if (i < 0) i = d->npen - 1;
+   return i;
+}
+
+/* round cap at face f, f pointing out of the stroke: half disc ccw -> pen vertices -> cw */
+static void d_round_cap(dasher_t *d, const dface_t *f)
+{
+   const int n = d->npen;
+   slope_t in = f->dev, outv = { -f->dev.dx, -f->dev.dy };
+   int start = pen_active_ccw(d, in);
+   if (slope_cmp(d->pccw[start], in) < 0) start = start == 0 ? n - 1 : start - 1;
+   int stop = pen_active_ccw(d, outv);
+   if (slope_cmp(d->pcw[stop], outv) > 0)
+   {
+      stop = stop + 1 == n ? 0 : stop + 1;
+      if (slope_cmp(d->pccw[stop], in) < 0) return;
+   }
+   int npoints = start - stop;
+   stop = stop == 0 ? n - 1 : stop - 1;
+   if (npoints < 0) npoints += n;
+   if (npoints <= 1) return;
+   pt_t poly[ORC_PEN_MAX + 2];
+   int m = 0;
+   poly[m++] = f->ccw;
+   for (int i = start; i != stop; i = i == 0 ? n - 1 : i - 1)
+   {
+      pt_t p = { f->point.x + d->pvx[i], f->point.y + d->pvy[i] };
+      poly[m++] = p;
+   }
+   poly[m++] = f->cw;
+   /* convex: fan of quads from the first point */
+   for (int k = 1; k + 1 < m; k += 2)
+   {
+      pt_t q[4] = { poly[0], poly[k], poly[k + 1], poly[k + 2 < m ? k + 2 : k + 1] };
+      d_emit(d, q, k + 2 < m ? 4 : 3);
+   }
+}
+
+static void d_cap_trailing(dasher_t *d, const dface_t *f) { if (d->round_cap) d_round_cap(d, f); }
+
+static void d_cap_leading(dasher_t *d, const dface_t *f)
+{
+   if (!d->round_cap) return;
+   dface_t r = *f;
+   r.ux = -f->ux; r.uy = -f->uy; r.dev.dx = -f->dev.dx; r.dev.dy = -f->dev.dy;
+   r.cw = f->ccw; r.ccw = f->cw;
+   d_round_cap(d, &r);
+}
+
+static void d_join(dasher_t *d, const dface_t *in, const dface_t *out)
+{
+   if (in->cw.x == out->cw.x && in->cw.y == out->cw.y && in->ccw.x == out->ccw.x && in->ccw.y == out->ccw.y) return;
+   slope_t so = { out->cw.x - out->point.x, out->cw.y - out->point.y }, si = { in->cw.x - in->point.x, in->cw.y - in->point.y };
+   int clockwise = slope_cmp(so, si) < 0;
+   pt_t inpt = clockwise ? in->ccw : in->cw, outpt = clockwise ? out->ccw : out->cw;
+   double in_dot_out = -in->ux * out->ux + -in->uy * out->uy, ml = 10.0;
+   if (2 <= ml * ml * (1 - in_dot_out))
+   {
+      double x1 = inpt.x / 256.0, y1 = inpt.y / 256.0, dx1 = in->ux * d->s, dy1 = in->uy * d->s;
+      double x2 = outpt.x / 256.0, y2 = outpt.y / 256.0, dx2 = out->ux * d->s, dy2 = out->uy * d->s;
+      double my = (((x2 - x1) * dy1 * dy2 - y2 * dx2 * dy1 + y1 * dx1 * dy2) / (dx1 * dy2 - dx2 * dy1));
+      double mx;
+      if (fabs(dy1) >= fabs(dy2)) mx = (my - y1) * dx1 / dy1 + x1;
+      else mx = (my - y2) * dx2 / dy2 + x2;
+      double ix = in->point.x / 256.0, iy = in->point.y / 256.0;
+      double fdx1 = x1 - ix, fdy1 = y1 - iy, fdx2 = x2 - ix, fdy2 = y2 - iy, mdx = mx - ix, mdy = my - iy;
+      if (sgn_cmp(fdx1, fdy1, mdx, mdy) != sgn_cmp(fdx2, fdy2, mdx, mdy))
+      {
+         pt_t q[4] = { in->point, inpt, { orc_fixed_from_double(mx), orc_fixed_from_double(my) }, outpt };
+         d_emit(d, q, 4);
+         return;
+      }
+   }
+   pt_t q[3] = { in->point, inpt, outpt };
+   d_emit(d, q, 3);
+}
+
+int orc_dash_edges(const int32_t *xy, int n, double hw_pt, int dpi, const double *dash, int ndash, int round_cap, tor_edge_t *out)
+{
+   dasher_t D;
+   D.s = (double) dpi / 72; D.hw = hw_pt; D.round_cap = round_cap; D.out = out; D.cnt = 0;
+   D.npen = round_cap ? orc_pen(hw_pt, dpi, D.pvx, D.pvy, ORC_PEN_MAX) : 0;
+   if (D.npen < 0) return -1;
+   for (int i = 0; i < D.npen; i++)
+   {
+      int pr = i == 0 ? D.npen - 1 : i - 1, nx = i + 1 == D.npen ? 0 : i + 1;
+      D.pcw[i].dx = D.pvx[i] - D.pvx[pr]; D.pcw[i].dy = D.pvy[i] - D.pvy[pr];
+      D.pccw[i].dx = D.pvx[nx] - D.pvx[i]; D.pccw[i].dy = D.pvy[nx] - D.pvy[i];
+   }
+   /* _cairo_stroker_dash_start with offset 0 */
+   int di = 0, on = 1;
+   const int starts_on = 1;
+   double dash_remain = dash[0];
+   int has_first = 0, has_cur = 0;
+   dface_t first, cur;
    pt_t p1 = { xy[0], xy[1] };
    for (int i = 1; i < n; i++)
    {
       pt_t p2 = { xy[2 * i], xy[2 * i + 1] };
-      if (p1.x == p2.x && p1.y == p2.y) continue;     /* degenerate segment skipped */
-      int32_t ddx = p2.x - p1.x, ddy = p2.y - p1.y;
-      face_t start, end;
-      compute_face(p1, ddx, ddy, hw_pt, s, &start);
-      end = start;
-      end.point = p2;
-      end.ccw.x += ddx; end.ccw.y += ddy; end.cw.x += ddx; end.cw.y += ddy;
-
-      if (have && !(cur.cw.x == start.cw.x && cur.cw.y == start.cw.y && cur.ccw.x == start.ccw.x && cur.ccw.y == start.ccw.y))
+      if (p1.x == p2.x && p1.y == p2.y) continue;
+      slope_t dev = { p2.x - p1.x, p2.y - p1.y };
+      double sdx = dev.dx / 256.0 * (1.0 / D.s), sdy = dev.dy / 256.0 * (1.0 / D.s);
+      double mag = normalize_slope(&sdx, &sdy);
+      double remain = mag;
+      pt_t a = p1;
+      while (remain)
       {
-         /* _cairo_slope_compare(in, out) < 0  <=>  in.dy*out.dx < out.dy*in.dx */
-         int64_t l = (int64_t) cur.ddy * start.ddx, r = (int64_t) start.ddy * cur.ddx;
-         int clockwise;
-         if (l != r) clockwise = l < r;
-         else clockwise = (cur.ddx > 0 || (cur.ddx == 0 && cur.ddy > 0));   /* anti-parallel */
-         pt_t inpt = clockwise ? cur.cw : cur.ccw, outpt = clockwise ? start.cw : start.ccw;
-         double in_dot_out = cur.sx * start.sx + cur.sy * start.sy;
-         double ml = 10.0;
-         int mitered = 0;
-         if (2 <= ml * ml * (1 + in_dot_out))
+         double step = dash_remain < remain ? dash_remain : remain;
+         remain -= step;
+         double dx2 = sdx * (mag - remain) * D.s, dy2 = sdy * (mag - remain) * D.s;
+         pt_t b = { orc_fixed_from_double(dx2) + p1.x, orc_fixed_from_double(dy2) + p1.y };
+         if (on)
          {
-            double x1 = inpt.x / 256.0, y1 = inpt.y / 256.0, dx1 = cur.sx, dy1 = cur.sy;
-            double x2 = outpt.x / 256.0, y2 = outpt.y / 256.0, dx2 = start.sx, dy2 = start.sy;
-            double my = (((x2 - x1) * dy1 * dy2 - y2 * dx2 * dy1 + y1 * dx1 * dy2) / (dx1 * dy2 - dx2 * dy1));
-            double mx;
-            if (fabs(dy1) >= fabs(dy2)) mx = (my - y1) * dx1 / dy1 + x1;
-            else mx = (my - y2) * dx2 / dy2 + x2;
-            double ix = p1.x / 256.0, iy = p1.y / 256.0;
-            double fdx1 = x1 - ix, fdy1 = y1 - iy, fdx2 = x2 - ix, fdy2 = y2 - iy, mdx = mx - ix, mdy = my - iy;
-            if (sgn_cmp(fdx1, fdy1, mdx, mdy) != sgn_cmp(fdx2, fdy2, mdx, mdy))
+            dface_t ss, se;
+            d_face(&D, a, dev, sdx, sdy, &ss);
+            se = ss;
+            if (a.x != b.x || a.y != b.y)
             {
-               pt_t q[4] = { p1, inpt, { orc_fixed_from_double(mx), orc_fixed_from_double(my) }, outpt };
-               cnt += emit_poly(q, 4, out + cnt);
-               mitered = 1;
+               se.point = b;
+               se.ccw.x += b.x - a.x; se.ccw.y += b.y - a.y; se.cw.x += b.x - a.x; se.cw.y += b.y - a.y;
+               pt_t q[4] = { ss.ccw, se.ccw, se.cw, ss.cw };
+               d_emit(&D, q, 4);
             }
+            if (has_cur) { d_join(&D, &cur, &ss); has_cur = 0; }
+            else if (!has_first && starts_on) { first = ss; has_first = 1; }
+            else d_cap_leading(&D, &ss);
+            if (remain) d_cap_trailing(&D, &se);
+            else { cur = se; has_cur = 1; }
          }
-         if (!mitered)
+         else if (has_cur) { d_cap_trailing(&D, &cur); has_cur = 0; }
+         /* _cairo_stroker_dash_step */
+         dash_remain -= step;
+         if (dash_remain < 1.0 / 512)
          {
-            pt_t q[3] = { p1, inpt, outpt };
-            cnt += emit_poly(q, 3, out + cnt);
+            if (++di == ndash) di = 0;
+            on = !on;
+            dash_remain += dash[di];
          }
+         a = b;
       }
-      pt_t q[4] = { start.ccw, end.ccw, end.cw, start.cw };
-      cnt += emit_poly(q, 4, out + cnt);
-      cur = end; have = 1;
+      if (on && !has_cur)
+      {
+         /* the segment ends exactly where a dash begins: a (degenerate) leading cap at the vertex */
+         d_face(&D, p2, dev, sdx, sdy, &cur);
+         d_cap_leading(&D, &cur);
+         has_cur = 1;
+      }
       p1 = p2;
    }
-   return cnt;
+   /* _cairo_stroker_add_caps; a path of coincident points only draws nothing with our dash arrays
+    * unless caps are round -- the reference's ways with >= 2 distinct nodes never get there */
+   if (has_first) d_cap_leading(&D, &first);
+   if (has_cur) d_cap_trailing(&D, &cur);
+   return D.cnt;
 }
 
 /* ---------------- colour + compositing ---------------- */
@@ -308,6 +582,7 @@ struct orc_canvas
    uint32_t *pix, *layer;
    uint8_t *cov;
    int layer_clear;
+   int cap_round;        /* line cap of the current rule's context (cairo_set_line_cap is never undone) */
 };
 
 orc_canvas_t *orc_canvas_new(int x0, int y0, int W, int H, int dpi, uint32_t bgcolor)
@@ -330,6 +605,7 @@ void orc_rule_begin(orc_canvas_t *c)
 {
    memset(c->layer, 0, sizeof(uint32_t) * c->W * c->H);
    c->layer_clear = 1;
+   c->cap_round = 0;
 }
 
 /* cairo_pop_group_to_source + cairo_paint (src/smrules_cairo.c:203-205, :1081-1082) */
@@ -424,7 +700,36 @@ uint32_t *orc_canvas_pixels_rw(orc_canvas_t *c) { return c->pix; }
 /* mm -> pt; width 0 -> 1 device pixel (THINLINE): src/smrules_cairo.c:67-69, src/rdata.c:50-53 */
 static double mm2wu(double mm, int dpi) { return mm == 0.0 ? 1.0 * 72 / dpi : mm * 72 / 25.4; }
 
-/* render_poly_line, src/smrules_cairo.c:953-1016 (solid styles, no pipe/image/curve) */
+/* cairo_smr_dash (:898-923) + cairo_stroke: dash lengths = mm2wu(border width) * ds[i]; rounddot and the pipe's
+ * dots switch the context to round caps, and nothing ever switches it back (c->cap_round lives as long as
+ * the rule's context) */
+static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double width_pt, int style, double bwidth_mm,
+                          const double *ds, int len, uint32_t col)
+{
+   double dash[4], l = 0;
+   int nd = 0;
+   for (; nd < len && nd < 4; nd++) { dash[nd] = mm2wu(bwidth_mm, c->dpi) * ds[nd]; l += dash[nd]; }
+   if (style == 5) c->cap_round = 1;
+   if (style == 4) { c->cap_round = 1; dash[0] = 0; dash[1] = l; nd = 2; }
+   tor_edge_t *e;
+   int ne;
+   if (nd == 0)
+   {
+      /* a solid stroke with round caps would take libcairo's other stroker: not restated */
+      e = malloc(sizeof(tor_edge_t) * 8 * n);
+      ne = orc_stroke_edges(dev, n, width_pt / 2, c->dpi, e);
+   }
+   else
+   {
+      ne = orc_dash_edges(dev, n, width_pt / 2, c->dpi, dash, nd, c->cap_round, NULL);
+      e = malloc(sizeof(tor_edge_t) * (ne > 0 ? ne : 1));
+      if (ne > 0) orc_dash_edges(dev, n, width_pt / 2, c->dpi, dash, nd, c->cap_round, e);
+   }
+   if (ne > 0) orc_layer_edges(c, e, ne, 1, col);
+   free(e);
+}
+
+/* render_poly_line, src/smrules_cairo.c:953-1016 (no image/curve) */
 void orc_draw_way(orc_canvas_t *c, const orc_draw_style_t *st, const double *x_px, const double *y_px, int n, int closed,
                   int has_fill_col, uint32_t fill_col, int has_border_col, uint32_t border_col)
 {
@@ -440,16 +745,18 @@ void orc_draw_way(orc_canvas_t *c, const orc_draw_style_t *st, const double *x_p
       if (!st->fill_used) bw = mm2wu(st->border_width_mm, c->dpi);
       else if (!closed) bw = mm2wu(2 * st->border_width_mm, c->dpi) + mm2wu(st->fill_width_mm, c->dpi);
       else bw = mm2wu(2 * st->border_width_mm, c->dpi);
-      int ne = orc_stroke_edges(dev, n, bw / 2, c->dpi, e);
-      orc_layer_edges(c, e, ne, 1, has_border_col ? border_col : st->border_col);
+      uint32_t col = has_border_col ? border_col : st->border_col;
+      stroke_styled(c, dev, n, bw, st->border_style == 4 ? 1 : st->border_style, st->border_width_mm, st->border_dash, st->border_ndash, col);
+      if (st->border_style == 4)       /* the pipe's dots, :979-986 */
+         stroke_styled(c, dev, n, bw * 2.5, 4, st->border_width_mm, st->border_dash, st->border_ndash, col);
    }
    if (st->fill_used)
    {
       uint32_t col = has_fill_col ? fill_col : st->fill_col;
       if (!closed)
       {
-         int ne = orc_stroke_edges(dev, n, mm2wu(st->fill_width_mm, c->dpi) / 2, c->dpi, e);   /* :1005-1007 */
-         orc_layer_edges(c, e, ne, 1, col);
+         /* :1005-1007; the fill's dashes scale with the BORDER width */
+         stroke_styled(c, dev, n, mm2wu(st->fill_width_mm, c->dpi), st->fill_style, st->border_width_mm, st->fill_dash, st->fill_ndash, col);
       }
       else
       {

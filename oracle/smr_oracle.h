@@ -39,6 +39,12 @@ void orc_pt_to_dev(const double *xy_pt, int64_t n, int dpi, int32_t *xy_dev);
  * butt caps, miter joins (limit 10).  hw_pt = half line width in pt.  Returns #edges,
  * out needs room for 8*(n-1) edges. */
 int orc_stroke_edges(const int32_t *xy_dev, int n, double hw_pt, int dpi, tor_edge_t *out);
+/* the same poly-line stroked with a dash array (lengths in pt, offset 0) and butt or round caps:
+ * libcairo's cairo-path-stroke.c dasher.  out == NULL: only counts.  Returns #edges (-1: pen too large). */
+#define ORC_PEN_MAX 256
+int orc_dash_edges(const int32_t *xy_dev, int n, double hw_pt, int dpi, const double *dash_pt, int ndash, int round_cap, tor_edge_t *out);
+/* the pen (_cairo_pen_init, tolerance 0.1): vertex offsets in device 24.8; returns #vertices, -needed if > cap */
+int orc_pen(double hw_pt, int dpi, int32_t *vx, int32_t *vy, int cap);
 /* fill polygon edges (implicitly closed): n edges */
 int orc_fill_edges(const int32_t *xy_dev, int n, tor_edge_t *out);
 
@@ -65,6 +71,10 @@ typedef struct
    uint32_t fill_col, border_col;   /* 0xTTRRGGBB */
    double fill_width_mm, border_width_mm;
    int ignore_open;
+   /* draw_style_t of border and fill (0 solid, 1 dashed, 2 dotted, 4 pipe, 5 rounddot: src/smrender_dev.h:145) and
+    * their dash arrays in multiples of the border width, defaults of parse_dash_style already applied */
+   int border_style, fill_style, border_ndash, fill_ndash;
+   double border_dash[4], fill_dash[4];
 } orc_draw_style_t;
 
 /* render_poly_line (src/smrules_cairo.c:953-1016) for one way given projected px coords */

@@ -151,8 +151,48 @@ __device__ __forceinline__ int smr_sgn_cmp(double dx1, double dy1, double dx2, d
    return c > 0 ? 1 : c < 0 ? -1 : 0;
 }
 
+/* join of two faces at one vertex (outer_join / inner_join of cairo-path-stroke-polygon.c, restated in
+ * oracle/smr_oracle.c stroke_join): kind 0 = the faces coincide, 1 = miter inside the limit (m = miter
+ * point), 2 = bevel; clockwise = the cw side is the outer one */
+struct smr_join_t { int kind; bool clockwise; int2 m; };
+
+__device__ __forceinline__ smr_join_t smr_join(const smr_face_t &in, const smr_face_t &out, int2 v)
+{
+   smr_join_t j; j.kind = 0; j.clockwise = false; j.m = v;
+   if (in.cw.x == out.cw.x && in.cw.y == out.cw.y && in.ccw.x == out.ccw.x && in.ccw.y == out.ccw.y) return j;
+   const int64_t l = (int64_t) in.ddy * out.ddx, r = (int64_t) out.ddy * in.ddx;
+   j.clockwise = l != r ? l < r : (in.ddx > 0 || (in.ddx == 0 && in.ddy > 0));
+   const int2 inpt = j.clockwise ? in.cw : in.ccw, outpt = j.clockwise ? out.cw : out.ccw;
+   const double in_dot_out = in.sx * out.sx + in.sy * out.sy;
+   j.kind = 2;
+   if (2 <= 100.0 * (1 + in_dot_out))
+   {
+      double x1 = inpt.x / 256.0, y1 = inpt.y / 256.0, dx1 = in.sx, dy1 = in.sy;
+      double x2 = outpt.x / 256.0, y2 = outpt.y / 256.0, dx2 = out.sx, dy2 = out.sy;
+      double my = (((x2 - x1) * dy1 * dy2 - y2 * dx2 * dy1 + y1 * dx1 * dy2) / (dx1 * dy2 - dx2 * dy1));
+      double mx;
+      if (fabs(dy1) >= fabs(dy2)) mx = (my - y1) * dx1 / dy1 + x1;
+      else mx = (my - y2) * dx2 / dy2 + x2;
+      double ix = v.x / 256.0, iy = v.y / 256.0;
+      double fdx1 = x1 - ix, fdy1 = y1 - iy, fdx2 = x2 - ix, fdy2 = y2 - iy, mdx = mx - ix, mdy = my - iy;
+      if (smr_sgn_cmp(fdx1, fdy1, mdx, mdy) != smr_sgn_cmp(fdx2, fdy2, mdx, mdy))
+      {
+         j.kind = 1;
+         j.m = make_int2((int32_t) rint(mx * 256.0), (int32_t) rint(my * 256.0));
+      }
+   }
+   return j;
+}
+
 /* mode 0: border strokes, widths per cairo_smr_border_width; mode 1: fill of open ways drawn
- * as a stroke of the fill width (src/smrules_cairo.c:1003-1008) */
+ * as a stroke of the fill width (src/smrules_cairo.c:1003-1008).
+ * libcairo's stroker runs an outer contour from miter point to miter point and an inner contour through the
+ * incoming face corner, the vertex and the outgoing face corner.  That polygon is cut into closed convex
+ * pieces whose outer edges are exactly its edges and whose other edges join vertices it has too (so the scan
+ * converter decides every row as it does for libcairo's polygon):
+ *   slots 4..7  body of the segment: quad over its four face corners, an outer corner replaced by the miter point
+ *   slots 0..3  join at the segment's start: miter -> triangle (vertex, incoming inner, outgoing inner corner),
+ *               bevel -> quad (vertex, incoming outer, outgoing outer, incoming inner corner)                  */
 __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__restrict__ way_off,
                                const int32_t *__restrict__ refway, int64_t n_refs,
                                const uint8_t *__restrict__ wayflags, int mode, int dpi,
@@ -162,8 +202,6 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
    int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    if (g >= n_refs) return;
    int64_t w = refway[g];
-   /* slots 0..3: join wedge at the segment's start point, slots 4..7: the segment's quad;
-    * every 4 aligned slots hold one closed convex piece (or nothing) */
    smr_edge_t loc[SMR_SLOTS];
    smr_edge_t z; z.x1 = z.y1 = z.x2 = z.y2 = 0;
 #pragma unroll
@@ -180,53 +218,52 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
          double s = (double) dpi / 72;
          int32_t ddx = p2.x - p1.x, ddy = p2.y - p1.y;
          smr_face_t start = smr_face(p1, ddx, ddy, hw, s);
+         int2 c_ccw0 = start.ccw, c_cw0 = start.cw;
+         int2 c_ccw1 = make_int2(start.ccw.x + ddx, start.ccw.y + ddy), c_cw1 = make_int2(start.cw.x + ddx, start.cw.y + ddy);
          /* previous non-degenerate segment of the same way ends at p1 */
          int64_t k = g - 1;
-         int2 p0 = p1;
+         int2 q0 = p1;
          bool have = false;
          while (k >= a)
          {
-            p0 = pts[k];
-            if (p0.x != p1.x || p0.y != p1.y) { have = true; break; }
+            q0 = pts[k];
+            if (q0.x != p1.x || q0.y != p1.y) { have = true; break; }
             k--;
          }
          if (have)
          {
-            int32_t pdx = p1.x - p0.x, pdy = p1.y - p0.y;
-            smr_face_t cur = smr_face(p1, pdx, pdy, hw, s);     /* face of the previous segment at its END point */
-            if (!(cur.cw.x == start.cw.x && cur.cw.y == start.cw.y && cur.ccw.x == start.ccw.x && cur.ccw.y == start.ccw.y))
+            smr_face_t cur = smr_face(p1, p1.x - q0.x, p1.y - q0.y, hw, s);     /* face of the previous segment at its END point */
+            smr_join_t j = smr_join(cur, start, p1);
+            int2 in_inner = j.clockwise ? cur.ccw : cur.cw, out_inner = j.clockwise ? start.ccw : start.cw;
+            int2 in_outer = j.clockwise ? cur.cw : cur.ccw, out_outer = j.clockwise ? start.cw : start.ccw;
+            if (j.kind == 1)
             {
-               int64_t l = (int64_t) cur.ddy * start.ddx, r = (int64_t) start.ddy * cur.ddx;
-               bool clockwise = l != r ? l < r : (cur.ddx > 0 || (cur.ddx == 0 && cur.ddy > 0));
-               int2 inpt = clockwise ? cur.cw : cur.ccw, outpt = clockwise ? start.cw : start.ccw;
-               double in_dot_out = cur.sx * start.sx + cur.sy * start.sy;
-               bool mitered = false;
-               if (2 <= 100.0 * (1 + in_dot_out))
-               {
-                  double x1 = inpt.x / 256.0, y1 = inpt.y / 256.0, dx1 = cur.sx, dy1 = cur.sy;
-                  double x2 = outpt.x / 256.0, y2 = outpt.y / 256.0, dx2 = start.sx, dy2 = start.sy;
-                  double my = (((x2 - x1) * dy1 * dy2 - y2 * dx2 * dy1 + y1 * dx1 * dy2) / (dx1 * dy2 - dx2 * dy1));
-                  double mx;
-                  if (fabs(dy1) >= fabs(dy2)) mx = (my - y1) * dx1 / dy1 + x1;
-                  else mx = (my - y2) * dx2 / dy2 + x2;
-                  double ix = p1.x / 256.0, iy = p1.y / 256.0;
-                  double fdx1 = x1 - ix, fdy1 = y1 - iy, fdx2 = x2 - ix, fdy2 = y2 - iy, mdx = mx - ix, mdy = my - iy;
-                  if (smr_sgn_cmp(fdx1, fdy1, mdx, mdy) != smr_sgn_cmp(fdx2, fdy2, mdx, mdy))
-                  {
-                     int2 q[4] = { p1, inpt, make_int2((int32_t) rint(mx * 256.0), (int32_t) rint(my * 256.0)), outpt };
-                     smr_emit_poly(q, 4, loc);
-                     mitered = true;
-                  }
-               }
-               if (!mitered)
-               {
-                  int2 q[3] = { p1, inpt, outpt };
-                  smr_emit_poly(q, 3, loc);
-               }
+               if (j.clockwise) c_cw0 = j.m; else c_ccw0 = j.m;
+               int2 q[3] = { p1, in_inner, out_inner };
+               smr_emit_poly(q, 3, loc);
+            }
+            else if (j.kind == 2)
+            {
+               int2 q[4] = { p1, in_outer, out_outer, in_inner };
+               smr_emit_poly(q, 4, loc);
             }
          }
-         int2 q[4] = { start.ccw, make_int2(start.ccw.x + ddx, start.ccw.y + ddy),
-                       make_int2(start.cw.x + ddx, start.cw.y + ddy), start.cw };
+         /* next non-degenerate segment of the same way starts at p2 */
+         k = g + 2;
+         have = false;
+         while (k < b)
+         {
+            q0 = pts[k];
+            if (q0.x != p2.x || q0.y != p2.y) { have = true; break; }
+            k++;
+         }
+         if (have)
+         {
+            smr_face_t end = smr_face(p2, ddx, ddy, hw, s), nstart = smr_face(p2, q0.x - p2.x, q0.y - p2.y, hw, s);
+            smr_join_t j = smr_join(end, nstart, p2);
+            if (j.kind == 1) { if (j.clockwise) c_cw1 = j.m; else c_ccw1 = j.m; }
+         }
+         int2 q[4] = { c_ccw0, c_ccw1, c_cw1, c_cw0 };
          smr_emit_poly(q, 4, loc + 4);
       }
    }

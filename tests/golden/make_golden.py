@@ -33,8 +33,9 @@ def open_ways(n_ways, W, H, seed):
 
 
 def style_tuple(st):
-    return np.array([st.fill_used, st.border_used, st.fill_col, st.border_col, st.ignore_open], np.int64), \
-        np.array([st.fill_width_mm, st.border_width_mm])
+    return np.array([st.fill_used, st.border_used, st.fill_col, st.border_col, st.ignore_open,
+                     st.border_style, st.fill_style, st.border_ndash, st.fill_ndash], np.int64), \
+        np.array([st.fill_width_mm, st.border_width_mm] + list(st.border_dash) + list(st.fill_dash))
 
 
 def main():
@@ -68,7 +69,10 @@ def main():
                                         rules=[(po.Style(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0), c2)])
     scenes["open_border_300"] = dict(dpi=300, W=256, H=200, bg=0xffffff,
                                      rules=[(po.Style(0, 1, 0, 0x204060, 0.0, 0.3, 0), ow)])
-    scenes["layers_translucent_600"] = dict(dpi=600, W=256, H=200, bg=0x7f336699, rules=[
+    # the page is larger than the window: at 600 dpi libcairo clips to the recording surface's extents in whole
+    # pt scaled by the 24.8-quantised 600/72, i.e. to y = 199.97 px for a 200-px page, and dims the page's last
+    # row by that fraction -- a page-edge effect this fixture keeps out of the window (deviations)
+    scenes["layers_translucent_600"] = dict(dpi=600, W=256, H=200, bg=0x7f336699, full_w=300, full_h=240, rules=[
         (po.Style(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0), synth.synth_ways(60, 256, 200, seed=79)),
         (po.Style(1, 1, 0x304080c0, 0x50102030, 0.4, 0.2, 0), ow),
         (po.Style(0, 1, 0, 0x000000, 0.0, 0.0, 0), synth.synth_ways(30, 256, 200, seed=80))])
@@ -77,9 +81,21 @@ def main():
     far = (far[0] + 15000.0, far[1] + 9000.0, far[2], far[3])
     scenes["far_window_300"] = dict(dpi=300, W=128, H=128, bg=0xffffff, x0=15000, y0=9000,
                                     rules=[(po.Style(1, 1, 0xc04020, 0x000000, 0.0, 0.1, 0), far)])
+    # dash styles (cairo_smr_dash, src/smrules_cairo.c:898-923): one rule per style
+    dw = open_ways(14, 256, 200, seed=82)
+    dc = synth.synth_ways(10, 256, 200, seed=83, rmin=10.0, rmax=60.0)
+    S = po.Style
+    scenes["dashes_300"] = dict(dpi=300, W=256, H=200, bg=0xffffff, rules=[
+        (S(0, 1, 0, 0x204060, 0, 0.25, 0).with_dash(border_style=S.DASHED), dw),
+        (S(1, 1, 0x30c0d8f0, 0x000000, 0.3, 0.1, 0).with_dash(border_style=S.DOTTED), dc),
+        (S(0, 1, 0, 0x802010, 0, 0.3, 0).with_dash(border_style=S.ROUNDDOT), open_ways(8, 256, 200, seed=84)),
+        (S(0, 1, 0, 0x103050, 0, 0.15, 0).with_dash(border_style=S.PIPE), open_ways(8, 256, 200, seed=85)),
+        (S(1, 1, 0x4080c0, 0x50000000, 0.4, 0.1, 0).with_dash(border_style=S.DASHED, fill_style=S.DASHED,
+                                                              border_dash=(5, 2, 1, 2)), open_ways(8, 256, 200, seed=86))])
     for name, sc in scenes.items():
         rules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in sc["rules"]]
-        img = po.cairo_scene(rules, sc["dpi"], sc["W"], sc["H"], sc["bg"], sc.get("x0", 0), sc.get("y0", 0))
+        img = po.cairo_scene(rules, sc["dpi"], sc["W"], sc["H"], sc["bg"], sc.get("x0", 0), sc.get("y0", 0),
+                             sc.get("full_w"), sc.get("full_h"))
         d = dict(dpi=sc["dpi"], W=sc["W"], H=sc["H"], bg=sc["bg"], win_x0=sc.get("x0", 0), win_y0=sc.get("y0", 0),
                  n_rules=len(sc["rules"]), image=img)
         for i, (st, (x, y, off, ref)) in enumerate(sc["rules"]):

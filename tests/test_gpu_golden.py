@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 from oracle import pyoracle as po
 from smrender_amd import synth
-from golden_io import SCENES, load_scene, within
+from golden_io import BARS, SCENES, load_scene, within
 
 pytestmark = pytest.mark.gpu
 
@@ -29,8 +29,7 @@ def gpu_render(sa, meta, rules):
 def test_golden_scene(hip, name):
     meta, rules, want = load_scene(name)
     got = gpu_render(hip, meta, rules)
-    bar = 0.99 if name == "layers_translucent_600" else 0.995      # see tests/test_oracle_golden.py
-    assert within(got, want, 2) >= bar
+    assert within(got, want, 2) >= max(BARS[name][0], 0.995) and within(got, want, 0) >= BARS[name][1]
     orules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in rules]
     o = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"])
     assert np.array_equal(got, o)

@@ -53,7 +53,7 @@ def test_c2_like_scene_statistics():
     a = po.oracle_scene(rules, 300, 512, 512, 0xffffff)
     b = po.cairo_scene(rules, 300, 512, 512, 0xffffff)
     d = po.chan_diff(a, b)
-    assert (d <= 2).mean() >= 0.995 and (d == 0).mean() >= 0.98
+    assert (d <= 2).mean() >= 0.9998 and (d == 0).mean() >= 0.9995, ((d > 2).sum(), (d > 0).sum())
 
 
 def test_rot_paint_exact():
@@ -95,5 +95,44 @@ def test_directional_compound_fill(col):
     a = po.oracle_directional(st, ways, 300, 200, 160, 0xffffff)
     b = po.cairo_directional(st, ways, 300, 200, 160, 0xffffff)
     d = po.chan_diff(a, b)
-    assert (d <= 2).mean() >= 0.995 and (d == 0).mean() >= 0.98, ((d > 2).sum(), d.max())
+    assert (d == 0).mean() >= 0.9995, ((d > 2).sum(), d.max())
     assert len(np.unique(a)) > 10
+
+
+def _dash_scene(W, H, seed):
+    rng = np.random.default_rng(seed)
+    ways = []
+    x, y, off, ref = po.synth_ways(6, W, H, seed=seed, rmin=12.0, rmax=0.3 * W)
+    ways += po.ways_from_arrays(x, y, off, ref)
+    for k in range(6):
+        n = int(rng.integers(2, 9))
+        ways.append((rng.uniform(4, W - 4, n), rng.uniform(4, H - 4, n), False))
+    return ways
+
+
+DASH_CASES = {
+    "dashed": po.Style(0, 1, 0, 0x204060, 0, 0.25, 0).with_dash(border_style=1),
+    "dotted": po.Style(0, 1, 0, 0x000000, 0, 0.2, 0).with_dash(border_style=2),
+    "rounddot": po.Style(0, 1, 0, 0x802010, 0, 0.3, 0).with_dash(border_style=5),
+    "pipe": po.Style(0, 1, 0, 0x103050, 0, 0.15, 0).with_dash(border_style=4),
+    "dash4": po.Style(0, 1, 0, 0x30204060, 0, 0.2, 0).with_dash(border_style=1, border_dash=(5, 2, 1, 2)),
+    "hairline-dashed": po.Style(0, 1, 0, 0x000000, 0, 0.0, 0).with_dash(border_style=1),
+    "fill+dashed-border": po.Style(1, 1, 0x4080c0, 0x000000, 0.3, 0.1, 0).with_dash(border_style=1),
+    "dashed-fill-stroke": po.Style(1, 1, 0x4080c0, 0x000000, 0.3, 0.1, 0).with_dash(fill_style=1),
+}
+
+
+@pytest.mark.parametrize("case", list(DASH_CASES))
+def test_dashed_strokes(case):
+    """cairo_smr_dash + cairo_stroke (src/smrules_cairo.c:898-923, :968-1009): the restated dasher
+    (cairo-path-stroke.c) against the real libcairo"""
+    st = DASH_CASES[case]
+    W, H = 220, 180
+    ways = _dash_scene(W, H, 5)
+    a = po.oracle_scene([(st, ways)], 300, W, H, 0xffffff)
+    b = po.cairo_scene([(st, ways)], 300, W, H, 0xffffff)
+    d = po.chan_diff(a, b)
+    touched = (a != 0xffffffff) | (b != 0xffffffff)
+    assert touched.sum() > 5000
+    # bit-identical but for one near-reversal (bevel) join of the scene whose vertex sits on a sample-row boundary
+    assert (d > 0).sum() <= 0.0008 * touched.sum(), ((d > 2).sum(), (d > 0).sum(), d.max())
