@@ -99,14 +99,21 @@ typedef struct
    uint32_t fill_col, border_col;           /* 0xTTRRGGBB */
    double fill_width_mm, border_width_mm;   /* width= / bwidth= (0 -> 1 px hairline) */
    int32_t ignore_open;                     /* ignore_open=1 */
-   int32_t fill_style, border_style;        /* DRAW_SOLID=0; anything else -> SMR_E_UNSUPPORTED */
+   int32_t fill_style, border_style;        /* draw_style_t, src/smrender_dev.h:145 (SMR_STYLE_*): style= / bstyle= */
    int32_t curve;                           /* curve=/wavy= -> SMR_E_UNSUPPORTED */
    int32_t directional;                     /* directional=1 with a fill: open ways first, then ALL closed ways of the batch as one
                                                non-zero fill in fill_col (act_draw_fini, src/smrules_cairo.c:1084-1140); the caller
                                                appends the page rectangle (:1103-1109) as one more closed way when it is due */
    int32_t direct;                          /* 1: draw straight onto the canvas, no group layer -- what a context without
                                                push_group does, i.e. act_cap's auto_ctx rectangles (src/smrules_cairo.c:2376-2382) */
+   /* dash= / bdash= (src/smrparse.c:1077-1102): up to 4 lengths in multiples of the BORDER width (cairo_smr_dash,
+    * src/smrules_cairo.c:898-923, scales the fill's dashes by it too); 0 lengths = the style's default array
+    * (dashed/pipe 7,3; dotted 1; rounddot 0,2; solid none).  Dashed strokes take libcairo's dashing stroker
+    * (butt caps; round caps for rounddot and for the pipe's dots, which stay on for every later stroke of the rule) */
+   int32_t border_ndash, fill_ndash;
+   double border_dash[4], fill_dash[4];
 } smr_draw_style_t;
+enum { SMR_STYLE_SOLID = 0, SMR_STYLE_DASHED = 1, SMR_STYLE_DOTTED = 2, SMR_STYLE_TRANSPARENT = 3, SMR_STYLE_PIPE = 4, SMR_STYLE_ROUNDDOT = 5 };
 
 typedef struct
 {

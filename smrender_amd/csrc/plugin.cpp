@@ -52,6 +52,7 @@ struct host_api_t
    double (*rdata_square_mm)(void) = nullptr;
    double (*rdata_square_nm)(void) = nullptr;
    const smr_osm_way_t *(*page_way)(void) = nullptr;
+   int (*parse_length_mm_array)(const char *, double *, int) = nullptr;
 };
 static host_api_t H;
 
@@ -67,6 +68,7 @@ static void host_resolve(void)
    host_sym(H.parse_style, "parse_style"); host_sym(H.parse_alignment, "parse_alignment");
    host_sym(H.poly_area, "poly_area"); host_sym(H.rdata_square_mm, "rdata_square_mm");
    host_sym(H.rdata_square_nm, "rdata_square_nm"); host_sym(H.page_way, "page_way");
+   host_sym(H.parse_length_mm_array, "parse_length_mm_array");
    H.resolved = true;
 }
 
@@ -215,6 +217,32 @@ struct draw_rule_t
    double max_area = -1; bool max_cw = false; uint32_t max_col = 0;
 };
 
+/* parse_dash_style, src/smrparse.c:1077-1102: "a:b:c:d" in mm (the host's parser knows the other units); no or
+ * no valid array = 0 lengths, for which the library takes the style's default */
+static int parse_dashes(const char *s, double *val)
+{
+   if (s == nullptr) return 0;
+   int n;
+   if (H.parse_length_mm_array) n = H.parse_length_mm_array(s, val, 4);
+   else
+   {
+      for (n = 0; s != nullptr && n < 4; n++)
+      {
+         char *e;
+         val[n] = strtod(s, &e);
+         if (e == s) return 0;
+         while (*e == ' ') e++;
+         if (*e != '\0' && *e != ':' && strncmp(e, "mm", 2) != 0)
+         {
+            plog(SMR_LOG_ERR, "draw: unit in dash array '%s' needs the host's parse_length_mm_array()", s);
+            return 0;
+         }
+         if ((s = strchr(s, ':')) != nullptr) s++;
+      }
+   }
+   return n > 0 ? n : 0;
+}
+
 static int draw_ini(smr_smrule_t *r)
 {
    int e;
@@ -243,9 +271,12 @@ static int draw_ini(smr_smrule_t *r)
    if (d->st.fill_style == 3) d->st.fill_style = 0;
    if (d->st.border_style == 3) d->st.border_style = 0;
 
+   d->st.fill_ndash = parse_dashes(H.get_param("dash", nullptr, r->act), d->st.fill_dash);
+   d->st.border_ndash = parse_dashes(H.get_param("bdash", nullptr, r->act), d->st.border_dash);
+
    const char *why = nullptr;
-   if (d->st.fill_style || d->st.border_style || H.get_param("dash", nullptr, r->act) || H.get_param("bdash", nullptr, r->act))
-      why = "dashed/dotted/pipe/rounddot styles";
+   if (d->st.fill_used && (d->st.fill_style == SMR_STYLE_PIPE || d->st.fill_style == SMR_STYLE_ROUNDDOT))
+      why = "style=pipe|rounddot (round caps on the fill strokes of open ways)";
    else if (d->st.curve) why = "curve/wavy";
    else if (H.get_param("file", nullptr, r->act)) why = "image pattern fill (file=)";
    if (why)

@@ -11,6 +11,8 @@
 #include "smr_dev.h"
 #include "smr_host.h"
 #include <algorithm>
+#include <cmath>
+#include <vector>
 
 /* ------------------------------------------------------------------------------------ */
 /* vertex setup: px (double) -> pt -> 24.8 -> replay scale (fixed * fixed(dpi/72) >> 8)   */
@@ -54,7 +56,7 @@ enum { SMR_PASS_NORMAL = 0, SMR_PASS_OPEN = 1, SMR_PASS_COMPOUND = 2 };
  * bit3 fill-as-stroke (open way) */
 __global__ void k_way_info(const int64_t *__restrict__ way_off, const int32_t *__restrict__ ref, int64_t n_ways,
                            int border_used, int fill_used, int ignore_open, int mode, uint8_t *__restrict__ wayflags,
-                           uint32_t *__restrict__ any_open_fill)
+                           uint32_t *__restrict__ any_open_fill, uint32_t *__restrict__ first_stroked)
 {
    int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    if (w >= n_ways) return;
@@ -78,6 +80,7 @@ __global__ void k_way_info(const int64_t *__restrict__ way_off, const int32_t *_
    if (mode == SMR_PASS_COMPOUND) f = closed ? (f & (1 | 4)) : 0;
    wayflags[w] = f;
    if (f & 8) atomicOr(any_open_fill, 1u);
+   if (first_stroked && (f & 2)) atomicMin(first_stroked, (uint32_t) w);
 }
 
 /* fill polygon: edge g = pts[g] -> pts[g+1]; the slot of the last ref closes the polygon
@@ -272,6 +275,267 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
    for (int i = 0; i < SMR_SLOTS; i++) out[i] = loc[i];
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* dashed strokes: libcairo's cairo-path-stroke.c dasher (restated in oracle/smr_oracle.c,  */
+/* orc_dash_edges).  The dash state runs along the whole way, so ONE LANE walks one way;     */
+/* a first pass counts the pieces (4 edge slots each), a scan places them, a second pass      */
+/* writes them: quad per "on" stretch, wedge per join of two stretches across a vertex,       */
+/* half disc per round cap (fan of quads over the pen's vertices).                            */
+/* ------------------------------------------------------------------------------------ */
+struct smr_dface_t { int2 ccw, cw, point; double ux, uy; int32_t ddx, ddy; };
+
+__device__ __forceinline__ int smr_slope_cmp(int32_t adx, int32_t ady, int32_t bdx, int32_t bdy)     /* _cairo_slope_compare */
+{
+   const int64_t l = (int64_t) ady * bdx, r = (int64_t) bdy * adx;
+   if (l != r) return l < r ? -1 : 1;
+   const bool az = adx == 0 && ady == 0, bz = bdx == 0 && bdy == 0;
+   if (az && bz) return 0;
+   if (az) return 1;
+   if (bz) return -1;
+   if ((adx ^ bdx) < 0 || (ady ^ bdy) < 0) return (adx > 0 || (adx == 0 && ady > 0)) ? -1 : 1;
+   return 0;
+}
+
+struct dash_args_t
+{
+   const int2 *pts; const int64_t *way_off; const uint8_t *wayflags; int64_t n_ways;
+   int mode;                       /* 0 border, 1 fill of open ways drawn as a stroke, 2 the pipe's dots */
+   int dpi, fill_used;
+   double hw_nofill, hw_open, hw_closed, hw_fill;       /* half widths in pt (the dots' already scaled) */
+   double dash[4]; int ndash;                           /* pt */
+   int cap_mode;                   /* 0 butt, 1 round, 2 round except on the rule's first stroked way (pipe) */
+   const uint32_t *first_way;
+   const int2 *pen; int pen_off[3], pen_n[3];           /* pens of the nofill / open / closed width (fill stroke: [0]) */
+   uint32_t *piece_cnt;            /* count pass */
+   const uint32_t *piece_off;      /* emit pass */
+   smr_edge_t *edges;
+};
+
+struct smr_dasher_t
+{
+   double s, hw; bool round;
+   const int2 *pen; int npen;
+   smr_edge_t *out; uint32_t cnt;
+
+   __device__ __forceinline__ void piece(const int2 *q, int n)
+   {
+      if (out)
+      {
+         smr_edge_t tmp[4];
+         smr_edge_t z; z.x1 = z.y1 = z.x2 = z.y2 = 0;
+         tmp[0] = tmp[1] = tmp[2] = tmp[3] = z;
+         smr_emit_poly(q, n, tmp);
+         smr_edge_t *o = out + 4 * (size_t) cnt;
+         o[0] = tmp[0]; o[1] = tmp[1]; o[2] = tmp[2]; o[3] = tmp[3];
+      }
+      cnt++;
+   }
+   __device__ __forceinline__ int2 pv(int i) const { return pen[i]; }
+   __device__ __forceinline__ int2 pcw(int i) const { int2 a = pen[i], b = pen[i == 0 ? npen - 1 : i - 1]; return make_int2(a.x - b.x, a.y - b.y); }
+   __device__ __forceinline__ int2 pccw(int i) const { int2 a = pen[i], b = pen[i + 1 == npen ? 0 : i + 1]; return make_int2(b.x - a.x, b.y - a.y); }
+   __device__ int active_ccw(int32_t dx, int32_t dy) const           /* _cairo_pen_find_active_ccw_vertex_index */
+   {
+      int i;
+      for (i = npen - 1; i >= 0; i--)
+      {
+         const int2 c = pccw(i), w = pcw(i);
+         if (smr_slope_cmp(c.x, c.y, -dx, -dy) >= 0 && smr_slope_cmp(w.x, w.y, -dx, -dy) < 0) break;
+      }
+      return i < 0 ? npen - 1 : i;
+   }
+   /* which pen vertices a round cap on a face of direction (dx, dy) takes: start, (exclusive) stop, stepping down */
+   __device__ bool fan_range(int32_t dx, int32_t dy, int &start, int &stop) const
+   {
+      const int n = npen;
+      start = active_ccw(dx, dy);
+      { const int2 c = pccw(start); if (smr_slope_cmp(c.x, c.y, dx, dy) < 0) start = start == 0 ? n - 1 : start - 1; }
+      stop = active_ccw(-dx, -dy);
+      { const int2 w = pcw(stop);
+        if (smr_slope_cmp(w.x, w.y, -dx, -dy) > 0)
+        {
+           stop = stop + 1 == n ? 0 : stop + 1;
+           const int2 c = pccw(stop);
+           if (smr_slope_cmp(c.x, c.y, dx, dy) < 0) return false;
+        } }
+      int npoints = start - stop;
+      stop = stop == 0 ? n - 1 : stop - 1;
+      if (npoints < 0) npoints += n;
+      return npoints > 1;
+   }
+   /* half disc ccw -> pen vertices -> cw, cut into a fan of quads from the first point */
+   __device__ void round_cap(int2 ccw, int2 cw, int2 mid, int start, int stop)
+   {
+      const int n = npen;
+      int m = 2;
+      for (int i = start; i != stop; i = i == 0 ? n - 1 : i - 1) m++;
+      auto poly = [&](int j) -> int2
+      {
+         if (j == 0) return ccw;
+         if (j == m - 1) return cw;
+         int i = start - (j - 1);
+         if (i < 0) i += n;
+         const int2 v = pen[i];
+         return make_int2(mid.x + v.x, mid.y + v.y);
+      };
+      for (int k = 1; k + 1 < m; k += 2)
+      {
+         int2 q[4] = { ccw, poly(k), poly(k + 1), poly(k + 2 < m ? k + 2 : k + 1) };
+         piece(q, k + 2 < m ? 4 : 3);
+      }
+   }
+   __device__ __forceinline__ smr_dface_t face(int2 p, int32_t ddx, int32_t ddy, double ux, double uy) const
+   {
+      smr_dface_t f;
+      double fx = -uy * hw, fy = ux * hw;
+      fx *= s; fy *= s;
+      const int32_t ox = (int32_t) rint(fx * 256.0), oy = (int32_t) rint(fy * 256.0);
+      f.point = p; f.ux = ux; f.uy = uy; f.ddx = ddx; f.ddy = ddy;
+      f.ccw = make_int2(p.x + ox, p.y + oy); f.cw = make_int2(p.x - ox, p.y - oy);
+      return f;
+   }
+   __device__ void join(const smr_dface_t &in, const smr_dface_t &o)
+   {
+      if (in.cw.x == o.cw.x && in.cw.y == o.cw.y && in.ccw.x == o.ccw.x && in.ccw.y == o.ccw.y) return;
+      const bool clockwise = smr_slope_cmp(o.cw.x - o.point.x, o.cw.y - o.point.y, in.cw.x - in.point.x, in.cw.y - in.point.y) < 0;
+      const int2 inpt = clockwise ? in.ccw : in.cw, outpt = clockwise ? o.ccw : o.cw;
+      const double in_dot_out = -in.ux * o.ux + -in.uy * o.uy;
+      if (2 <= 100.0 * (1 - in_dot_out))
+      {
+         double x1 = inpt.x / 256.0, y1 = inpt.y / 256.0, dx1 = in.ux * s, dy1 = in.uy * s;
+         double x2 = outpt.x / 256.0, y2 = outpt.y / 256.0, dx2 = o.ux * s, dy2 = o.uy * s;
+         double my = (((x2 - x1) * dy1 * dy2 - y2 * dx2 * dy1 + y1 * dx1 * dy2) / (dx1 * dy2 - dx2 * dy1));
+         double mx;
+         if (fabs(dy1) >= fabs(dy2)) mx = (my - y1) * dx1 / dy1 + x1;
+         else mx = (my - y2) * dx2 / dy2 + x2;
+         double ix = in.point.x / 256.0, iy = in.point.y / 256.0;
+         double fdx1 = x1 - ix, fdy1 = y1 - iy, fdx2 = x2 - ix, fdy2 = y2 - iy, mdx = mx - ix, mdy = my - iy;
+         if (smr_sgn_cmp(fdx1, fdy1, mdx, mdy) != smr_sgn_cmp(fdx2, fdy2, mdx, mdy))
+         {
+            int2 q[4] = { in.point, inpt, make_int2((int32_t) rint(mx * 256.0), (int32_t) rint(my * 256.0)), outpt };
+            piece(q, 4);
+            return;
+         }
+      }
+      int2 q[3] = { in.point, inpt, outpt };
+      piece(q, 3);
+   }
+};
+
+template <bool EMIT>
+__global__ void k_dash(dash_args_t A)
+{
+   const int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (w >= A.n_ways) return;
+   const uint8_t wf = A.wayflags[w];
+   const bool on = A.mode == 1 ? (wf & 8) != 0 : (wf & 2) != 0;
+   smr_dasher_t D;
+   D.cnt = 0; D.out = nullptr;
+   if (on)
+   {
+      const int64_t a = A.way_off[w], b = A.way_off[w + 1];
+      const int cls = A.mode == 1 || !A.fill_used ? 0 : ((wf & 1) ? 2 : 1);
+      D.hw = A.mode == 1 ? A.hw_fill : (!A.fill_used ? A.hw_nofill : ((wf & 1) ? A.hw_closed : A.hw_open));
+      D.s = (double) A.dpi / 72;
+      D.round = A.cap_mode == 1 || (A.cap_mode == 2 && (uint32_t) w != *A.first_way);
+      D.pen = A.pen + A.pen_off[cls]; D.npen = A.pen_n[cls];
+      if (EMIT) D.out = A.edges + 4 * (size_t) A.piece_off[w];
+      /* _cairo_stroker_dash_start, offset 0 */
+      int di = 0; bool dash_on = true;
+      double dash_remain = A.dash[0];
+      bool has_first = false, has_cur = false;
+      smr_dface_t first, cur;
+      int2 p1 = A.pts[a];
+      for (int64_t g = a + 1; g < b; g++)
+      {
+         const int2 p2 = A.pts[g];
+         if (p1.x == p2.x && p1.y == p2.y) continue;
+         const int32_t ddx = p2.x - p1.x, ddy = p2.y - p1.y;
+         double sdx = ddx / 256.0 * (1.0 / D.s), sdy = ddy / 256.0 * (1.0 / D.s), mag;
+         if (sdx == 0.0) { if (sdy > 0.0) { mag = sdy; sdy = 1.0; } else { mag = -sdy; sdy = -1.0; } }
+         else if (sdy == 0.0) { if (sdx > 0.0) { mag = sdx; sdx = 1.0; } else { mag = -sdx; sdx = -1.0; } }
+         else { mag = hypot(sdx, sdy); sdx = sdx / mag; sdy = sdy / mag; }
+         /* the caps of this segment's dashes all look along (ddx, ddy) or against it */
+         int ts = 0, te = 0, ls = 0, le = 0;
+         bool tcap = false, lcap = false;
+         if (D.round) { tcap = D.fan_range(ddx, ddy, ts, te); lcap = D.fan_range(-ddx, -ddy, ls, le); }
+         double remain = mag;
+         int2 pa = p1;
+         uint32_t guard = 0;
+         while (remain > 0 && ++guard < (1u << 20))        /* the host refuses dash arrays that could spin here */
+         {
+            const double step = dash_remain < remain ? dash_remain : remain;
+            remain -= step;
+            const double dx2 = sdx * (mag - remain) * D.s, dy2 = sdy * (mag - remain) * D.s;
+            const int2 pb = make_int2((int32_t) rint(dx2 * 256.0) + p1.x, (int32_t) rint(dy2 * 256.0) + p1.y);
+            if (dash_on)
+            {
+               smr_dface_t ss = D.face(pa, ddx, ddy, sdx, sdy), se = ss;
+               if (pa.x != pb.x || pa.y != pb.y)
+               {
+                  se.point = pb;
+                  se.ccw.x += pb.x - pa.x; se.ccw.y += pb.y - pa.y; se.cw.x += pb.x - pa.x; se.cw.y += pb.y - pa.y;
+                  int2 q[4] = { ss.ccw, se.ccw, se.cw, ss.cw };
+                  D.piece(q, 4);
+               }
+               if (has_cur) { D.join(cur, ss); has_cur = false; }
+               else if (!has_first) { first = ss; has_first = true; }                    /* the dash pattern starts "on" */
+               else if (lcap) D.round_cap(ss.cw, ss.ccw, ss.point, ls, le);            /* leading cap: the face turned round */
+               if (remain) { if (tcap) D.round_cap(se.ccw, se.cw, se.point, ts, te); }
+               else { cur = se; has_cur = true; }
+            }
+            else if (has_cur)
+            {
+               /* cur belongs to the previous segment: its own direction decides the pen range */
+               if (D.round)
+               {
+                  int cs, ce;
+                  if (D.fan_range(cur.ddx, cur.ddy, cs, ce)) D.round_cap(cur.ccw, cur.cw, cur.point, cs, ce);
+               }
+               has_cur = false;
+            }
+            /* _cairo_stroker_dash_step */
+            dash_remain -= step;
+            if (dash_remain < 1.0 / 512)
+            {
+               if (++di == A.ndash) di = 0;
+               dash_on = !dash_on;
+               dash_remain += A.dash[di];
+            }
+            pa = pb;
+         }
+         if (dash_on && !has_cur)
+         {
+            /* the segment ends exactly where a dash begins: a leading cap at the vertex */
+            cur = D.face(p2, ddx, ddy, sdx, sdy);
+            if (lcap) D.round_cap(cur.cw, cur.ccw, cur.point, ls, le);
+            has_cur = true;
+         }
+         p1 = p2;
+      }
+      /* _cairo_stroker_add_caps */
+      if (D.round)
+      {
+         int cs, ce;
+         if (has_first && D.fan_range(-first.ddx, -first.ddy, cs, ce)) D.round_cap(first.cw, first.ccw, first.point, cs, ce);
+         if (has_cur && D.fan_range(cur.ddx, cur.ddy, cs, ce)) D.round_cap(cur.ccw, cur.cw, cur.point, cs, ce);
+      }
+   }
+   if (!EMIT) A.piece_cnt[w] = D.cnt;
+}
+
+/* id room of a way whose strokes are dashed: enough 8-slot groups for its refs and for each of its piece lists */
+__global__ void k_id_groups(const int64_t *__restrict__ way_off, int64_t n_ways, const uint32_t *__restrict__ c0,
+                            const uint32_t *__restrict__ c1, const uint32_t *__restrict__ c2, uint32_t *__restrict__ out)
+{
+   const int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (w >= n_ways) return;
+   uint32_t g = (uint32_t) (way_off[w + 1] - way_off[w]);
+   if (c0) g = max(g, (c0[w] + 1) >> 1);
+   if (c1) g = max(g, (c1[w] + 1) >> 1);
+   if (c2) g = max(g, (c2[w] + 1) >> 1);
+   out[w] = g;
+}
+
 /* 0xTTRRGGBB -> premultiplied source pixel, per way (color=%key rules) */
 __global__ void k_color_pixels(const uint32_t *__restrict__ col, int64_t n, uint32_t *__restrict__ pix)
 {
@@ -316,6 +580,11 @@ struct setup_args_t
    uint32_t mask_cap;         /* words */
    uint32_t *small;           /* [1] first_prim [2] status [4] mask words demanded */
    uint32_t compound;         /* primitive id all items belong to (directional compound fill), 0xffffffff: their own */
+   /* dashed strokes: piece lists (4 slots per piece) instead of the 8 slots per ref, and an id room of their own */
+   int K;                     /* primitives per way: border, [the pipe's dots,] fill */
+   uint64_t off_dots;
+   const uint32_t *po_border, *po_dots, *po_open;      /* [n_ways+1] piece offsets; NULL: the plain layout */
+   const uint32_t *id_off;                             /* [n_ways+1] in 8-slot groups; NULL: way_off */
 };
 
 struct setup_lds_t
@@ -358,24 +627,32 @@ __device__ __forceinline__ void smr_setup_edge(const smr_oedge_t &o, int row0, i
 __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const int64_t p, const int lane, setup_lds_t &L, uint32_t *lmask,
                                                    uint32_t &arena_pos, uint32_t &arena_left, uint32_t &first_valid)
 {
-   const int64_t w = p >> 1;
-   const int kind = (int) (p & 1);
+   const int64_t w = p / A.K;
+   const int kind = (int) (p - w * A.K);
+   const int role = A.K == 3 ? kind : 2 * kind;                  /* 0 border, 1 the pipe's dots, 2 fill */
    const uint8_t wf = A.wayflags[w];
    const int64_t a = A.way_off[w], b = A.way_off[w + 1], n = b - a;
-   const int64_t base = (a >> 3) + w, span = (b >> 3) + (w + 1) - base;
-   const int64_t item0 = 2 * base + (kind ? span : 0);
-   const bool on = kind == 0 ? (wf & 2) != 0 : (wf & 12) != 0;
-   const bool pieces = kind == 0 || (wf & 8);
+   const int64_t ua = A.id_off ? (int64_t) A.id_off[w] : a, ub = A.id_off ? (int64_t) A.id_off[w + 1] : b;
+   const int64_t base = (ua >> 3) + w, span = (ub >> 3) + (w + 1) - base;
+   const int64_t item0 = A.K * base + kind * span;
+   const bool on = role != 2 ? (wf & 2) != 0 : (wf & 12) != 0;
+   const bool pieces = role != 2 || (wf & 8);
    smr_prim_t P;
    P.edge_off = 0; P.edge_cnt = 0; P.color = 0; P.minx = P.miny = INT32_MAX; P.maxx = P.maxy = INT32_MIN;
    P.flags = 0; P.mask_off = 0; P.row0 = 0; P.nrows = 0;
    int64_t nitems = 0;
    if (on)
    {
-      if (kind == 0) { P.edge_off = A.off_border + (uint64_t) SMR_SLOTS * a; P.edge_cnt = (uint32_t) (SMR_SLOTS * n); }
+      auto stroke_range = [&](uint64_t off, const uint32_t *po)
+      {
+         if (po) { P.edge_off = off + 4ull * po[w]; P.edge_cnt = 4u * (po[w + 1] - po[w]); }
+         else { P.edge_off = off + (uint64_t) SMR_SLOTS * a; P.edge_cnt = (uint32_t) (SMR_SLOTS * n); }
+      };
+      if (role == 0) stroke_range(A.off_border, A.po_border);
+      else if (role == 1) stroke_range(A.off_dots, A.po_dots);
       else if (wf & 4) { P.edge_off = A.off_fill + (uint64_t) a; P.edge_cnt = (uint32_t) n; }
-      else { P.edge_off = A.off_open + (uint64_t) SMR_SLOTS * a; P.edge_cnt = (uint32_t) (SMR_SLOTS * n); }
-      P.color = kind == 0 ? (A.way_border_pix ? A.way_border_pix[w] : A.border_pix) : (A.way_fill_pix ? A.way_fill_pix[w] : A.fill_pix);
+      else stroke_range(A.off_open, A.po_open);
+      P.color = role != 2 ? (A.way_border_pix ? A.way_border_pix[w] : A.border_pix) : (A.way_fill_pix ? A.way_fill_pix[w] : A.fill_pix);
       nitems = ((int64_t) P.edge_cnt + 63) >> 6;
    }
    /* every slot of this kind's id range is written: unused ones as invalid */
@@ -928,6 +1205,7 @@ struct raster_args_t
    int W, band_y0, band_h, TX;
    uint32_t n_tiles;
    int direct;                /* no group layer: primitives composite straight onto the canvas */
+   uint32_t vgroup;           /* vertically adjacent tiles one wavefront takes in a row */
 };
 
 struct raster_lds_t
@@ -1050,9 +1328,14 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
    const uint32_t jw = (blockIdx.x >> 3) * SMR_RASTER_WAVES + (threadIdx.x >> 6), nwx = (gridDim.x >> 3) * SMR_RASTER_WAVES;
    const uint32_t TYt = A.n_tiles / A.TX;
    const uint32_t ncol = ((uint32_t) A.TX + 7u - xcd) >> 3;
-   for (uint32_t kt = jw; kt < ncol * TYt; kt += nwx)
+   /* a wavefront takes A.vgroup vertically adjacent tiles in a row: an item spanning them is fetched again while
+    * its edge slots are still in the cache */
+   const uint32_t NG = (TYt + A.vgroup - 1) / A.vgroup;
+   for (uint32_t kg = jw; kg < ncol * NG; kg += nwx)
+   for (uint32_t sub = 0; sub < A.vgroup; sub++)
    {
-      const int tx = (int) (xcd + 8u * (kt / TYt)), ty = (int) (kt % TYt);
+      const int tx = (int) (xcd + 8u * (kg / NG)), ty = (int) ((kg % NG) * A.vgroup + sub);
+      if ((uint32_t) ty >= TYt) break;
       const uint32_t tile = (uint32_t) ty * A.TX + tx;
       const uint32_t beg = A.tile_off[tile], end = A.tile_off[tile + 1];
       if (beg == end) continue;
@@ -1708,6 +1991,75 @@ static double mm2wu(double mm, int dpi) { return mm == 0.0 ? 1.0 * 72 / dpi : mm
 
 static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, int mode);
 
+__global__ void k_max_u32(const uint32_t *__restrict__ v, int64_t n, uint32_t *__restrict__ keep)
+{
+   const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (i < n) keep[i] = max(keep[i], v[i]);
+}
+
+/* in-place exclusive scan of buf[0, n) on the stream, buf[n] = total, which also comes back to the host */
+static int count_finish(uint32_t *buf, uint32_t n, uint32_t *sums, uint32_t *total_dev, uint32_t *total, hipStream_t s)
+{
+   const uint32_t nb = (n + SCAN_B - 1) / SCAN_B;
+   k_scan_block<<<nb, 256, 0, s>>>(buf, buf, sums, n);
+   k_scan_sums<<<1, 1024, 0, s>>>(sums, nb, total_dev);
+   k_scan_add<<<nb, 256, 0, s>>>(buf, sums, n);
+   k_set_u32<<<1, 1, 0, s>>>(&buf[n], total_dev);
+   SMR_HIP(hipGetLastError());
+   SMR_HIP(hipMemcpyAsync(total, total_dev, 4, hipMemcpyDeviceToHost, s));
+   SMR_HIP(hipStreamSynchronize(s));
+   return SMR_OK;
+}
+
+/* cairo_smr_dash (:898-923) + parse_dash_style (src/smrparse.c:1077-1102): the dash array of one stroke in pt */
+struct dash_spec_t { int n; double d[4]; double sum; };
+
+static int dash_spec(int style, const double *mult, int nmult, double bwidth_mm, int dpi, dash_spec_t *o)
+{
+   static const double def_dashed[2] = { 7, 3 }, def_dotted[1] = { 1 }, def_round[2] = { 0, 2 };
+   o->n = 0; o->sum = 0; o->d[0] = o->d[1] = o->d[2] = o->d[3] = 0;
+   if (nmult < 0 || nmult > 4) return smr_fail(SMR_E_INVAL, "draw: %d dash lengths (at most 4)", nmult);
+   if (nmult == 0)
+   {
+      if (style == SMR_STYLE_DASHED || style == SMR_STYLE_PIPE) { mult = def_dashed; nmult = 2; }
+      else if (style == SMR_STYLE_DOTTED) { mult = def_dotted; nmult = 1; }
+      else if (style == SMR_STYLE_ROUNDDOT) { mult = def_round; nmult = 2; }
+      else return SMR_OK;
+   }
+   for (int i = 0; i < nmult; i++)
+   {
+      o->d[i] = mm2wu(bwidth_mm, dpi) * mult[i];
+      if (!(o->d[i] >= 0) || !std::isfinite(o->d[i])) return smr_fail(SMR_E_INVAL, "draw: dash length %g (libcairo rejects the array; the rule would draw nothing)", mult[i]);
+      o->sum += o->d[i];
+   }
+   o->n = nmult;
+   if (!(o->sum * dpi / 72 >= 1.0 / 16)) return smr_fail(SMR_E_INVAL, "draw: dash period of %g px", o->sum * dpi / 72);
+   return SMR_OK;
+}
+
+/* the stroker's pen (_cairo_pen_init, tolerance 0.1): on the host, with the libm libcairo itself would use */
+static int host_pen(double hw_pt, int dpi, std::vector<int2> &out)
+{
+   const double s = (double) dpi / 72, tol = 0.1;
+   const double major = hw_pt * sqrt(s * s);
+   int n;
+   if (tol >= 4 * major) n = 1;
+   else if (tol >= major) n = 4;
+   else
+   {
+      n = (int) ceil(2 * M_PI / acos(1 - tol / major));
+      if (n % 2) n++;
+      if (n < 4) n = 4;
+   }
+   if (n > 256) return smr_fail(SMR_E_CAPACITY, "draw: round caps of a %g px wide stroke need a pen of %d vertices (limit 256)", 2 * hw_pt * s, n);
+   for (int i = 0; i < n; i++)
+   {
+      const double th = 2 * M_PI * i / (double) n;
+      out.push_back(make_int2((int32_t) nearbyint(hw_pt * cos(th) * s * 256.0), (int32_t) nearbyint(hw_pt * sin(th) * s * 256.0)));
+   }
+   return SMR_OK;
+}
+
 extern "C" uint32_t smr_hip_draw_status(void) { return smr_g.draw_status; }
 
 extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b)
@@ -1715,8 +2067,10 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    smr_g.draw_status = 0;
    SMR_NEED_INIT();
    if (!c || !st || !b) return smr_fail(SMR_E_INVAL, "draw: NULL argument");
-   if (st->fill_style != 0 || st->border_style != 0)
-      return smr_fail(SMR_E_UNSUPPORTED, "draw: only style=solid is implemented on the GPU path (dashed/dotted/pipe pending)");
+   if (st->fill_style < 0 || st->fill_style > 5 || st->border_style < 0 || st->border_style > 5)
+      return smr_fail(SMR_E_INVAL, "draw: unknown style %d / %d", st->fill_style, st->border_style);
+   if (st->fill_used && (st->fill_style == SMR_STYLE_PIPE || st->fill_style == SMR_STYLE_ROUNDDOT))
+      return smr_fail(SMR_E_UNSUPPORTED, "draw: style=pipe|rounddot on the fill of open ways leaves round caps on every later stroke of the rule: not implemented on the GPU path");
    if (st->curve) return smr_fail(SMR_E_UNSUPPORTED, "draw: curve/wavy not implemented on the GPU path");
    if (st->directional && st->fill_used)
    {
@@ -1739,8 +2093,16 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    if (!b->d_x || !b->d_y || !b->d_way_off) return smr_fail(SMR_E_INVAL, "draw: missing device arrays");
 
    hipStream_t s = smr_g.stream;
-   const int64_t n_ways = b->n_ways, n_refs = b->n_refs, n_prims = 2 * n_ways;
-   const int64_t n_items = 2 * ((n_refs >> 3) + n_ways);           /* id space of k_prim_setup, sparse */
+   /* dash arrays in pt: cairo_smr_dash (:898-923) scales the multipliers by the BORDER width, also for the fill */
+   dash_spec_t dsb, dso;
+   SMR_TRY(dash_spec(st->border_used ? st->border_style : 0, st->border_dash, st->border_ndash, st->border_width_mm, c->dpi, &dsb));
+   SMR_TRY(dash_spec(st->fill_used ? st->fill_style : 0, st->fill_dash, st->fill_ndash, st->border_width_mm, c->dpi, &dso));
+   const bool pipe = st->border_used && st->border_style == SMR_STYLE_PIPE;
+   const bool round_border = st->border_used && (st->border_style == SMR_STYLE_ROUNDDOT || pipe);
+   const int K = pipe ? 3 : 2;
+   if (pipe && mode == SMR_PASS_COMPOUND) return smr_fail(SMR_E_INVAL, "draw: internal: compound pass with a border");
+   const int64_t n_ways = b->n_ways, n_refs = b->n_refs, n_prims = K * n_ways;
+   int64_t n_items = 2 * ((n_refs >> 3) + n_ways);           /* id space of k_prim_setup, sparse */
    const int TX = (c->W + SMR_TW - 1) / SMR_TW, TY = (c->band_h + SMR_TH - 1) / SMR_TH;
    const uint32_t n_tiles = (uint32_t) TX * TY;
    smr_timer_t T(smr_g.profiling);
@@ -1755,7 +2117,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    const uint32_t compound = mode == SMR_PASS_COMPOUND ? (uint32_t) n_prims : 0xffffffffu;
    const uint32_t cwords = mode == SMR_PASS_COMPOUND ? (uint32_t) (c->H + 31) / 32 + 1 : 0;
    SMR_TRY(c->ensure(SMR_BUF_ITEMS, (size_t) n_items * sizeof(smr_item_t), (void **) &items));
-   uint32_t init_small[8] = { 0, 0xffffffffu, 0, 0, 0, 0, 0, 0 };
+   uint32_t init_small[8] = { 0, 0xffffffffu, 0, 0, 0, 0xffffffffu, 0, 0 };     /* [5] first stroked way, [6] scan totals */
 #ifdef SMR_SECTION_PROFILE
    SMR_HIP(hipMemsetAsync(small, 0, 512, s));
 #endif
@@ -1769,30 +2131,121 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       k_dev_points<<<nb, TB, 0, s>>>(b->d_x, b->d_y, b->d_ref, n_refs, c->dpi, sfix, b->d_way_off, n_ways, pts, refway);
    }
    k_way_info<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, b->d_ref, n_ways, st->border_used, st->fill_used,
-                                                st->ignore_open, mode, wayflags, &small[0]);
+                                                st->ignore_open, mode, wayflags, &small[0], &small[5]);
    uint32_t h_small[8];
    SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
    const bool open_fill = h_small[0] != 0;
 
-   /* edge arena: [border strokes: 8/ref][fill polygons: 1/ref][open-way fill strokes: 8/ref] */
-   uint64_t off_border = 0, off_fill = st->border_used ? (uint64_t) SMR_SLOTS * n_refs : 0;
-   uint64_t off_open = off_fill + (st->fill_used ? (uint64_t) n_refs : 0);
-   uint64_t n_edges = off_open + (open_fill ? (uint64_t) SMR_SLOTS * n_refs : 0);
-   if (n_edges >= 0xffffff00ull) return smr_fail(SMR_E_CAPACITY, "draw: %llu edge slots in one rule (limit 2^32)", (unsigned long long) n_edges);
-   smr_edge_t *edges;
-   SMR_TRY(c->ensure(SMR_BUF_EDGES, (size_t) n_edges * sizeof(smr_edge_t), (void **) &edges));
-
    double hw_nofill = mm2wu(st->border_width_mm, c->dpi) / 2;
    double hw_open = (mm2wu(2 * st->border_width_mm, c->dpi) + mm2wu(st->fill_width_mm, c->dpi)) / 2;
    double hw_closed = mm2wu(2 * st->border_width_mm, c->dpi) / 2;
    double hw_fill = mm2wu(st->fill_width_mm, c->dpi) / 2;
-   if (st->border_used)
+   if (open_fill && round_border && dso.n == 0)
+      return smr_fail(SMR_E_UNSUPPORTED, "draw: bstyle=rounddot|pipe leaves round caps on the solid fill strokes of open ways: not implemented on the GPU path");
+
+   /* dashed strokes: count the pieces of every way, place them with a scan */
+   const bool dash_b = st->border_used && dsb.n > 0, dash_o = open_fill && dso.n > 0;
+   uint32_t *po_border = nullptr, *po_dots = nullptr, *po_open = nullptr, *id_off = nullptr;
+   uint32_t tot_b = 0, tot_d = 0, tot_o = 0;
+   dash_args_t DA[3];
+   if (dash_b || dash_o)
+   {
+      const size_t stride = (size_t) n_ways + 1;
+      uint32_t *dbuf, *sums;
+      SMR_TRY(c->ensure(SMR_BUF_DASH, 5 * stride * 4, (void **) &dbuf));
+      SMR_TRY(c->ensure(SMR_BUF_SUMS, ((size_t) n_ways / SCAN_B + 2) * 4, (void **) &sums));
+      /* pens of the three border widths, of the dots' and of the fill stroke: on the host, where libm is libcairo's */
+      std::vector<int2> pens;
+      int pen_off[7], pen_n[7];
+      const double pw[7] = { hw_nofill, hw_open, hw_closed, hw_nofill * 2.5, hw_open * 2.5, hw_closed * 2.5, hw_fill };
+      for (int i = 0; i < 7; i++)
+      {
+         pen_off[i] = (int) pens.size(); pen_n[i] = 0;
+         const bool need = i < 3 ? (dash_b && round_border) : i < 6 ? pipe : (dash_o && round_border);
+         if (need) { SMR_TRY(host_pen(pw[i], c->dpi, pens)); pen_n[i] = (int) pens.size() - pen_off[i]; }
+      }
+      int2 *d_pen;
+      SMR_TRY(c->ensure(SMR_BUF_PEN, (pens.size() + 1) * sizeof(int2), (void **) &d_pen));
+      if (!pens.empty()) SMR_HIP(hipMemcpyAsync(d_pen, pens.data(), pens.size() * sizeof(int2), hipMemcpyHostToDevice, s));
+      auto fill_args = [&](dash_args_t &A, int dmode, const dash_spec_t &ds, int cap_mode, int pen0, double scale)
+      {
+         A.pts = pts; A.way_off = b->d_way_off; A.wayflags = wayflags; A.n_ways = n_ways; A.mode = dmode;
+         A.dpi = c->dpi; A.fill_used = st->fill_used;
+         A.hw_nofill = hw_nofill * scale; A.hw_open = hw_open * scale; A.hw_closed = hw_closed * scale; A.hw_fill = hw_fill;
+         for (int i = 0; i < 4; i++) A.dash[i] = ds.d[i];
+         A.ndash = ds.n; A.cap_mode = cap_mode; A.first_way = &small[5]; A.pen = d_pen;
+         for (int i = 0; i < 3; i++) { A.pen_off[i] = pen_off[dmode == 1 ? 6 : pen0 + i]; A.pen_n[i] = pen_n[dmode == 1 ? 6 : pen0 + i]; }
+         A.piece_cnt = nullptr; A.piece_off = nullptr; A.edges = nullptr;
+      };
+      /* the group counts need the per-way piece COUNTS: keep them beside the offsets */
+      uint32_t *cnt_keep = dbuf + 4 * stride;
+      SMR_HIP(hipMemsetAsync(cnt_keep, 0, stride * 4, s));
+      if (dash_b)
+      {
+         dash_spec_t d1 = dsb;
+         fill_args(DA[0], 0, d1, st->border_style == SMR_STYLE_ROUNDDOT ? 1 : pipe ? 2 : 0, 0, 1.0);
+         po_border = dbuf;
+         DA[0].piece_cnt = po_border;
+         k_dash<false><<<blocks(n_ways, 64), 64, 0, s>>>(DA[0]);
+         k_max_u32<<<blocks(n_ways, TB), TB, 0, s>>>(po_border, n_ways, cnt_keep);
+         SMR_TRY(count_finish(po_border, (uint32_t) n_ways, sums, &small[6], &tot_b, s));
+         DA[0].piece_cnt = nullptr; DA[0].piece_off = po_border;
+         if (pipe)
+         {
+            /* the dots: dash {0, sum} with round caps at 2.5 times the width (:979-986, PIPE_DOT_SCALE) */
+            dash_spec_t d2; d2.n = 2; d2.d[0] = 0; d2.d[1] = dsb.sum; d2.d[2] = d2.d[3] = 0; d2.sum = dsb.sum;
+            fill_args(DA[1], 2, d2, 1, 3, 2.5);
+            po_dots = dbuf + stride;
+            DA[1].piece_cnt = po_dots;
+            k_dash<false><<<blocks(n_ways, 64), 64, 0, s>>>(DA[1]);
+            k_max_u32<<<blocks(n_ways, TB), TB, 0, s>>>(po_dots, n_ways, cnt_keep);
+            SMR_TRY(count_finish(po_dots, (uint32_t) n_ways, sums, &small[6], &tot_d, s));
+            DA[1].piece_cnt = nullptr; DA[1].piece_off = po_dots;
+         }
+      }
+      if (dash_o)
+      {
+         fill_args(DA[2], 1, dso, round_border ? 1 : 0, 0, 1.0);
+         po_open = dbuf + 2 * stride;
+         DA[2].piece_cnt = po_open;
+         k_dash<false><<<blocks(n_ways, 64), 64, 0, s>>>(DA[2]);
+         k_max_u32<<<blocks(n_ways, TB), TB, 0, s>>>(po_open, n_ways, cnt_keep);
+         SMR_TRY(count_finish(po_open, (uint32_t) n_ways, sums, &small[6], &tot_o, s));
+         DA[2].piece_cnt = nullptr; DA[2].piece_off = po_open;
+      }
+      /* id room per way: its refs or half its pieces (8-slot groups), whichever is more */
+      id_off = dbuf + 3 * stride;
+      k_id_groups<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, n_ways, cnt_keep, nullptr, nullptr, id_off);
+      uint32_t tot_groups = 0;
+      SMR_TRY(count_finish(id_off, (uint32_t) n_ways, sums, &small[6], &tot_groups, s));
+      n_items = (int64_t) K * (((int64_t) tot_groups >> 3) + n_ways);
+      SMR_TRY(c->ensure(SMR_BUF_ITEMS, (size_t) n_items * sizeof(smr_item_t), (void **) &items));
+   }
+
+   /* edge arena: [border strokes: 8/ref or 4/piece][the pipe's dots][fill polygons: 1/ref][open-way fill strokes] */
+   uint64_t off_border = 0;
+   uint64_t off_dots = !st->border_used ? 0 : dash_b ? 4ull * tot_b : (uint64_t) SMR_SLOTS * n_refs;
+   uint64_t off_fill = off_dots + 4ull * tot_d;
+   uint64_t off_open = off_fill + (st->fill_used ? (uint64_t) n_refs : 0);
+   uint64_t n_edges = off_open + (!open_fill ? 0 : dash_o ? 4ull * tot_o : (uint64_t) SMR_SLOTS * n_refs);
+   if (n_edges >= 0xffffff00ull) return smr_fail(SMR_E_CAPACITY, "draw: %llu edge slots in one rule (limit 2^32)", (unsigned long long) n_edges);
+   smr_edge_t *edges;
+   SMR_TRY(c->ensure(SMR_BUF_EDGES, (size_t) n_edges * sizeof(smr_edge_t), (void **) &edges));
+
+   if (dash_b)
+   {
+      DA[0].edges = edges + off_border;
+      k_dash<true><<<blocks(n_ways, 64), 64, 0, s>>>(DA[0]);
+      if (pipe) { DA[1].edges = edges + off_dots; k_dash<true><<<blocks(n_ways, 64), 64, 0, s>>>(DA[1]); }
+   }
+   else if (st->border_used)
       k_stroke_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill,
                                                        hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border);
    if (st->fill_used)
       k_fill_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, refway, n_refs, wayflags, edges + off_fill);
-   if (open_fill)
+   if (dash_o) { DA[2].edges = edges + off_open; k_dash<true><<<blocks(n_ways, 64), 64, 0, s>>>(DA[2]); }
+   else if (open_fill)
       k_stroke_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill,
                                                        hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open);
    uint32_t *wb_pix = nullptr, *wf_pix = nullptr;
@@ -1823,6 +2276,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SA.way_border_pix = wb_pix; SA.way_fill_pix = wf_pix; SA.W = c->W; SA.H = c->H;
       SA.prims = prims; SA.items = items; SA.mask = maskbuf; SA.mask_cap = (uint32_t) std::min<size_t>(mask_cap, 0xffffffffu);
       SA.small = small; SA.compound = compound;
+      SA.K = K; SA.off_dots = off_dots; SA.po_border = po_border; SA.po_dots = po_dots; SA.po_open = po_open; SA.id_off = id_off;
       if (mode == SMR_PASS_COMPOUND)
       {
          /* the compound's own row mask sits at the start of the arena; the members' words follow */
@@ -1894,6 +2348,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
    A.direct = st->direct != 0;
+   { const char *e = getenv("SMR_VGROUP"); int g = e ? atoi(e) : 4; A.vgroup = (uint32_t) (g < 1 ? 1 : g > 64 ? 64 : g); }
    {
       /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
       unsigned nwg = std::min<unsigned>((n_tiles + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES, 256u * 8u);

@@ -27,11 +27,19 @@ class Projection(C.Structure):
 
 
 class DrawStyle(C.Structure):
-    """smr_draw_style_t: the solid subset of struct actDraw (src/smrender_dev.h:252-268)."""
+    """smr_draw_style_t: struct actDraw (src/smrender_dev.h:252-268) without image/curve."""
     _fields_ = [("fill_used", C.c_int32), ("border_used", C.c_int32), ("fill_col", C.c_uint32),
                 ("border_col", C.c_uint32), ("fill_width_mm", C.c_double), ("border_width_mm", C.c_double),
                 ("ignore_open", C.c_int32), ("fill_style", C.c_int32), ("border_style", C.c_int32),
-                ("curve", C.c_int32), ("directional", C.c_int32), ("direct", C.c_int32)]
+                ("curve", C.c_int32), ("directional", C.c_int32), ("direct", C.c_int32),
+                ("border_ndash", C.c_int32), ("fill_ndash", C.c_int32),
+                ("border_dash", C.c_double * 4), ("fill_dash", C.c_double * 4)]
+
+    def set_dashes(self, border=(), fill=()):
+        self.border_ndash, self.fill_ndash = len(border), len(fill)
+        for i, v in enumerate(border): self.border_dash[i] = v
+        for i, v in enumerate(fill): self.fill_dash[i] = v
+        return self
 
 
 class _DrawBatch(C.Structure):

@@ -31,6 +31,13 @@ BARS = {"c2_fill_border_300": (0.9999, 0.9999), "open_border_300": (0.999, 0.998
         "far_window_300": (1.0, 0.999), "dashes_300": (0.9998, 0.9995)}
 
 
+def draw_style(sa, st, **kw):
+    """oracle Style -> smr_draw_style_t (ctypes mirror)"""
+    gs = sa.DrawStyle(st.fill_used, st.border_used, st.fill_col, st.border_col, st.fill_width_mm, st.border_width_mm,
+                      st.ignore_open, st.fill_style, st.border_style, 0, kw.get("directional", 0), kw.get("direct", 0))
+    return gs.set_dashes([st.border_dash[i] for i in range(st.border_ndash)], [st.fill_dash[i] for i in range(st.fill_ndash)])
+
+
 def within(a, b, tol=2):
     """fraction of pixels whose every channel differs by <= tol (north_star: >= 99.5 % at tol 2)"""
     return float((po.chan_diff(a, b) <= tol).mean())

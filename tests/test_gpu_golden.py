@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 from oracle import pyoracle as po
 from smrender_amd import synth
-from golden_io import BARS, SCENES, load_scene, within
+from golden_io import BARS, SCENES, draw_style, load_scene, within
 
 pytestmark = pytest.mark.gpu
 
@@ -15,8 +15,7 @@ def gpu_render(sa, meta, rules):
     W, H = meta["x0"] + meta["W"], meta["y0"] + meta["H"]
     cv = sa.Canvas(W, H, meta["dpi"], meta["bg"], meta["y0"], meta["H"])
     for st, (x, y, off, ref) in rules:
-        gs = sa.DrawStyle(st.fill_used, st.border_used, st.fill_col, st.border_col, st.fill_width_mm,
-                          st.border_width_mm, st.ignore_open, 0, 0, 0, 0, 0)
+        gs = draw_style(sa, st)
         cv.draw(gs, sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y),
                 sa.DeviceArray.from_numpy(off.astype(np.int64)), sa.DeviceArray.from_numpy(ref.astype(np.int32)),
                 len(off) - 1, len(ref))

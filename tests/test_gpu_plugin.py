@@ -83,8 +83,27 @@ def test_draw_relation_members_and_key_colours(chart):
 
 def test_unsupported_draw_styles_are_refused_loudly(chart):
     sa, proj = chart
-    for params in ("bcolor=black;bstyle=dashed", "color=red;curve=1"):
+    for params in ("color=red;style=rounddot", "color=red;curve=1", "color=red;wavy=1"):
         assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, []) == 2001      # "Rule will be ignored"
+
+
+@pytest.mark.parametrize("params,style", [
+    ("bcolor=#204060;bwidth=0.25;bstyle=dashed", dict(border_style=1)),
+    ("bcolor=#204060;bwidth=0.25;bstyle=dashed;bdash=5:2:1:2", dict(border_style=1, border_dash=(5, 2, 1, 2))),
+    ("bcolor=#204060;bwidth=0.25;bstyle=pipe", dict(border_style=4)),
+    ("bcolor=#204060;bwidth=0.25;bstyle=rounddot;bdash=0:3mm", dict(border_style=5, border_dash=(0, 3))),
+    ("bcolor=#204060;bwidth=0.25;bdash=2:1", dict(border_style=0, border_dash=(2, 1)))])       # a dash array makes any style dashed
+def test_dashed_rule_through_the_action_api(chart, params, style):
+    """bstyle= / bdash= parsed by the plugin as act_draw_ini does (:623, :645; parse_dash_style src/smrparse.c:1077-1102)"""
+    from test_oracle_cairo import _dash_scene
+    from test_gpu_raster import _ways_to_arrays
+    sa, proj = chart
+    wids, oways = load_ways(sa, proj, _ways_to_arrays(_dash_scene(W, H, 9)))
+    rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, wids)
+    assert rc == 0, sa.lib().smr_hip_last_error()
+    st = po.Style(0, 1, 0, 0x204060, 0, 0.25, 0).with_dash(**style)
+    want = po.oracle_scene([(st, oways)], DPI, W, H, 0xfff8e0)
+    assert np.array_equal(plugin_canvas(sa), want)
 
 
 @pytest.mark.parametrize("sea_first", [True, False])

@@ -4,6 +4,7 @@ arithmetic end to end, so the bar is bit-exact ARGB."""
 import numpy as np
 import pytest
 from oracle import pyoracle as po
+from golden_io import draw_style
 
 pytestmark = pytest.mark.gpu
 
@@ -11,8 +12,7 @@ pytestmark = pytest.mark.gpu
 def gpu_scene(sa, rules, dpi, W, H, bg, band_y0=0, band_h=None):
     cv = sa.Canvas(W, H, dpi, bg, band_y0, band_h)
     for st, (x, y, way_off, ref) in rules:
-        gs = sa.DrawStyle(st.fill_used, st.border_used, st.fill_col, st.border_col, st.fill_width_mm,
-                          st.border_width_mm, st.ignore_open, 0, 0, 0, 0, 0)
+        gs = draw_style(sa, st)
         d_x, d_y = sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y)
         d_off = sa.DeviceArray.from_numpy(way_off.astype(np.int64))
         d_ref = sa.DeviceArray.from_numpy(ref.astype(np.int32))
@@ -192,3 +192,37 @@ def test_rows_beyond_the_exact_path_are_subsampled_and_reported(hip):
     # an ordinary scene afterwards clears the flag
     gpu_scene(sa, [(st, po.synth_ways(5, 64, 64, seed=1))], 300, 64, 64, 0xffffff)
     assert sa.lib().smr_hip_draw_status() == 0
+
+
+@pytest.mark.parametrize("case", ["dashed", "dotted", "rounddot", "pipe", "dash4", "hairline-dashed", "fill+dashed-border",
+                                  "dashed-fill-stroke", "pipe+fill-closed", "rounddot+dashed-fill"])
+def test_dashed_strokes_bit_exact(hip, case):
+    """style=/bstyle=/dash=/bdash= (cairo_smr_dash :898-923, the pipe's second stroke :979-986): the lane-per-way
+    dasher against the oracle's restatement of libcairo's dashing stroker, bit for bit"""
+    from test_oracle_cairo import DASH_CASES, _dash_scene
+    S = po.Style
+    extra = {"pipe+fill-closed": S(1, 1, 0x30c0d8f0, 0x103050, 0, 0.15, 1).with_dash(border_style=S.PIPE),
+             "rounddot+dashed-fill": S(1, 1, 0x4080c0, 0x802010, 0.5, 0.2, 0).with_dash(border_style=S.ROUNDDOT, fill_style=S.DOTTED)}
+    st = DASH_CASES.get(case) or extra[case]
+    W, H = 220, 180
+    ways = _dash_scene(W, H, 5)
+    arrs = _ways_to_arrays(ways)
+    want = po.oracle_scene([(st, ways)], 300, W, H, 0xffffff)
+    got = gpu_scene(hip, [(st, arrs)], 300, W, H, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
+    assert (got != 0xffffffff).sum() > 2000
+
+
+def test_dash_styles_the_gpu_path_refuses(hip):
+    sa = hip
+    x, y, off, ref = _ways_to_arrays([(np.array([3.0, 40.0, 50.0]), np.array([4.0, 30.0, 8.0]), False)])
+    cv = sa.Canvas(64, 64, 300, 0xffffff)
+    args = (sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off),
+            sa.DeviceArray.from_numpy(ref), 1, len(ref))
+    S = po.Style
+    for st in (S(1, 0, 0, 0, 0.3, 0, 0).with_dash(fill_style=S.ROUNDDOT),                  # round caps on fill strokes
+               S(1, 1, 0, 0, 0.3, 0.1, 0).with_dash(border_style=S.PIPE),                   # solid fill stroke after round caps
+               S(0, 1, 0, 0, 0, 0.1, 0).with_dash(border_style=S.DASHED, border_dash=(0, 0))):   # libcairo: invalid dash
+        with pytest.raises(sa.SmrHipError):
+            cv.draw(draw_style(sa, st), *args)
+    cv.close()
