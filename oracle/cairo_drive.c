@@ -233,6 +233,26 @@ int cd_direct_fill(const double *xy, int n, uint32_t col, uint32_t bg, int W, in
    return 0;
 }
 
+/* micro-probe for the spline decomposition: one Bezier chain in device px (exact 24.8 values) filled straight
+ * onto an image */
+int cd_direct_curve_fill(double x0, double y0, const double *c, int n, uint32_t col, uint32_t bg, int W, int H, uint32_t *out)
+{
+   cairo_surface_t *img = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, W, H);
+   cairo_t *cr = p_cairo_create(img);
+   set_color(cr, bg); p_cairo_paint(cr);
+   p_cairo_new_sub_path(cr);
+   p_cairo_move_to(cr, x0, y0);
+   for (int i = 0; i < n; i++, c += 6) p_cairo_curve_to(cr, c[0], c[1], c[2], c[3], c[4], c[5]);
+   set_color(cr, col); p_cairo_fill(cr);
+   p_cairo_destroy(cr);
+   p_cairo_surface_flush(img);
+   unsigned char *d = p_cairo_image_surface_get_data(img);
+   int stride = p_cairo_image_surface_get_stride(img);
+   for (int y = 0; y < H; y++) memcpy(out + (size_t) y * W, d + (size_t) y * stride, (size_t) W * 4);
+   p_cairo_surface_destroy(img);
+   return 0;
+}
+
 /* ---- caption scan pieces (cairo_smr_diff): paint src rotated by a about the
  * centre of dst, OVER, default (bilinear) filter.  dst is updated in place. ---- */
 int cd_rot_paint(uint32_t *dstpix, int dw, int dh, const uint32_t *srcpix, int sw, int sh, double a)

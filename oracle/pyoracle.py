@@ -32,7 +32,8 @@ class Style(C.Structure):
     _fields_ = [("fill_used", C.c_int), ("border_used", C.c_int), ("fill_col", C.c_uint32), ("border_col", C.c_uint32),
                 ("fill_width_mm", C.c_double), ("border_width_mm", C.c_double), ("ignore_open", C.c_int),
                 ("border_style", C.c_int), ("fill_style", C.c_int), ("border_ndash", C.c_int), ("fill_ndash", C.c_int),
-                ("border_dash", C.c_double * 4), ("fill_dash", C.c_double * 4)]
+                ("border_dash", C.c_double * 4), ("fill_dash", C.c_double * 4),
+                ("curve", C.c_int), ("curve_fact", C.c_double)]
 
     SOLID, DASHED, DOTTED, TRANSPARENT, PIPE, ROUNDDOT = range(6)
     DEFAULT_DASH = {1: (7.0, 3.0), 4: (7.0, 3.0), 2: (1.0,), 5: (0.0, 2.0)}      # parse_dash_style, src/smrparse.c:1077-1102
@@ -46,6 +47,12 @@ class Style(C.Structure):
         s.border_ndash, s.fill_ndash = len(bd), len(fd)
         for i, v in enumerate(bd): s.border_dash[i] = v
         for i, v in enumerate(fd): s.fill_dash[i] = v
+        return s
+
+    def with_curve(self, factor=0.2):
+        """copy with curve=1 (curve_factor default: DIV_PART, src/smrender_dev.h:114)"""
+        s = Style.from_buffer_copy(bytes(self))
+        s.curve, s.curve_fact = 1, factor
         return s
 
 
@@ -69,6 +76,11 @@ def orc():
         L.orc_px_to_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
         L.orc_stroke_edges.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
         L.orc_fill_edges.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_control_points.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_curve_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_curve_flatten.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_canvas_set_image.argtypes = [C.c_void_p] + [C.c_int] * 4
+        L.orc_stroke_edges_tan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
         L.orc_color_pixel.argtypes = [C.c_uint32]
         L.orc_color_pixel.restype = C.c_uint32
         L.orc_canvas_new.restype = C.c_void_p
@@ -115,6 +127,7 @@ def cairo():
         L.cd_version.restype = C.c_char_p
         L.cd_begin.argtypes = [C.c_double, C.c_double, C.c_uint32]
         L.cd_poly_line.argtypes = [C.c_void_p, C.c_int]
+        L.cd_poly_curve.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_int]
         L.cd_stroke.argtypes = [C.c_uint32, C.c_double]
         L.cd_fill.argtypes = [C.c_uint32]
         L.cd_render.argtypes = [C.c_double] + [C.c_int] * 4 + [C.c_void_p]
@@ -241,6 +254,34 @@ def _cd_dash(L, style, bwidth_mm, ds, n, dpi):
     L.cd_set_dash(arr, len(dash), int(rnd))
 
 
+def curve_path(xy_pt, closed, factor):
+    """cairo_smr_poly_curve (src/smrules_cairo.c:697-749) through the oracle's restatement: start point, [n, 6] curves"""
+    xp, yp = np.ascontiguousarray(xy_pt[:, 0]), np.ascontiguousarray(xy_pt[:, 1])
+    start, curves = np.zeros(2), np.zeros((len(xp), 6))
+    n = orc().orc_curve_path(P(xp), P(yp), len(xp), int(closed), factor, P(start), P(curves))
+    return start, np.ascontiguousarray(curves[:n])
+
+
+def _cairo_curve_way(L, st, xy, closed, dpi):
+    """render_poly_line (:953-1016) with cairo_smr_poly -> cairo_smr_poly_curve; solid strokes"""
+    start, curves = curve_path(xy, closed, st.curve_fact)
+    if st.border_used:
+        if not st.fill_used:
+            bw = mm2wu(st.border_width_mm, dpi)
+        elif not closed:
+            bw = mm2wu(2 * st.border_width_mm, dpi) + mm2wu(st.fill_width_mm, dpi)
+        else:
+            bw = mm2wu(2 * st.border_width_mm, dpi)
+        L.cd_poly_curve(start[0], start[1], P(curves), len(curves))
+        L.cd_stroke(st.border_col, bw)
+    if st.fill_used:
+        L.cd_poly_curve(start[0], start[1], P(curves), len(curves))
+        if not closed:
+            L.cd_stroke(st.fill_col, mm2wu(st.fill_width_mm, dpi))
+        else:
+            L.cd_fill(st.fill_col)
+
+
 def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None):
     """Same scene through the real libcairo with the reference's call sequence."""
     L = cairo()
@@ -253,6 +294,9 @@ def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None):
             if len(x) < 2 or (not closed and st.ignore_open):
                 continue
             xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
+            if st.curve:
+                _cairo_curve_way(L, st, xy, closed, dpi)
+                continue
             if st.border_used:
                 if not st.fill_used:
                     bw = mm2wu(st.border_width_mm, dpi)

@@ -276,6 +276,53 @@ int orc_stroke_edges(const int32_t *xy, int n, double hw_pt, int dpi, tor_edge_t
    return cnt;
 }
 
+/* The stroke of a decomposed curve (curve_to / spline_to of cairo-path-stroke-polygon.c): the same contour
+ * stroker, but the face at every point looks along the curve's TANGENT there (tin: the face closing the segment
+ * that arrives, tout: the face opening the segment that leaves; they differ only where two Beziers meet, and
+ * only there is a join).  With tin[i+1] = tout[i] = the chord this is orc_stroke_edges. */
+int orc_stroke_edges_tan(const int32_t *xy, const int32_t *tin, const int32_t *tout, int m, double hw_pt, int dpi, tor_edge_t *out)
+{
+   double s = (double) dpi / 72;
+   int cnt = 0;
+   for (int i = 0; i + 1 < m; i++)
+   {
+      pt_t p0 = { xy[2 * i], xy[2 * i + 1] }, p1 = { xy[2 * i + 2], xy[2 * i + 3] };
+      face_t start, end;
+      compute_face(p0, tout[2 * i], tout[2 * i + 1], hw_pt, s, &start);
+      compute_face(p1, tin[2 * i + 2], tin[2 * i + 3], hw_pt, s, &end);
+      pt_t c_ccw0 = start.ccw, c_cw0 = start.cw, c_ccw1 = end.ccw, c_cw1 = end.cw;
+      if (i > 0)
+      {
+         face_t prev_end;
+         compute_face(p0, tin[2 * i], tin[2 * i + 1], hw_pt, s, &prev_end);
+         join_t j = stroke_join(&prev_end, &start);
+         pt_t in_inner = j.clockwise ? prev_end.ccw : prev_end.cw, out_inner = j.clockwise ? start.ccw : start.cw;
+         pt_t in_outer = j.clockwise ? prev_end.cw : prev_end.ccw, out_outer = j.clockwise ? start.cw : start.ccw;
+         if (j.kind == 1)
+         {
+            if (j.clockwise) c_cw0 = j.m; else c_ccw0 = j.m;
+            pt_t q[3] = { p0, in_inner, out_inner };
+            cnt += emit_poly(q, 3, out + cnt);
+         }
+         else if (j.kind == 2)
+         {
+            pt_t q[4] = { p0, in_outer, out_outer, in_inner };
+            cnt += emit_poly(q, 4, out + cnt);
+         }
+      }
+      if (i + 2 < m)
+      {
+         face_t nstart;
+         compute_face(p1, tout[2 * i + 2], tout[2 * i + 3], hw_pt, s, &nstart);
+         join_t j = stroke_join(&end, &nstart);
+         if (j.kind == 1) { if (j.clockwise) c_cw1 = j.m; else c_ccw1 = j.m; }
+      }
+      pt_t q[4] = { c_ccw0, c_ccw1, c_cw1, c_cw0 };
+      cnt += emit_poly(q, 4, out + cnt);
+   }
+   return cnt;
+}
+
 /* ---------------- dashed strokes ----------------
  * libcairo 1.16 sends a stroke with a dash array through the older stroker (cairo-path-stroke.c,
  * _cairo_path_fixed_stroke_dashed_to_polygon): every "on" stretch of a segment is one sub-edge
@@ -582,6 +629,7 @@ struct orc_canvas
    uint32_t *pix, *layer;
    uint8_t *cov;
    int layer_clear;
+   int img[4];           /* the image's rectangle on the chart, px (curve limits) */
    int cap_round;        /* line cap of the current rule's context (cairo_set_line_cap is never undone) */
 };
 
@@ -589,12 +637,24 @@ orc_canvas_t *orc_canvas_new(int x0, int y0, int W, int H, int dpi, uint32_t bgc
 {
    orc_canvas_t *c = calloc(1, sizeof(*c));
    c->x0 = x0; c->y0 = y0; c->W = W; c->H = H; c->dpi = dpi;
+   c->img[0] = x0; c->img[1] = y0; c->img[2] = x0 + W; c->img[3] = y0 + H;
    c->pix = malloc(sizeof(uint32_t) * W * H);
    c->layer = malloc(sizeof(uint32_t) * W * H);
    c->cov = malloc((size_t) W * H);
    uint32_t bg = orc_color_pixel(bgcolor);       /* paint onto a clear image == SOURCE */
    for (size_t i = 0; i < (size_t) W * H; i++) c->pix[i] = bg;
    return c;
+}
+
+void orc_canvas_set_image(orc_canvas_t *c, int x0, int y0, int x1, int y1) { c->img[0] = x0; c->img[1] = y0; c->img[2] = x1; c->img[3] = y1; }
+
+/* _cairo_stroke_style_max_distance_from_path: butt caps 0.5, miter joins sqrt(2) * limit, times the width, in device px */
+double orc_stroke_reach_px(double width_pt, int dpi)
+{
+   double e = 0.5;
+   if (e < M_SQRT2 * 10.0) e = M_SQRT2 * 10.0;
+   e *= width_pt;
+   return e * hypot((double) dpi / 72, 0.0);
 }
 
 void orc_canvas_free(orc_canvas_t *c) { free(c->pix); free(c->layer); free(c->cov); free(c); }
@@ -729,12 +789,61 @@ static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double wid
    free(e);
 }
 
+/* render_poly_line with curve=1 (cairo_smr_poly -> cairo_smr_poly_curve, :926-937): border stroke, then fill /
+ * open stroke, each over the way's Bezier chain; solid strokes only (a dashed curve takes libcairo's other
+ * stroker: not restated, nothing is drawn and the caller is told) */
+int orc_curve_unsupported_;
+static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const double *x_px, const double *y_px, int n, int closed,
+                           int has_fill_col, uint32_t fill_col, int has_border_col, uint32_t border_col)
+{
+   if ((st->border_used && st->border_style != 0) || (st->fill_used && !closed && st->fill_style != 0)) { orc_curve_unsupported_ = 1; return; }
+   double *xp = malloc(sizeof(double) * 2 * n), *yp = xp + n, start[2];
+   double *curves = malloc(sizeof(double) * 6 * n);
+   for (int i = 0; i < n; i++) { xp[i] = x_px[i] * 72 / c->dpi; yp[i] = y_px[i] * 72 / c->dpi; }     /* geo2pt */
+   int nc = orc_curve_path(xp, yp, n, closed, st->curve_fact, start, curves);
+   int cap = 64 * (nc + 2), m = 0;
+   int32_t *pts = NULL;
+   tor_edge_t *e = NULL;
+   /* one decomposition per cairo_stroke / cairo_fill: the limits differ (the stroker grows the image by its reach) */
+   #define FLATTEN(reach_px) do { \
+      int32_t lim[4]; double rf = (reach_px); \
+      lim[0] = c->img[0] * 256 - orc_fixed_from_double(rf); lim[1] = c->img[1] * 256 - orc_fixed_from_double(rf); \
+      lim[2] = c->img[2] * 256 + orc_fixed_from_double(rf); lim[3] = c->img[3] * 256 + orc_fixed_from_double(rf); \
+      for (;;) { \
+         pts = realloc(pts, sizeof(int32_t) * 6 * cap); \
+         m = orc_curve_flatten(start, curves, nc, c->dpi, lim, pts, pts + 2 * cap, pts + 4 * cap, cap); \
+         if (m >= 0) break; \
+         cap *= 4; } \
+      e = realloc(e, sizeof(tor_edge_t) * 8 * (m + 1)); } while (0)
+   if (st->border_used)
+   {
+      double bw;
+      if (!st->fill_used) bw = mm2wu(st->border_width_mm, c->dpi);
+      else if (!closed) bw = mm2wu(2 * st->border_width_mm, c->dpi) + mm2wu(st->fill_width_mm, c->dpi);
+      else bw = mm2wu(2 * st->border_width_mm, c->dpi);
+      FLATTEN(orc_stroke_reach_px(bw, c->dpi));
+      int ne = m >= 2 ? orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e) : 0;
+      if (ne > 0) orc_layer_edges(c, e, ne, 1, has_border_col ? border_col : st->border_col);
+   }
+   if (st->fill_used)
+   {
+      uint32_t col = has_fill_col ? fill_col : st->fill_col;
+      double fw = mm2wu(st->fill_width_mm, c->dpi);
+      FLATTEN(closed ? 0.0 : orc_stroke_reach_px(fw, c->dpi));
+      int ne = m < 2 ? 0 : closed ? orc_fill_edges(pts, m, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e);
+      if (ne > 0) orc_layer_edges(c, e, ne, 1, col);
+   }
+   #undef FLATTEN
+   free(e); free(pts); free(curves); free(xp);
+}
+
 /* render_poly_line, src/smrules_cairo.c:953-1016 (no image/curve) */
 void orc_draw_way(orc_canvas_t *c, const orc_draw_style_t *st, const double *x_px, const double *y_px, int n, int closed,
                   int has_fill_col, uint32_t fill_col, int has_border_col, uint32_t border_col)
 {
    if (n < 2) return;                                   /* :962-966 */
    if (!closed && st->ignore_open) return;              /* :1030-1033 */
+   if (st->curve) { draw_way_curve(c, st, x_px, y_px, n, closed, has_fill_col, fill_col, has_border_col, border_col); return; }
    int32_t *dev = malloc(sizeof(int32_t) * 2 * n);
    tor_edge_t *e = malloc(sizeof(tor_edge_t) * 8 * n);
    orc_px_to_dev(x_px, y_px, n, c->dpi, dev);

@@ -45,6 +45,16 @@ int orc_stroke_edges(const int32_t *xy_dev, int n, double hw_pt, int dpi, tor_ed
 int orc_dash_edges(const int32_t *xy_dev, int n, double hw_pt, int dpi, const double *dash_pt, int ndash, int round_cap, tor_edge_t *out);
 /* the pen (_cairo_pen_init, tolerance 0.1): vertex offsets in device 24.8; returns #vertices, -needed if > cap */
 int orc_pen(double hw_pt, int dpi, int32_t *vx, int32_t *vy, int cap);
+/* curve=1 (oracle/curve.c): control points (src/bspline_ctrl.c:64-105), the Bezier chain of a way in pt
+ * (src/smrules_cairo.c:697-749), its decomposition in device space (cairo-spline.c, tolerance 0.1) and the stroke
+ * of the decomposed curve (faces along the tangents).  out of the stroker: room for 8 * m edges. */
+void orc_control_points(const double *g, const double *l, double f, double *p1, double *p2);
+int orc_curve_path(const double *x_pt, const double *y_pt, int n, int closed, double f, double *start, double *curves);
+int orc_curve_flatten(const double *start_pt, const double *curves_pt, int ncurves, int dpi, const int32_t *lim,
+                      int32_t *pts, int32_t *tin, int32_t *tout, int cap);
+/* reach of a stroke beyond its path, px: _cairo_stroke_style_max_distance_from_path (miter joins, limit 10) */
+double orc_stroke_reach_px(double width_pt, int dpi);
+int orc_stroke_edges_tan(const int32_t *xy, const int32_t *tin, const int32_t *tout, int m, double hw_pt, int dpi, tor_edge_t *out);
 /* fill polygon edges (implicitly closed): n edges */
 int orc_fill_edges(const int32_t *xy_dev, int n, tor_edge_t *out);
 
@@ -55,6 +65,9 @@ typedef struct orc_canvas orc_canvas_t;
 /* window of W x H pixels whose top-left is (x0,y0) on the full chart */
 orc_canvas_t *orc_canvas_new(int x0, int y0, int W, int H, int dpi, uint32_t bgcolor);
 void orc_canvas_free(orc_canvas_t *c);
+/* the image libcairo would render into (px on the full chart; default: the window itself): curves that cannot
+ * reach it are drawn as lines (oracle/curve.c).  A window of a larger chart sets the chart's rectangle here. */
+void orc_canvas_set_image(orc_canvas_t *c, int x0, int y0, int x1, int y1);
 const uint32_t *orc_canvas_pixels(const orc_canvas_t *c);
 void orc_rule_begin(orc_canvas_t *c);
 void orc_rule_end(orc_canvas_t *c);
@@ -75,6 +88,8 @@ typedef struct
     * their dash arrays in multiples of the border width, defaults of parse_dash_style already applied */
    int border_style, fill_style, border_ndash, fill_ndash;
    double border_dash[4], fill_dash[4];
+   int curve;            /* curve=1: the way as a chain of Beziers (cairo_smr_poly_curve, src/smrules_cairo.c:697-749) */
+   double curve_fact;    /* curve_factor=, default DIV_PART 0.2 (src/smrender_dev.h:114) */
 } orc_draw_style_t;
 
 /* render_poly_line (src/smrules_cairo.c:953-1016) for one way given projected px coords */

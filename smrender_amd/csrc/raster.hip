@@ -892,7 +892,7 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_
    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
    const int64_t gwave = (int64_t) blockIdx.x * SMR_SETUP_WAVES + wv, nwaves = (int64_t) gridDim.x * SMR_SETUP_WAVES;
    uint32_t arena_pos = 0, arena_left = 0, first_valid = 0xffffffffu;
-   for (int64_t p = gwave; p < 2 * A.n_ways; p += nwaves)
+   for (int64_t p = gwave; p < (int64_t) A.K * A.n_ways; p += nwaves)
    {
       smr_prim_setup_one(A, p, lane, LL[wv], lmask_all + (size_t) wv * mask_words, arena_pos, arena_left, first_valid);
       SMR_WAVE_SYNC();

@@ -105,9 +105,9 @@ def test_edge_cases(hip):
     d = sa.DeviceArray((4,), np.float64)
     cv.draw(gs, d, d, sa.DeviceArray.from_numpy(np.zeros(1, np.int64)), None, 0, 0)      # nothing to draw
     assert np.all(cv.read() == 0xffffffff)
-    for bad in ("fill_style", "curve"):
+    for bad, val in (("fill_style", 4), ("curve", 2)):       # pipe on the fill stroke; wavy=1
         gs2 = sa.DrawStyle(1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
-        setattr(gs2, bad, 1)
+        setattr(gs2, bad, val)
         with pytest.raises(sa.SmrHipError) as e:       # unsupported styles fail loudly
             cv.draw(gs2, d, d, sa.DeviceArray.from_numpy(np.array([0, 4], np.int64)), None, 1, 4)
         assert e.value.code == -5
