@@ -100,7 +100,8 @@ typedef struct
    double fill_width_mm, border_width_mm;   /* width= / bwidth= (0 -> 1 px hairline) */
    int32_t ignore_open;                     /* ignore_open=1 */
    int32_t fill_style, border_style;        /* draw_style_t, src/smrender_dev.h:145 (SMR_STYLE_*): style= / bstyle= */
-   int32_t curve;                           /* curve=/wavy= -> SMR_E_UNSUPPORTED */
+   int32_t curve;                           /* 1: curve=1, the way as a chain of Beziers (cairo_smr_poly_curve, src/smrules_cairo.c:697-749;
+                                               control_points, src/bspline_ctrl.c:64-105), solid strokes only; 2: wavy=1 -> SMR_E_UNSUPPORTED */
    int32_t directional;                     /* directional=1 with a fill: open ways first, then ALL closed ways of the batch as one
                                                non-zero fill in fill_col (act_draw_fini, src/smrules_cairo.c:1084-1140); the caller
                                                appends the page rectangle (:1103-1109) as one more closed way when it is due */
@@ -112,6 +113,7 @@ typedef struct
     * (butt caps; round caps for rounddot and for the pipe's dots, which stay on for every later stroke of the rule) */
    int32_t border_ndash, fill_ndash;
    double border_dash[4], fill_dash[4];
+   double curve_factor;                     /* curve_factor=, the reference's default is DIV_PART 0.2 (src/smrender_dev.h:114; act_draw_ini :625-631) */
 } smr_draw_style_t;
 enum { SMR_STYLE_SOLID = 0, SMR_STYLE_DASHED = 1, SMR_STYLE_DOTTED = 2, SMR_STYLE_TRANSPARENT = 3, SMR_STYLE_PIPE = 4, SMR_STYLE_ROUNDDOT = 5 };
 
@@ -171,6 +173,11 @@ typedef struct
 } smr_timings_t;
 int smr_hip_set_profiling(int on);
 int smr_hip_timings(smr_timings_t *t);
+
+/* diagnostics: the edge slots (x1, y1, x2, y2 in 24.8 device space; all-zero slots are empty) the last draw pass on this
+ * canvas generated, i.e. what libcairo's stroker/filler would hand to its scan converter.  No counterpart in the
+ * reference; used by tools/ and tests to compare the geometry stage with the oracle's. */
+int smr_hip_debug_edges(smr_canvas_t *c, int32_t *host_xyxy, uint64_t max_edges, uint64_t *n_edges);
 
 /* device memory helpers so hosts without a HIP binding (ctypes, cgo, the C plugin) can
  * stage SoA arrays */

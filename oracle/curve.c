@@ -125,8 +125,6 @@ static void decompose_into(knots_t *s1, double tol2, sink_t *s, int depth)
    decompose_into(&s2, tol2, s, depth + 1);
 }
 
-/* one curve_to from the current point a: _cairo_spline_init + _cairo_spline_decompose, or the line_to both the
- * filler and the stroker fall back to.  tout of the point the curve starts at becomes the curve's initial slope. */
 /* _cairo_spline_intersects: does the box of the four knots meet the limit box lim = { x0, y0, x1, y1 }? */
 static int spline_intersects(pt_t a, pt_t b, pt_t c, pt_t d, const int32_t *lim)
 {
@@ -143,6 +141,8 @@ static int spline_intersects(pt_t a, pt_t b, pt_t c, pt_t d, const int32_t *lim)
    return !(x1 <= lim[0] || x0 >= lim[2] || y1 <= lim[1] || y0 >= lim[3]);
 }
 
+/* one curve_to from the current point a: _cairo_spline_init + _cairo_spline_decompose, or the line_to both the
+ * filler and the stroker fall back to.  tout of the point the curve starts at becomes the curve's initial slope. */
 static void curve_to(sink_t *s, pt_t a, pt_t b, pt_t c, pt_t d, const int32_t *lim)
 {
    int32_t *tout_a = s->m > 0 ? s->tout + 2 * (s->m - 1) : NULL;

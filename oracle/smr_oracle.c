@@ -276,6 +276,41 @@ int orc_stroke_edges(const int32_t *xy, int n, double hw_pt, int dpi, tor_edge_t
    return cnt;
 }
 
+/* Where a curve bends within less than half the line width, the inner corners of two consecutive faces change
+ * places and the quad over the four face corners crosses itself.  libcairo resolves such spots through the winding
+ * of its whole contour; the pieces here have to be convex (the GPU path takes a piece as ONE interval per sub-row),
+ * so a quad that is not convex is replaced by the convex hull of its corners -- a deviation inside the stroke's own
+ * inner side, measured in tests/test_oracle_cairo.py. */
+static int64_t turn(pt_t a, pt_t b, pt_t c) { return (int64_t) (b.x - a.x) * (c.y - b.y) - (int64_t) (b.y - a.y) * (c.x - b.x); }
+
+static int convex4(const pt_t *q)
+{
+   int pos = 0, neg = 0;
+   for (int k = 0; k < 4; k++)
+   {
+      int64_t t = turn(q[k], q[(k + 1) & 3], q[(k + 2) & 3]);
+      if (t > 0) pos = 1;
+      if (t < 0) neg = 1;
+   }
+   return !(pos && neg);
+}
+
+static int hull4(const pt_t *q, pt_t *h)
+{
+   const pt_t o1[4] = { q[0], q[1], q[3], q[2] }, o2[4] = { q[0], q[2], q[1], q[3] };
+   const pt_t *pick = convex4(q) ? q : convex4(o1) ? o1 : convex4(o2) ? o2 : NULL;
+   if (pick) { memcpy(h, pick, sizeof(pt_t) * 4); return 4; }
+   for (int k = 0; k < 4; k++)
+   {
+      pt_t t[3]; int m = 0;
+      for (int i = 0; i < 4; i++) if (i != k) t[m++] = q[i];
+      int64_t a = turn(t[0], t[1], q[k]), b = turn(t[1], t[2], q[k]), c = turn(t[2], t[0], q[k]);
+      if ((a >= 0 && b >= 0 && c >= 0) || (a <= 0 && b <= 0 && c <= 0)) { memcpy(h, t, sizeof(t)); return 3; }
+   }
+   memcpy(h, q, sizeof(pt_t) * 4);
+   return 4;
+}
+
 /* The stroke of a decomposed curve (curve_to / spline_to of cairo-path-stroke-polygon.c): the same contour
  * stroker, but the face at every point looks along the curve's TANGENT there (tin: the face closing the segment
  * that arrives, tout: the face opening the segment that leaves; they differ only where two Beziers meet, and
@@ -317,8 +352,9 @@ int orc_stroke_edges_tan(const int32_t *xy, const int32_t *tin, const int32_t *t
          join_t j = stroke_join(&end, &nstart);
          if (j.kind == 1) { if (j.clockwise) c_cw1 = j.m; else c_ccw1 = j.m; }
       }
-      pt_t q[4] = { c_ccw0, c_ccw1, c_cw1, c_cw0 };
-      cnt += emit_poly(q, 4, out + cnt);
+      pt_t q[4] = { c_ccw0, c_ccw1, c_cw1, c_cw0 }, h[4];
+      int nh = hull4(q, h);
+      cnt += emit_poly(h, nh, out + cnt);
    }
    return cnt;
 }

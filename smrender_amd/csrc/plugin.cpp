@@ -264,7 +264,14 @@ static int draw_ini(smr_smrule_t *r)
    if (H.get_param("bwidth", &d->st.border_width_mm, r->act) == nullptr) d->st.border_width_mm = 0;
    d->st.border_style = H.parse_style ? H.parse_style(H.get_param("bstyle", nullptr, r->act)) : 0;
    d->st.fill_col = d->fill_cs.col; d->st.border_col = d->border_cs.col;
-   d->st.curve = H.get_param_bool("curve", r->act) ? 1 : H.get_param_bool("wavy", r->act) ? 2 : 0;
+   /* curve / wavy, :625-642: wavy wins when both are given; curve_factor defaults to DIV_PART (src/smrender_dev.h:114) */
+   d->st.curve = 0;
+   if (H.get_param_bool("curve", r->act))
+   {
+      d->st.curve = 1;
+      if (H.get_param("curve_factor", &d->st.curve_factor, r->act) == nullptr) d->st.curve_factor = 0.2;
+   }
+   if (H.get_param_bool("wavy", r->act)) d->st.curve = 2;
    d->st.directional = H.get_param_bool("directional", r->act);
    d->st.ignore_open = H.get_param_bool("ignore_open", r->act);
    /* DRAW_TRANSPARENT parses but draws solid (cairo_smr_dash has no case for it) */
@@ -277,7 +284,10 @@ static int draw_ini(smr_smrule_t *r)
    const char *why = nullptr;
    if (d->st.fill_used && (d->st.fill_style == SMR_STYLE_PIPE || d->st.fill_style == SMR_STYLE_ROUNDDOT))
       why = "style=pipe|rounddot (round caps on the fill strokes of open ways)";
-   else if (d->st.curve) why = "curve/wavy";
+   else if (d->st.curve == 2) why = "wavy=1";
+   else if (d->st.curve == 1 && ((d->st.border_used && (d->st.border_style != 0 || d->st.border_ndash)) ||
+                                 (d->st.fill_used && (d->st.fill_style != 0 || d->st.fill_ndash))))
+      why = "dashed strokes along curves (curve=1 with style/bstyle/dash/bdash)";
    else if (H.get_param("file", nullptr, r->act)) why = "image pattern fill (file=)";
    if (why)
    {
@@ -326,6 +336,13 @@ static int draw_way(draw_rule_t *d, const smr_osm_way_t *w)
          break;
       }
       const smr_osm_node_t *n = (const smr_osm_node_t *) H.get_object(SMR_OSM_NODE, w->ref[i]);
+      if (n == nullptr && d->st.curve == 1)
+      {
+         /* cairo_smr_poly_curve gives the way up (:718-723): nothing of it is drawn */
+         plog(SMR_LOG_EMERG, "node %lld of way %lld at pos %d does not exist", (long long) w->ref[i], (long long) w->obj.id, i);
+         d->lat.resize(first); d->lon.resize(first); d->ref.resize((size_t) d->way_off.back());
+         return 0;
+      }
       if (n == nullptr)      /* cairo_smr_poly_line skips missing nodes, src/smrules_cairo.c:853-857 */
       {
          plog(SMR_LOG_WARN, "node %lld of way %lld at pos %d does not exist", (long long) w->ref[i], (long long) w->obj.id, i);

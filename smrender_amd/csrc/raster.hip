@@ -87,19 +87,244 @@ __global__ void k_way_info(const int64_t *__restrict__ way_off, const int32_t *_
  * (cairo_fill closes sub-paths implicitly) */
 __global__ void k_fill_edges(const int2 *__restrict__ pts, const int64_t *__restrict__ way_off,
                              const int32_t *__restrict__ refway, int64_t n_refs,
-                             const uint8_t *__restrict__ wayflags, smr_edge_t *__restrict__ edges)
+                             const uint8_t *__restrict__ wayflags, smr_edge_t *__restrict__ edges,
+                             const uint8_t *__restrict__ skip)
 {
    int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    if (g >= n_refs) return;
    int64_t w = refway[g];
    smr_edge_t e; e.x1 = e.y1 = e.x2 = e.y2 = 0;
-   if (wayflags[w] & 4)
+   if ((wayflags[w] & 4) && !(skip && skip[g] == 1))
    {
       int64_t a = way_off[w], b = way_off[w + 1];
-      int2 p = pts[g], q = pts[g + 1 < b ? g + 1 : a];
+      int64_t nx = g + 1;
+      if (skip) while (nx < b && skip[nx] == 1) nx++;      /* points of the border's decomposition only (k_curve) */
+      int2 p = pts[g], q = pts[nx < b ? nx : a];
       e.x1 = p.x; e.y1 = p.y; e.x2 = q.x; e.y2 = q.y;
    }
    edges[g] = e;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* curve=1: the way as a chain of cubic Beziers (cairo_smr_poly_curve, src/smrules_cairo.c:697-749;
+ * control_points, src/bspline_ctrl.c:64-105), decomposed like libcairo 1.16 does at replay
+ * (cairo-spline.c: de Casteljau halving in 24.8 until both control points are within 0.1 px of
+ * the chord; restated and pinned in oracle/curve.c).  ONE LANE per ref slot: slot 0 of a way is
+ * the move_to, every other slot one curve_to.  A count pass, a scan, an emit pass; what comes out
+ * is a longer poly-line per way plus, per point, the direction of the stroker's face on the
+ * segment arriving (tin) and leaving (tout): libcairo's stroker puts the faces of a decomposed
+ * curve along its TANGENTS and joins only where two Beziers meet.  Everything downstream (edges,
+ * primitives, bins, raster) runs on the decomposed way as on any other.                        */
+/* ------------------------------------------------------------------------------------ */
+struct curve_args_t
+{
+   const double *x, *y; const int32_t *ref;
+   const int2 *pts; const int64_t *way_off; const int32_t *refway; const uint8_t *wayflags;
+   int64_t n_refs, n_ways;
+   int dpi; int32_t sfix; double f;
+   int border_used, fill_used;
+   int32_t W256, H256;                 /* the chart in 24.8 */
+   int32_t reach[4];                   /* reach of the border stroke (no fill / open / closed way) and of the open ways' fill stroke, 24.8 */
+   uint32_t *cnt;                      /* count pass */
+   const uint32_t *off;                /* emit pass: first point of every slot */
+   int2 *fpts, *tin, *tout; int32_t *frefway; int64_t *fway_off;
+   uint8_t *fskip;                     /* 1: the point exists for the border stroke only, 2: the fill arrives here by a line_to (see k_curve) */
+   uint32_t *status;
+};
+
+#define SMR_CURVE_STACK 28
+
+struct smr_knots_t { int2 a, b, c, d; };
+
+__device__ __forceinline__ double smr_spline_err2(const smr_knots_t &k)      /* _cairo_spline_error_squared */
+{
+   double bdx = (k.b.x - k.a.x) / 256.0, bdy = (k.b.y - k.a.y) / 256.0;
+   double cdx = (k.c.x - k.a.x) / 256.0, cdy = (k.c.y - k.a.y) / 256.0;
+   if (k.a.x != k.d.x || k.a.y != k.d.y)
+   {
+      const double dx = (k.d.x - k.a.x) / 256.0, dy = (k.d.y - k.a.y) / 256.0;
+      const double v = dx * dx + dy * dy;
+      double u = bdx * dx + bdy * dy;
+      if (u <= 0) { }
+      else if (u >= v) { bdx -= dx; bdy -= dy; }
+      else { bdx -= u / v * dx; bdy -= u / v * dy; }
+      u = cdx * dx + cdy * dy;
+      if (u <= 0) { }
+      else if (u >= v) { cdx -= dx; cdy -= dy; }
+      else { cdx -= u / v * dx; cdy -= u / v * dy; }
+   }
+   const double berr = bdx * bdx + bdy * bdy, cerr = cdx * cdx + cdy * cdy;
+   return berr > cerr ? berr : cerr;
+}
+
+__device__ __forceinline__ int2 smr_lerp_half(int2 a, int2 b) { return make_int2(a.x + ((b.x - a.x) >> 1), a.y + ((b.y - a.y) >> 1)); }
+
+/* src/bspline_ctrl.c:64-105 */
+__device__ __forceinline__ void smr_control_points(double gax, double gay, double gbx, double gby, double lax, double lay, double lbx, double lby,
+                                                   double f, double &p1x, double &p1y, double &p2x, double &p2y)
+{
+   const double lgt = smr_hypot(gbx - lax, gby - lay);
+   const double ag = atan2(gby - gay, gbx - gax);
+   const double hax = gbx - lgt * cos(ag), hay = gby - lgt * sin(ag);
+   double a = atan2(lay - hay, lax - hax);
+   p1x = gbx + lgt * cos(a) * f;
+   p1y = gby + lgt * sin(a) * f;
+   const double al = atan2(lby - lay, lbx - lax);
+   const double hbx = lax + lgt * cos(al), hby = lay + lgt * sin(al);
+   a = atan2(hby - gby, hbx - gbx);
+   p2x = lax - lgt * cos(a) * f;
+   p2y = lay - lgt * sin(a) * f;
+}
+
+template <bool EMIT>
+__global__ void k_curve(curve_args_t A)
+{
+   const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= A.n_refs) return;
+   const int64_t w = A.refway[g];
+   const uint8_t wf = A.wayflags[w];
+   const int64_t a0 = A.way_off[w], b0 = A.way_off[w + 1], n = b0 - a0, j = g - a0;
+   const bool closed = wf & 1;
+   uint32_t cnt = 0;
+   const uint32_t base = EMIT ? A.off[g] : 0;
+   int2 last = make_int2(0, 0);
+   bool fill_line = false;
+   auto sink = [&](int2 p, int32_t tdx, int32_t tdy, bool interior)
+   {
+      if (EMIT)
+      {
+         /* a tangent of zero length would take libcairo's cusp branch (a fan over the pen): the chord stands in */
+         if (tdx == 0 && tdy == 0) { tdx = p.x - last.x; tdy = p.y - last.y; }
+         const uint32_t q = base + cnt;
+         A.fpts[q] = p; A.tin[q] = make_int2(tdx, tdy); A.frefway[q] = (int32_t) w;
+         A.fskip[q] = !fill_line ? 0 : interior ? 1 : 2;
+         if (interior) A.tout[q] = make_int2(tdx, tdy);
+      }
+      last = p;
+      cnt++;
+   };
+   if ((wf & (2 | 4 | 8)) && n >= 2)
+   {
+      const int64_t npt = closed ? n - 1 : n;
+      const int st = closed ? 0 : 1;
+      if (j == 0)
+      {
+         const int2 p = A.pts[a0 + (st - 1 + npt) % npt];
+         last = p;
+         sink(p, 0, 0, false);
+         if (EMIT) A.fway_off[w] = base;
+      }
+      else
+      {
+         const int64_t i = closed ? j - 1 : j;
+         const int64_t i0 = (i + npt - 2) % npt, i1 = (i + npt - 1) % npt, i2 = i % npt, i3 = (i + 1) % npt;
+         auto node = [&](int64_t k) { return A.ref ? (int64_t) A.ref[a0 + k] : a0 + k; };
+         const int64_t n0 = node(i0), n1 = node(i1), n2 = node(i2), n3 = node(i3);
+         /* geo2pt = geo2pxf * 72 / dpi (src/rdata.c:240-245, :307-308) */
+         const double gax = A.x[n0] * 72 / A.dpi, gay = A.y[n0] * 72 / A.dpi, gbx = A.x[n1] * 72 / A.dpi, gby = A.y[n1] * 72 / A.dpi;
+         const double lax = A.x[n2] * 72 / A.dpi, lay = A.y[n2] * 72 / A.dpi, lbx = A.x[n3] * 72 / A.dpi, lby = A.y[n3] * 72 / A.dpi;
+         double c1x, c1y, c2x, c2y;
+         smr_control_points(gax, gay, gbx, gby, lax, lay, lbx, lby, A.f, c1x, c1y, c2x, c2y);
+         if (st)
+         {
+            if (i == 1) { c1x = gbx; c1y = gby; }
+            if (i == npt - 1) { c2x = lax; c2y = lay; }
+         }
+         auto dev = [&](double v) { return (int32_t) (((int64_t) (int32_t) rint(v * 256.0) * A.sfix) >> 8); };
+         smr_knots_t K;
+         K.a = A.pts[a0 + i1]; K.d = A.pts[a0 + i2];
+         K.b = make_int2(dev(c1x), dev(c1y)); K.c = make_int2(dev(c2x), dev(c2y));
+         last = K.a;
+         bool line = K.a.x == K.b.x && K.a.y == K.b.y && K.c.x == K.d.x && K.c.y == K.d.y;
+         /* _cairo_spline_intersects against the image (grown by the stroke's reach): a curve that cannot reach it is a line_to */
+         {
+            const int32_t r = A.border_used ? A.reach[!A.fill_used ? 0 : closed ? 2 : 1] : closed ? 0 : A.reach[3];
+            const int32_t lx0 = -r, ly0 = -r, lx1 = A.W256 + r, ly1 = A.H256 + r;
+            const int2 kk[4] = { K.a, K.b, K.c, K.d };
+            bool inside = false;
+            int32_t x0 = K.a.x, x1 = K.a.x, y0 = K.a.y, y1 = K.a.y;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+            {
+               if (lx0 <= kk[t].x && kk[t].x <= lx1 && ly0 <= kk[t].y && kk[t].y <= ly1) inside = true;
+               x0 = min(x0, kk[t].x); x1 = max(x1, kk[t].x); y0 = min(y0, kk[t].y); y1 = max(y1, kk[t].y);
+            }
+            if (!inside && (x1 <= lx0 || x0 >= lx1 || y1 <= ly0 || y0 >= ly1)) line = true;
+            /* the fill of a bordered way has limits of its own (the image; grown by the fill stroke's reach for open ways):
+             * a curve inside the border's reach but outside those is decomposed for the border and a line_to for the fill,
+             * which skips its inner points (k_fill_edges, k_stroke_edges mode 1) */
+            if (A.border_used && A.fill_used)
+            {
+               const int32_t r2 = closed ? 0 : A.reach[3];       /* open ways: the fill is a stroke of the fill width */
+               bool in0 = false;
+#pragma unroll
+               for (int t = 0; t < 4; t++) if (-r2 <= kk[t].x && kk[t].x <= A.W256 + r2 && -r2 <= kk[t].y && kk[t].y <= A.H256 + r2) in0 = true;
+               fill_line = !in0 && (x1 <= -r2 || x0 >= A.W256 + r2 || y1 <= -r2 || y0 >= A.H256 + r2);
+            }
+         }
+         int2 is = make_int2(0, 0), fs = make_int2(0, 0);
+         if (!line)
+         {
+            if (K.a.x != K.b.x || K.a.y != K.b.y) is = make_int2(K.b.x - K.a.x, K.b.y - K.a.y);
+            else if (K.a.x != K.c.x || K.a.y != K.c.y) is = make_int2(K.c.x - K.a.x, K.c.y - K.a.y);
+            else if (K.a.x != K.d.x || K.a.y != K.d.y) is = make_int2(K.d.x - K.a.x, K.d.y - K.a.y);
+            else line = true;
+         }
+         if (!line)
+         {
+            if (K.c.x != K.d.x || K.c.y != K.d.y) fs = make_int2(K.d.x - K.c.x, K.d.y - K.c.y);
+            else if (K.b.x != K.d.x || K.b.y != K.d.y) fs = make_int2(K.d.x - K.b.x, K.d.y - K.b.y);
+            else line = true;
+         }
+         if (line)
+         {
+            if (K.a.x != K.d.x || K.a.y != K.d.y)
+            {
+               if (EMIT) A.tout[base - 1] = make_int2(K.d.x - K.a.x, K.d.y - K.a.y);
+               sink(K.d, K.d.x - K.a.x, K.d.y - K.a.y, false);
+            }
+         }
+         else
+         {
+            if (EMIT) A.tout[base - 1] = is;
+            /* _cairo_spline_decompose_into without the recursion: left halves first, right halves wait on a stack */
+            smr_knots_t stk[SMR_CURVE_STACK];
+            int sp = 0;
+            smr_knots_t cur = K;
+            int2 lastpt = K.a;                         /* spline->last_point */
+            for (;;)
+            {
+               if (smr_spline_err2(cur) < 0.1 * 0.1 || sp >= SMR_CURVE_STACK)
+               {
+                  if (sp >= SMR_CURVE_STACK) atomicOr(A.status, SMR_ST_CURVE_DEPTH);
+                  if (lastpt.x != cur.a.x || lastpt.y != cur.a.y)
+                  {
+                     lastpt = cur.a;
+                     sink(cur.a, cur.b.x - cur.a.x, cur.b.y - cur.a.y, true);
+                  }
+                  if (sp == 0) break;
+                  cur = stk[--sp];
+                  continue;
+               }
+               const int2 ab = smr_lerp_half(cur.a, cur.b), bc = smr_lerp_half(cur.b, cur.c), cd = smr_lerp_half(cur.c, cur.d);
+               const int2 abbc = smr_lerp_half(ab, bc), bccd = smr_lerp_half(bc, cd), fin = smr_lerp_half(abbc, bccd);
+               smr_knots_t s2; s2.a = fin; s2.b = bccd; s2.c = cd; s2.d = cur.d;
+               stk[sp++] = s2;
+               cur.b = ab; cur.c = abbc; cur.d = fin;
+            }
+            sink(K.d, fs.x, fs.y, false);
+         }
+      }
+   }
+   if (!EMIT) A.cnt[g] = cnt;
+}
+
+__global__ void k_curve_finish(int64_t *fway_off, const int64_t *way_off, const uint32_t *off, const uint8_t *wayflags, int64_t n_ways, uint32_t total)
+{
+   const int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (w > n_ways) return;
+   /* ways that emit nothing (not drawn) still need their (empty) range */
+   fway_off[w] = w == n_ways ? (int64_t) total : (int64_t) off[way_off[w]];
 }
 
 /* ---- stroker (cairo-path-stroke-polygon.c semantics, see oracle/smr_oracle.c): butt caps,
@@ -110,7 +335,7 @@ __device__ __forceinline__ void smr_normalize(double &dx, double &dy)
 {
    if (dx == 0.0) { dy = dy > 0.0 ? 1.0 : -1.0; }
    else if (dy == 0.0) { dx = dx > 0.0 ? 1.0 : -1.0; }
-   else { double mag = hypot(dx, dy); dx = dx / mag; dy = dy / mag; }
+   else { double mag = smr_hypot(dx, dy); dx = dx / mag; dy = dy / mag; }
 }
 
 __device__ __forceinline__ smr_face_t smr_face(int2 p, int32_t ddx, int32_t ddy, double hw_pt, double s)
@@ -152,6 +377,32 @@ __device__ __forceinline__ int smr_sgn_cmp(double dx1, double dy1, double dx2, d
 {
    double c = dx1 * dy2 - dx2 * dy1;
    return c > 0 ? 1 : c < 0 ? -1 : 0;
+}
+
+__device__ __forceinline__ int64_t smr_turn(int2 a, int2 b, int2 c) { return (int64_t) (b.x - a.x) * (c.y - b.y) - (int64_t) (b.y - a.y) * (c.x - b.x); }
+
+__device__ __forceinline__ bool smr_convex4(int2 a, int2 b, int2 c, int2 d)
+{
+   const int64_t t0 = smr_turn(a, b, c), t1 = smr_turn(b, c, d), t2 = smr_turn(c, d, a), t3 = smr_turn(d, a, b);
+   const bool pos = t0 > 0 || t1 > 0 || t2 > 0 || t3 > 0, neg = t0 < 0 || t1 < 0 || t2 < 0 || t3 < 0;
+   return !(pos && neg);
+}
+
+/* convex hull of the corners of a quad that may cross itself; same decisions as hull4 of oracle/smr_oracle.c */
+__device__ __forceinline__ int smr_hull4(const int2 *q, int2 *h)
+{
+   if (smr_convex4(q[0], q[1], q[2], q[3])) { h[0] = q[0]; h[1] = q[1]; h[2] = q[2]; h[3] = q[3]; return 4; }
+   if (smr_convex4(q[0], q[1], q[3], q[2])) { h[0] = q[0]; h[1] = q[1]; h[2] = q[3]; h[3] = q[2]; return 4; }
+   if (smr_convex4(q[0], q[2], q[1], q[3])) { h[0] = q[0]; h[1] = q[2]; h[2] = q[1]; h[3] = q[3]; return 4; }
+#pragma unroll
+   for (int k = 0; k < 4; k++)
+   {
+      const int2 t0 = q[k == 0 ? 1 : 0], t1 = q[k <= 1 ? 2 : 1], t2 = q[k <= 2 ? 3 : 2];
+      const int64_t a = smr_turn(t0, t1, q[k]), b = smr_turn(t1, t2, q[k]), c = smr_turn(t2, t0, q[k]);
+      if ((a >= 0 && b >= 0 && c >= 0) || (a <= 0 && b <= 0 && c <= 0)) { h[0] = t0; h[1] = t1; h[2] = t2; h[3] = t2; return 3; }
+   }
+   h[0] = q[0]; h[1] = q[1]; h[2] = q[2]; h[3] = q[3];
+   return 4;
 }
 
 /* join of two faces at one vertex (outer_join / inner_join of cairo-path-stroke-polygon.c, restated in
@@ -196,11 +447,15 @@ __device__ __forceinline__ smr_join_t smr_join(const smr_face_t &in, const smr_f
  *   slots 4..7  body of the segment: quad over its four face corners, an outer corner replaced by the miter point
  *   slots 0..3  join at the segment's start: miter -> triangle (vertex, incoming inner, outgoing inner corner),
  *               bevel -> quad (vertex, incoming outer, outgoing outer, incoming inner corner)                  */
+/* TAN: the way is a decomposed curve; the face at a point looks along tin (arriving segment) / tout (leaving
+ * segment) instead of along the chords, and consecutive points are taken as they come (oracle: orc_stroke_edges_tan) */
+template <bool TAN>
 __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__restrict__ way_off,
                                const int32_t *__restrict__ refway, int64_t n_refs,
                                const uint8_t *__restrict__ wayflags, int mode, int dpi,
                                double hw_nofill_pt, double hw_open_pt, double hw_closed_pt, double hw_fill_pt,
-                               int fill_used, smr_edge_t *__restrict__ edges)
+                               int fill_used, smr_edge_t *__restrict__ edges,
+                               const int2 *__restrict__ tin, const int2 *__restrict__ tout, const uint8_t *__restrict__ skip)
 {
    int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    if (g >= n_refs) return;
@@ -212,30 +467,47 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
    uint8_t wf = wayflags[w];
    int64_t a = way_off[w], b = way_off[w + 1];
    bool on = mode == 0 ? (wf & 2) != 0 : (wf & 8) != 0;
+   /* TAN, fill stroke of a bordered open way: points that only the border's decomposition has are passed over, and the
+    * segment across them is the line_to libcairo's stroker draws there, faces along the chord (k_curve) */
+   const bool sk = TAN && mode == 1 && skip != nullptr;
+   if (sk && skip[g] == 1) on = false;
    if (on && g + 1 < b)
    {
-      int2 p1 = pts[g], p2 = pts[g + 1];
-      if (p1.x != p2.x || p1.y != p2.y)
+      int64_t nx = g + 1, pv = g - 1;
+      if (sk) { while (nx + 1 < b && skip[nx] == 1) nx++; while (pv > a && skip[pv] == 1) pv--; }
+      const bool chord_out = sk && skip[nx] == 2, chord_in = sk && skip[g] == 2;
+      int2 p1 = pts[g], p2 = pts[nx];
+      if (TAN || p1.x != p2.x || p1.y != p2.y)
       {
          double hw = mode == 1 ? hw_fill_pt : (!fill_used ? hw_nofill_pt : ((wf & 1) ? hw_closed_pt : hw_open_pt));
          double s = (double) dpi / 72;
          int32_t ddx = p2.x - p1.x, ddy = p2.y - p1.y;
+         if (TAN && !chord_out) { const int2 t = tout[g]; ddx = t.x; ddy = t.y; }
          smr_face_t start = smr_face(p1, ddx, ddy, hw, s);
          int2 c_ccw0 = start.ccw, c_cw0 = start.cw;
          int2 c_ccw1 = make_int2(start.ccw.x + ddx, start.ccw.y + ddy), c_cw1 = make_int2(start.cw.x + ddx, start.cw.y + ddy);
+         smr_face_t endf = start;
+         if (TAN)
+         {
+            const int2 t = !chord_out ? tin[nx] : make_int2(ddx, ddy);
+            endf = smr_face(p2, t.x, t.y, hw, s); c_ccw1 = endf.ccw; c_cw1 = endf.cw;
+         }
          /* previous non-degenerate segment of the same way ends at p1 */
          int64_t k = g - 1;
          int2 q0 = p1;
          bool have = false;
-         while (k >= a)
+         while (!TAN && k >= a)
          {
             q0 = pts[k];
             if (q0.x != p1.x || q0.y != p1.y) { have = true; break; }
             k--;
          }
+         if (TAN) have = g > a;
          if (have)
          {
-            smr_face_t cur = smr_face(p1, p1.x - q0.x, p1.y - q0.y, hw, s);     /* face of the previous segment at its END point */
+            int32_t pdx = p1.x - q0.x, pdy = p1.y - q0.y;
+            if (TAN) { const int2 t = !chord_in ? tin[g] : make_int2(p1.x - pts[pv].x, p1.y - pts[pv].y); pdx = t.x; pdy = t.y; }
+            smr_face_t cur = smr_face(p1, pdx, pdy, hw, s);     /* face of the previous segment at its END point */
             smr_join_t j = smr_join(cur, start, p1);
             int2 in_inner = j.clockwise ? cur.ccw : cur.cw, out_inner = j.clockwise ? start.ccw : start.cw;
             int2 in_outer = j.clockwise ? cur.cw : cur.ccw, out_outer = j.clockwise ? start.cw : start.ccw;
@@ -254,20 +526,33 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
          /* next non-degenerate segment of the same way starts at p2 */
          k = g + 2;
          have = false;
-         while (k < b)
+         while (!TAN && k < b)
          {
             q0 = pts[k];
             if (q0.x != p2.x || q0.y != p2.y) { have = true; break; }
             k++;
          }
+         int64_t nn = nx + 1;
+         if (sk) while (nn + 1 < b && skip[nn] == 1) nn++;
+         if (TAN) have = nx + 1 < b;
          if (have)
          {
-            smr_face_t end = smr_face(p2, ddx, ddy, hw, s), nstart = smr_face(p2, q0.x - p2.x, q0.y - p2.y, hw, s);
+            int32_t ndx = q0.x - p2.x, ndy = q0.y - p2.y;
+            if (TAN) { const int2 t = !(sk && skip[nn] == 2) ? tout[nx] : make_int2(pts[nn].x - p2.x, pts[nn].y - p2.y); ndx = t.x; ndy = t.y; }
+            smr_face_t end = TAN ? endf : smr_face(p2, ddx, ddy, hw, s), nstart = smr_face(p2, ndx, ndy, hw, s);
             smr_join_t j = smr_join(end, nstart, p2);
             if (j.kind == 1) { if (j.clockwise) c_cw1 = j.m; else c_ccw1 = j.m; }
          }
          int2 q[4] = { c_ccw0, c_ccw1, c_cw1, c_cw0 };
-         smr_emit_poly(q, 4, loc + 4);
+         if (TAN)
+         {
+            /* a curve that bends within half the line width makes this quad cross itself: the piece has to be convex
+             * (one interval per sub-row), so the hull of the four corners stands in (oracle: hull4) */
+            int2 h[4];
+            const int nh = smr_hull4(q, h);
+            smr_emit_poly(h, nh, loc + 4);
+         }
+         else smr_emit_poly(q, 4, loc + 4);
       }
    }
    smr_edge_t *out = edges + (size_t) SMR_SLOTS * g;
@@ -453,7 +738,7 @@ __global__ void k_dash(dash_args_t A)
          double sdx = ddx / 256.0 * (1.0 / D.s), sdy = ddy / 256.0 * (1.0 / D.s), mag;
          if (sdx == 0.0) { if (sdy > 0.0) { mag = sdy; sdy = 1.0; } else { mag = -sdy; sdy = -1.0; } }
          else if (sdy == 0.0) { if (sdx > 0.0) { mag = sdx; sdx = 1.0; } else { mag = -sdx; sdx = -1.0; } }
-         else { mag = hypot(sdx, sdy); sdx = sdx / mag; sdy = sdy / mag; }
+         else { mag = smr_hypot(sdx, sdy); sdx = sdx / mag; sdy = sdy / mag; }
          /* the caps of this segment's dashes all look along (ddx, ddy) or against it */
          int ts = 0, te = 0, ls = 0, le = 0;
          bool tcap = false, lcap = false;
@@ -1987,6 +2272,20 @@ extern "C" int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *str
    return SMR_OK;
 }
 
+extern "C" int smr_hip_debug_edges(smr_canvas_t *c, int32_t *host_xyxy, uint64_t max_edges, uint64_t *n_edges)
+{
+   SMR_NEED_INIT();
+   if (!c || !n_edges) return smr_fail(SMR_E_INVAL, "debug_edges: NULL");
+   *n_edges = c->last_n_edges;
+   if (host_xyxy && c->last_n_edges)
+   {
+      SMR_HIP(hipStreamSynchronize(smr_g.stream));
+      const uint64_t n = c->last_n_edges < max_edges ? c->last_n_edges : max_edges;
+      SMR_HIP(hipMemcpy(host_xyxy, c->buf[SMR_BUF_EDGES].p, (size_t) n * sizeof(smr_edge_t), hipMemcpyDeviceToHost));
+   }
+   return SMR_OK;
+}
+
 static double mm2wu(double mm, int dpi) { return mm == 0.0 ? 1.0 * 72 / dpi : mm * 72 / 25.4; }
 
 static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, int mode);
@@ -2071,7 +2370,8 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
       return smr_fail(SMR_E_INVAL, "draw: unknown style %d / %d", st->fill_style, st->border_style);
    if (st->fill_used && (st->fill_style == SMR_STYLE_PIPE || st->fill_style == SMR_STYLE_ROUNDDOT))
       return smr_fail(SMR_E_UNSUPPORTED, "draw: style=pipe|rounddot on the fill of open ways leaves round caps on every later stroke of the rule: not implemented on the GPU path");
-   if (st->curve) return smr_fail(SMR_E_UNSUPPORTED, "draw: curve/wavy not implemented on the GPU path");
+   if (st->curve != 0 && st->curve != 1) return smr_fail(SMR_E_UNSUPPORTED, "draw: wavy=1 is not implemented on the GPU path");
+   if (st->curve == 1 && !(st->curve_factor > 0 && st->curve_factor < 100)) return smr_fail(SMR_E_INVAL, "draw: curve_factor %g", st->curve_factor);
    if (st->directional && st->fill_used)
    {
       /* act_draw_ini disables the border in directional mode (:674-680); open ways are drawn at once into the
@@ -2101,7 +2401,9 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    const bool round_border = st->border_used && (st->border_style == SMR_STYLE_ROUNDDOT || pipe);
    const int K = pipe ? 3 : 2;
    if (pipe && mode == SMR_PASS_COMPOUND) return smr_fail(SMR_E_INVAL, "draw: internal: compound pass with a border");
-   const int64_t n_ways = b->n_ways, n_refs = b->n_refs, n_prims = K * n_ways;
+   const int64_t n_ways = b->n_ways, n_prims = K * n_ways;
+   int64_t n_refs = b->n_refs;
+   const int64_t *way_off = b->d_way_off;      /* curve=1 swaps in the decomposed ways below */
    int64_t n_items = 2 * ((n_refs >> 3) + n_ways);           /* id space of k_prim_setup, sparse */
    const int TX = (c->W + SMR_TW - 1) / SMR_TW, TY = (c->band_h + SMR_TH - 1) / SMR_TH;
    const uint32_t n_tiles = (uint32_t) TX * TY;
@@ -2146,6 +2448,48 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
 
    /* dashed strokes: count the pieces of every way, place them with a scan */
    const bool dash_b = st->border_used && dsb.n > 0, dash_o = open_fill && dso.n > 0;
+   int2 *tin = nullptr, *tout = nullptr;
+   uint8_t *fskip = nullptr;
+   if (st->curve == 1)
+   {
+      if (dash_b || dash_o)
+         return smr_fail(SMR_E_UNSUPPORTED, "draw: a dashed stroke along a curve (curve=1 with style/bstyle/dash/bdash) is not implemented on the GPU path");
+      uint32_t *ccnt, *sums; int2 *fpts; int32_t *frefway; int64_t *fway_off;
+      SMR_TRY(c->ensure(SMR_BUF_CURVE_CNT, ((size_t) n_refs + 1) * 4, (void **) &ccnt));
+      SMR_TRY(c->ensure(SMR_BUF_SUMS, ((size_t) n_refs / SCAN_B + 2) * 4, (void **) &sums));
+      curve_args_t CA;
+      CA.x = b->d_x; CA.y = b->d_y; CA.ref = b->d_ref; CA.pts = pts; CA.way_off = way_off; CA.refway = refway; CA.wayflags = wayflags;
+      CA.n_refs = n_refs; CA.n_ways = n_ways; CA.dpi = c->dpi; CA.sfix = sfix; CA.f = st->curve_factor;
+      CA.border_used = st->border_used; CA.fill_used = st->fill_used;
+      CA.W256 = c->W * 256; CA.H256 = c->H * 256;
+      /* _cairo_stroke_style_max_distance_from_path: miter joins, limit 10 -> sqrt(2) * 10 line widths, in device px */
+      const double wpt[4] = { 2 * hw_nofill, 2 * hw_open, 2 * hw_closed, 2 * hw_fill };
+      for (int i = 0; i < 4; i++)
+      {
+         const double r = M_SQRT2 * 10.0 * wpt[i] * hypot((double) c->dpi / 72, 0.0);
+         if (!(r * 256.0 < 1e9)) return smr_fail(SMR_E_INVAL, "draw: stroke width of %g pt", wpt[i]);
+         CA.reach[i] = (int32_t) nearbyint(r * 256.0);
+      }
+      CA.cnt = ccnt; CA.off = nullptr; CA.fpts = nullptr; CA.tin = CA.tout = nullptr; CA.frefway = nullptr; CA.fway_off = nullptr; CA.fskip = nullptr;
+      CA.status = &small[2];
+      k_curve<false><<<blocks(n_refs, 64), 64, 0, s>>>(CA);
+      uint32_t total = 0;
+      SMR_TRY(count_finish(ccnt, (uint32_t) n_refs, sums, &small[6], &total, s));
+      if (total == 0) return SMR_OK;
+      SMR_TRY(c->ensure(SMR_BUF_FPTS, (size_t) total * sizeof(int2), (void **) &fpts));
+      SMR_TRY(c->ensure(SMR_BUF_FTIN, (size_t) total * sizeof(int2), (void **) &tin));
+      SMR_TRY(c->ensure(SMR_BUF_FTOUT, (size_t) total * sizeof(int2), (void **) &tout));
+      SMR_TRY(c->ensure(SMR_BUF_FREFWAY, (size_t) total * 4, (void **) &frefway));
+      SMR_TRY(c->ensure(SMR_BUF_FWAYOFF, ((size_t) n_ways + 1) * 8, (void **) &fway_off));
+      SMR_TRY(c->ensure(SMR_BUF_FSKIP, (size_t) total, (void **) &fskip));
+      CA.cnt = nullptr; CA.off = ccnt; CA.fpts = fpts; CA.tin = tin; CA.tout = tout; CA.frefway = frefway; CA.fway_off = fway_off; CA.fskip = fskip;
+      k_curve_finish<<<blocks(n_ways + 1, TB), TB, 0, s>>>(fway_off, way_off, ccnt, wayflags, n_ways, total);
+      k_curve<true><<<blocks(n_refs, 64), 64, 0, s>>>(CA);
+      SMR_HIP(hipGetLastError());
+      pts = fpts; refway = frefway; way_off = fway_off; n_refs = total;
+      n_items = 2 * ((n_refs >> 3) + n_ways);
+      SMR_TRY(c->ensure(SMR_BUF_ITEMS, (size_t) n_items * sizeof(smr_item_t), (void **) &items));
+   }
    uint32_t *po_border = nullptr, *po_dots = nullptr, *po_open = nullptr, *id_off = nullptr;
    uint32_t tot_b = 0, tot_d = 0, tot_o = 0;
    dash_args_t DA[3];
@@ -2170,7 +2514,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       if (!pens.empty()) SMR_HIP(hipMemcpyAsync(d_pen, pens.data(), pens.size() * sizeof(int2), hipMemcpyHostToDevice, s));
       auto fill_args = [&](dash_args_t &A, int dmode, const dash_spec_t &ds, int cap_mode, int pen0, double scale)
       {
-         A.pts = pts; A.way_off = b->d_way_off; A.wayflags = wayflags; A.n_ways = n_ways; A.mode = dmode;
+         A.pts = pts; A.way_off = way_off; A.wayflags = wayflags; A.n_ways = n_ways; A.mode = dmode;
          A.dpi = c->dpi; A.fill_used = st->fill_used;
          A.hw_nofill = hw_nofill * scale; A.hw_open = hw_open * scale; A.hw_closed = hw_closed * scale; A.hw_fill = hw_fill;
          for (int i = 0; i < 4; i++) A.dash[i] = ds.d[i];
@@ -2216,7 +2560,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       }
       /* id room per way: its refs or half its pieces (8-slot groups), whichever is more */
       id_off = dbuf + 3 * stride;
-      k_id_groups<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, n_ways, cnt_keep, nullptr, nullptr, id_off);
+      k_id_groups<<<blocks(n_ways, TB), TB, 0, s>>>(way_off, n_ways, cnt_keep, nullptr, nullptr, id_off);
       uint32_t tot_groups = 0;
       SMR_TRY(count_finish(id_off, (uint32_t) n_ways, sums, &small[6], &tot_groups, s));
       n_items = (int64_t) K * (((int64_t) tot_groups >> 3) + n_ways);
@@ -2232,6 +2576,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    if (n_edges >= 0xffffff00ull) return smr_fail(SMR_E_CAPACITY, "draw: %llu edge slots in one rule (limit 2^32)", (unsigned long long) n_edges);
    smr_edge_t *edges;
    SMR_TRY(c->ensure(SMR_BUF_EDGES, (size_t) n_edges * sizeof(smr_edge_t), (void **) &edges));
+   c->last_n_edges = n_edges;
 
    if (dash_b)
    {
@@ -2240,14 +2585,22 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       if (pipe) { DA[1].edges = edges + off_dots; k_dash<true><<<blocks(n_ways, 64), 64, 0, s>>>(DA[1]); }
    }
    else if (st->border_used)
-      k_stroke_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill,
-                                                       hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border);
+   {
+      if (tin) k_stroke_edges<true><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill,
+                                                                      hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border, tin, tout, fskip);
+      else k_stroke_edges<false><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill,
+                                                                   hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border, nullptr, nullptr, nullptr);
+   }
    if (st->fill_used)
-      k_fill_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, refway, n_refs, wayflags, edges + off_fill);
+      k_fill_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, edges + off_fill, fskip);
    if (dash_o) { DA[2].edges = edges + off_open; k_dash<true><<<blocks(n_ways, 64), 64, 0, s>>>(DA[2]); }
    else if (open_fill)
-      k_stroke_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, b->d_way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill,
-                                                       hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open);
+   {
+      if (tin) k_stroke_edges<true><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill,
+                                                                      hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open, tin, tout, fskip);
+      else k_stroke_edges<false><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill,
+                                                                   hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open, nullptr, nullptr, nullptr);
+   }
    uint32_t *wb_pix = nullptr, *wf_pix = nullptr;
    if (b->d_way_border_col || b->d_way_fill_col)
    {
@@ -2270,7 +2623,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    {
       SMR_TRY(c->ensure(SMR_BUF_MASK, mask_cap * 4, (void **) &maskbuf));
       setup_args_t SA;
-      SA.edges = edges; SA.way_off = b->d_way_off; SA.wayflags = wayflags; SA.n_ways = n_ways;
+      SA.edges = edges; SA.way_off = way_off; SA.wayflags = wayflags; SA.n_ways = n_ways;
       SA.off_border = off_border; SA.off_fill = off_fill; SA.off_open = off_open;
       SA.border_pix = host_color_pixel(st->border_col); SA.fill_pix = host_color_pixel(st->fill_col);
       SA.way_border_pix = wb_pix; SA.way_fill_pix = wf_pix; SA.W = c->W; SA.H = c->H;
@@ -2375,6 +2728,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       t.edges_ms = T.ms(0, 1); t.prims_ms = T.ms(1, 2); t.bin_ms = T.ms(2, 3); t.raster_ms = T.ms(3, 4); t.total_ms = T.ms(0, 4);
       t.n_prims = (uint64_t) n_prims; t.n_edges = n_edges; t.n_tile_refs = n_entries; t.n_tiles = n_tiles;
    }
+   if (h_small[2] & SMR_ST_CURVE_DEPTH)
+      return smr_fail(SMR_E_CAPACITY, "draw: a curve needs more than %d levels of subdivision", SMR_CURVE_STACK);
    if (h_small[2] & SMR_ST_DEGRADED) smr_g.draw_status |= SMR_DRAW_DEGRADED_ROWS;
    if (h_small[2] & SMR_ST_ROWCAP)
       return smr_fail(SMR_E_CAPACITY, "draw: more than %d edges of one primitive span a vertex-free pixel row inside one tile", SMR_ROWCAP);

@@ -18,7 +18,7 @@ extern "C" {
 
 enum { SMR_OSM_NA, SMR_OSM_NODE, SMR_OSM_WAY, SMR_OSM_REL };          /* osm_inplace.h:38 */
 enum { SMR_POS_N = 1, SMR_POS_S = 2, SMR_POS_E = 4, SMR_POS_W = 8, SMR_POS_UC = 16 };   /* smrender_dev.h:55-71 */
-enum { SMR_LOG_ERR = 3, SMR_LOG_WARN = 4, SMR_LOG_NOTICE = 5, SMR_LOG_INFO = 6, SMR_LOG_DEBUG = 7 };   /* syslog levels */
+enum { SMR_LOG_EMERG = 0, SMR_LOG_ERR = 3, SMR_LOG_WARN = 4, SMR_LOG_NOTICE = 5, SMR_LOG_INFO = 6, SMR_LOG_DEBUG = 7 };   /* syslog levels */
 
 typedef struct { int len; char *buf; } smr_bstring_t;
 struct smr_otag { smr_bstring_t k, v; };

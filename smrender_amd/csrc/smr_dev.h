@@ -66,6 +66,7 @@ struct __attribute__((aligned(16))) smr_thdr_t
 #define SMR_ST_BUCKET_OVERFLOW 1u
 #define SMR_ST_ROWCAP 2u
 #define SMR_ST_MASK_ARENA 4u
+#define SMR_ST_CURVE_DEPTH 16u  /* a Bezier needed more levels of subdivision than the decomposition's stack holds */
 #define SMR_ST_DEGRADED 8u      /* a compound row with more than SMR_ROWCAP spanning edges was sub-sampled */
 
 __device__ __forceinline__ int smr_to_grid_y(int32_t y) { return (int) ((15ll * y + 128) >> 8); }
@@ -146,6 +147,33 @@ __device__ __forceinline__ void smr_edge_qr(int64_t c, int32_t dxs2, int32_t D, 
    if (r < 0) { qq--; r += D; }
    else if (r >= D) { qq++; r -= D; }
    q = qq; rem = (int32_t) r;
+}
+
+/* hypot as glibc 2.35 computes it (sysdeps/ieee754/dbl-64/e_hypot.c, the kernel without FMA, which is the one x86-64
+ * builds run): libcairo normalises slopes with the C library's hypot, and a join of two nearly parallel faces turns the
+ * last bit of that into miter-or-bevel.  Every operation below is a correctly rounded IEEE one on the device too, so the
+ * result is bit-equal (checked against glibc on 2*10^7 inputs); the operands here are far from the
+ * library's overflow / underflow rescaling branches. */
+__device__ __forceinline__ double smr_hypot(double x, double y)
+{
+   x = fabs(x); y = fabs(y);
+   const double ax = x < y ? y : x, ay = x < y ? x : y;
+   if (ax >= ay / 0x1p-54) return ax + ay;
+   double h = sqrt(ax * ax + ay * ay), t1, t2;
+   if (h <= 2.0 * ay)
+   {
+      const double delta = h - ay;
+      t1 = ax * (2.0 * delta - ax);
+      t2 = (delta - 2.0 * (ax - ay)) * delta;
+   }
+   else
+   {
+      const double delta = h - ax;
+      t1 = 2.0 * delta * (ax - 2.0 * ay);
+      t2 = (4.0 * delta - ay) * ay + delta * delta;
+   }
+   h -= (t1 + t2) / (2.0 * h);
+   return h;
 }
 
 __device__ __forceinline__ double smr_i64_to_f64(int64_t n)

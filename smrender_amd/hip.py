@@ -33,12 +33,17 @@ class DrawStyle(C.Structure):
                 ("ignore_open", C.c_int32), ("fill_style", C.c_int32), ("border_style", C.c_int32),
                 ("curve", C.c_int32), ("directional", C.c_int32), ("direct", C.c_int32),
                 ("border_ndash", C.c_int32), ("fill_ndash", C.c_int32),
-                ("border_dash", C.c_double * 4), ("fill_dash", C.c_double * 4)]
+                ("border_dash", C.c_double * 4), ("fill_dash", C.c_double * 4), ("curve_factor", C.c_double)]
 
     def set_dashes(self, border=(), fill=()):
         self.border_ndash, self.fill_ndash = len(border), len(fill)
         for i, v in enumerate(border): self.border_dash[i] = v
         for i, v in enumerate(fill): self.fill_dash[i] = v
+        return self
+
+    def set_curve(self, factor=0.2):
+        """curve=1 with curve_factor (default DIV_PART, src/smrender_dev.h:114)"""
+        self.curve, self.curve_factor = 1, factor
         return self
 
 
@@ -65,7 +70,7 @@ EXPORTS = [
     "smr_hip_proj_from_window", "smr_hip_set_projection", "smr_hip_project", "smr_hip_unproject",
     "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_read", "smr_hip_canvas_device",
     "smr_hip_canvas_set_halo", "smr_hip_canvas_clone",
-    "smr_hip_draw", "smr_hip_draw_status", "smr_hip_caprot", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
+    "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
     "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
     "act_draw_ini", "act_draw_main", "act_draw_fini", "act_cap_ini", "act_cap_main", "act_cap_fini",
@@ -97,6 +102,7 @@ def lib():
         L.smr_hip_canvas_set_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.smr_hip_canvas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.smr_hip_draw.argtypes = [C.c_void_p, C.POINTER(DrawStyle), C.POINTER(_DrawBatch)]
+        L.smr_hip_debug_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.smr_hip_caprot.argtypes = [C.c_void_p, C.POINTER(_CapBatch), C.c_void_p, C.c_void_p]
         L.smr_hip_caprot_steps.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.smr_hip_timings.argtypes = [C.POINTER(Timings)]
@@ -236,6 +242,15 @@ class Canvas:
         b = None if below is None else np.ascontiguousarray(below, np.uint32)
         _chk(lib().smr_hip_canvas_set_halo(self.h, a.ctypes.data if a is not None else None, 0 if a is None else a.shape[0],
                                            b.ctypes.data if b is not None else None, 0 if b is None else b.shape[0]))
+
+    def debug_edges(self):
+        """edge slots of the last draw pass, int32 [n, 4] (diagnostics)"""
+        n = C.c_uint64()
+        _chk(lib().smr_hip_debug_edges(self.h, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 4), np.int32)
+        if n.value:
+            _chk(lib().smr_hip_debug_edges(self.h, out.ctypes.data, n.value, C.byref(n)))
+        return out
 
     def clear(self):
         _chk(lib().smr_hip_canvas_clear(self.h))

@@ -34,8 +34,8 @@ def open_ways(n_ways, W, H, seed):
 
 def style_tuple(st):
     return np.array([st.fill_used, st.border_used, st.fill_col, st.border_col, st.ignore_open,
-                     st.border_style, st.fill_style, st.border_ndash, st.fill_ndash], np.int64), \
-        np.array([st.fill_width_mm, st.border_width_mm] + list(st.border_dash) + list(st.fill_dash))
+                     st.border_style, st.fill_style, st.border_ndash, st.fill_ndash, st.curve], np.int64), \
+        np.array([st.fill_width_mm, st.border_width_mm] + list(st.border_dash) + list(st.fill_dash) + [st.curve_fact])
 
 
 def main():
@@ -92,6 +92,11 @@ def main():
         (S(0, 1, 0, 0x103050, 0, 0.15, 0).with_dash(border_style=S.PIPE), open_ways(8, 256, 200, seed=85)),
         (S(1, 1, 0x4080c0, 0x50000000, 0.4, 0.1, 0).with_dash(border_style=S.DASHED, fill_style=S.DASHED,
                                                               border_dash=(5, 2, 1, 2)), open_ways(8, 256, 200, seed=86))])
+    # curve=1 (cairo_smr_poly_curve, src/smrules_cairo.c:697-749): closed ways crossing the page edge, open ways
+    scenes["curves_300"] = dict(dpi=300, W=256, H=200, bg=0xffffff, rules=[
+        (S(1, 1, 0x4080c0, 0x000000, 0, 0.2, 0).with_curve(), synth.synth_ways(14, 256, 200, seed=87, rmin=10.0, rmax=60.0)),
+        (S(0, 1, 0, 0x204060, 0, 0.3, 0).with_curve(), open_ways(10, 256, 200, seed=88)),
+        (S(1, 1, 0x30c0d8f0, 0x000000, 0.4, 0.15, 0).with_curve(0.35), open_ways(8, 256, 200, seed=89))])
     for name, sc in scenes.items():
         rules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in sc["rules"]]
         img = po.cairo_scene(rules, sc["dpi"], sc["W"], sc["H"], sc["bg"], sc.get("x0", 0), sc.get("y0", 0),

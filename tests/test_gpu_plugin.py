@@ -83,7 +83,7 @@ def test_draw_relation_members_and_key_colours(chart):
 
 def test_unsupported_draw_styles_are_refused_loudly(chart):
     sa, proj = chart
-    for params in ("color=red;style=rounddot", "color=red;curve=1", "color=red;wavy=1"):
+    for params in ("color=red;style=rounddot", "color=red;wavy=1", "bcolor=red;curve=1;bstyle=dashed"):
         assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, []) == 2001      # "Rule will be ignored"
 
 
@@ -102,6 +102,21 @@ def test_dashed_rule_through_the_action_api(chart, params, style):
     rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, wids)
     assert rc == 0, sa.lib().smr_hip_last_error()
     st = po.Style(0, 1, 0, 0x204060, 0, 0.25, 0).with_dash(**style)
+    want = po.oracle_scene([(st, oways)], DPI, W, H, 0xfff8e0)
+    assert np.array_equal(plugin_canvas(sa), want)
+
+
+@pytest.mark.parametrize("params,factor", [("color=#4080c0;bcolor=black;bwidth=0.2;curve=1", 0.2),
+                                           ("color=#4080c0;bcolor=black;bwidth=0.2;width=0.3;curve=yes;curve_factor=0.35", 0.35)])
+def test_curve_rule_through_the_action_api(chart, params, factor):
+    """curve=1 / curve_factor= parsed as act_draw_ini does (:625-631); the ways go through cairo_smr_poly_curve's path (:697-749)"""
+    from test_oracle_cairo import _dash_scene
+    from test_gpu_raster import _ways_to_arrays
+    sa, proj = chart
+    wids, oways = load_ways(sa, proj, _ways_to_arrays(_dash_scene(W, H, 9)))
+    rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, wids)
+    assert rc == 0, sa.lib().smr_hip_last_error()
+    st = po.Style(1, 1, 0x4080c0, 0x000000, 0.3 if "width=0.3" in params else 0, 0.2, 0).with_curve(factor)
     want = po.oracle_scene([(st, oways)], DPI, W, H, 0xfff8e0)
     assert np.array_equal(plugin_canvas(sa), want)
 

@@ -114,6 +114,67 @@ def test_edge_cases(hip):
     cv.close()
 
 
+# ---- curve=1 (cairo_smr_poly_curve, src/smrules_cairo.c:697-749): Bezier chain, libcairo's spline decomposition,
+# faces along the tangents.  The control points go through atan2/cos/sin/hypot on the device, whose last bit may
+# differ from glibc's: the decomposition is integer from there on, so the bar stays bit-exact and a failure here
+# with a handful of pixels would point at that.
+def _inside(arrs, sx, sy, dx, dy):
+    return (arrs[0] * sx + dx, arrs[1] * sy + dy, arrs[2], arrs[3])
+
+
+CURVE_STYLES = {
+    "fill": po.Style(1, 0, 0x4080c0, 0, 0, 0, 0),
+    "border": po.Style(0, 1, 0, 0x000000, 0, 0.3, 0),
+    "fill+border": po.Style(1, 1, 0x4080c0, 0x000000, 0, 0.2, 0),
+    "hairline": po.Style(0, 1, 0, 0x000000, 0, 0.0, 0),
+    "translucent": po.Style(1, 1, 0x304080c0, 0x50102030, 0.4, 0.15, 0),
+}
+
+
+@pytest.mark.parametrize("style", list(CURVE_STYLES))
+@pytest.mark.parametrize("scene", ["closed_inside", "closed_crossing", "open"])
+def test_curves_bit_exact(hip, style, scene):
+    st = CURVE_STYLES[style].with_curve(0.35 if style == "translucent" else 0.2)
+    if scene == "closed_inside":
+        arrs = _inside(po.synth_ways(12, 200, 150, seed=5, rmin=10.0, rmax=40.0), 0.6, 0.6, 50, 40)
+    elif scene == "closed_crossing":       # ways leaving the chart: curves off the image are lines (libcairo's limits)
+        arrs = po.synth_ways(40, 256, 200, seed=6, rmin=10.0, rmax=60.0)
+    else:
+        arrs = _open_ways(30, 256, 200, seed=7)
+    rules = [(st, arrs)]
+    g = gpu_scene(hip, rules, 300, 256, 200, 0xffffff)
+    o = oracle_of(rules, 300, 256, 200, 0xffffff)
+    assert np.array_equal(g, o), report(g, o)
+
+
+def test_curves_600dpi_many_ways_and_bands(hip):
+    st = po.Style(1, 1, 0x4080c0, 0x000000, 0, 25.4 / 300, 0).with_curve()
+    arrs = po.synth_ways(3000, 1024, 1024, seed=8)
+    rules = [(st, arrs)]
+    full = gpu_scene(hip, rules, 600, 1024, 1024, 0xffffff)
+    o = oracle_of(rules, 600, 1024, 1024, 0xffffff)
+    assert np.array_equal(full, o), report(full, o)
+    # a band renders its rows of the full chart: the curve limits are the chart's, not the band's
+    band = gpu_scene(hip, rules, 600, 1024, 1024, 0xffffff, 300, 200)
+    assert np.array_equal(band, full[300:500])
+
+
+def test_curve_refusals(hip):
+    sa = hip
+    cv = sa.Canvas(64, 64, 300, 0xffffff)
+    d = sa.DeviceArray.from_numpy(np.array([5.0, 20, 40, 50]))
+    off = sa.DeviceArray.from_numpy(np.array([0, 4], np.int64))
+    gs = sa.DrawStyle(0, 1, 0, 0, 0, 0.2, 0, 0, 1, 0, 0, 0).set_curve()       # bstyle=dashed along a curve
+    with pytest.raises(sa.SmrHipError) as e:
+        cv.draw(gs, d, d, off, None, 1, 4)
+    assert e.value.code == -5
+    gs = sa.DrawStyle(0, 1, 0, 0, 0, 0.2, 0, 0, 0, 0, 0, 0).set_curve(0.0)   # curve_factor must be positive
+    with pytest.raises(sa.SmrHipError) as e:
+        cv.draw(gs, d, d, off, None, 1, 4)
+    assert e.value.code == -2
+    cv.close()
+
+
 def test_bands_stitch_to_full_canvas(hip):
     """multi-GPU layout: each rank owns a band of rows; bands must stitch bit-identically"""
     arrs = po.synth_ways(150, 320, 301, seed=21)

@@ -136,3 +136,83 @@ def test_dashed_strokes(case):
     assert touched.sum() > 5000
     # bit-identical but for one near-reversal (bevel) join of the scene whose vertex sits on a sample-row boundary
     assert (d > 0).sum() <= 0.0008 * touched.sum(), ((d > 2).sum(), (d > 0).sum(), d.max())
+
+
+# ---- curve=1 -------------------------------------------------------------------------------------------------------
+def test_control_points_match_the_reference_source():
+    """control_points restated (oracle/curve.c) vs the reference's own src/bspline_ctrl.c compiled where it lies
+    (oracle/_ref/libref_bspline.so).  The two builds may order the libm calls differently: allow the last bit."""
+    import ctypes as C, os
+    path = os.path.join(os.path.dirname(po.__file__), "_ref", "libref_bspline.so")
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref not built (reference absent)")
+    ref = C.CDLL(path)
+    ref.ref_control_points.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(1)
+    exact = 0
+    for t in range(5000):
+        g, l, f = rng.uniform(-500, 500, 4), rng.uniform(-500, 500, 4), rng.uniform(0.05, 0.5)
+        a1, a2, b1, b2 = np.zeros(2), np.zeros(2), np.zeros(2), np.zeros(2)
+        ref.ref_control_points(po.P(g), po.P(l), f, po.P(a1), po.P(a2))
+        po.orc().orc_control_points(po.P(g), po.P(l), f, po.P(b1), po.P(b2))
+        assert np.allclose(a1, b1, rtol=0, atol=1e-10) and np.allclose(a2, b2, rtol=0, atol=1e-10)
+        exact += int(np.array_equal(a1, b1) and np.array_equal(a2, b2))
+    assert exact >= 4950
+
+
+def _open_ways(n_ways, W, H, seed):
+    rng = np.random.default_rng(seed)
+    ways = []
+    for _ in range(n_ways):
+        n = int(rng.integers(2, 14))
+        step = rng.uniform(2, 30)
+        ways.append((rng.uniform(0, W) + np.cumsum(rng.normal(0, step, n)), rng.uniform(0, H) + np.cumsum(rng.normal(0, step, n)), False))
+    return ways
+
+
+# (style, scene, share of pixels within +-2, share identical): fills and thin strokes are bit-identical; what is left are the
+# inner sides of bends tighter than half the line width, where libcairo's contour cancels by winding and the oracle's
+# pieces take the convex hull (oracle/smr_oracle.c hull4)
+CURVE_CASES = {
+    "fill_closed": (po.Style(1, 0, 0x4080c0, 0, 0, 0, 0), "closed", 1.0, 1.0),
+    "fill_border_closed": (po.Style(1, 1, 0x4080c0, 0x000000, 0, 0.2, 0), "closed", 0.9999, 0.9998),
+    "hairline_closed": (po.Style(0, 1, 0, 0x000000, 0, 0.0, 0), "closed", 1.0, 1.0),
+    "border_closed": (po.Style(0, 1, 0, 0x000000, 0, 0.3, 0), "closed", 0.9998, 0.9995),
+    "border_open": (po.Style(0, 1, 0, 0x204060, 0, 0.3, 0), "open", 0.9999, 0.9995),
+    "fill_border_open": (po.Style(1, 1, 0x30c0d8f0, 0x000000, 0.4, 0.15, 0), "open", 0.9995, 0.999),
+    "wide_border_open": (po.Style(0, 1, 0, 0x204060, 0, 1.0, 0), "open", 0.998, 0.997),
+}
+
+
+@pytest.mark.parametrize("case", list(CURVE_CASES))
+def test_curves(case):
+    st, scene, bar2, bar0 = CURVE_CASES[case]
+    st = st.with_curve(0.35 if case == "fill_border_open" else 0.2)
+    ways = po.ways_from_arrays(*po.synth_ways(12, 256, 200, seed=5, rmin=10.0, rmax=60.0)) if scene == "closed" else _open_ways(14, 256, 200, 82)
+    a = po.oracle_scene([(st, ways)], 300, 256, 200, 0xffffff)
+    b = po.cairo_scene([(st, ways)], 300, 256, 200, 0xffffff)
+    d = po.chan_diff(a, b)
+    assert (d <= 2).mean() >= bar2 and (d == 0).mean() >= bar0, ((d > 2).sum(), (d > 0).sum(), d.max())
+
+
+def test_single_beziers_decompose_like_libcairo():
+    """one Bezier at a time, given in exact 24.8 device coordinates and filled straight onto an image: the decomposition
+    (points and their number) must reproduce libcairo's coverage bit for bit"""
+    import ctypes as C
+    cd, L = po.cairo(), po.orc()
+    cd.cd_direct_curve_fill.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(3)
+    W = H = 96
+    for t in range(300):
+        k = np.rint(rng.uniform(8, 88, (4, 2)) * 256) / 256
+        if t % 5 == 0:
+            k[1] = k[0] + np.rint(rng.uniform(-3, 3, 2) * 256) / 256       # short first handle
+        start, curves = k[0].copy(), np.ascontiguousarray(k[1:].reshape(1, 6))
+        out = np.zeros((H, W), np.uint32)
+        cd.cd_direct_curve_fill(start[0], start[1], po.P(curves), 1, 0x000000, 0xffffff, W, H, po.P(out))
+        cap = 4096
+        pts, tin, tout = np.zeros(2 * cap, np.int32), np.zeros(2 * cap, np.int32), np.zeros(2 * cap, np.int32)
+        m = L.orc_curve_flatten(po.P(start), po.P(curves), 1, 72, None, po.P(pts), po.P(tin), po.P(tout), cap)
+        e = np.zeros((m, 4), np.int32)
+        L.orc_fill_edges(po.P(pts), m, po.P(e))
+        assert np.array_equal(po.tor_coverage(e, W, H), (255 - (out & 0xff)).astype(np.uint8)), t
