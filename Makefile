@@ -26,4 +26,10 @@ clean:
 	rm -rf build smrender_amd/libsmr_hip.so
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean prof
+
+# diagnostic build with s_memtime stamps around the sections of k_raster (never the shipped library)
+prof: tools/libsmr_hip_prof.so
+tools/libsmr_hip_prof.so: $(SRCS) $(CSRC)/smr_dev.h $(CSRC)/smr_host.h include/smr_hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -DSMR_SECTION_PROFILE -x hip -shared -o $@ $(SRCS) -ldl

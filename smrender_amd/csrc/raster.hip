@@ -1115,7 +1115,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
                {
                   const int32_t D = 60 * le.w;
                   const int64_t ec = 256 - 30ll * le.y;
-                  const double inv = 1.0 / (double) D;
+                  const double inv = smr_rcp((double) D);
                   L.act0[lane][cnt] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs0);
                   L.act1[lane][cnt] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs1);
                   cnt++;
@@ -1243,7 +1243,7 @@ __global__ __launch_bounds__(64) void k_compound_rows(const smr_edge_t *__restri
       if (act && pos < SMR_ROWCAP)
       {
          const int64_t ec = 256 - 30ll * o.p1y;
-         const double inv = 1.0 / (double) o.D;
+         const double inv = smr_rcp((double) o.D);
          f0[pos] = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs0);
          f1[pos] = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs1);
       }
@@ -1490,7 +1490,6 @@ struct raster_args_t
    int W, band_y0, band_h, TX;
    uint32_t n_tiles;
    int direct;                /* no group layer: primitives composite straight onto the canvas */
-   uint32_t vgroup;           /* vertically adjacent tiles one wavefront takes in a row */
 };
 
 struct raster_lds_t
@@ -1500,9 +1499,13 @@ struct raster_lds_t
    int left[SMR_TH];
    uint32_t rowlist[SMR_TH][SMR_ROWCAP];
    int redge[SMR_TH][16][5];  /* p1x, p1y, dxs, D, dir of the first 16 edges spanning each full row */
-   unsigned long long key[64];
-   int perm[64];
-   uint16_t bucket[SMR_NSUB][SMR_BKS];
+   /* the crossing buckets are drained (spans of the sub-sampled rows) before the rank sort of the rarely taken slow
+    * full-row path needs its keys: they share the storage */
+   union
+   {
+      uint16_t bucket[SMR_NSUB][SMR_BKS];
+      struct { unsigned long long key[64]; int perm[64]; } srt;
+   };
 };
 
 __device__ __forceinline__ void smr_cell_add(raster_lds_t &L, int row, int ix, int dcover, int duarea)
@@ -1586,6 +1589,12 @@ __device__ void smr_render_edge(raster_lds_t &L, int row, int32_t X0, int32_t dx
 #define TICK(i) do { } while (0)
 #endif
 
+/* 4 waves per SIMD (128 VGPRs, a few spilled) measured 10 % faster than the 3 the allocator settles on by itself:
+ * the kernel waits on LDS and L2 more than it issues */
+#ifndef SMR_RASTER_WPE
+#define SMR_RASTER_WPE 4
+#endif
+__attribute__((amdgpu_waves_per_eu(SMR_RASTER_WPE, SMR_RASTER_WPE)))
 __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t A)
 {
    __shared__ raster_lds_t LL[SMR_RASTER_WAVES];
@@ -1613,14 +1622,9 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
    const uint32_t jw = (blockIdx.x >> 3) * SMR_RASTER_WAVES + (threadIdx.x >> 6), nwx = (gridDim.x >> 3) * SMR_RASTER_WAVES;
    const uint32_t TYt = A.n_tiles / A.TX;
    const uint32_t ncol = ((uint32_t) A.TX + 7u - xcd) >> 3;
-   /* a wavefront takes A.vgroup vertically adjacent tiles in a row: an item spanning them is fetched again while
-    * its edge slots are still in the cache */
-   const uint32_t NG = (TYt + A.vgroup - 1) / A.vgroup;
-   for (uint32_t kg = jw; kg < ncol * NG; kg += nwx)
-   for (uint32_t sub = 0; sub < A.vgroup; sub++)
+   for (uint32_t kg = jw; kg < ncol * TYt; kg += nwx)
    {
-      const int tx = (int) (xcd + 8u * (kg / NG)), ty = (int) ((kg % NG) * A.vgroup + sub);
-      if ((uint32_t) ty >= TYt) break;
+      const int tx = (int) (xcd + 8u * (kg / TYt)), ty = (int) (kg % TYt);
       const uint32_t tile = (uint32_t) ty * A.TX + tx;
       const uint32_t beg = A.tile_off[tile], end = A.tile_off[tile + 1];
       if (beg == end) continue;
@@ -1812,7 +1816,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                   smr_oedge_t o;
                   { const int *re = L.redge[grp][es]; o.p1x = re[0]; o.p1y = re[1]; o.dxs = re[2]; o.D = re[3]; o.dir = re[4]; }
                   const int64_t ec = 256 - 30ll * o.p1y;
-                  const double inv = 1.0 / (double) o.D;
+                  const double inv = smr_rcp((double) o.D);
                   D = o.D; dir = o.dir; dxs = o.dxs;
                   smr_edge_qr(ec, 2 * o.dxs, o.D, inv, rs0, q1, r1);
                   smr_edge_qr(ec, 2 * o.dxs, o.D, inv, rs0 + SMR_GRID_Y, q2, r2);
@@ -1875,7 +1879,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                         const int64_t dx = (int64_t) (qb - qa) * D + (rb - ra);
                         const int64_t tmp0 = ((int64_t) (256 - fx1) * D - ra) * SMR_GRID_Y;
                         const int64_t step = (int64_t) (SMR_GRID_Y * 256) * D;
-                        const double inv = 1.0 / smr_i64_to_f64(dx);
+                        const double inv = smr_rcp(smr_i64_to_f64(dx));
                         /* y (in sub-rows) at which the edge crosses the right boundary of cell `cell` */
                         auto Y = [&](int cell) -> int
                         {
@@ -1919,17 +1923,17 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                }
                /* rank sort by (cell, next cell) */
                unsigned long long key = ((unsigned long long) (uint32_t) (c0 + 0x40000000) << 32) | (uint32_t) (c1 + 0x40000000);
-               L.key[lane] = key;
+               L.srt.key[lane] = key;
                SMR_WAVE_SYNC();
                int rank = 0;
                for (uint32_t j = 0; j < n; j++)
                {
-                  unsigned long long kj = L.key[j];
+                  unsigned long long kj = L.srt.key[j];
                   rank += (kj < key || (kj == key && j < (uint32_t) lane)) ? 1 : 0;
                }
-               if (on) L.perm[rank] = lane;
+               if (on) L.srt.perm[rank] = lane;
                SMR_WAVE_SYNC();
-               int src = on ? L.perm[lane] : lane;
+               int src = on ? L.srt.perm[lane] : lane;
                q0 = __shfl(q0, src); q1 = __shfl(q1, src);
                r0 = __shfl(r0, src); r1 = __shfl(r1, src); c0 = __shfl(c0, src); c1 = __shfl(c1, src);
                dxs = __shfl(dxs, src); D = __shfl(D, src); dir = __shfl(dir, src);
@@ -2042,7 +2046,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                const int64_t e_c = 256 - 30ll * o.p1y;
                const int e_clo = (int) (uint32_t) e_c, e_chi = (int) (e_c >> 32);
                const int e_dxs2 = 2 * o.dxs;
-               const double e_inv = 1.0 / (double) o.D;
+               const double e_inv = smr_rcp((double) o.D);
                const int e_ilo = (int) (uint32_t) __double_as_longlong(e_inv), e_ihi = (int) (__double_as_longlong(e_inv) >> 32);
                /* sub-row window of the edge relative to the tile, [0, 60]; empty for empty slots */
                const int e_t0 = o.dir == 0 ? 64 : min(max(o.ytop - ysbase, 0), 64), e_t1 = o.dir == 0 ? 0 : min(max(o.ybot - ysbase, 0), 64);
@@ -2701,7 +2705,6 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
    A.direct = st->direct != 0;
-   { const char *e = getenv("SMR_VGROUP"); int g = e ? atoi(e) : 4; A.vgroup = (uint32_t) (g < 1 ? 1 : g > 64 ? 64 : g); }
    {
       /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
       unsigned nwg = std::min<unsigned>((n_tiles + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES, 256u * 8u);

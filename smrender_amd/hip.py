@@ -4,7 +4,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libsmr_hip.so")
+_LIB_PATH = os.environ.get("SMR_HIP_LIBRARY") or os.path.join(_HERE, "libsmr_hip.so")      # the override is for diagnostic builds
 
 
 class SmrHipError(RuntimeError):
