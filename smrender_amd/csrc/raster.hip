@@ -879,8 +879,28 @@ struct setup_lds_t
    uint32_t nlong;
 };
 
-__device__ __forceinline__ int smr_wave_min(int v) { for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d)); return v; }
-__device__ __forceinline__ int smr_wave_max(int v) { for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d)); return v; }
+/* wave-wide min / max through DPP row shifts and broadcasts (VALU only; the __shfl_xor form is an LDS round trip per step):
+ * lane 63 ends up with the reduction of all 64 lanes, v_readlane hands it to everyone */
+__device__ __forceinline__ int smr_wave_min(int v)
+{
+   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+   v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+   return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int smr_wave_max(int v)
+{
+   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x111, 0xf, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x112, 0xf, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x114, 0xf, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x118, 0xf, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
+   return __builtin_amdgcn_readlane(v, 63);
+}
 
 /* mark the rows in which edge o starts or ends, and remember o if it spans a whole row */
 __device__ __forceinline__ void smr_setup_edge(const smr_oedge_t &o, int row0, int nrows, uint32_t *lmask, setup_lds_t &L)
@@ -1105,24 +1125,30 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
             }
             continue;
          }
+         /* first which edges span the row (a compare per candidate), then their cells in a loop all lanes walk together:
+          * the lanes' active edges sit at different places of the list, and evaluating inside the scan would make every
+          * lane pay for every other lane's evaluations */
          for (uint32_t i = 0; i < nlong; i++)
          {
             const int4 le = L.l_edge[i];
             const int ytop = smr_to_grid_y(le.y), ybot = smr_to_grid_y(le.y + le.w);
             if (mine && !over && ytop <= rs0 && ybot >= rs1)
             {
-               if (cnt < SMR_ACTCAP)
-               {
-                  const int32_t D = 60 * le.w;
-                  const int64_t ec = 256 - 30ll * le.y;
-                  const double inv = smr_rcp((double) D);
-                  L.act0[lane][cnt] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs0);
-                  L.act1[lane][cnt] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs1);
-                  cnt++;
-               }
+               if (cnt < SMR_ACTCAP) L.act0[lane][cnt++] = (int) i;
                else over = true;
             }
          }
+         const int kmax = smr_wave_max(over ? 0 : cnt);
+         for (int k = 0; k < kmax; k++)
+            if (!over && k < cnt)
+            {
+               const int4 le = L.l_edge[L.act0[lane][k]];
+               const int32_t D = 60 * le.w;
+               const int64_t ec = 256 - 30ll * le.y;
+               const double inv = smr_rcp((double) D);
+               L.act0[lane][k] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs0);
+               L.act1[lane][k] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs1);
+            }
          bool viol = false;
          if (!over)
             for (int i = 0; i < cnt; i++)
