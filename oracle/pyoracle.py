@@ -190,13 +190,16 @@ def oracle_scene(rules, dpi, W, H, bg, x0=0, y0=0):
     return out
 
 
-def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0):
+def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0, image=None):
     """One directional draw rule (act_draw_main :1039-1052, act_draw_fini :1084-1140): group 1 = the open ways,
     group 2 = ALL closed ways as one path with one non-zero fill (a page rectangle, if the reference adds
     one, is just another closed way of `ways`).  The border is off in directional mode (:674-680)."""
     L = orc()
     c = L.orc_canvas_new(x0, y0, W, H, dpi, bg)
     s1 = Style(st.fill_used, 0, st.fill_col, 0, st.fill_width_mm, st.border_width_mm, st.ignore_open)
+    s1.curve, s1.curve_fact = st.curve, st.curve_fact
+    if image is not None:
+        L.orc_canvas_set_image(c, *image)
     L.orc_rule_begin(c)
     for x, y, closed in ways:
         if not closed:
@@ -204,8 +207,24 @@ def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0):
             L.orc_draw_way(c, C.byref(s1), P(x), P(y), len(x), 0, 0, 0, 0, 0)
     L.orc_rule_end(c)
     edges = []
+    img = image if image is not None else (x0, y0, x0 + W, y0 + H)
+    lim = np.array([v * 256 for v in img], np.int32)
     for x, y, closed in ways:
-        if closed:
+        if closed and st.curve:
+            # the closed ways as Bezier chains (cairo_smr_poly_curve), decomposed against the image's limits
+            xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
+            start, curves = curve_path(xy, True, st.curve_fact)
+            cap = 64 * (len(curves) + 2)
+            while True:
+                pts, tin, tout = np.zeros(2 * cap, np.int32), np.zeros(2 * cap, np.int32), np.zeros(2 * cap, np.int32)
+                m = L.orc_curve_flatten(P(start), P(curves), len(curves), dpi, P(lim), P(pts), P(tin), P(tout), cap)
+                if m >= 0:
+                    break
+                cap *= 4
+            e = np.zeros((m, 4), np.int32)
+            L.orc_fill_edges(P(pts), m, P(e))
+            edges.append(e)
+        elif closed:
             x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
             dev = np.zeros(2 * len(x), np.int32)
             L.orc_px_to_dev(P(x), P(y), len(x), dpi, P(dev))
@@ -230,14 +249,22 @@ def cairo_directional(st, ways, dpi, W, H, bg):
     for x, y, closed in ways:
         if not closed and len(x) >= 2 and not st.ignore_open:
             xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
-            L.cd_poly_line(P(xy), len(xy))
+            if st.curve:
+                start, curves = curve_path(xy, False, st.curve_fact)
+                L.cd_poly_curve(start[0], start[1], P(curves), len(curves))
+            else:
+                L.cd_poly_line(P(xy), len(xy))
             L.cd_stroke(st.fill_col, mm2wu(st.fill_width_mm, dpi))
     L.cd_rule_end()
     L.cd_rule_begin()
     for x, y, closed in ways:
         if closed:
             xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
-            L.cd_poly_line(P(xy), len(xy))
+            if st.curve:
+                start, curves = curve_path(xy, True, st.curve_fact)
+                L.cd_poly_curve(start[0], start[1], P(curves), len(curves))
+            else:
+                L.cd_poly_line(P(xy), len(xy))
     L.cd_fill(st.fill_col)
     L.cd_rule_end()
     out = np.zeros((H, W), np.uint32)

@@ -870,6 +870,7 @@ struct setup_args_t
    uint64_t off_dots;
    const uint32_t *po_border, *po_dots, *po_open;      /* [n_ways+1] piece offsets; NULL: the plain layout */
    const uint32_t *id_off;                             /* [n_ways+1] in 8-slot groups; NULL: way_off */
+   uint32_t *biglist;                                  /* primitives left to k_big_rows ([0] = their number, then the ids) */
 };
 
 struct setup_lds_t
@@ -926,6 +927,171 @@ __device__ __forceinline__ void smr_setup_edge(const smr_oedge_t &o, int row0, i
       }
    }
 }
+
+#define SMR_BIG_SLOTS 4096u   /* edge slots from which a primitive with an overflowing row-spanning list goes to k_big_rows */
+
+/* analysis of the vertex-free rows of one primitive: which of them libcairo's scan converter sub-samples after all
+ * because two of the edges spanning the row cross inside it.  Used by the wavefront that sets the primitive up and,
+ * for long primitives, by the wavefronts of k_big_rows (one window of 64 rows each). */
+struct smr_rowscan_t
+{
+   int row0, nrows; uint32_t edge_cnt;
+   const smr_edge_t *E;
+   setup_lds_t *L;
+   uint32_t *lmask;               /* LDS: bit r - mbase = row r of the primitive is sub-sampled */
+   int mbase;                     /* first row lmask holds (a multiple of 64) */
+   int lane;
+   uint32_t *status;
+   uint32_t list_n;               /* entries of L->l_edge that count; more than SMR_LONGCAP: the list overflowed, scan every slot */
+
+   /* one vertex-free row decided by the whole wavefront: lanes walk the candidate edges (the LDS list of row-spanning
+    * edges, or every edge slot when that list overflowed), the active ones' cells at the top and the bottom of the row
+    * go to LDS, then every pair is compared */
+   __device__ void row_by_wave(int r)
+   {
+      const int rs0 = (row0 + r) * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
+      int *f0 = &L->act0[0][0], *f1 = &L->act1[0][0];
+      uint32_t cnt = 0;
+      const uint32_t ncand = list_n <= SMR_LONGCAP ? list_n : edge_cnt;
+      SMR_WAVE_SYNC();
+      for (uint32_t base_i = 0; base_i < ncand; base_i += 64)
+      {
+         uint32_t idx = base_i + lane;
+         int32_t p1x = 0, p1y = 0, dxs = 0, D = 1, ytop = 0, ybot = 0;
+         bool have = false;
+         if (idx < ncand)
+         {
+            if (list_n <= SMR_LONGCAP)
+            {
+               const int4 le = L->l_edge[idx];
+               p1x = le.x; p1y = le.y; dxs = le.z; D = 60 * le.w; ytop = smr_to_grid_y(le.y); ybot = smr_to_grid_y(le.y + le.w);
+               have = true;
+            }
+            else
+            {
+               smr_oedge_t o = smr_orient(E[idx]);
+               p1x = o.p1x; p1y = o.p1y; dxs = o.dxs; D = o.D; ytop = o.ytop; ybot = o.ybot;
+               have = o.dir != 0;
+            }
+         }
+         bool act = have && ytop <= rs0 && ybot >= rs1;
+         unsigned long long am = __ballot(act);
+         if (!am) continue;
+         uint32_t pos = cnt + __popcll(am & ((1ull << lane) - 1ull));
+         if (act && pos < SMR_ROWCAP)
+         {
+            int64_t q; int32_t rem;
+            smr_edge_x(p1x, p1y, dxs, D, rs0, q, rem);
+            f0[pos] = smr_cell(q, rem, D, dxs);
+            smr_edge_x(p1x, p1y, dxs, D, rs1, q, rem);
+            f1[pos] = smr_cell(q, rem, D, dxs);
+         }
+         cnt += __popcll(am);
+      }
+      SMR_WAVE_SYNC();
+      bool viol = false;
+      /* more spanning edges than the exact full-row path holds: the row is sub-sampled instead (reported) */
+      if (cnt > SMR_ROWCAP) { if (lane == 0) atomicOr(status, SMR_ST_DEGRADED); viol = true; }
+      else if ((uint32_t) lane < cnt)
+      {
+         int a0 = f0[lane], a1 = f1[lane];
+         for (uint32_t j = 0; j < cnt; j++) if (a0 < f0[j] && a1 > f1[j]) viol = true;
+      }
+      if (__ballot(viol) && lane == 0) lmask[(r - mbase) >> 5] |= 1u << (r & 31);
+      SMR_WAVE_SYNC();
+   }
+
+   /* 64 rows at a time, lane = row: every vertex-free row collects the edges of the list spanning it and checks that
+    * their order at the top of the row is their order at the bottom; rows with more than SMR_ACTCAP active edges, and
+    * windows whose list overflowed, are left to row_by_wave */
+   __device__ void window(int rb)
+   {
+      const int r = rb + lane;
+      const bool mine = r < nrows && !((lmask[(r - mbase) >> 5] >> (r & 31)) & 1u);
+      const int rs0 = (row0 + r) * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
+      int cnt = 0;
+      bool over = false;
+      const unsigned long long rows = __ballot(mine);
+      if (!rows) return;
+      /* few vertex-free rows in this batch (or no list): one wavefront pass over the candidates per row is cheaper
+       * than every lane walking the whole list */
+      if (list_n > SMR_LONGCAP || __popcll(rows) * 8 <= (int) list_n)
+      {
+         unsigned long long rm = rows;
+         while (rm)
+         {
+            int j = __ffsll((long long) rm) - 1;
+            rm &= rm - 1;
+            row_by_wave(rb + j);
+         }
+         return;
+      }
+      /* first which edges span the row (a compare per candidate), then their cells in a loop all lanes walk together:
+       * the lanes' active edges sit at different places of the list, and evaluating inside the scan would make every
+       * lane pay for every other lane's evaluations */
+      for (uint32_t i = 0; i < list_n; i++)
+      {
+         const int4 le = L->l_edge[i];
+         const int ytop = smr_to_grid_y(le.y), ybot = smr_to_grid_y(le.y + le.w);
+         if (mine && !over && ytop <= rs0 && ybot >= rs1)
+         {
+            if (cnt < SMR_ACTCAP) L->act0[lane][cnt++] = (int) i;
+            else over = true;
+         }
+      }
+      const int kmax = smr_wave_max(over ? 0 : cnt);
+      for (int k = 0; k < kmax; k++)
+         if (!over && k < cnt)
+         {
+            const int4 le = L->l_edge[L->act0[lane][k]];
+            const int32_t D = 60 * le.w;
+            const int64_t ec = 256 - 30ll * le.y;
+            const double inv = smr_rcp((double) D);
+            L->act0[lane][k] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs0);
+            L->act1[lane][k] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs1);
+         }
+      bool viol = false;
+      if (!over)
+         for (int i = 0; i < cnt; i++)
+         {
+            int a0 = L->act0[lane][i], a1 = L->act1[lane][i];
+            for (int j = 0; j < cnt; j++) if (a0 < L->act0[lane][j] && a1 > L->act1[lane][j]) viol = true;
+         }
+      if (mine && viol) atomicOr(&lmask[(r - mbase) >> 5], 1u << (r & 31));
+      unsigned long long om = __ballot(over);
+      while (om)
+      {
+         int j = __ffsll((long long) om) - 1;
+         om &= om - 1;
+         row_by_wave(rb + j);
+      }
+   }
+
+   /* the list of the edges that span a row of the window [rb, rb + 64): one pass over the primitive's edge slots.
+    * Returns false when the window has no vertex-free row (nothing to analyse). */
+   __device__ bool build_list(int rb)
+   {
+      const int r = rb + lane;
+      const bool mine = r < nrows && !((lmask[(r - mbase) >> 5] >> (r & 31)) & 1u);
+      if (!__ballot(mine)) return false;
+      const int wr0 = row0 + rb, wr1 = min(row0 + rb + 63, row0 + nrows - 1);
+      if (lane == 0) L->nlong = 0;
+      SMR_WAVE_SYNC();
+      for (uint32_t idx = lane; idx < edge_cnt; idx += 64)
+      {
+         const smr_oedge_t o = smr_orient(E[idx]);
+         if (o.dir == 0) continue;
+         const int first_full = o.ytop >= 0 ? (o.ytop + SMR_GRID_Y - 1) / SMR_GRID_Y : -((-o.ytop) / SMR_GRID_Y);
+         const int last_full = (o.ybot >= 0 ? o.ybot / SMR_GRID_Y : -((-o.ybot + SMR_GRID_Y - 1) / SMR_GRID_Y)) - 1;
+         if (first_full > last_full || first_full > wr1 || last_full < wr0) continue;
+         const uint32_t k = atomicAdd(&L->nlong, 1u);
+         if (k < SMR_LONGCAP) L->l_edge[k] = make_int4(o.p1x, o.p1y, o.dxs, o.D / 60);
+      }
+      SMR_WAVE_SYNC();
+      list_n = L->nlong;
+      return true;
+   }
+};
 
 #define SMR_MASK_BLOCK 2048u   /* words a wavefront takes from the mask arena with one atomic */
 
@@ -1035,136 +1201,23 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    }
    SMR_WAVE_SYNC();
    const uint32_t nlong = L.nlong;
-   /* one vertex-free row decided by the whole wavefront: lanes walk the candidate edges (the LDS list
-    * of row-spanning edges, or every edge slot when that list overflowed), the active ones' cells at
-    * the top and the bottom of the row go to LDS, then every pair is compared */
-   auto row_by_wave = [&](int r)
+   smr_rowscan_t RS;
+   RS.row0 = P.row0; RS.nrows = P.nrows; RS.edge_cnt = P.edge_cnt; RS.E = E; RS.L = &L; RS.lmask = lmask; RS.lane = lane;
+   RS.status = &A.small[2]; RS.list_n = nlong; RS.mbase = 0;
+   bool deferred = false;
+   if (nlong > SMR_LONGCAP && P.edge_cnt >= SMR_BIG_SLOTS && A.biglist)
    {
-      const int rs0 = (P.row0 + r) * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
-      int *f0 = &L.act0[0][0], *f1 = &L.act1[0][0];
-      uint32_t cnt = 0;
-      const uint32_t ncand = nlong <= SMR_LONGCAP ? nlong : P.edge_cnt;
-      SMR_WAVE_SYNC();
-      for (uint32_t base_i = 0; base_i < ncand; base_i += 64)
-      {
-         uint32_t idx = base_i + lane;
-         int32_t p1x = 0, p1y = 0, dxs = 0, D = 1, ytop = 0, ybot = 0;
-         bool have = false;
-         if (idx < ncand)
-         {
-            if (nlong <= SMR_LONGCAP)
-            {
-               const int4 le = L.l_edge[idx];
-               p1x = le.x; p1y = le.y; dxs = le.z; D = 60 * le.w; ytop = smr_to_grid_y(le.y); ybot = smr_to_grid_y(le.y + le.w);
-               have = true;
-            }
-            else
-            {
-               smr_oedge_t o = smr_orient(E[idx]);
-               p1x = o.p1x; p1y = o.p1y; dxs = o.dxs; D = o.D; ytop = o.ytop; ybot = o.ybot;
-               have = o.dir != 0;
-            }
-         }
-         bool act = have && ytop <= rs0 && ybot >= rs1;
-         unsigned long long am = __ballot(act);
-         if (!am) continue;
-         uint32_t pos = cnt + __popcll(am & ((1ull << lane) - 1ull));
-         if (act && pos < SMR_ROWCAP)
-         {
-            int64_t q; int32_t rem;
-            smr_edge_x(p1x, p1y, dxs, D, rs0, q, rem);
-            f0[pos] = smr_cell(q, rem, D, dxs);
-            smr_edge_x(p1x, p1y, dxs, D, rs1, q, rem);
-            f1[pos] = smr_cell(q, rem, D, dxs);
-         }
-         cnt += __popcll(am);
-      }
-      SMR_WAVE_SYNC();
-      bool viol = false;
-      /* more spanning edges than the exact full-row path holds: the row is sub-sampled instead (reported) */
-      if (cnt > SMR_ROWCAP) { if (lane == 0) atomicOr(&A.small[2], SMR_ST_DEGRADED); viol = true; }
-      else if ((uint32_t) lane < cnt)
-      {
-         int a0 = f0[lane], a1 = f1[lane];
-         for (uint32_t j = 0; j < cnt; j++) if (a0 < f0[j] && a1 > f1[j]) viol = true;
-      }
-      if (__ballot(viol) && lane == 0) lmask[r >> 5] |= 1u << (r & 31);
-      SMR_WAVE_SYNC();
-   };
-   if (nlong > SMR_LONGCAP)
+      /* a long primitive (a contour line, a coastline's border): its vertex-free rows are analysed window by window by
+       * MANY wavefronts (k_big_rows) once its vertex rows are in the arena */
+      deferred = true;
+   }
+   else if (nlong > SMR_LONGCAP)
    {
-      /* more row-spanning edges than the LDS list holds (rare: such primitives have a vertex in
-       * almost every row) */
-      for (int r = 0; r < P.nrows; r++)
-         if (!((lmask[r >> 5] >> (r & 31)) & 1u)) row_by_wave(r);
+      for (int rb = 0; rb < P.nrows; rb += 64) if (RS.build_list(rb)) { RS.window(rb); SMR_WAVE_SYNC(); }
    }
    else if (nlong > 0)
    {
-      /* lane = row: every vertex-free row collects the edges spanning it and checks that their order
-       * at the top of the row is their order at the bottom; rows with more than SMR_ACTCAP active
-       * edges are left to row_by_wave */
-      for (int rb = 0; rb < P.nrows; rb += 64)
-      {
-         const int r = rb + lane;
-         const bool mine = r < P.nrows && !((lmask[r >> 5] >> (r & 31)) & 1u);
-         const int rs0 = (P.row0 + r) * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
-         int cnt = 0;
-         bool over = false;
-         if (!__ballot(mine)) continue;
-         /* few vertex-free rows in this batch: one wavefront pass over the candidates per row is cheaper
-          * than every lane walking the whole list */
-         const unsigned long long rows = __ballot(mine);
-         if (__popcll(rows) * 8 <= (int) nlong)
-         {
-            unsigned long long rm = rows;
-            while (rm)
-            {
-               int j = __ffsll((long long) rm) - 1;
-               rm &= rm - 1;
-               row_by_wave(rb + j);
-            }
-            continue;
-         }
-         /* first which edges span the row (a compare per candidate), then their cells in a loop all lanes walk together:
-          * the lanes' active edges sit at different places of the list, and evaluating inside the scan would make every
-          * lane pay for every other lane's evaluations */
-         for (uint32_t i = 0; i < nlong; i++)
-         {
-            const int4 le = L.l_edge[i];
-            const int ytop = smr_to_grid_y(le.y), ybot = smr_to_grid_y(le.y + le.w);
-            if (mine && !over && ytop <= rs0 && ybot >= rs1)
-            {
-               if (cnt < SMR_ACTCAP) L.act0[lane][cnt++] = (int) i;
-               else over = true;
-            }
-         }
-         const int kmax = smr_wave_max(over ? 0 : cnt);
-         for (int k = 0; k < kmax; k++)
-            if (!over && k < cnt)
-            {
-               const int4 le = L.l_edge[L.act0[lane][k]];
-               const int32_t D = 60 * le.w;
-               const int64_t ec = 256 - 30ll * le.y;
-               const double inv = smr_rcp((double) D);
-               L.act0[lane][k] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs0);
-               L.act1[lane][k] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs1);
-            }
-         bool viol = false;
-         if (!over)
-            for (int i = 0; i < cnt; i++)
-            {
-               int a0 = L.act0[lane][i], a1 = L.act1[lane][i];
-               for (int j = 0; j < cnt; j++) if (a0 < L.act0[lane][j] && a1 > L.act1[lane][j]) viol = true;
-            }
-         if (mine && viol) atomicOr(&lmask[r >> 5], 1u << (r & 31));
-         unsigned long long om = __ballot(over);
-         while (om)
-         {
-            int j = __ffsll((long long) om) - 1;
-            om &= om - 1;
-            row_by_wave(rb + j);
-         }
-      }
+      for (int rb = 0; rb < P.nrows; rb += 64) RS.window(rb);
    }
    SMR_WAVE_SYNC();
    /* mask words come from a block this wavefront owns: one global atomic per SMR_MASK_BLOCK words
@@ -1189,6 +1242,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    for (uint32_t i = lane; i < nwords; i += 64) A.mask[moff + i] = lmask[i];
    P.mask_off = moff;
    if (lane == 0) A.prims[p] = P;
+   if (deferred && lane == 0) A.biglist[1 + atomicAdd(&A.biglist[0], 1u)] = (uint32_t) p;
    first_valid = min(first_valid, A.compound != 0xffffffffu ? A.compound : (uint32_t) p);
 }
 
@@ -1209,6 +1263,48 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_
       SMR_WAVE_SYNC();
    }
    if (lane == 0 && first_valid != 0xffffffffu) atomicMin(&A.small[1], first_valid);
+}
+
+/* long primitives: the windows of 64 rows of every primitive in the list are dealt round robin to persistent wavefronts;
+ * each reads the window's two mask words (vertex rows, written by k_prim_setup), builds the window's list of spanning
+ * edges with one pass over the primitive's slots and ORs the rows found crossing back into the arena */
+__global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_big_rows(const smr_prim_t *__restrict__ prims, const smr_edge_t *__restrict__ edges,
+                                                                   const uint32_t *__restrict__ biglist, uint32_t *mask, uint32_t *status)
+{
+   __shared__ setup_lds_t LL[SMR_SETUP_WAVES];
+   __shared__ uint32_t wmask[SMR_SETUP_WAVES][2];
+   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   const uint32_t gwave = blockIdx.x * SMR_SETUP_WAVES + wv, nwaves = gridDim.x * SMR_SETUP_WAVES;
+   const uint32_t nbig = biglist[0];
+   uint32_t first = 0;                                  /* windows of the primitives before this one */
+   for (uint32_t b = 0; b < nbig; b++)
+   {
+      const smr_prim_t P = prims[biglist[1 + b]];
+      const uint32_t nwin = ((uint32_t) P.nrows + 63u) >> 6;
+      /* window w of this primitive belongs to wavefront (first + w) mod nwaves */
+      uint32_t w = (gwave + nwaves - first % nwaves) % nwaves;
+      for (; w < nwin; w += nwaves)
+      {
+         const int rb = (int) (w * 64);
+         const uint32_t nw = min(2u, (((uint32_t) P.nrows + 31u) >> 5) - 2u * w);
+         if (lane < 2) wmask[wv][lane] = (uint32_t) lane < nw ? mask[P.mask_off + 2u * w + lane] : 0xffffffffu;
+         SMR_WAVE_SYNC();
+         smr_rowscan_t RS;
+         RS.row0 = P.row0; RS.nrows = P.nrows; RS.edge_cnt = P.edge_cnt; RS.E = edges + P.edge_off; RS.L = &LL[wv];
+         RS.lmask = &wmask[wv][0]; RS.mbase = rb;
+         RS.lane = lane; RS.status = status; RS.list_n = 0;
+         const uint32_t before0 = wmask[wv][0], before1 = wmask[wv][1];
+         if (RS.build_list(rb)) RS.window(rb);
+         SMR_WAVE_SYNC();
+         if (lane < (int) nw)
+         {
+            const uint32_t now = wmask[wv][lane], was = lane == 0 ? before0 : before1;
+            if (now != was) atomicOr(&mask[P.mask_off + 2u * w + lane], now);
+         }
+         SMR_WAVE_SYNC();
+      }
+      first += nwin;
+   }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -1795,36 +1891,10 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             uint32_t fullrows = 0;
 #pragma unroll
             for (int r = 0; r < SMR_TH; r++) if (!((partial >> r) & 1u) && rowcnt[r] > 0) fullrows |= 1u << r;
-            if (fullrows && pieces && (cur_flags & SMR_PF_MULTI))
-            {
-               const smr_prim_t P = A.prims[cur];
-               /* a stroke's pieces left of this tile carry winding into it and were not binned here:
-                * collect the row's active edges from the whole primitive (rare: rows free of vertices
-                * in a multi-item stroke) */
-#pragma unroll
-               for (int r = 0; r < SMR_TH; r++) rowcnt[r] = 0;
-               for (uint32_t base = 0; base < P.edge_cnt; base += 64)
-               {
-                  uint32_t idx = base + lane;
-                  smr_oedge_t o; o.dir = 0; o.ytop = 0; o.ybot = 0;
-                  if (idx < P.edge_cnt) o = smr_orient(E[P.edge_off + idx]);
-#pragma unroll
-                  for (int r = 0; r < SMR_TH; r++)
-                  {
-                     if (!((fullrows >> r) & 1u)) continue;
-                     int rs0 = ysbase + r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
-                     bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs1;
-                     unsigned long long am = __ballot(act);
-                     if (am)
-                     {
-                        uint32_t pos = rowcnt[r] + __popcll(am & lt_mask);
-                        if (act && pos < SMR_ROWCAP) L.rowlist[r][pos] = (uint32_t) (P.edge_off + idx);
-                        if (act && pos < 16) { int *re = L.redge[r][pos]; re[0] = o.p1x; re[1] = o.p1y; re[2] = o.dxs; re[3] = o.D; re[4] = o.dir; }
-                        rowcnt[r] += __popcll(am);
-                     }
-                  }
-               }
-            }
+            /* Pieces need no edges from beyond the items binned here: a piece lies wholly inside one item, and one that spans
+             * a vertex-free row has exactly its left and its right edge active in it, so the pieces of items that do not
+             * reach this tile add +1 and -1 to the winding left of it -- nothing.  (Fill chunks are binned up to the
+             * primitive's right edge for the same purpose.) */
             SMR_WAVE_SYNC();
             uint32_t nmax = 0;
 #pragma unroll
@@ -2660,6 +2730,10 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SA.prims = prims; SA.items = items; SA.mask = maskbuf; SA.mask_cap = (uint32_t) std::min<size_t>(mask_cap, 0xffffffffu);
       SA.small = small; SA.compound = compound;
       SA.K = K; SA.off_dots = off_dots; SA.po_border = po_border; SA.po_dots = po_dots; SA.po_open = po_open; SA.id_off = id_off;
+      uint32_t *biglist;
+      SMR_TRY(c->ensure(SMR_BUF_BIGLIST, ((size_t) n_prims + 2) * 4, (void **) &biglist));
+      SMR_HIP(hipMemsetAsync(biglist, 0, 4, s));
+      SA.biglist = biglist;
       if (mode == SMR_PASS_COMPOUND)
       {
          /* the compound's own row mask sits at the start of the arena; the members' words follow */
@@ -2677,6 +2751,17 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SMR_HIP(hipStreamSynchronize(s));
       if (!(h_small[2] & SMR_ST_MASK_ARENA))
       {
+         /* long primitives: their vertex-free rows window by window, on as many wavefronts as there are windows */
+         uint32_t nbig = 0;
+         SMR_HIP(hipMemcpyAsync(&nbig, biglist, 4, hipMemcpyDeviceToHost, s));
+         SMR_HIP(hipStreamSynchronize(s));
+         if (nbig)
+         {
+            k_big_rows<<<256 * 4, 64 * SMR_SETUP_WAVES, 0, s>>>(prims, edges, biglist, maskbuf, &small[2]);
+            SMR_HIP(hipGetLastError());
+            SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
+            SMR_HIP(hipStreamSynchronize(s));
+         }
          if (mode == SMR_PASS_COMPOUND)
          {
             uint32_t *covered = (uint32_t *) c->buf[SMR_BUF_COVERED].p;

@@ -52,3 +52,43 @@ def px_to_geo(p, x, y):
     lon = x * p.wc / p.w + p.lon0
     lat = np.degrees(np.arctan(np.sinh(p.lath_len * (0.5 - y / p.h) + p.lath)))
     return lat, lon
+
+
+def synth_coast(n_coast, n_islands, n_rings, W, H, seed=1234, hurst=0.75):
+    """C3-like: one fractal coastline polygon of n_coast vertices (spectral synthesis of the radius over the
+    bearing: star-shaped, so simple), n_islands small islands, n_rings depth contours nested around the coast.
+    Returns (land, rings): two (x_px, y_px, way_off, ref) sets of closed ways; land ways run counterclockwise on the chart."""
+    rng = np.random.default_rng(seed)
+    th = np.linspace(0, 2 * np.pi, n_coast, endpoint=False)
+    rad = np.ones(n_coast)
+    k = 1
+    while k < n_coast // 4:
+        rad += 0.35 * k ** (-hurst - 0.5) * np.sin(k * th + rng.uniform(0, 2 * np.pi)) * rng.uniform(0.5, 1.0)
+        k = k + 1 if k < 64 else int(k * 1.37) + 1
+    rad = np.clip(rad, 0.35, None)
+    cx, cy, R = 0.5 * W, 0.5 * H, 0.30 * min(W, H)
+    ways = [(cx + R * rad * np.cos(-th), cy + R * rad * np.sin(-th))]          # y points down: -th runs counterclockwise on the chart
+    for _ in range(n_islands):
+        n = int(rng.integers(8, 64))
+        r = np.exp(rng.uniform(np.log(5.0), np.log(80.0))) * rng.uniform(0.7, 1.0, n)
+        a = rng.uniform(0, 2 * np.pi) - 2 * np.pi * np.arange(n) / n
+        ix, iy = rng.uniform(0, W), rng.uniform(0, H)
+        ways.append((ix + r * np.cos(a), iy + r * np.sin(a)))
+    rings = []
+    for j in range(n_rings):
+        sc = 1.03 + 0.5 * (j + 1) / max(n_rings, 1)
+        step = max(1, n_coast // max(2000, n_coast // (4 + j)))
+        rings.append((cx + sc * R * rad[::step] * np.cos(-th[::step]), cy + sc * R * rad[::step] * np.sin(-th[::step])))
+
+    def pack(ws):
+        xs, ys, off, ref, base = [], [], [0], [], 0
+        for wx, wy in ws:
+            n = len(wx)
+            xs.append(wx); ys.append(wy)
+            ref.append(np.concatenate([np.arange(base, base + n), [base]]))
+            base += n
+            off.append(off[-1] + n + 1)
+        if not ws:
+            return np.zeros(0), np.zeros(0), np.zeros(1, np.int64), np.zeros(0, np.int32)
+        return np.concatenate(xs), np.concatenate(ys), np.array(off, np.int64), np.concatenate(ref).astype(np.int32)
+    return pack(ways), pack(rings)

@@ -175,6 +175,30 @@ def test_curve_refusals(hip):
     cv.close()
 
 
+@pytest.mark.parametrize("case", ["stroke", "curve_stroke", "fill_border", "zigzag"])
+def test_long_primitives_bit_exact(hip, case):
+    """ways of thousands of nodes (contour lines, coastlines): their vertex-free rows are analysed window by window by
+    k_big_rows, and a stroke's full rows are built from the items binned to the tile alone"""
+    from smrender_amd import synth
+    W, H = 1024, 1024
+    land, rings = synth.synth_coast(6000, 0, 2, W, H, seed=5)
+    if case == "stroke":
+        rules = [(po.Style(0, 1, 0, 0x204060, 0, 0.25, 0), rings)]
+    elif case == "curve_stroke":
+        rules = [(po.Style(0, 1, 0, 0x204060, 0, 0.25, 0).with_curve(), rings)]
+    elif case == "fill_border":
+        rules = [(po.Style(1, 1, 0xf0e0a0, 0x000000, 0, 0.1, 0), land)]
+    else:
+        # long steep segments, 3 px wide, across several tile columns: vertex-free rows in a stroke of many items
+        n = 24          # 46 edges span the middle rows: under the 64 the exact whole-row path keeps (beyond: sub-sampled + reported)
+        x = 100.0 + 20.0 * np.arange(n) + np.where(np.arange(n) % 2, 7.3, 0.0)
+        y = np.where(np.arange(n) % 2, 900.4, 80.7) + 3.1 * np.arange(n)
+        rules = [(po.Style(0, 1, 0, 0x000000, 0, 0.254, 0), (x, y, np.array([0, n], np.int64), np.arange(n, dtype=np.int32)))]
+    g = gpu_scene(hip, rules, 300, W, H, 0xffffff)
+    o = oracle_of(rules, 300, W, H, 0xffffff)
+    assert np.array_equal(g, o), report(g, o)
+
+
 def test_bands_stitch_to_full_canvas(hip):
     """multi-GPU layout: each rank owns a band of rows; bands must stitch bit-identically"""
     arrs = po.synth_ways(150, 320, 301, seed=21)
