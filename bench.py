@@ -101,6 +101,49 @@ def cpu_baseline(args):
     return out
 
 
+def other_charts(args):
+    """Outside the timed region, N=1 only: the two other single-GPU charts BASELINE.json names, each timed over 3 draws
+    after one warm-up.  (a) north_star's target: 1 M ways / 10 M nodes on a 32768^2 canvas; (b) C3-like: a fractal
+    coastline of 200 k vertices + 5 000 islands as ONE directional curve=1 fill, 50 depth contours as curve=1 borders,
+    A0 at 600 dpi (19866 x 28087 px)."""
+    out = {}
+
+    def timed(cv, rules):
+        ms = []
+        for it in range(4):
+            cv.clear(); sa.sync()
+            t0 = time.perf_counter()
+            for st, (dx, dy, doff, dref, nw, nr) in rules:
+                cv.draw(st, dx, dy, doff, dref, nw, nr)
+            sa.sync()
+            ms.append((time.perf_counter() - t0) * 1e3)
+        return float(np.mean(ms[1:]))
+
+    def dev(arrs):
+        x, y, off, ref = arrs
+        return (sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off.astype(np.int64)),
+                sa.DeviceArray.from_numpy(ref.astype(np.int32)), len(off) - 1, len(ref))
+
+    S = 32768
+    arrs = synth.synth_ways(1000000, S, S, seed=4242, mean_nodes=10)
+    cv = sa.Canvas(S, S, 300, 0xffffff)
+    ms = timed(cv, [(sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0, 0, 0, 0, 0, 0), dev(arrs))])
+    cv.close()
+    out["target_32k"] = {"workload": f"1000000 closed ways / {len(arrs[0])} nodes, fill + 2 px border, {S}x{S} px @ 300 dpi (draw only, nodes projected)",
+                         "ms": round(ms, 2), "Mpx_per_s": round(S * S / 1e6 / (ms * 1e-3), 1)}
+    W, H = 19866, 28087
+    land, rings = synth.synth_coast(200000, 5000, 50, W, H, seed=1234)
+    cv = sa.Canvas(W, H, 600, 0xc0d8f0)
+    st_land = sa.DrawStyle(1, 0, 0xf0e0a0, 0, 0.0, 0.0, 0, 0, 0, 0, 1, 0).set_curve(0.2)
+    st_ring = sa.DrawStyle(0, 1, 0, 0x4060a0, 0.0, 0.15, 0, 0, 0, 0, 0, 0).set_curve(0.2)
+    ms = timed(cv, [(st_land, dev(land)), (st_ring, dev(rings))])
+    cv.close()
+    out["c3_coast"] = {"workload": f"coastline 200000 vertices + 5000 islands (directional=1;curve=1 fill), 50 depth contours "
+                                   f"({len(rings[3])} refs, curve=1 borders 0.15 mm), {W}x{H} px @ 600 dpi (draw only)",
+                       "ms": round(ms, 2), "Mpx_per_s": round(W * H / 1e6 / (ms * 1e-3), 1)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +155,7 @@ def main():
     ap.add_argument("--captions", type=int, default=20000, help="C4 captions scanned after the timed region (0 = skip)")
     ap.add_argument("--cpu-window", type=int, default=3072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-charts", action="store_true", help="skip the 32k target and the C3-like chart (reported outside the timed region)")
     args = ap.parse_args()
 
     from smrender_amd import dist as smrdist
@@ -222,6 +266,9 @@ def main():
             res["roofline_proj"]["frac"] = round(res["roofline_proj"]["achieved"] * 1e9 / HBM_PEAK, 4)
         if cap is not None:
             res["caption_scan"] = cap
+        if world == 1 and not args.no_other_charts:
+            cv.close()
+            res["other_charts"] = other_charts(args)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(res), flush=True)
