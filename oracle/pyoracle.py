@@ -171,10 +171,14 @@ def tor_coverage(edges, W, H, x0=0, y0=0, nonzero=1):
     return out
 
 
-def oracle_scene(rules, dpi, W, H, bg, x0=0, y0=0):
-    """rules: list of (Style, [(x_px, y_px, closed), ...]).  Returns premultiplied ARGB32 (H,W)."""
+def oracle_scene(rules, dpi, W, H, bg, x0=0, y0=0, image=None):
+    """rules: list of (Style, [(x_px, y_px, closed), ...]).  Returns premultiplied ARGB32 (H,W).
+    image = (x0, y0, x1, y1): the rectangle of the image libcairo would render into when the canvas is only a window of
+    it (curve limits, oracle/curve.c); default: the window itself."""
     L = orc()
     c = L.orc_canvas_new(x0, y0, W, H, dpi, bg)
+    if image is not None:
+        L.orc_canvas_set_image(c, *image)
     for st, ways in rules:
         L.orc_rule_begin(c)
         for way in ways:

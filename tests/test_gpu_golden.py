@@ -60,3 +60,40 @@ def test_full_size_c2_windows_vs_oracle(hip):
             sa.DeviceArray.from_numpy(ref), len(off) - 1, len(ref))
     assert np.array_equal(cv.read(4000, 4000, 512, 512), first)
     cv.close()
+
+
+def test_full_size_c3_windows_vs_oracle(hip):
+    """BASELINE config 3 at full size (A0 at 600 dpi, 19866 x 28087 px): a fractal coastline of 200 k vertices + 5 000 islands
+    as ONE directional curve=1 fill, 50 depth contours of ~10 k nodes as curve=1 borders.  Windows on the coast must equal
+    the oracle's render of the whole ways clipped to the window (curve limits = the full chart)."""
+    sa = hip
+    W, H, dpi = 19866, 28087, 600
+    land, rings = synth.synth_coast(200000, 5000, 50, W, H, seed=1234)
+    st_land = po.Style(1, 0, 0xf0e0a0, 0, 0, 0, 0).with_curve()
+    st_ring = po.Style(0, 1, 0, 0x4060a0, 0, 0.15, 0).with_curve()
+    from golden_io import draw_style
+
+    def draw(cv, st, arrs, **kw):
+        x, y, off, ref = arrs
+        cv.draw(draw_style(sa, st, **kw), sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y),
+                sa.DeviceArray.from_numpy(off.astype(np.int64)), sa.DeviceArray.from_numpy(ref.astype(np.int32)), len(off) - 1, len(ref))
+    S = 160
+    wins = [(int(land[0][k]) - S // 2, int(land[1][k]) - S // 2) for k in (0, 50000, 123456)]
+    cv = sa.Canvas(W, H, dpi, 0xc0d8f0)
+    draw(cv, st_land, land, directional=1)
+    got_land = [cv.read(wx, wy, S, S) for wx, wy in wins]
+    cv.clear()
+    draw(cv, st_ring, rings)
+    rwins = [(int(rings[0][k]) - S // 2, int(rings[1][k]) - S // 2) for k in (10, 7000, 33333)]
+    got_ring = [cv.read(wx, wy, S, S) for wx, wy in rwins]
+    assert sa.lib().smr_hip_draw_status() == 0
+    cv.close()
+    lways, rways = po.ways_from_arrays(*land), po.ways_from_arrays(*rings)
+    for (wx, wy), g in zip(wins, got_land):
+        o = po.oracle_directional(st_land, lways, dpi, S, S, 0xc0d8f0, wx, wy, image=(0, 0, W, H))
+        assert np.array_equal(g, o), (wx, wy, int((g != o).sum()))
+        assert len(np.unique(g)) > 2          # the window does sit on the coast
+    for (wx, wy), g in zip(rwins, got_ring):
+        o = po.oracle_scene([(st_ring, rways)], dpi, S, S, 0xc0d8f0, wx, wy, image=(0, 0, W, H))
+        assert np.array_equal(g, o), (wx, wy, int((g != o).sum()))
+        assert len(np.unique(g)) > 2
