@@ -1254,7 +1254,7 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_
 {
    extern __shared__ uint32_t lmask_all[];         /* [SMR_SETUP_WAVES][mask_words] */
    __shared__ setup_lds_t LL[SMR_SETUP_WAVES];
-   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      /* uniform: keeps the loop control in SGPRs */
    const int64_t gwave = (int64_t) blockIdx.x * SMR_SETUP_WAVES + wv, nwaves = (int64_t) gridDim.x * SMR_SETUP_WAVES;
    uint32_t arena_pos = 0, arena_left = 0, first_valid = 0xffffffffu;
    for (int64_t p = gwave; p < (int64_t) A.K * A.n_ways; p += nwaves)
@@ -1273,7 +1273,7 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_big_rows(const smr_pri
 {
    __shared__ setup_lds_t LL[SMR_SETUP_WAVES];
    __shared__ uint32_t wmask[SMR_SETUP_WAVES][2];
-   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      /* uniform: keeps the loop control in SGPRs */
    const uint32_t gwave = blockIdx.x * SMR_SETUP_WAVES + wv, nwaves = gridDim.x * SMR_SETUP_WAVES;
    const uint32_t nbig = biglist[0];
    uint32_t first = 0;                                  /* windows of the primitives before this one */
@@ -1720,7 +1720,10 @@ __attribute__((amdgpu_waves_per_eu(SMR_RASTER_WPE, SMR_RASTER_WPE)))
 __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t A)
 {
    __shared__ raster_lds_t LL[SMR_RASTER_WAVES];
-   raster_lds_t &L = LL[threadIdx.x >> 6];
+   /* the wavefront's index is uniform, but the compiler cannot know: without readfirstlane every value derived from it
+    * (tile, work-stream position, primitive state, all loop control) lives in VGPRs and branches through exec masks */
+   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   raster_lds_t &L = LL[wave];
    const int lane = threadIdx.x & 63;
    const unsigned long long lt_mask = (1ull << lane) - 1ull;
    const int my_row = lane / SMR_GRID_Y;               /* sub-row lane -> pixel row (lanes 60..63 idle) */
@@ -1741,7 +1744,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
     * vertically adjacent tiles at the same time, and an item's 1 KB of edge slots, needed by every tile
     * the item spans, comes from HBM once and from that L2 afterwards */
    const uint32_t xcd = blockIdx.x & 7u;
-   const uint32_t jw = (blockIdx.x >> 3) * SMR_RASTER_WAVES + (threadIdx.x >> 6), nwx = (gridDim.x >> 3) * SMR_RASTER_WAVES;
+   const uint32_t jw = (blockIdx.x >> 3) * SMR_RASTER_WAVES + wave, nwx = (gridDim.x >> 3) * SMR_RASTER_WAVES;
    const uint32_t TYt = A.n_tiles / A.TX;
    const uint32_t ncol = ((uint32_t) A.TX + 7u - xcd) >> 3;
    for (uint32_t kg = jw; kg < ncol * TYt; kg += nwx)
@@ -2148,6 +2151,13 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                const int e_t0 = o.dir == 0 ? 64 : min(max(o.ytop - ysbase, 0), 64), e_t1 = o.dir == 0 ? 0 : min(max(o.ybot - ysbase, 0), 64);
                const int e_win = e_t0 | (e_t1 << 8) | ((o.dir > 0 ? 1 : 0) << 16);
                const int e_rcpf = __float_as_int((float) e_inv);
+               /* the 32-bit path's form of the same edge: with ys = ysbase + lane the numerator of the ROUNDED cell,
+                * dxs2 * (512 * ys + c) + D / 2, is e_A * lane + e_B (wrapping arithmetic: the true values are small whenever
+                * the piece meets the strip); window and D share one word: first sub-row (6 bits), sub-rows (7), D (18) */
+               const int e_c32 = (int) ((uint32_t) ysbase * 512u + 256u - 30u * (uint32_t) o.p1y);
+               const int e_A = o.dxs * 1024;
+               const int e_B = (int) ((uint32_t) e_dxs2 * (uint32_t) e_c32 + (uint32_t) (o.D >> 1));
+               const int e_W = e_t0 < e_t1 ? (e_t0 | ((e_t1 - e_t0) << 6) | (o.D << 13)) : (o.D << 13);
                /* a piece takes the 32-bit path when each of its edges is empty or short in x and y */
                int e_small = (o.dir == 0 || (abs(o.dxs) < 4096 && o.D <= 60 * 4096)) ? 1 : 0;
                e_small &= __shfl_xor(e_small, 1); e_small &= __shfl_xor(e_small, 2);      /* no short-circuit: every lane shuffles */
@@ -2187,21 +2197,20 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                      int32_t lo = INT32_MAX, hi = INT32_MIN;
                      if ((smallmask >> j) & 1ull)
                      {
-                        /* all four edges are short (|dx|, dy < 16 px): the numerator fits 32 bits, the quotient
-                         * 13, so 24-bit multiplies and one fp32 estimate give the exact floor; branch-free */
+                        /* all four edges are short (|dx|, dy < 16 px): the numerator fits 32 bits, the quotient 13, so 24-bit
+                         * multiplies and one fp32 estimate (within 1 of the floor on either side, corrected through the exact
+                         * remainder) give floor((n + D/2) / D) = the rounded cell; branch-free */
 #pragma unroll
                         for (int k = 0; k < 4; k++)
                         {
                            const int jj = j + k;
-                           const int win = __builtin_amdgcn_readlane(e_win, jj);
-                           const int D = __builtin_amdgcn_readlane(o.D, jj);
-                           const int t = my_ys * 512 + __builtin_amdgcn_readlane(e_clo, jj);
-                           const int n = __mul24(__builtin_amdgcn_readlane(e_dxs2, jj), t);
-                           int q = (int) floorf((float) n * __int_as_float(__builtin_amdgcn_readlane(e_rcpf, jj)));
-                           int rem = n - __mul24(q, D);
-                           if (rem < 0) { q--; rem += D; } else if (rem >= D) { q++; rem -= D; }
-                           const int cell = __builtin_amdgcn_readlane(o.p1x, jj) + q + (rem >= (D >> 1) ? 1 : 0);
-                           const bool in = lane >= (win & 0xff) && lane < ((win >> 8) & 0xff);
+                           const uint32_t Wd = (uint32_t) __builtin_amdgcn_readlane(e_W, jj);
+                           const int D = (int) (Wd >> 13);
+                           const int n = __mul24(__builtin_amdgcn_readlane(e_A, jj), lane) + __builtin_amdgcn_readlane(e_B, jj);
+                           const int q = (int) fmaf((float) n, __int_as_float(__builtin_amdgcn_readlane(e_rcpf, jj)), -0.5f);
+                           const int rem = __mul24(q, -D) + n;
+                           const int cell = __builtin_amdgcn_readlane(o.p1x, jj) + q + (rem >= D ? 1 : 0) + (rem >> 31);
+                           const bool in = (uint32_t) (lane - (int) (Wd & 63u)) < ((Wd >> 6) & 127u);
                            lo = in ? min(lo, cell) : lo; hi = in ? max(hi, cell) : hi;
                         }
                      }
