@@ -1247,6 +1247,9 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
 }
 
 #define SMR_SETUP_WAVES 4
+#ifndef SMR_SETUP_CHUNK
+#define SMR_SETUP_CHUNK 16      /* primitives a wavefront takes from its XCD's queue with one atomic */
+#endif
 
 /* persistent wavefronts, each sets up primitive gwave, gwave + nwaves, ... (2 M one-wave workgroups
  * would be bound by the workgroup dispatch rate, not by the work) */
@@ -1255,12 +1258,24 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_
    extern __shared__ uint32_t lmask_all[];         /* [SMR_SETUP_WAVES][mask_words] */
    __shared__ setup_lds_t LL[SMR_SETUP_WAVES];
    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      /* uniform: keeps the loop control in SGPRs */
-   const int64_t gwave = (int64_t) blockIdx.x * SMR_SETUP_WAVES + wv, nwaves = (int64_t) gridDim.x * SMR_SETUP_WAVES;
    uint32_t arena_pos = 0, arena_left = 0, first_valid = 0xffffffffu;
-   for (int64_t p = gwave; p < (int64_t) A.K * A.n_ways; p += nwaves)
+   /* XCD x takes the x-th eighth of the primitives (workgroups b and b+8 share an XCD), SMR_SETUP_CHUNK consecutive ones per
+    * atomic: borders cost several times what fills do, and a static share leaves most wavefronts waiting for the slowest */
+   const int64_t nprim = (int64_t) A.K * A.n_ways, per = (nprim + 7) >> 3;
+   const int64_t xcd = blockIdx.x & 7u, pend = min(nprim, (xcd + 1) * per);
+   uint32_t *const ctr = A.small + 128 + 8 * xcd;
+   for (;;)
    {
-      smr_prim_setup_one(A, p, lane, LL[wv], lmask_all + (size_t) wv * mask_words, arena_pos, arena_left, first_valid);
-      SMR_WAVE_SYNC();
+      uint32_t k = 0;
+      if (lane == 0) k = atomicAdd(ctr, (uint32_t) SMR_SETUP_CHUNK);
+      const int64_t p0 = xcd * per + (int64_t) (uint32_t) __builtin_amdgcn_readfirstlane(k);
+      if (p0 >= pend) break;
+      const int64_t p1 = min(p0 + SMR_SETUP_CHUNK, pend);
+      for (int64_t p = p0; p < p1; p++)
+      {
+         smr_prim_setup_one(A, p, lane, LL[wv], lmask_all + (size_t) wv * mask_words, arena_pos, arena_left, first_valid);
+         SMR_WAVE_SYNC();
+      }
    }
    if (lane == 0 && first_valid != 0xffffffffu) atomicMin(&A.small[1], first_valid);
 }
@@ -1609,6 +1624,7 @@ struct raster_args_t
    const uint32_t *tile_off;
    uint32_t *canvas;          /* band pixels, stride W */
    uint32_t *status;
+   uint32_t *tile_ctr;        /* [8 * xcd]: next tile of the XCD's columns, zero at launch */
    int W, band_y0, band_h, TX;
    uint32_t n_tiles;
    int direct;                /* no group layer: primitives composite straight onto the canvas */
@@ -1702,6 +1718,9 @@ __device__ void smr_render_edge(raster_lds_t &L, int row, int32_t X0, int32_t dx
 }
 
 #define SMR_RASTER_WAVES 4      /* independent wavefronts per workgroup, one tile at a time each */
+#ifndef SMR_TILE_CHUNK
+#define SMR_TILE_CHUNK 2        /* tiles a wavefront takes from its XCD's queue with one atomic */
+#endif
 
 /* -DSMR_SECTION_PROFILE: s_memtime stamps around the sections of k_raster, summed per section into
  * status[14..] (diagnostic build only; the stamps cost ~10 % and no output depends on them) */
@@ -1744,10 +1763,20 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
     * vertically adjacent tiles at the same time, and an item's 1 KB of edge slots, needed by every tile
     * the item spans, comes from HBM once and from that L2 afterwards */
    const uint32_t xcd = blockIdx.x & 7u;
-   const uint32_t jw = (blockIdx.x >> 3) * SMR_RASTER_WAVES + wave, nwx = (gridDim.x >> 3) * SMR_RASTER_WAVES;
    const uint32_t TYt = A.n_tiles / A.TX;
    const uint32_t ncol = ((uint32_t) A.TX + 7u - xcd) >> 3;
-   for (uint32_t kg = jw; kg < ncol * TYt; kg += nwx)
+   /* ... and the tiles of an XCD's columns are handed out dynamically, SMR_TILE_CHUNK vertically adjacent ones at a time:
+    * a chart's load per tile varies, and a static share leaves wavefronts idle at the end of the launch */
+   const uint32_t ktotal = ncol * TYt;
+   uint32_t *const ctr = A.tile_ctr + 8u * xcd;
+   for (;;)
+   {
+   uint32_t k0 = 0;
+   if (lane == 0) k0 = atomicAdd(ctr, (uint32_t) SMR_TILE_CHUNK);
+   k0 = __builtin_amdgcn_readfirstlane(k0);
+   if (k0 >= ktotal) break;
+   const uint32_t k1 = min(k0 + (uint32_t) SMR_TILE_CHUNK, ktotal);
+   for (uint32_t kg = k0; kg < k1; kg++)
    {
       const int tx = (int) (xcd + 8u * (kg / TYt)), ty = (int) (kg % TYt);
       const uint32_t tile = (uint32_t) ty * A.TX + tx;
@@ -2145,12 +2174,18 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                const int64_t e_c = 256 - 30ll * o.p1y;
                const int e_clo = (int) (uint32_t) e_c, e_chi = (int) (e_c >> 32);
                const int e_dxs2 = 2 * o.dxs;
-               const double e_inv = smr_rcp((double) o.D);
+               /* 1/D for the quotient estimates: short edges (nearly all of a chart of small polygons) need it in fp32 only */
+               int e_small = (o.dir == 0 || (abs(o.dxs) < 4096 && o.D <= 60 * 4096)) ? 1 : 0;
+               const unsigned long long smalledge = __ballot(e_small != 0);               /* fills: edge by edge */
+               double e_inv = 0.0;
+               float e_invf;
+               if (~smalledge) { e_inv = smr_rcp((double) o.D); e_invf = (float) e_inv; }
+               else e_invf = __builtin_amdgcn_rcpf((float) o.D);
                const int e_ilo = (int) (uint32_t) __double_as_longlong(e_inv), e_ihi = (int) (__double_as_longlong(e_inv) >> 32);
                /* sub-row window of the edge relative to the tile, [0, 60]; empty for empty slots */
                const int e_t0 = o.dir == 0 ? 64 : min(max(o.ytop - ysbase, 0), 64), e_t1 = o.dir == 0 ? 0 : min(max(o.ybot - ysbase, 0), 64);
                const int e_win = e_t0 | (e_t1 << 8) | ((o.dir > 0 ? 1 : 0) << 16);
-               const int e_rcpf = __float_as_int((float) e_inv);
+               const int e_rcpf = __float_as_int(e_invf);
                /* the 32-bit path's form of the same edge: with ys = ysbase + lane the numerator of the ROUNDED cell,
                 * dxs2 * (512 * ys + c) + D / 2, is e_A * lane + e_B (wrapping arithmetic: the true values are small whenever
                 * the piece meets the strip); window and D share one word: first sub-row (6 bits), sub-rows (7), D (18) */
@@ -2159,9 +2194,8 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                const int e_B = (int) ((uint32_t) e_dxs2 * (uint32_t) e_c32 + (uint32_t) (o.D >> 1));
                const int e_W = e_t0 < e_t1 ? (e_t0 | ((e_t1 - e_t0) << 6) | (o.D << 13)) : (o.D << 13);
                /* a piece takes the 32-bit path when each of its edges is empty or short in x and y */
-               int e_small = (o.dir == 0 || (abs(o.dxs) < 4096 && o.D <= 60 * 4096)) ? 1 : 0;
                e_small &= __shfl_xor(e_small, 1); e_small &= __shfl_xor(e_small, 2);      /* no short-circuit: every lane shuffles */
-               const unsigned long long smallmask = pieces ? __ballot(e_small != 0) : 0ull;
+               const unsigned long long smallmask = pieces ? __ballot(e_small != 0) : smalledge;
                TICK(5);   /* per-edge constants */
                while (om)
                {
@@ -2174,6 +2208,25 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                      {
                         /* the edge lies left of the tile: every crossing is, so only its winding counts */
                         if (mine && lane >= (win & 0xff) && lane < ((win >> 8) & 0xff)) lw += (win >> 16) ? 1 : -1;
+                     }
+                     else if ((smallmask >> j) & 1ull)
+                     {
+                        /* a short edge: the 32-bit evaluation of the piece path below */
+                        const uint32_t Wd = (uint32_t) __builtin_amdgcn_readlane(e_W, j);
+                        const int D = (int) (Wd >> 13);
+                        const int n = __mul24(__builtin_amdgcn_readlane(e_A, j), lane) + __builtin_amdgcn_readlane(e_B, j);
+                        const int q = (int) fmaf((float) n, __int_as_float(__builtin_amdgcn_readlane(e_rcpf, j)), -0.5f);
+                        const int rem = __mul24(q, -D) + n;
+                        const int cell = __builtin_amdgcn_readlane(o.p1x, j) + q + (rem >= D ? 1 : 0) + (rem >> 31);
+                        if (mine && (uint32_t) (lane - (int) (Wd & 63u)) < ((Wd >> 6) & 127u))
+                        {
+                           if (cell < X0) lw += (win >> 16) ? 1 : -1;
+                           else if (cell < X1)
+                           {
+                              if (cnt < SMR_BK) bk[cnt++] = (uint16_t) (((cell - X0) << 1) | (win >> 16));
+                              else ovf = true;
+                           }
+                        }
                      }
                      else if (mine && lane >= (win & 0xff) && lane < ((win >> 8) & 0xff))
                      {
@@ -2263,6 +2316,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
          }
       }
       TICK(8);            /* layer OVER canvas */
+   }
    }
 #ifdef SMR_SECTION_PROFILE
    if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd((unsigned long long *) (A.status + 14) + i, prof[i]);
@@ -2523,15 +2577,13 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    SMR_TRY(c->ensure(SMR_BUF_PTS, (size_t) n_refs * sizeof(int2), (void **) &pts));
    SMR_TRY(c->ensure(SMR_BUF_REFWAY, (size_t) n_refs * 4, (void **) &refway));
    SMR_TRY(c->ensure(SMR_BUF_WAYFLAGS, (size_t) n_ways, (void **) &wayflags));
-   SMR_TRY(c->ensure(SMR_BUF_SMALL, 512, (void **) &small));     /* [0] any_open_fill [1] first_prim [2] status [3] entries [4] mask words */
+   SMR_TRY(c->ensure(SMR_BUF_SMALL, 1024, (void **) &small));     /* [0] any_open_fill [1] first_prim [2] status [3] entries [4] mask words */
    SMR_TRY(c->ensure(SMR_BUF_PRIMS, ((size_t) n_prims + 1) * sizeof(smr_prim_t), (void **) &prims));
    const uint32_t compound = mode == SMR_PASS_COMPOUND ? (uint32_t) n_prims : 0xffffffffu;
    const uint32_t cwords = mode == SMR_PASS_COMPOUND ? (uint32_t) (c->H + 31) / 32 + 1 : 0;
    SMR_TRY(c->ensure(SMR_BUF_ITEMS, (size_t) n_items * sizeof(smr_item_t), (void **) &items));
    uint32_t init_small[8] = { 0, 0xffffffffu, 0, 0, 0, 0xffffffffu, 0, 0 };     /* [5] first stroked way, [6] scan totals */
-#ifdef SMR_SECTION_PROFILE
-   SMR_HIP(hipMemsetAsync(small, 0, 512, s));
-#endif
+   SMR_HIP(hipMemsetAsync(small, 0, 1024, s));                  /* [64 + 8 * xcd]: k_raster's tile queues, [128 + 8 * xcd]: k_prim_setup's */
    SMR_HIP(hipMemcpyAsync(small, init_small, sizeof(init_small), hipMemcpyHostToDevice, s));
 
    const int TB = 256;
@@ -2722,7 +2774,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
 
    /* primitive set-up (items, boxes, row masks); the mask arena grows on demand */
    uint32_t *maskbuf;
-   const unsigned setup_wg = (unsigned) std::min<int64_t>((n_prims + SMR_SETUP_WAVES - 1) / SMR_SETUP_WAVES, 256 * 6);
+   /* a multiple of 8, and at least 8: every XCD's share of the primitives needs a workgroup (k_prim_setup) */
+   const unsigned setup_wg = ((unsigned) std::min<int64_t>((n_prims + SMR_SETUP_WAVES - 1) / SMR_SETUP_WAVES, 256 * 6) + 7u) & ~7u;
    size_t mask_cap = c->buf[SMR_BUF_MASK].cap / 4;
    {
       size_t want = (size_t) n_prims * 2 + (size_t) setup_wg * SMR_SETUP_WAVES * SMR_MASK_BLOCK + 65536 + cwords;
@@ -2754,6 +2807,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          k_compound_init<<<1, 1, 0, s>>>(prims, compound, off_fill, (uint32_t) n_refs, host_color_pixel(st->fill_col), c->H);
       }
       int mask_words = (c->H + 31) / 32 + 1;
+      SMR_HIP(hipMemsetAsync(small + 128, 0, 256, s));           /* the set-up's queues start at zero on every attempt */
       k_prim_setup<<<setup_wg, 64 * SMR_SETUP_WAVES, (size_t) mask_words * 4 * SMR_SETUP_WAVES, s>>>(SA, mask_words);
       SMR_HIP(hipGetLastError());
       SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
@@ -2822,6 +2876,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
 
    raster_args_t A;
    A.prims = prims; A.hdrs = hdrs; A.edges = edges; A.tile_off = tile_off;
+   A.tile_ctr = &small[64];       /* zero since the memset at the top of the pass */
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
    A.direct = st->direct != 0;

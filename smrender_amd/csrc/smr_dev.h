@@ -214,28 +214,45 @@ __device__ __forceinline__ uint32_t smr_mul7f(uint32_t a, uint32_t b) { uint32_t
 __device__ __forceinline__ uint32_t smr_mul80(uint32_t a, uint32_t b) { uint32_t t = a * b + 0x80; return (t + (t >> 8)) >> 8; }
 __device__ __forceinline__ uint32_t smr_sat(uint32_t v) { return v > 255u ? 255u : v; }
 
-/* two 8-bit channels per 32-bit word (0x00XX00YY), as pixman's UN8x4 macros do it: the per-channel results are the ones of
- * smr_mul7f / smr_mul80 / smr_sat bit for bit (checked exhaustively per channel on the host) */
+/* two 8-bit channels per 32-bit word (0x00XX00YY) in the packed 16-bit VALU (v_pk_mad_u16, v_pk_lshrrev_b16, v_pk_add_u16,
+ * v_pk_min_u16): every intermediate of pixman's MUL_UN8 / ADD_UN8 stays below 2^16, so the two halves never meet and the
+ * per-channel results are the ones of smr_mul7f / smr_mul80 / smr_sat bit for bit */
 #define SMR_RB 0x00ff00ffu
-__device__ __forceinline__ uint32_t smr_pk_mul(uint32_t x, uint32_t a, uint32_t half) { uint32_t t = x * a + half; return ((t + ((t >> 8) & SMR_RB)) >> 8) & SMR_RB; }
-__device__ __forceinline__ uint32_t smr_pk_addsat(uint32_t x, uint32_t y) { uint32_t t = x + y; t |= 0x01000100u - ((t >> 8) & SMR_RB); return t & SMR_RB; }
+typedef unsigned short smr_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ smr_u16x2 smr_pk(uint32_t x) { return __builtin_bit_cast(smr_u16x2, x); }
+__device__ __forceinline__ uint32_t smr_unpk(smr_u16x2 x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ smr_u16x2 smr_pk_mul(smr_u16x2 x, smr_u16x2 a, unsigned short half)
+{
+   smr_u16x2 t = x * a + (smr_u16x2) (half);
+   t = t + (t >> 8);
+   return t >> 8;
+}
+__device__ __forceinline__ smr_u16x2 smr_pk_addsat(smr_u16x2 x, smr_u16x2 y) { return __builtin_elementwise_min((smr_u16x2) (x + y), (smr_u16x2) (255)); }
+__device__ __forceinline__ smr_u16x2 smr_pk_rb(uint32_t p) { return smr_pk(p & SMR_RB); }
+__device__ __forceinline__ smr_u16x2 smr_pk_ag(uint32_t p) { return smr_pk(p) >> 8; }
+__device__ __forceinline__ uint32_t smr_pk_join(smr_u16x2 rb, smr_u16x2 ag) { return smr_unpk(rb) | (smr_unpk(ag) << 8); }
 
 __device__ __forceinline__ uint32_t smr_blend_lerp(uint32_t s, uint32_t a, uint32_t d)
 {
    if (a == 255u) return s;
-   const uint32_t ia = 255u - a;
-   const uint32_t rb = smr_pk_addsat(smr_pk_mul(s & SMR_RB, a, 0x007f007fu), smr_pk_mul(d & SMR_RB, ia, 0x007f007fu));
-   const uint32_t ag = smr_pk_addsat(smr_pk_mul((s >> 8) & SMR_RB, a, 0x007f007fu), smr_pk_mul((d >> 8) & SMR_RB, ia, 0x007f007fu));
-   return rb | (ag << 8);
+   const smr_u16x2 a2 = smr_pk(a * 0x10001u), ia2 = smr_pk(SMR_RB - a * 0x10001u);
+   const smr_u16x2 rb = smr_pk_addsat(smr_pk_mul(smr_pk_rb(s), a2, 0x7f), smr_pk_mul(smr_pk_rb(d), ia2, 0x7f));
+   const smr_u16x2 ag = smr_pk_addsat(smr_pk_mul(smr_pk_ag(s), a2, 0x7f), smr_pk_mul(smr_pk_ag(d), ia2, 0x7f));
+   return smr_pk_join(rb, ag);
 }
 
 __device__ __forceinline__ uint32_t smr_blend_over_mask(uint32_t s, uint32_t m, uint32_t d)
 {
-   if (m != 255u) s = smr_pk_mul(s & SMR_RB, m, 0x00800080u) | (smr_pk_mul((s >> 8) & SMR_RB, m, 0x00800080u) << 8);
-   const uint32_t ia = 255u - (s >> 24);
-   const uint32_t rb = smr_pk_addsat(s & SMR_RB, smr_pk_mul(d & SMR_RB, ia, 0x00800080u));
-   const uint32_t ag = smr_pk_addsat((s >> 8) & SMR_RB, smr_pk_mul((d >> 8) & SMR_RB, ia, 0x00800080u));
-   return rb | (ag << 8);
+   smr_u16x2 srb = smr_pk_rb(s), sag = smr_pk_ag(s);
+   if (m != 255u)
+   {
+      const smr_u16x2 m2 = smr_pk(m * 0x10001u);
+      srb = smr_pk_mul(srb, m2, 0x80); sag = smr_pk_mul(sag, m2, 0x80);
+   }
+   const smr_u16x2 ia2 = smr_pk((255u - (smr_unpk(sag) >> 16)) * 0x10001u);
+   const smr_u16x2 rb = smr_pk_addsat(srb, smr_pk_mul(smr_pk_rb(d), ia2, 0x80));
+   const smr_u16x2 ag = smr_pk_addsat(sag, smr_pk_mul(smr_pk_ag(d), ia2, 0x80));
+   return smr_pk_join(rb, ag);
 }
 
 __device__ __forceinline__ uint32_t smr_blend_over(uint32_t s, uint32_t d)
@@ -243,10 +260,10 @@ __device__ __forceinline__ uint32_t smr_blend_over(uint32_t s, uint32_t d)
    const uint32_t a = s >> 24;
    if (a == 255u) return s;
    if (s == 0u) return d;
-   const uint32_t ia = 255u - a;
-   const uint32_t rb = smr_pk_addsat(s & SMR_RB, smr_pk_mul(d & SMR_RB, ia, 0x00800080u));
-   const uint32_t ag = smr_pk_addsat((s >> 8) & SMR_RB, smr_pk_mul((d >> 8) & SMR_RB, ia, 0x00800080u));
-   return rb | (ag << 8);
+   const smr_u16x2 ia2 = smr_pk((255u - a) * 0x10001u);
+   const smr_u16x2 rb = smr_pk_addsat(smr_pk_rb(s), smr_pk_mul(smr_pk_rb(d), ia2, 0x80));
+   const smr_u16x2 ag = smr_pk_addsat(smr_pk_ag(s), smr_pk_mul(smr_pk_ag(d), ia2, 0x80));
+   return smr_pk_join(rb, ag);
 }
 
 /* XCD-aware, bijective blockIdx -> work item map: blocks b and b+8 share an XCD (and its
