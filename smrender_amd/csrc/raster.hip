@@ -1247,30 +1247,29 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
 }
 
 #define SMR_SETUP_WAVES 4
-#ifndef SMR_SETUP_CHUNK
-#define SMR_SETUP_CHUNK 16      /* primitives a wavefront takes from its XCD's queue with one atomic */
-#endif
+#define SMR_SETUP_CHUNK 16      /* most primitives a wavefront takes from its XCD's queue with one atomic */
 
 /* persistent wavefronts, each sets up primitive gwave, gwave + nwaves, ... (2 M one-wave workgroups
  * would be bound by the workgroup dispatch rate, not by the work) */
-__global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_t A, int mask_words)
+__global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_t A, int mask_words, int chunk)
 {
    extern __shared__ uint32_t lmask_all[];         /* [SMR_SETUP_WAVES][mask_words] */
    __shared__ setup_lds_t LL[SMR_SETUP_WAVES];
    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      /* uniform: keeps the loop control in SGPRs */
    uint32_t arena_pos = 0, arena_left = 0, first_valid = 0xffffffffu;
-   /* XCD x takes the x-th eighth of the primitives (workgroups b and b+8 share an XCD), SMR_SETUP_CHUNK consecutive ones per
-    * atomic: borders cost several times what fills do, and a static share leaves most wavefronts waiting for the slowest */
-   const int64_t nprim = (int64_t) A.K * A.n_ways, per = (nprim + 7) >> 3;
-   const int64_t xcd = blockIdx.x & 7u, pend = min(nprim, (xcd + 1) * per);
+   /* XCD x takes the chunks x, x + 8, ... of `chunk` consecutive primitives (workgroups b and b+8 share an XCD), one chunk per
+    * atomic: borders cost several times what fills do and a contour line thousands of times what an island does, so a static
+    * share leaves most wavefronts waiting for the slowest */
+   const int64_t nprim = (int64_t) A.K * A.n_ways;
+   const int64_t xcd = blockIdx.x & 7u;
    uint32_t *const ctr = A.small + 128 + 8 * xcd;
    for (;;)
    {
       uint32_t k = 0;
-      if (lane == 0) k = atomicAdd(ctr, (uint32_t) SMR_SETUP_CHUNK);
-      const int64_t p0 = xcd * per + (int64_t) (uint32_t) __builtin_amdgcn_readfirstlane(k);
-      if (p0 >= pend) break;
-      const int64_t p1 = min(p0 + SMR_SETUP_CHUNK, pend);
+      if (lane == 0) k = atomicAdd(ctr, 1u);
+      const int64_t p0 = ((int64_t) (uint32_t) __builtin_amdgcn_readfirstlane(k) * 8 + xcd) * chunk;
+      if (p0 >= nprim) break;
+      const int64_t p1 = min(p0 + chunk, nprim);
       for (int64_t p = p0; p < p1; p++)
       {
          smr_prim_setup_one(A, p, lane, LL[wv], lmask_all + (size_t) wv * mask_words, arena_pos, arena_left, first_valid);
@@ -1729,6 +1728,14 @@ __device__ void smr_render_edge(raster_lds_t &L, int row, int32_t X0, int32_t dx
 #else
 #define TICK(i) do { } while (0)
 #endif
+/* -DSMR_COUNT_PROFILE: how often the parts of k_raster run, summed into small[192..] (diagnostic build only) */
+#ifdef SMR_COUNT_PROFILE
+#define COUNT(i) do { cnts[i]++; } while (0)
+#define COUNTN(i, n) do { cnts[i] += (unsigned long long) (n); } while (0)
+#else
+#define COUNT(i) do { } while (0)
+#define COUNTN(i, n) do { } while (0)
+#endif
 
 /* 4 waves per SIMD (128 VGPRs, a few spilled) measured 10 % faster than the 3 the allocator settles on by itself:
  * the kernel waits on LDS and L2 more than it issues */
@@ -1758,6 +1765,9 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
 #ifdef SMR_SECTION_PROFILE
    unsigned long long prof[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef SMR_COUNT_PROFILE
+   unsigned long long cnts[24] = { 0 };
+#endif
    /* XCD-aware tile order: workgroups b and b+8 share an XCD and its L2, so XCD x rasterizes the tile
     * columns tx = x, x+8, ... and walks each column top to bottom: the waves resident on one XCD work on
     * vertically adjacent tiles at the same time, and an item's 1 KB of edge slots, needed by every tile
@@ -1782,6 +1792,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
       const uint32_t tile = (uint32_t) ty * A.TX + tx;
       const uint32_t beg = A.tile_off[tile], end = A.tile_off[tile + 1];
       if (beg == end) continue;
+      COUNT(0);
       const int32_t X0 = tx * SMR_TW * 256, X1 = X0 + SMR_TW * 256;
       const int row0 = A.band_y0 + ty * SMR_TH;          /* absolute pixel row of the tile */
       const int ysbase = row0 * SMR_GRID_Y;
@@ -1867,9 +1878,11 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
          TICK(0);      /* header hand-out + the previous entry's crossing loop */
 
          /* ================= flush: the previous primitive is complete ================= */
+         if (ei < end) COUNT(1);
          if (it.prim != cur && cur != 0xffffffffu && touched)
          {
             const bool pieces = (cur_flags & SMR_PF_PIECES) != 0;
+            COUNT(2); if (pieces) COUNT(3);
             const uint32_t mask = (cur_flags & SMR_PF_EVENODD) ? 1u : ~0u;
             const smr_edge_t *E = A.edges;
 
@@ -1887,6 +1900,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                }
                else smr_cell_add(L, my_row, ix1, 0, 2 * (fx1 - fx2));
             };
+            COUNTN(4, smr_wave_max(mine ? cnt : 0));
             if (mine && pieces)
             {
                if (cl <= cr) push_interval(cl, cr);
@@ -1933,6 +1947,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             for (int r = 0; r < SMR_TH; r++) if ((fullrows >> r) & 1u) nmax = max(nmax, rowcnt[r]);
             if (fullrows && nmax <= 16)
             {
+               COUNT(5); COUNTN(16, nmax);
                /* ---- fast form: lane = (row, edge slot), 16 slots per row, all full rows at once ---- */
                const int grp = lane >> 4, es = lane & 15;
                const uint32_t my_n = grp == 0 ? rowcnt[0] : grp == 1 ? rowcnt[1] : grp == 2 ? rowcnt[2] : rowcnt[3];
@@ -1994,6 +2009,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                   }
                   else
                   {
+                     COUNT(17);
                      int32_t qa = q1, ra = r1, qb = q2, rb = r2;
                      if (ix2 < ix1)
                      {
@@ -2038,6 +2054,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                if (!((fullrows >> r) & 1u)) continue;
                uint32_t n = rowcnt[r];
                if (n > SMR_ROWCAP) { if (lane == 0) atomicOr(A.status, SMR_ST_ROWCAP); continue; }
+               COUNT(6);
                const int rs0 = ysbase + r * SMR_GRID_Y;
                int64_t q0 = 0, q1 = 0; int32_t r0 = 0, r1 = 0, c0 = 0, c1 = 0, dxs = 0, D = 1, dir = 0;
                const bool on = (uint32_t) lane < n;
@@ -2094,6 +2111,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                const int lf = L.left[r];
                if (!__ballot((c | ua) != 0) && lf == 0) continue;        /* nothing of this primitive on the row */
                L.cover[r][lane] = 0; L.uarea[r][lane] = 0;
+               COUNT(7);
                /* interior rows carry no cover change at all: the prefix sum is the left cover */
                c = __ballot(c != 0) ? smr_wave_scan(c) + lf : lf;
                int area = c * 512 - ua;
@@ -2101,6 +2119,8 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                a = a < 0 ? 0 : a > 255 ? 255 : a;
                if (!col_in || !((cur_rowin >> r) & 1u)) a = 0;
                if (lerp && !__ballot(a != 0 && a != 255)) layer[r] = a ? spix : layer[r];      /* no edge pixel on the row */
+               else if (__ballot(a != 0)) COUNT(8);
+               if (lerp && !__ballot(a != 0 && a != 255)) { }
                else if (a) layer[r] = lerp ? smr_blend_lerp(spix, (uint32_t) a, layer[r]) : smr_blend_over_mask(spix, (uint32_t) a, layer[r]);
             }
             SMR_WAVE_SYNC();
@@ -2132,6 +2152,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
          /* full rows: remember who spans them */
          if (~partial & 0xfu)
          {
+            COUNT(9);
 #pragma unroll
             for (int r = 0; r < SMR_TH; r++)
             {
@@ -2170,6 +2191,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             if (om)
             {
                touched = true;
+               COUNT(10);
                /* per-edge constants of the fast exact evaluation, broadcast by v_readlane */
                const int64_t e_c = 256 - 30ll * o.p1y;
                const int e_clo = (int) (uint32_t) e_c, e_chi = (int) (e_c >> 32);
@@ -2206,11 +2228,13 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                      const int win = __builtin_amdgcn_readlane(e_win, j);
                      if (__builtin_amdgcn_readlane(emaxx, j) < X0)
                      {
+                        COUNT(13);
                         /* the edge lies left of the tile: every crossing is, so only its winding counts */
                         if (mine && lane >= (win & 0xff) && lane < ((win >> 8) & 0xff)) lw += (win >> 16) ? 1 : -1;
                      }
                      else if ((smallmask >> j) & 1ull)
                      {
+                        COUNT(14);
                         /* a short edge: the 32-bit evaluation of the piece path below */
                         const uint32_t Wd = (uint32_t) __builtin_amdgcn_readlane(e_W, j);
                         const int D = (int) (Wd >> 13);
@@ -2230,6 +2254,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                      }
                      else if (mine && lane >= (win & 0xff) && lane < ((win >> 8) & 0xff))
                      {
+                        COUNT(15);
                         const int64_t c = ((int64_t) __builtin_amdgcn_readlane(e_chi, j) << 32) | (uint32_t) __builtin_amdgcn_readlane(e_clo, j);
                         const double inv = __longlong_as_double(((long long) __builtin_amdgcn_readlane(e_ihi, j) << 32) |
                                                                 (uint32_t) __builtin_amdgcn_readlane(e_ilo, j));
@@ -2248,6 +2273,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                      /* convex piece: its two crossings bound one covered interval; the stroke is
                       * the union of the intervals of all pieces (every piece winds the same way) */
                      int32_t lo = INT32_MAX, hi = INT32_MIN;
+                     if ((smallmask >> j) & 1ull) COUNT(11); else COUNT(12);
                      if ((smallmask >> j) & 1ull)
                      {
                         /* all four edges are short (|dx|, dy < 16 px): the numerator fits 32 bits, the quotient 13, so 24-bit
@@ -2320,6 +2346,9 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
    }
 #ifdef SMR_SECTION_PROFILE
    if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd((unsigned long long *) (A.status + 14) + i, prof[i]);
+#endif
+#ifdef SMR_COUNT_PROFILE
+   if (lane == 0) for (int i = 0; i < 24; i++) atomicAdd((unsigned long long *) (A.status + 190) + i, cnts[i]);
 #endif
 }
 
@@ -2807,8 +2836,10 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          k_compound_init<<<1, 1, 0, s>>>(prims, compound, off_fill, (uint32_t) n_refs, host_color_pixel(st->fill_col), c->H);
       }
       int mask_words = (c->H + 31) / 32 + 1;
+      /* at least 8 takes per wavefront before the chunks grow: few primitives (a chart's 50 contour lines) go one by one */
+      const int setup_chunk = (int) std::max<int64_t>(1, std::min<int64_t>(SMR_SETUP_CHUNK, n_prims / ((int64_t) setup_wg * SMR_SETUP_WAVES * 8)));
       SMR_HIP(hipMemsetAsync(small + 128, 0, 256, s));           /* the set-up's queues start at zero on every attempt */
-      k_prim_setup<<<setup_wg, 64 * SMR_SETUP_WAVES, (size_t) mask_words * 4 * SMR_SETUP_WAVES, s>>>(SA, mask_words);
+      k_prim_setup<<<setup_wg, 64 * SMR_SETUP_WAVES, (size_t) mask_words * 4 * SMR_SETUP_WAVES, s>>>(SA, mask_words, setup_chunk);
       SMR_HIP(hipGetLastError());
       SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
       SMR_HIP(hipStreamSynchronize(s));
@@ -2890,6 +2921,15 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    T.mark(s);                                                   /* 4: rastered */
    SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
+#ifdef SMR_COUNT_PROFILE
+   {
+      unsigned long long pr[24];
+      hipMemcpy(pr, small + 192, sizeof(pr), hipMemcpyDeviceToHost);
+      fprintf(stderr, "k_raster counts:");
+      for (int i = 0; i < 18; i++) fprintf(stderr, " %d:%.3fM", i, (double) pr[i] / 1e6);
+      fprintf(stderr, "\n");
+   }
+#endif
 #ifdef SMR_SECTION_PROFILE
    {
       unsigned long long pr[12]; double tot = 0;
