@@ -1901,6 +1901,9 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                else smr_cell_add(L, my_row, ix1, 0, 2 * (fx1 - fx2));
             };
             COUNTN(4, smr_wave_max(mine ? cnt : 0));
+#ifdef SMR_KO
+            if (SMR_KO & 8) cnt = 0;
+#endif
             if (mine && pieces)
             {
                if (cl <= cr) push_interval(cl, cr);
@@ -1945,6 +1948,9 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             uint32_t nmax = 0;
 #pragma unroll
             for (int r = 0; r < SMR_TH; r++) if ((fullrows >> r) & 1u) nmax = max(nmax, rowcnt[r]);
+#ifdef SMR_KO
+            if (SMR_KO & 1) fullrows = 0;
+#endif
             if (fullrows && nmax <= 16)
             {
                COUNT(5); COUNTN(16, nmax);
@@ -1954,24 +1960,50 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                const bool onr = ((fullrows >> grp) & 1u) && (uint32_t) es < my_n;
                const int rs0 = ysbase + grp * SMR_GRID_Y;
                int32_t c0 = 0, c1 = 0, dir = 0, D = 1, q1 = 0, r1 = 0, q2 = 0, r2 = 0, dxs = 0;
+               smr_oedge_t o; o.p1x = o.p1y = o.dxs = 0; o.D = 1; o.dir = 0;
+               if (onr) { const int *re = L.redge[grp][es]; o.p1x = re[0]; o.p1y = re[1]; o.dxs = re[2]; o.D = re[3]; o.dir = re[4]; }
+               /* short edges (|dx|, dy < 16 px: every edge of a chart of small polygons) evaluate in 32 bits, as in the crossing loop */
+               const bool allshort = !__ballot(onr && !(abs(o.dxs) < 4096 && o.D <= 60 * 4096));
                if (onr)
                {
-                  smr_oedge_t o;
-                  { const int *re = L.redge[grp][es]; o.p1x = re[0]; o.p1y = re[1]; o.dxs = re[2]; o.D = re[3]; o.dir = re[4]; }
-                  const int64_t ec = 256 - 30ll * o.p1y;
-                  const double inv = smr_rcp((double) o.D);
                   D = o.D; dir = o.dir; dxs = o.dxs;
-                  smr_edge_qr(ec, 2 * o.dxs, o.D, inv, rs0, q1, r1);
-                  smr_edge_qr(ec, 2 * o.dxs, o.D, inv, rs0 + SMR_GRID_Y, q2, r2);
+                  int32_t hq, hr;
+                  if (allshort)
+                  {
+                     const float rf = __builtin_amdgcn_rcpf((float) o.D);
+                     /* floor(n / D) and the remainder: truncating fp32 estimate within 1 of the floor, exact correction */
+                     auto qr32 = [&](int n, int32_t &q, int32_t &r)
+                     {
+                        const int qe = (int) fmaf((float) n, rf, -0.5f);
+                        const int rr = __mul24(qe, -o.D) + n;
+                        const int adj = (rr >= o.D ? 1 : 0) + (rr >> 31);
+                        q = qe + adj; r = rr - __mul24(adj, o.D);
+                     };
+                     const int c32 = (int) ((uint32_t) rs0 * 512u + 256u - 30u * (uint32_t) o.p1y);
+                     const int n1 = __mul24(2 * o.dxs, c32);
+                     qr32(n1, q1, r1);
+                     qr32(n1 + __mul24(2 * o.dxs, 512 * SMR_GRID_Y), q2, r2);
+                     const int nn = o.dxs * 1024;
+                     int32_t qa, ra;
+                     qr32(abs(nn), qa, ra);
+                     hq = nn < 0 ? -(qa >> 1) : (qa >> 1); hr = nn < 0 ? -(ra >> 1) : (ra >> 1);
+                  }
+                  else
+                  {
+                     const int64_t ec = 256 - 30ll * o.p1y;
+                     const double inv = smr_rcp((double) o.D);
+                     smr_edge_qr(ec, 2 * o.dxs, o.D, inv, rs0, q1, r1);
+                     smr_edge_qr(ec, 2 * o.dxs, o.D, inv, rs0 + SMR_GRID_Y, q2, r2);
+                     const int64_t nn = (int64_t) dxs * 1024;
+                     int64_t dq = (int64_t) trunc((double) nn * inv);
+                     int64_t dr = nn - dq * D;
+                     if (nn >= 0) { if (dr < 0) { dq--; dr += D; } else if (dr >= D) { dq++; dr -= D; } }
+                     else { if (dr > 0) { dq++; dr -= D; } else if (dr <= -(int64_t) D) { dq--; dr += D; } }
+                     hq = (int32_t) (dq / 2); hr = (int32_t) (dr / 2);
+                  }
                   q1 += o.p1x; q2 += o.p1x;
                   c0 = q1 + (r1 >= (D >> 1) ? 1 : 0); c1 = q2 + (r2 >= (D >> 1) ? 1 : 0);
                   /* step back from the sample location (half a sub-row) to the row boundary */
-                  const int64_t nn = (int64_t) dxs * 1024;
-                  int64_t dq = (int64_t) trunc((double) nn * inv);
-                  int64_t dr = nn - dq * D;
-                  if (nn >= 0) { if (dr < 0) { dq--; dr += D; } else if (dr >= D) { dq++; dr -= D; } }
-                  else { if (dr > 0) { dq++; dr -= D; } else if (dr <= -(int64_t) D) { dq--; dr += D; } }
-                  const int32_t hq = (int32_t) (dq / 2), hr = (int32_t) (dr / 2);
                   q1 -= hq; r1 -= hr;
                   if (r1 < 0) { --q1; r1 += D; } else if (r1 >= D) { ++q1; r1 -= D; }
                   q2 -= hq; r2 -= hr;
@@ -2103,6 +2135,9 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             const bool lerp = (spix >> 24) == 255u || (cur_first && !A.direct);
             /* libcairo composites inside the primitive's pixel extents only */
             const bool col_in = lane >= cur_colmin && lane <= cur_colmax;
+#ifdef SMR_KO
+            if (!(SMR_KO & 2))
+#endif
 #pragma unroll
             for (int r = 0; r < SMR_TH; r++)
             {
@@ -2219,6 +2254,9 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                e_small &= __shfl_xor(e_small, 1); e_small &= __shfl_xor(e_small, 2);      /* no short-circuit: every lane shuffles */
                const unsigned long long smallmask = pieces ? __ballot(e_small != 0) : smalledge;
                TICK(5);   /* per-edge constants */
+#ifdef SMR_KO
+               if (SMR_KO & 4) om = 0;
+#endif
                while (om)
                {
                   const int j = __ffsll((long long) om) - 1;
