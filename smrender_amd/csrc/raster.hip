@@ -2250,6 +2250,11 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                const int e_A = o.dxs * 1024;
                const int e_B = (int) ((uint32_t) e_dxs2 * (uint32_t) e_c32 + (uint32_t) (o.D >> 1));
                const int e_W = e_t0 < e_t1 ? (e_t0 | ((e_t1 - e_t0) << 6) | (o.D << 13)) : (o.D << 13);
+               /* pieces: the windows of the piece's four edges side by side in its lanes (two words), and -D */
+               const int e_w13 = e_W & 0x1fff;
+               const int e_W01 = __builtin_amdgcn_update_dpp(0, e_w13, 0x00, 0xf, 0xf, false) | (__builtin_amdgcn_update_dpp(0, e_w13, 0x55, 0xf, 0xf, false) << 13);
+               const int e_W23 = __builtin_amdgcn_update_dpp(0, e_w13, 0xaa, 0xf, 0xf, false) | (__builtin_amdgcn_update_dpp(0, e_w13, 0xff, 0xf, 0xf, false) << 13);
+               const int e_nD = -o.D;
                /* a piece takes the 32-bit path when each of its edges is empty or short in x and y */
                e_small &= __shfl_xor(e_small, 1); e_small &= __shfl_xor(e_small, 2);      /* no short-circuit: every lane shuffles */
                const unsigned long long smallmask = pieces ? __ballot(e_small != 0) : smalledge;
@@ -2316,19 +2321,46 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                      {
                         /* all four edges are short (|dx|, dy < 16 px): the numerator fits 32 bits, the quotient 13, so 24-bit
                          * multiplies and one fp32 estimate (within 1 of the floor on either side, corrected through the exact
-                         * remainder) give floor((n + D/2) / D) = the rounded cell; branch-free */
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
+                         * remainder) give floor((n + D/2) / D) = the rounded cell; branch-free.
+                         * A sub-row meets two edges of a convex piece, its left and its right one: every lane picks its
+                         * two among the four from their windows and fetches their constants with ds_bpermute (the LDS
+                         * crossbar, no VALU work) instead of evaluating all four and masking two away. */
+                        const uint32_t W01 = (uint32_t) __builtin_amdgcn_readlane(e_W01, j), W23 = (uint32_t) __builtin_amdgcn_readlane(e_W23, j);
+                        const bool i0 = (uint32_t) (lane - (int) (W01 & 63u)) < ((W01 >> 6) & 127u);
+                        const bool i1 = (uint32_t) (lane - (int) ((W01 >> 13) & 63u)) < ((W01 >> 19) & 127u);
+                        const bool i2 = (uint32_t) (lane - (int) (W23 & 63u)) < ((W23 >> 6) & 127u);
+                        const bool i3 = (uint32_t) (lane - (int) ((W23 >> 13) & 63u)) < ((W23 >> 19) & 127u);
+                        const unsigned long long m0 = __ballot(i0), m1 = __ballot(i1), m2 = __ballot(i2), m3 = __ballot(i3);
+                        if (!((m0 & m1 & (m2 | m3)) | (m2 & m3 & (m0 | m1))))
                         {
-                           const int jj = j + k;
-                           const uint32_t Wd = (uint32_t) __builtin_amdgcn_readlane(e_W, jj);
-                           const int D = (int) (Wd >> 13);
-                           const int n = __mul24(__builtin_amdgcn_readlane(e_A, jj), lane) + __builtin_amdgcn_readlane(e_B, jj);
-                           const int q = (int) fmaf((float) n, __int_as_float(__builtin_amdgcn_readlane(e_rcpf, jj)), -0.5f);
-                           const int rem = __mul24(q, -D) + n;
-                           const int cell = __builtin_amdgcn_readlane(o.p1x, jj) + q + (rem >= D ? 1 : 0) + (rem >> 31);
-                           const bool in = (uint32_t) (lane - (int) (Wd & 63u)) < ((Wd >> 6) & 127u);
-                           lo = in ? min(lo, cell) : lo; hi = in ? max(hi, cell) : hi;
+                           auto cell_of = [&](int idx) -> int
+                           {
+                              const int ad = (j + idx) << 2;
+                              const int D_ = __builtin_amdgcn_ds_bpermute(ad, e_nD);
+                              const int n = __mul24(__builtin_amdgcn_ds_bpermute(ad, e_A), lane) + __builtin_amdgcn_ds_bpermute(ad, e_B);
+                              const int q = (int) fmaf((float) n, __int_as_float(__builtin_amdgcn_ds_bpermute(ad, e_rcpf)), -0.5f);
+                              const int rem = __mul24(q, D_) + n;
+                              return __builtin_amdgcn_ds_bpermute(ad, o.p1x) + q + (rem + D_ >= 0 ? 1 : 0) + (rem >> 31);
+                           };
+                           const int ca = cell_of(i0 ? 0 : i1 ? 1 : i2 ? 2 : 3), cb = cell_of(i3 ? 3 : i2 ? 2 : i1 ? 1 : 0);
+                           if (i0 || i1 || i2 || i3) { lo = min(ca, cb); hi = max(ca, cb); }
+                        }
+                        else
+                        {
+                           /* more than two edges on one sub-row (a degenerate piece): all four */
+#pragma unroll
+                           for (int k = 0; k < 4; k++)
+                           {
+                              const int jj = j + k;
+                              const uint32_t Wd = (uint32_t) __builtin_amdgcn_readlane(e_W, jj);
+                              const int D = (int) (Wd >> 13);
+                              const int n = __mul24(__builtin_amdgcn_readlane(e_A, jj), lane) + __builtin_amdgcn_readlane(e_B, jj);
+                              const int q = (int) fmaf((float) n, __int_as_float(__builtin_amdgcn_readlane(e_rcpf, jj)), -0.5f);
+                              const int rem = __mul24(q, -D) + n;
+                              const int cell = __builtin_amdgcn_readlane(o.p1x, jj) + q + (rem >= D ? 1 : 0) + (rem >> 31);
+                              const bool in = (uint32_t) (lane - (int) (Wd & 63u)) < ((Wd >> 6) & 127u);
+                              lo = in ? min(lo, cell) : lo; hi = in ? max(hi, cell) : hi;
+                           }
                         }
                      }
                      else
