@@ -119,7 +119,9 @@ struct caprot_args_t
    double *out_angle, *out_dv;
 };
 
-__device__ __forceinline__ double smr_alphad(uint32_t p) { return 1.0 - (double) (((p & 0x7f000000u) >> 23) & 0xff) / 255.0; }
+/* ALPHAD(p) > 0.2 (cairo_smr_dist :1683-1690) with ALPHAD(p) = 1 - 2 * ((p >> 24) & 0x7f) / 255 in doubles: true up to
+ * 2 * 101 = 202 (1 - 202/255 = 0.2078), false from 204 on (1 - 204/255 rounds to 0.19999999999999996 < 0.2) */
+__device__ __forceinline__ bool smr_transp(uint32_t p) { return ((p >> 24) & 0x7fu) < 102u; }
 
 /* cairo_smr_color_bw_stretch: the rotate / divide by 1.25 / rotate back chain is the affine
  * map c' = m + (c - m) / 1.25 about the gray value m; in 8-bit units round((S + 12 c) / 15),
@@ -130,9 +132,11 @@ __device__ __forceinline__ void smr_bw_stretch(uint32_t col, int &r, int &g, int
    r = (2 * (S + 12 * R) + 15) / 30; g = (2 * (S + 12 * G) + 15) / 30; b = (2 * (S + 12 * B) + 15) / 30;
 }
 
-__device__ __forceinline__ double smr_lum(int r, int g, int b)
+/* T[v] = (double) v / 255.0, the IEEE quotient itself, from a table in LDS: three fp64 divisions per pixel and angle were a
+ * third of the kernel's instructions */
+__device__ __forceinline__ double smr_lum(const double *T, int r, int g, int b)
 {
-   return 0.2125 * ((double) r / 255.0) + 0.7154 * ((double) g / 255.0) + 0.0721 * ((double) b / 255.0);
+   return 0.2125 * T[r & 255] + 0.7154 * T[g & 255] + 0.0721 * T[b & 255];
 }
 
 __device__ __forceinline__ uint32_t smr_cut_fetch(const caprot_args_t &A, int ox, int oy, int x, int y)
@@ -151,18 +155,20 @@ __global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
    double *dv = (double *) smem;                              /* [num_steps] */
-   uint32_t *dst = (uint32_t *) (smem + (((size_t) A.num_steps * 8 + 15) & ~(size_t) 15));   /* [fg_w * fg_h] */
+   double *T = dv + A.num_steps;                              /* [256] */
+   uint32_t *dst = (uint32_t *) (smem + (((size_t) (A.num_steps + 256) * 8 + 15) & ~(size_t) 15));   /* the plane */
    const int64_t cap = blockIdx.x;
    const int lane = threadIdx.x;
-   const int npix = A.fg_w * A.fg_h;
+   /* dst holds the plane's opaque columns only (all of them with explicit plane pixels), indexed like the walk below */
+   const int npix = (A.fg_w - (A.fg ? 0 : A.fg_x)) * A.fg_h;
    const int ox = (int) round(A.cx[cap] - A.r / 2.0), oy = (int) round(A.cy[cap] - A.r / 2.0);
-   const bool fg_skip = smr_alphad(A.fg_pix) > 0.2;
+   const bool fg_skip = smr_transp(A.fg_pix);
    int sr, sg, sb;
    smr_bw_stretch(A.fg_pix, sr, sg, sb);
-   const double lum_s = smr_lum(sr, sg, sb);
-
+   for (int v = lane; v < 256; v += 64) T[v] = (double) v / 255.0;
    for (int p = lane; p < npix; p += 64) dst[p] = 0;
    __syncthreads();
+   const double lum_s = smr_lum(T, sr, sg, sb);
 
    for (int i = 0; i < A.num_steps; i++)
    {
@@ -171,26 +177,30 @@ __global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
       int cnt = 0;
       if (!fg_skip || A.fg)
       {
-         for (int p = lane; p < npix; p += 64)
+         /* without explicit plane pixels only the columns from fg_x on are opaque (cairo_smr_plane: the left half of an
+          * E/W-aligned caption's plane is clear): the lanes walk those alone, line and column stepped without a division */
+         const int c0 = A.fg ? 0 : A.fg_x, nq = (A.fg_w - c0) * A.fg_h, cw = max(1, A.fg_w - c0);
+         int line = lane / cw, col = lane - line * cw;
+         for (int q = lane; q < nq; q += 64, col += 64)
          {
-            int line = p / A.fg_w, col = p - line * A.fg_w;
+            while (col >= cw) { col -= cw; line++; }
+            const int p = line * A.fg_w + c0 + col;
             int psr = sr, psg = sg, psb = sb;
             double plum = lum_s;
             if (A.fg)
             {
                uint32_t fp = A.fg[p];
-               if (smr_alphad(fp) > 0.2) continue;            /* transparent plane pixel: never counted */
+               if (smr_transp(fp)) continue;            /* transparent plane pixel: never counted */
                smr_bw_stretch(fp, psr, psg, psb);
-               plum = smr_lum(psr, psg, psb);
+               plum = smr_lum(T, psr, psg, psb);
             }
-            else if (col < A.fg_x) continue;                  /* transparent part of the plane */
             /* pixman: transform the scanline start (pixel centre), then step by the first matrix column */
             int32_t vx = M.xoff * 65536 + 0x8000, vy = (line + M.yoff) * 65536 + 0x8000;
             int64_t X = (int64_t) M.m[0][0] * (vx >> 16) + (int64_t) M.m[0][1] * (vy >> 16) + M.m[0][2] +
                         (((int64_t) M.m[0][0] * (vx & 0xffff) + (int64_t) M.m[0][1] * (vy & 0xffff) + 0x8000) >> 16);
             int64_t Y = (int64_t) M.m[1][0] * (vx >> 16) + (int64_t) M.m[1][1] * (vy >> 16) + M.m[1][2] +
                         (((int64_t) M.m[1][0] * (vx & 0xffff) + (int64_t) M.m[1][1] * (vy & 0xffff) + 0x8000) >> 16);
-            X += (int64_t) col * M.m[0][0]; Y += (int64_t) col * M.m[1][0];
+            X += (int64_t) (c0 + col) * M.m[0][0]; Y += (int64_t) (c0 + col) * M.m[1][0];
             int64_t x1 = X - 0x8000, y1 = Y - 0x8000;
             uint32_t distx = (uint32_t) ((x1 >> 9) & 0x7f) << 1, disty = (uint32_t) ((y1 >> 9) & 0x7f) << 1;
             int ix = (int) (x1 >> 16), iy = (int) (y1 >> 16);
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
                }
             }
             /* OVER onto what the previous angle left in dst */
-            uint32_t d = dst[p];
+            uint32_t d = dst[q];
             uint32_t al = s >> 24;
             if (al == 0xff) d = s;
             else if (s)
@@ -222,17 +232,17 @@ __global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
                d = o;
             }
             /* cairo_smr_dist */
-            if (smr_alphad(d) > 0.2) { dst[p] = SMR_TRANSPIX; continue; }
+            if (smr_transp(d)) { dst[q] = SMR_TRANSPIX; continue; }
             int dr, dg, db;
             smr_bw_stretch(d, dr, dg, db);
             long long k = 2125ll * (dr - psr) + 7154ll * (dg - psg) + 721ll * (db - psb);
             ksum += k < 0 ? -k : k;
             cnt++;
-            double dist = fabs(smr_lum(dr, dg, db) - plum);
+            double dist = fabs(smr_lum(T, dr, dg, db) - plum);
             if (dist > 1.0) dist = 1;
             if (dist < 0.0) dist = 0.0;
             uint32_t c = (uint32_t) (int) round(dist * 255.0);
-            dst[p] = c | c << 8 | c << 16 | 0xff000000u;
+            dst[q] = c | c << 8 | c << 16 | 0xff000000u;
          }
       }
 #pragma unroll
@@ -318,7 +328,7 @@ extern "C" int smr_hip_caprot(smr_canvas_t *c, const smr_cap_batch_t *b, double 
    int n_steps, r;
    SMR_TRY(smr_hip_caprot_steps(b->fg_w, b->fg_h, c->dpi, &n_steps, &r));
    if (n_steps < 1) return smr_fail(SMR_E_INVAL, "caprot: plane too small (num_steps = %d)", n_steps);
-   size_t lds = (((size_t) n_steps * 8 + 15) & ~(size_t) 15) + (size_t) b->fg_w * b->fg_h * 4;
+   size_t lds = (((size_t) (n_steps + 256) * 8 + 15) & ~(size_t) 15) + (size_t) (b->fg_w - (b->d_fg ? 0 : b->fg_x)) * b->fg_h * 4;
    if (lds > 64 * 1024)
       return smr_fail(SMR_E_CAPACITY, "caprot: plane of %dx%d px needs %zu bytes of LDS (limit 65536)", b->fg_w, b->fg_h, lds);
 
