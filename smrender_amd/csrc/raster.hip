@@ -2185,10 +2185,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
          const bool inband = o.dir != 0 && o.ytop < ysbase + SMR_NSUB && o.ybot > ysbase && eminx < X1;
 
          /* full rows: remember who spans them */
-         /* (an edge that spans one of the tile's rows is at least a row tall and reaches from the tile's last row start
-          * or above to its first row end or below: most items of a stroke hold none) */
-         if ((~partial & 0xfu) && __ballot(o.dir != 0 && o.ybot - o.ytop >= SMR_GRID_Y && o.ytop <= ysbase + (SMR_TH - 1) * SMR_GRID_Y &&
-                                           o.ybot >= ysbase + SMR_GRID_Y))
+         if (~partial & 0xfu)
          {
             COUNT(9);
 #pragma unroll
@@ -2231,21 +2228,17 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                touched = true;
                COUNT(10);
                /* per-edge constants of the fast exact evaluation, broadcast by v_readlane */
+               const int64_t e_c = 256 - 30ll * o.p1y;
+               const int e_clo = (int) (uint32_t) e_c, e_chi = (int) (e_c >> 32);
                const int e_dxs2 = 2 * o.dxs;
                /* 1/D for the quotient estimates: short edges (nearly all of a chart of small polygons) need it in fp32 only */
                int e_small = (o.dir == 0 || (abs(o.dxs) < 4096 && o.D <= 60 * 4096)) ? 1 : 0;
                const unsigned long long smalledge = __ballot(e_small != 0);               /* fills: edge by edge */
+               double e_inv = 0.0;
                float e_invf;
-               int e_clo = 0, e_chi = 0, e_ilo = 0, e_ihi = 0;       /* the 64-bit path's constants: only when an edge needs it */
-               if (~smalledge)
-               {
-                  const int64_t e_c = 256 - 30ll * o.p1y;
-                  const double e_inv = smr_rcp((double) o.D);
-                  e_clo = (int) (uint32_t) e_c; e_chi = (int) (e_c >> 32);
-                  e_ilo = (int) (uint32_t) __double_as_longlong(e_inv); e_ihi = (int) (__double_as_longlong(e_inv) >> 32);
-                  e_invf = (float) e_inv;
-               }
+               if (~smalledge) { e_inv = smr_rcp((double) o.D); e_invf = (float) e_inv; }
                else e_invf = __builtin_amdgcn_rcpf((float) o.D);
+               const int e_ilo = (int) (uint32_t) __double_as_longlong(e_inv), e_ihi = (int) (__double_as_longlong(e_inv) >> 32);
                /* sub-row window of the edge relative to the tile, [0, 60]; empty for empty slots */
                const int e_t0 = o.dir == 0 ? 64 : min(max(o.ytop - ysbase, 0), 64), e_t1 = o.dir == 0 ? 0 : min(max(o.ybot - ysbase, 0), 64);
                const int e_win = e_t0 | (e_t1 << 8) | ((o.dir > 0 ? 1 : 0) << 16);
