@@ -61,6 +61,10 @@ class Group:
             import torch
             import torch.distributed as dist
             backend = backend or os.environ.get("SMR_DIST_BACKEND", "nccl")
+            # rehearsals of more ranks than the box has GPUs (gloo only: RCCL wants one device per rank) share the devices
+            ndev = torch.cuda.device_count()
+            if backend != "nccl" and ndev > 0:
+                self.local %= ndev
             if backend == "nccl":
                 torch.cuda.set_device(self.local)
                 self.device = torch.device("cuda", self.local)
