@@ -207,8 +207,19 @@ __global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
             uint32_t s = 0;
             if (!(ix >= A.r || ix + 1 < 0 || iy >= A.r || iy + 1 < 0))
             {
-               uint32_t tl = smr_cut_fetch(A, ox, oy, ix, iy), tr = smr_cut_fetch(A, ox, oy, ix + 1, iy);
-               uint32_t bl = smr_cut_fetch(A, ox, oy, ix, iy + 1), br = smr_cut_fetch(A, ox, oy, ix + 1, iy + 1);
+               uint32_t tl, tr, bl, br;
+               const int gx = ox + ix, gy = oy + iy - A.band_y0;
+               if (ix >= 0 && ix + 1 < A.r && iy >= 0 && iy + 1 < A.r && gx >= 0 && gx + 1 < A.W && gy >= 0 && gy + 1 < A.band_h)
+               {
+                  /* all four inside the cut-out, the chart and this band (nearly every sample): one address */
+                  const uint32_t *q0 = A.canvas + ((size_t) gy * A.W + gx);
+                  tl = q0[0]; tr = q0[1]; bl = q0[A.W]; br = q0[A.W + 1];
+               }
+               else
+               {
+                  tl = smr_cut_fetch(A, ox, oy, ix, iy); tr = smr_cut_fetch(A, ox, oy, ix + 1, iy);
+                  bl = smr_cut_fetch(A, ox, oy, ix, iy + 1); br = smr_cut_fetch(A, ox, oy, ix + 1, iy + 1);
+               }
                uint32_t wxy = distx * disty, wxiy = distx * (256 - disty), wixy = (256 - distx) * disty,
                         wixiy = (256 - distx) * (256 - disty);
 #pragma unroll
@@ -221,16 +232,8 @@ __global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
             }
             /* OVER onto what the previous angle left in dst */
             uint32_t d = dst[q];
-            uint32_t al = s >> 24;
-            if (al == 0xff) d = s;
-            else if (s)
-            {
-               uint32_t ia = al ^ 0xff, o = 0;
-#pragma unroll
-               for (int sh = 0; sh < 32; sh += 8)
-                  o |= smr_sat(((s >> sh) & 0xff) + smr_mul80((d >> sh) & 0xff, ia)) << sh;
-               d = o;
-            }
+            if ((s >> 24) == 0xff) d = s;
+            else if (s) d = smr_blend_over(s, d);
             /* cairo_smr_dist */
             if (smr_transp(d)) { dst[q] = SMR_TRANSPIX; continue; }
             int dr, dg, db;
@@ -241,7 +244,9 @@ __global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
             double dist = fabs(smr_lum(T, dr, dg, db) - plum);
             if (dist > 1.0) dist = 1;
             if (dist < 0.0) dist = 0.0;
-            uint32_t c = (uint32_t) (int) round(dist * 255.0);
+            /* round() of a non-negative value: truncate, then the exact half test */
+            const double d255 = dist * 255.0, dtr = trunc(d255);
+            uint32_t c = (uint32_t) (int) dtr + (d255 - dtr >= 0.5 ? 1u : 0u);
             dst[q] = c | c << 8 | c << 16 | 0xff000000u;
          }
       }
