@@ -846,7 +846,9 @@ __global__ void k_color_pixels(const uint32_t *__restrict__ col, int64_t n, uint
  * increasing in w and leaves room for ceil(n/8) chunks per kind, so no scan is needed and ids
  * ascend in drawing order (way, border before fill, chunk).                               */
 /* ------------------------------------------------------------------------------------ */
+#ifndef SMR_LONGCAP
 #define SMR_LONGCAP 256      /* edges spanning a whole pixel row, kept in LDS per primitive */
+#endif
 #define SMR_ACTCAP 8         /* active edges per vertex-free row in the lane-per-row analysis */
 
 struct setup_args_t
@@ -1246,7 +1248,9 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    first_valid = min(first_valid, A.compound != 0xffffffffu ? A.compound : (uint32_t) p);
 }
 
-#define SMR_SETUP_WAVES 4
+#ifndef SMR_SETUP_WAVES
+#define SMR_SETUP_WAVES 2       /* 21 KB of LDS per workgroup: 14 wavefronts per CU where 4 per workgroup left room for 12 */
+#endif
 #define SMR_SETUP_CHUNK 16      /* most primitives a wavefront takes from its XCD's queue with one atomic */
 
 /* persistent wavefronts, each sets up primitive gwave, gwave + nwaves, ... (2 M one-wave workgroups
@@ -2874,7 +2878,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    /* primitive set-up (items, boxes, row masks); the mask arena grows on demand */
    uint32_t *maskbuf;
    /* a multiple of 8, and at least 8: every XCD's share of the primitives needs a workgroup (k_prim_setup) */
-   const unsigned setup_wg = ((unsigned) std::min<int64_t>((n_prims + SMR_SETUP_WAVES - 1) / SMR_SETUP_WAVES, 256 * 6) + 7u) & ~7u;
+   const unsigned setup_wg = ((unsigned) std::min<int64_t>((n_prims + SMR_SETUP_WAVES - 1) / SMR_SETUP_WAVES, 256 * 24 / SMR_SETUP_WAVES) + 7u) & ~7u;
    size_t mask_cap = c->buf[SMR_BUF_MASK].cap / 4;
    {
       size_t want = (size_t) n_prims * 2 + (size_t) setup_wg * SMR_SETUP_WAVES * SMR_MASK_BLOCK + 65536 + cwords;
@@ -2921,7 +2925,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          SMR_HIP(hipStreamSynchronize(s));
          if (nbig)
          {
-            k_big_rows<<<256 * 4, 64 * SMR_SETUP_WAVES, 0, s>>>(prims, edges, biglist, maskbuf, &small[2]);
+            k_big_rows<<<256 * 16 / SMR_SETUP_WAVES, 64 * SMR_SETUP_WAVES, 0, s>>>(prims, edges, biglist, maskbuf, &small[2]);
             SMR_HIP(hipGetLastError());
             SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
             SMR_HIP(hipStreamSynchronize(s));
