@@ -945,6 +945,8 @@ struct smr_rowscan_t
    int lane;
    uint32_t *status;
    uint32_t list_n;               /* entries of L->l_edge that count; more than SMR_LONGCAP: the list overflowed, scan every slot */
+   const smr_item_t *items;       /* the primitive's items (64 slots each, with their boxes), or NULL: build_list skips the items that
+                                     cannot reach the window instead of reading every slot of a long primitive once per window */
 
    /* one vertex-free row decided by the whole wavefront: lanes walk the candidate edges (the LDS list of row-spanning
     * edges, or every edge slot when that list overflowed), the active ones' cells at the top and the bottom of the row
@@ -956,9 +958,8 @@ struct smr_rowscan_t
       uint32_t cnt = 0;
       const uint32_t ncand = list_n <= SMR_LONGCAP ? list_n : edge_cnt;
       SMR_WAVE_SYNC();
-      for (uint32_t base_i = 0; base_i < ncand; base_i += 64)
+      auto visit = [&](uint32_t idx)
       {
-         uint32_t idx = base_i + lane;
          int32_t p1x = 0, p1y = 0, dxs = 0, D = 1, ytop = 0, ybot = 0;
          bool have = false;
          if (idx < ncand)
@@ -978,7 +979,7 @@ struct smr_rowscan_t
          }
          bool act = have && ytop <= rs0 && ybot >= rs1;
          unsigned long long am = __ballot(act);
-         if (!am) continue;
+         if (!am) return;
          uint32_t pos = cnt + __popcll(am & ((1ull << lane) - 1ull));
          if (act && pos < SMR_ROWCAP)
          {
@@ -989,7 +990,30 @@ struct smr_rowscan_t
             f1[pos] = smr_cell(q, rem, D, dxs);
          }
          cnt += __popcll(am);
+      };
+      if (list_n > SMR_LONGCAP && items)
+      {
+         /* the list overflowed: every slot is a candidate, but only the items whose box meets the row hold any */
+         const uint32_t nit = (edge_cnt + 63u) >> 6;
+         for (uint32_t kb = 0; kb < nit; kb += 64)
+         {
+            bool ov = false;
+            if (kb + lane < nit)
+            {
+               const smr_item_t *it = items + kb + lane;
+               ov = it->cnt_flags != 0 && (it->maxy >> 8) >= row0 + r && (it->miny >> 8) <= row0 + r;
+            }
+            unsigned long long om = __ballot(ov);
+            while (om)
+            {
+               const int j = __ffsll((long long) om) - 1;
+               om &= om - 1;
+               visit((kb + (uint32_t) j) * 64u + (uint32_t) lane);
+            }
+         }
       }
+      else
+         for (uint32_t base_i = 0; base_i < ncand; base_i += 64) visit(base_i + lane);
       SMR_WAVE_SYNC();
       bool viol = false;
       /* more spanning edges than the exact full-row path holds: the row is sub-sampled instead (reported) */
@@ -1079,16 +1103,40 @@ struct smr_rowscan_t
       const int wr0 = row0 + rb, wr1 = min(row0 + rb + 63, row0 + nrows - 1);
       if (lane == 0) L->nlong = 0;
       SMR_WAVE_SYNC();
-      for (uint32_t idx = lane; idx < edge_cnt; idx += 64)
+      auto visit = [&](uint32_t idx)
       {
+         if (idx >= edge_cnt) return;
          const smr_oedge_t o = smr_orient(E[idx]);
-         if (o.dir == 0) continue;
+         if (o.dir == 0) return;
          const int first_full = o.ytop >= 0 ? (o.ytop + SMR_GRID_Y - 1) / SMR_GRID_Y : -((-o.ytop) / SMR_GRID_Y);
          const int last_full = (o.ybot >= 0 ? o.ybot / SMR_GRID_Y : -((-o.ybot + SMR_GRID_Y - 1) / SMR_GRID_Y)) - 1;
-         if (first_full > last_full || first_full > wr1 || last_full < wr0) continue;
+         if (first_full > last_full || first_full > wr1 || last_full < wr0) return;
          const uint32_t k = atomicAdd(&L->nlong, 1u);
          if (k < SMR_LONGCAP) L->l_edge[k] = make_int4(o.p1x, o.p1y, o.dxs, o.D / 60);
+      };
+      if (items)
+      {
+         /* lanes = 64 items at a time: whose box (of its slots' end points) meets the window's rows? */
+         const uint32_t nit = (edge_cnt + 63u) >> 6;
+         for (uint32_t kb = 0; kb < nit; kb += 64)
+         {
+            bool ov = false;
+            if (kb + lane < nit)
+            {
+               const smr_item_t *it = items + kb + lane;
+               ov = it->cnt_flags != 0 && (it->maxy >> 8) >= wr0 && (it->miny >> 8) <= wr1;
+            }
+            unsigned long long om = __ballot(ov);
+            while (om)
+            {
+               const int j = __ffsll((long long) om) - 1;
+               om &= om - 1;
+               visit((kb + (uint32_t) j) * 64u + (uint32_t) lane);
+            }
+         }
       }
+      else
+         for (uint32_t idx = lane; idx < edge_cnt; idx += 64) visit(idx);
       SMR_WAVE_SYNC();
       list_n = L->nlong;
       return true;
@@ -1206,6 +1254,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    smr_rowscan_t RS;
    RS.row0 = P.row0; RS.nrows = P.nrows; RS.edge_cnt = P.edge_cnt; RS.E = E; RS.L = &L; RS.lmask = lmask; RS.lane = lane;
    RS.status = &A.small[2]; RS.list_n = nlong; RS.mbase = 0;
+   RS.items = nitems > 64 ? A.items + item0 : nullptr;
    bool deferred = false;
    if (nlong > SMR_LONGCAP && P.edge_cnt >= SMR_BIG_SLOTS && A.biglist)
    {
@@ -1244,7 +1293,11 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    for (uint32_t i = lane; i < nwords; i += 64) A.mask[moff + i] = lmask[i];
    P.mask_off = moff;
    if (lane == 0) A.prims[p] = P;
-   if (deferred && lane == 0) A.biglist[1 + atomicAdd(&A.biglist[0], 1u)] = (uint32_t) p;
+   if (deferred && lane == 0)
+   {
+      const uint32_t b = atomicAdd(&A.biglist[0], 1u);
+      A.biglist[1 + 2 * b] = (uint32_t) p; A.biglist[2 + 2 * b] = (uint32_t) item0;
+   }
    first_valid = min(first_valid, A.compound != 0xffffffffu ? A.compound : (uint32_t) p);
 }
 
@@ -1287,7 +1340,7 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_
  * each reads the window's two mask words (vertex rows, written by k_prim_setup), builds the window's list of spanning
  * edges with one pass over the primitive's slots and ORs the rows found crossing back into the arena */
 __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_big_rows(const smr_prim_t *__restrict__ prims, const smr_edge_t *__restrict__ edges,
-                                                                   const uint32_t *__restrict__ biglist, uint32_t *mask, uint32_t *status)
+                                                                   const smr_item_t *__restrict__ items, const uint32_t *__restrict__ biglist, uint32_t *mask, uint32_t *status)
 {
    __shared__ setup_lds_t LL[SMR_SETUP_WAVES];
    __shared__ uint32_t wmask[SMR_SETUP_WAVES][2];
@@ -1297,7 +1350,7 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_big_rows(const smr_pri
    uint32_t first = 0;                                  /* windows of the primitives before this one */
    for (uint32_t b = 0; b < nbig; b++)
    {
-      const smr_prim_t P = prims[biglist[1 + b]];
+      const smr_prim_t P = prims[biglist[1 + 2 * b]];
       const uint32_t nwin = ((uint32_t) P.nrows + 63u) >> 6;
       /* window w of this primitive belongs to wavefront (first + w) mod nwaves */
       uint32_t w = (gwave + nwaves - first % nwaves) % nwaves;
@@ -1310,7 +1363,7 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_big_rows(const smr_pri
          smr_rowscan_t RS;
          RS.row0 = P.row0; RS.nrows = P.nrows; RS.edge_cnt = P.edge_cnt; RS.E = edges + P.edge_off; RS.L = &LL[wv];
          RS.lmask = &wmask[wv][0]; RS.mbase = rb;
-         RS.lane = lane; RS.status = status; RS.list_n = 0;
+         RS.lane = lane; RS.status = status; RS.list_n = 0; RS.items = items + biglist[2 + 2 * b];
          const uint32_t before0 = wmask[wv][0], before1 = wmask[wv][1];
          if (RS.build_list(rb)) RS.window(rb);
          SMR_WAVE_SYNC();
@@ -2896,7 +2949,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SA.small = small; SA.compound = compound;
       SA.K = K; SA.off_dots = off_dots; SA.po_border = po_border; SA.po_dots = po_dots; SA.po_open = po_open; SA.id_off = id_off;
       uint32_t *biglist;
-      SMR_TRY(c->ensure(SMR_BUF_BIGLIST, ((size_t) n_prims + 2) * 4, (void **) &biglist));
+      SMR_TRY(c->ensure(SMR_BUF_BIGLIST, ((size_t) n_prims * 2 + 2) * 4, (void **) &biglist));
       SMR_HIP(hipMemsetAsync(biglist, 0, 4, s));
       SA.biglist = biglist;
       if (mode == SMR_PASS_COMPOUND)
@@ -2925,7 +2978,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          SMR_HIP(hipStreamSynchronize(s));
          if (nbig)
          {
-            k_big_rows<<<256 * 16 / SMR_SETUP_WAVES, 64 * SMR_SETUP_WAVES, 0, s>>>(prims, edges, biglist, maskbuf, &small[2]);
+            k_big_rows<<<256 * 16 / SMR_SETUP_WAVES, 64 * SMR_SETUP_WAVES, 0, s>>>(prims, edges, items, biglist, maskbuf, &small[2]);
             SMR_HIP(hipGetLastError());
             SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
             SMR_HIP(hipStreamSynchronize(s));
