@@ -851,6 +851,15 @@ __global__ void k_color_pixels(const uint32_t *__restrict__ col, int64_t n, uint
 #endif
 #define SMR_ACTCAP 8         /* active edges per vertex-free row in the lane-per-row analysis */
 
+/* a long primitive (SMR_BIG_SLOTS edge slots and more: a contour line, a coastline) is not set up by ONE wavefront: k_prim_setup
+ * only registers it, and its items, its box, its vertex rows and its vertex-free rows are then spread over all wavefronts
+ * (k_big_items, k_big_finish, k_big_vrows, k_big_rows) */
+struct smr_bigacc_t
+{
+   int32_t minx, miny, maxx, maxy, bin_maxx;     /* atomicMin / atomicMax over the items */
+   uint32_t item_flags, prim_id, valid;          /* SMR_PF_* of the items; the id the items carry (compound or own); set by k_big_finish */
+};
+
 struct setup_args_t
 {
    const smr_edge_t *edges;
@@ -872,7 +881,8 @@ struct setup_args_t
    uint64_t off_dots;
    const uint32_t *po_border, *po_dots, *po_open;      /* [n_ways+1] piece offsets; NULL: the plain layout */
    const uint32_t *id_off;                             /* [n_ways+1] in 8-slot groups; NULL: way_off */
-   uint32_t *biglist;                                  /* primitives left to k_big_rows ([0] = their number, then the ids) */
+   uint32_t *biglist;                                  /* long primitives, left to the k_big_* kernels ([0] = their number, then (id, first item)) */
+   struct smr_bigacc_t *bigacc;                        /* [biglist entry] what those kernels need of them */
 };
 
 struct setup_lds_t
@@ -1185,6 +1195,20 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    if (!on) { if (lane == 0) A.prims[p] = P; return; }
    const smr_edge_t *E = A.edges + P.edge_off;
    const uint32_t item_flags = SMR_PF_VALID | (pieces ? SMR_PF_PIECES : 0u) | (nitems > 1 ? SMR_PF_MULTI : 0u);
+   if (P.edge_cnt >= SMR_BIG_SLOTS && A.biglist)
+   {
+      if (lane == 0)
+      {
+         const uint32_t b = atomicAdd(&A.biglist[0], 1u);
+         A.biglist[1 + 2 * b] = (uint32_t) p; A.biglist[2 + 2 * b] = (uint32_t) item0;
+         smr_bigacc_t a;
+         a.minx = a.miny = INT32_MAX; a.maxx = a.maxy = a.bin_maxx = INT32_MIN;
+         a.item_flags = item_flags; a.prim_id = A.compound != 0xffffffffu ? A.compound : (uint32_t) p; a.valid = 0;
+         A.bigacc[b] = a;
+         A.prims[p] = P;                 /* edge range and colour; not valid before k_big_finish */
+      }
+      return;
+   }
 
    /* ---- pass A: items + bbox ---- */
    int bin_maxx = INT32_MIN;
@@ -1255,14 +1279,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    RS.row0 = P.row0; RS.nrows = P.nrows; RS.edge_cnt = P.edge_cnt; RS.E = E; RS.L = &L; RS.lmask = lmask; RS.lane = lane;
    RS.status = &A.small[2]; RS.list_n = nlong; RS.mbase = 0;
    RS.items = nitems > 64 ? A.items + item0 : nullptr;
-   bool deferred = false;
-   if (nlong > SMR_LONGCAP && P.edge_cnt >= SMR_BIG_SLOTS && A.biglist)
-   {
-      /* a long primitive (a contour line, a coastline's border): its vertex-free rows are analysed window by window by
-       * MANY wavefronts (k_big_rows) once its vertex rows are in the arena */
-      deferred = true;
-   }
-   else if (nlong > SMR_LONGCAP)
+   if (nlong > SMR_LONGCAP)
    {
       for (int rb = 0; rb < P.nrows; rb += 64) if (RS.build_list(rb)) { RS.window(rb); SMR_WAVE_SYNC(); }
    }
@@ -1293,11 +1310,6 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    for (uint32_t i = lane; i < nwords; i += 64) A.mask[moff + i] = lmask[i];
    P.mask_off = moff;
    if (lane == 0) A.prims[p] = P;
-   if (deferred && lane == 0)
-   {
-      const uint32_t b = atomicAdd(&A.biglist[0], 1u);
-      A.biglist[1 + 2 * b] = (uint32_t) p; A.biglist[2 + 2 * b] = (uint32_t) item0;
-   }
    first_valid = min(first_valid, A.compound != 0xffffffffu ? A.compound : (uint32_t) p);
 }
 
@@ -1336,8 +1348,131 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_
    if (lane == 0 && first_valid != 0xffffffffu) atomicMin(&A.small[1], first_valid);
 }
 
+/* ---- long primitives, step 1: items and boxes.  The items of all long primitives are dealt round robin to the wavefronts
+ * (item k of the b-th primitive to wavefront (items before + k) mod nwaves); the primitive's box grows by atomics ---- */
+__global__ __launch_bounds__(256) void k_big_items(const smr_prim_t *__restrict__ prims, const smr_edge_t *__restrict__ edges, smr_item_t *items,
+                                                   const uint32_t *__restrict__ biglist, smr_bigacc_t *acc)
+{
+   const int lane = threadIdx.x & 63;
+   const uint32_t gwave = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+   const uint32_t nbig = biglist[0];
+   uint32_t first = 0;
+   for (uint32_t b = 0; b < nbig; b++)
+   {
+      const smr_prim_t P = prims[biglist[1 + 2 * b]];
+      const uint32_t item0 = biglist[2 + 2 * b], nitems = (P.edge_cnt + 63u) >> 6;
+      const uint32_t item_flags = acc[b].item_flags, prim_id = acc[b].prim_id;
+      const bool pieces = (item_flags & SMR_PF_PIECES) != 0;
+      const smr_edge_t *E = edges + P.edge_off;
+      for (uint32_t k = (gwave + nwaves - first % nwaves) % nwaves; k < nitems; k += nwaves)
+      {
+         const uint32_t idx = k * 64u + (uint32_t) lane;
+         smr_edge_t e; e.x1 = e.y1 = e.x2 = e.y2 = 0;
+         if (idx < P.edge_cnt) e = E[idx];
+         bool has = idx < P.edge_cnt && (e.x1 != e.x2 || e.y1 != e.y2 || !pieces);
+         if (pieces && e.x1 == 0 && e.y1 == 0 && e.x2 == 0 && e.y2 == 0) has = false;
+         int mnx = has ? min(e.x1, e.x2) : INT32_MAX, mxx = has ? max(e.x1, e.x2) : INT32_MIN;
+         int mny = has ? min(e.y1, e.y2) : INT32_MAX, mxy = has ? max(e.y1, e.y2) : INT32_MIN;
+         int ext = 0;                     /* as in smr_prim_setup_one: the reach of the exact full-row path beyond an edge's end points */
+         if (has && mxy - mny >= 239) ext = (int) (((int64_t) (mxx - mnx) * 9) / (mxy - mny)) + 2;
+         const int bmn = smr_wave_min(has ? mnx - ext : INT32_MAX), bmx = smr_wave_max(has ? mxx + ext : INT32_MIN);
+         mnx = smr_wave_min(mnx); mny = smr_wave_min(mny); mxx = smr_wave_max(mxx); mxy = smr_wave_max(mxy);
+         if (lane == 0)
+         {
+            smr_item_t it;
+            it.edge_off = (uint32_t) (P.edge_off + (uint64_t) k * 64);
+            it.prim = prim_id;
+            it.cnt_flags = mnx <= mxx ? (min(64u, P.edge_cnt - k * 64u) | (item_flags << 8)) : 0;
+            it.color = P.color;
+            it.minx = bmn; it.miny = mny; it.maxx = bmx; it.maxy = mxy;
+            items[item0 + k] = it;
+            if (mnx <= mxx)
+            {
+               atomicMin(&acc[b].minx, mnx); atomicMin(&acc[b].miny, mny); atomicMax(&acc[b].maxx, mxx); atomicMax(&acc[b].maxy, mxy);
+               atomicMax(&acc[b].bin_maxx, bmx);
+            }
+         }
+      }
+      first += nitems;
+   }
+}
+
+/* ---- step 2, one lane per long primitive: chart test, rows, mask words (zeroed here, ORed into by step 3) ---- */
+__global__ void k_big_finish(smr_prim_t *prims, const uint32_t *__restrict__ biglist, smr_bigacc_t *acc, uint32_t *mask, uint32_t mask_cap,
+                             uint32_t *small, int W, int H)
+{
+   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+   if (b >= biglist[0]) return;
+   const uint32_t p = biglist[1 + 2 * b];
+   smr_prim_t P = prims[p];
+   const smr_bigacc_t a = acc[b];
+   P.minx = a.minx; P.miny = a.miny; P.maxx = a.maxx; P.maxy = a.maxy;
+   bool valid = P.minx <= P.maxx;
+   if (valid)
+   {
+      const int c0 = P.minx >> 8, c1 = P.maxx >> 8, r0 = P.miny >> 8, r1 = P.maxy >> 8;
+      if (c1 < 0 || r1 < 0 || c0 >= W || r0 >= H) valid = false;
+   }
+   if (!valid) { prims[p] = P; return; }
+   P.row0 = max(0, P.miny >> 8);
+   P.nrows = min(H - 1, P.maxy >> 8) - P.row0 + 1;
+   const uint32_t nwords = ((uint32_t) P.nrows + 31u) >> 5;
+   const uint32_t moff = atomicAdd(&small[4], nwords);
+   if ((uint64_t) moff + nwords > mask_cap) { atomicOr(&small[2], SMR_ST_MASK_ARENA); P.nrows = 0; prims[p] = P; return; }
+   for (uint32_t i = 0; i < nwords; i++) mask[moff + i] = 0;
+   P.mask_off = moff; P.flags = a.item_flags;
+   prims[p] = P;
+   acc[b].valid = 1;
+   atomicMin(&small[1], a.prim_id);
+}
+
+/* ---- step 3: the rows in which an edge starts or ends (smr_setup_edge, into the arena), and the binning box of a fill's
+ * chunks (up to the primitive's right edge) ---- */
+__global__ __launch_bounds__(256) void k_big_vrows(const smr_prim_t *__restrict__ prims, const smr_edge_t *__restrict__ edges, smr_item_t *items,
+                                                   const uint32_t *__restrict__ biglist, const smr_bigacc_t *__restrict__ acc, uint32_t *mask)
+{
+   const int lane = threadIdx.x & 63;
+   const uint32_t gwave = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4u;
+   const uint32_t nbig = biglist[0];
+   uint32_t first = 0;
+   for (uint32_t b = 0; b < nbig; b++)
+   {
+      const smr_prim_t P = prims[biglist[1 + 2 * b]];
+      const uint32_t item0 = biglist[2 + 2 * b], nitems = (P.edge_cnt + 63u) >> 6;
+      const smr_bigacc_t a = acc[b];
+      if (a.valid)
+      {
+         const smr_edge_t *E = edges + P.edge_off;
+         uint32_t *m = mask + P.mask_off;
+         for (uint32_t k = (gwave + nwaves - first % nwaves) % nwaves; k < nitems; k += nwaves)
+         {
+            const uint32_t idx = k * 64u + (uint32_t) lane;
+            if (idx < P.edge_cnt)
+            {
+               const smr_oedge_t o = smr_orient(E[idx]);
+               if (o.dir != 0)
+               {
+                  if (o.ytop % SMR_GRID_Y != 0)
+                  {
+                     const int r = o.ytop / SMR_GRID_Y - P.row0;
+                     if (o.ytop >= 0 && r >= 0 && r < P.nrows) atomicOr(&m[r >> 5], 1u << (r & 31));
+                  }
+                  if (o.ybot % SMR_GRID_Y != 0)
+                  {
+                     const int r = (o.ybot > 0 ? (o.ybot - 1) / SMR_GRID_Y : -1) - P.row0;
+                     if (o.ybot > 0 && r >= 0 && r < P.nrows) atomicOr(&m[r >> 5], 1u << (r & 31));
+                  }
+               }
+            }
+            if (lane == 0 && !(a.item_flags & SMR_PF_PIECES)) items[item0 + k].maxx = a.bin_maxx;
+         }
+      }
+      first += nitems;
+   }
+}
+
 /* long primitives: the windows of 64 rows of every primitive in the list are dealt round robin to persistent wavefronts;
- * each reads the window's two mask words (vertex rows, written by k_prim_setup), builds the window's list of spanning
+ * each reads the window's two mask words (vertex rows, written by k_big_vrows), builds the window's list of spanning
  * edges with one pass over the primitive's slots and ORs the rows found crossing back into the arena */
 __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_big_rows(const smr_prim_t *__restrict__ prims, const smr_edge_t *__restrict__ edges,
                                                                    const smr_item_t *__restrict__ items, const uint32_t *__restrict__ biglist, uint32_t *mask, uint32_t *status)
@@ -2952,6 +3087,10 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SMR_TRY(c->ensure(SMR_BUF_BIGLIST, ((size_t) n_prims * 2 + 2) * 4, (void **) &biglist));
       SMR_HIP(hipMemsetAsync(biglist, 0, 4, s));
       SA.biglist = biglist;
+      /* a long primitive has at least SMR_BIG_SLOTS edge slots */
+      smr_bigacc_t *bigacc;
+      SMR_TRY(c->ensure(SMR_BUF_BIGACC, ((size_t) (n_edges / SMR_BIG_SLOTS) + 2) * sizeof(smr_bigacc_t), (void **) &bigacc));
+      SA.bigacc = bigacc;
       if (mode == SMR_PASS_COMPOUND)
       {
          /* the compound's own row mask sits at the start of the arena; the members' words follow */
@@ -2972,17 +3111,24 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SMR_HIP(hipStreamSynchronize(s));
       if (!(h_small[2] & SMR_ST_MASK_ARENA))
       {
-         /* long primitives: their vertex-free rows window by window, on as many wavefronts as there are windows */
+         /* long primitives: items and box, rows and mask words, vertex rows, then the vertex-free rows window by window, each step on
+          * as many wavefronts as it has items or windows */
          uint32_t nbig = 0;
          SMR_HIP(hipMemcpyAsync(&nbig, biglist, 4, hipMemcpyDeviceToHost, s));
          SMR_HIP(hipStreamSynchronize(s));
          if (nbig)
          {
+            k_big_items<<<256 * 4, 256, 0, s>>>(prims, edges, items, biglist, bigacc);
+            k_big_finish<<<(nbig + 63) / 64, 64, 0, s>>>(prims, biglist, bigacc, maskbuf, SA.mask_cap, small, c->W, c->H);
+            k_big_vrows<<<256 * 4, 256, 0, s>>>(prims, edges, items, biglist, bigacc, maskbuf);
             k_big_rows<<<256 * 16 / SMR_SETUP_WAVES, 64 * SMR_SETUP_WAVES, 0, s>>>(prims, edges, items, biglist, maskbuf, &small[2]);
             SMR_HIP(hipGetLastError());
             SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
             SMR_HIP(hipStreamSynchronize(s));
          }
+      }
+      if (!(h_small[2] & SMR_ST_MASK_ARENA))
+      {
          if (mode == SMR_PASS_COMPOUND)
          {
             uint32_t *covered = (uint32_t *) c->buf[SMR_BUF_COVERED].p;
