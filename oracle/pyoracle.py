@@ -55,6 +55,12 @@ class Style(C.Structure):
         s.curve, s.curve_fact = 1, factor
         return s
 
+    def with_knots(self):
+        """copy with curve=2: a way's points are p0 and (c1, c2, p) triples, the path cairo_smr_wavy records (:752-840)"""
+        s = Style.from_buffer_copy(bytes(self))
+        s.curve = 2
+        return s
+
 
 def P(a):
     return a.ctypes.data_as(C.c_void_p)
@@ -285,8 +291,13 @@ def _cd_dash(L, style, bwidth_mm, ds, n, dpi):
     L.cd_set_dash(arr, len(dash), int(rnd))
 
 
-def curve_path(xy_pt, closed, factor):
-    """cairo_smr_poly_curve (src/smrules_cairo.c:697-749) through the oracle's restatement: start point, [n, 6] curves"""
+def curve_path(xy_pt, closed, factor, explicit=False):
+    """cairo_smr_poly_curve (src/smrules_cairo.c:697-749) through the oracle's restatement: start point, [n, 6] curves.
+    explicit (style.curve == 2): the points are p0 and (c1, c2, p) triples already (cairo_smr_wavy's path, :752-840)."""
+    if explicit:
+        assert not closed
+        nc = (len(xy_pt) - 1) // 3
+        return np.ascontiguousarray(xy_pt[0], np.float64), np.ascontiguousarray(np.asarray(xy_pt[1:1 + 3 * nc], np.float64).reshape(nc, 6))
     xp, yp = np.ascontiguousarray(xy_pt[:, 0]), np.ascontiguousarray(xy_pt[:, 1])
     start, curves = np.zeros(2), np.zeros((len(xp), 6))
     n = orc().orc_curve_path(P(xp), P(yp), len(xp), int(closed), factor, P(start), P(curves))
@@ -295,7 +306,7 @@ def curve_path(xy_pt, closed, factor):
 
 def _cairo_curve_way(L, st, xy, closed, dpi):
     """render_poly_line (:953-1016) with cairo_smr_poly -> cairo_smr_poly_curve; solid strokes"""
-    start, curves = curve_path(xy, closed, st.curve_fact)
+    start, curves = curve_path(xy, closed, st.curve_fact, st.curve == 2)
     if st.border_used:
         if not st.fill_used:
             bw = mm2wu(st.border_width_mm, dpi)

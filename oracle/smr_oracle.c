@@ -836,7 +836,18 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
    double *xp = malloc(sizeof(double) * 2 * n), *yp = xp + n, start[2];
    double *curves = malloc(sizeof(double) * 6 * n);
    for (int i = 0; i < n; i++) { xp[i] = x_px[i] * 72 / c->dpi; yp[i] = y_px[i] * 72 / c->dpi; }     /* geo2pt */
-   int nc = orc_curve_path(xp, yp, n, closed, st->curve_fact, start, curves);
+   int nc;
+   if (st->curve == 2)
+   {
+      /* the way's points ARE the path: move_to p0, then one curve_to per (c1, c2, p) triple, as cairo_smr_wavy records them
+       * (src/smrules_cairo.c:752-840: cairo_move_to :800, cairo_curve_to :772); the path is never closed */
+      if (closed) { orc_curve_unsupported_ = 1; free(curves); free(xp); return; }
+      nc = (n - 1) / 3;
+      start[0] = xp[0]; start[1] = yp[0];
+      for (int k = 0; k < nc; k++)
+         for (int t = 0; t < 3; t++) { curves[6 * k + 2 * t] = xp[1 + 3 * k + t]; curves[6 * k + 2 * t + 1] = yp[1 + 3 * k + t]; }
+   }
+   else nc = orc_curve_path(xp, yp, n, closed, st->curve_fact, start, curves);
    int cap = 64 * (nc + 2), m = 0;
    int32_t *pts = NULL;
    tor_edge_t *e = NULL;

@@ -92,3 +92,31 @@ def synth_coast(n_coast, n_islands, n_rings, W, H, seed=1234, hurst=0.75):
             return np.zeros(0), np.zeros(0), np.zeros(1, np.int64), np.zeros(0, np.int32)
         return np.concatenate(xs), np.concatenate(ys), np.array(off, np.int64), np.concatenate(ref).astype(np.int32)
     return pack(ways), pack(rings)
+
+
+def synth_wavy_knots(n_ways, W, H, seed=7, wave_px=(6.0, 30.0)):
+    """Open ways as explicit Bezier paths of the shape cairo_smr_wavy records (src/smrules_cairo.c:752-840): the way is
+    resampled every `d` px and every step is one curve_to whose control points sit at -45 and +45 degrees of the step's
+    bearing, d / sqrt(2) from its start.  Returns [(x, y, False)] with x, y = p0, (c1, c2, p) * n in px."""
+    rng = np.random.default_rng(seed)
+    ways = []
+    for _ in range(n_ways):
+        d = rng.uniform(*wave_px)
+        n = int(rng.integers(2, 9))
+        vx = rng.uniform(0, W) + np.cumsum(rng.normal(0, 4 * d, n)); vy = rng.uniform(0, H) + np.cumsum(rng.normal(0, 4 * d, n))
+        xs, ys = [vx[0]], [vy[0]]
+        sx, sy, rest = vx[0], vy[0], 0.0
+        for i in range(1, n):
+            seg = np.hypot(vx[i] - sx, vy[i] - sy) + rest
+            while seg > d:
+                b = np.arctan2(vy[i] - sy, vx[i] - sx)
+                ex, ey = sx + d * np.cos(b), sy + d * np.sin(b)
+                for a in (b - np.pi / 4, b + np.pi / 4):
+                    xs.append(sx + d * np.sqrt(0.5) * np.cos(a)); ys.append(sy + d * np.sqrt(0.5) * np.sin(a))
+                xs.append(ex); ys.append(ey)
+                sx, sy = ex, ey
+                seg -= d
+            rest = seg
+        if len(xs) >= 4:
+            ways.append((np.array(xs), np.array(ys), False))
+    return ways

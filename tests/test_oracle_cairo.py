@@ -216,3 +216,25 @@ def test_single_beziers_decompose_like_libcairo():
         e = np.zeros((m, 4), np.int32)
         L.orc_fill_edges(po.P(pts), m, po.P(e))
         assert np.array_equal(po.tor_coverage(e, W, H), (255 - (out & 0xff)).astype(np.uint8)), t
+
+
+# explicit Bezier paths (style.curve == 2: what cairo_smr_wavy records for `wavy=1`, src/smrules_cairo.c:752-840): the oracle's
+# decomposition + tangent stroker against the real libcairo on the same curve_to sequence
+WAVY_CASES = {
+    "hairline": (po.Style(1, 0, 0xff00ff, 0, 0.0, 0, 0), 1.0, 0.9999),             # draw:color=magenta;wavy=yes (the shipped rule)
+    "line_02": (po.Style(1, 0, 0xff00ff, 0, 0.2, 0, 0), 0.9995, 0.999),           # test/rules/0131.osm: width=.2
+    "bordered": (po.Style(1, 1, 0xff00ff, 0x000000, 0.2, 0.1, 0), 0.999, 0.998),
+}
+
+
+@pytest.mark.parametrize("case", list(WAVY_CASES))
+def test_explicit_bezier_paths(case):
+    from smrender_amd import synth
+    st, bar2, bar0 = WAVY_CASES[case]
+    st = st.with_knots()
+    ways = synth.synth_wavy_knots(10, 256, 200, seed=11)
+    a = po.oracle_scene([(st, ways)], 300, 256, 200, 0xffffff)
+    b = po.cairo_scene([(st, ways)], 300, 256, 200, 0xffffff)
+    d = po.chan_diff(a, b)
+    assert len(np.unique(a)) > 2
+    assert (d <= 2).mean() >= bar2 and (d == 0).mean() >= bar0, ((d > 2).sum(), (d > 0).sum(), d.max())
