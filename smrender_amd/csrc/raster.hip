@@ -123,6 +123,8 @@ struct curve_args_t
    int64_t n_refs, n_ways;
    int dpi; int32_t sfix; double f;
    int border_used, fill_used;
+   int knots;                          /* curve=2: the way's refs are p0 and (c1, c2, p) triples, the path cairo_smr_wavy records
+                                          (src/smrules_cairo.c:752-840); never closed */
    int32_t W256, H256;                 /* the chart in 24.8 */
    int32_t reach[4];                   /* reach of the border stroke (no fill / open / closed way) and of the open ways' fill stroke, 24.8 */
    uint32_t *cnt;                      /* count pass */
@@ -203,17 +205,22 @@ __global__ void k_curve(curve_args_t A)
       last = p;
       cnt++;
    };
-   if ((wf & (2 | 4 | 8)) && n >= 2)
+   if (A.knots && closed && (wf & (2 | 4 | 8)))
+   {
+      if (j == 0) atomicOr(A.status, SMR_ST_KNOTS_CLOSED);      /* first ref == last ref: not a path this mode draws */
+   }
+   else if ((wf & (2 | 4 | 8)) && n >= 2)
    {
       const int64_t npt = closed ? n - 1 : n;
       const int st = closed ? 0 : 1;
       if (j == 0)
       {
-         const int2 p = A.pts[a0 + (st - 1 + npt) % npt];
+         const int2 p = A.pts[a0 + (A.knots ? 0 : (st - 1 + npt) % npt)];
          last = p;
          sink(p, 0, 0, false);
          if (EMIT) A.fway_off[w] = base;
       }
+      else if (A.knots && j % 3 != 0) { }      /* a control point: its curve belongs to the slot of the curve's end point */
       else
       {
          const int64_t i = closed ? j - 1 : j;
@@ -223,17 +230,21 @@ __global__ void k_curve(curve_args_t A)
          /* geo2pt = geo2pxf * 72 / dpi (src/rdata.c:240-245, :307-308) */
          const double gax = A.x[n0] * 72 / A.dpi, gay = A.y[n0] * 72 / A.dpi, gbx = A.x[n1] * 72 / A.dpi, gby = A.y[n1] * 72 / A.dpi;
          const double lax = A.x[n2] * 72 / A.dpi, lay = A.y[n2] * 72 / A.dpi, lbx = A.x[n3] * 72 / A.dpi, lby = A.y[n3] * 72 / A.dpi;
-         double c1x, c1y, c2x, c2y;
-         smr_control_points(gax, gay, gbx, gby, lax, lay, lbx, lby, A.f, c1x, c1y, c2x, c2y);
-         if (st)
-         {
-            if (i == 1) { c1x = gbx; c1y = gby; }
-            if (i == npt - 1) { c2x = lax; c2y = lay; }
-         }
-         auto dev = [&](double v) { return (int32_t) (((int64_t) (int32_t) rint(v * 256.0) * A.sfix) >> 8); };
          smr_knots_t K;
-         K.a = A.pts[a0 + i1]; K.d = A.pts[a0 + i2];
-         K.b = make_int2(dev(c1x), dev(c1y)); K.c = make_int2(dev(c2x), dev(c2y));
+         if (A.knots) { K.a = A.pts[a0 + j - 3]; K.b = A.pts[a0 + j - 2]; K.c = A.pts[a0 + j - 1]; K.d = A.pts[a0 + j]; }
+         else
+         {
+            double c1x, c1y, c2x, c2y;
+            smr_control_points(gax, gay, gbx, gby, lax, lay, lbx, lby, A.f, c1x, c1y, c2x, c2y);
+            if (st)
+            {
+               if (i == 1) { c1x = gbx; c1y = gby; }
+               if (i == npt - 1) { c2x = lax; c2y = lay; }
+            }
+            auto dev = [&](double v) { return (int32_t) (((int64_t) (int32_t) rint(v * 256.0) * A.sfix) >> 8); };
+            K.a = A.pts[a0 + i1]; K.d = A.pts[a0 + i2];
+            K.b = make_int2(dev(c1x), dev(c1y)); K.c = make_int2(dev(c2x), dev(c2y));
+         }
          last = K.a;
          bool line = K.a.x == K.b.x && K.a.y == K.b.y && K.c.x == K.d.x && K.c.y == K.d.y;
          /* _cairo_spline_intersects against the image (grown by the stroke's reach): a curve that cannot reach it is a line_to */
@@ -2824,7 +2835,8 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
       return smr_fail(SMR_E_INVAL, "draw: unknown style %d / %d", st->fill_style, st->border_style);
    if (st->fill_used && (st->fill_style == SMR_STYLE_PIPE || st->fill_style == SMR_STYLE_ROUNDDOT))
       return smr_fail(SMR_E_UNSUPPORTED, "draw: style=pipe|rounddot on the fill of open ways leaves round caps on every later stroke of the rule: not implemented on the GPU path");
-   if (st->curve != 0 && st->curve != 1) return smr_fail(SMR_E_UNSUPPORTED, "draw: wavy=1 is not implemented on the GPU path");
+   if (st->curve < 0 || st->curve > 2) return smr_fail(SMR_E_INVAL, "draw: curve mode %d", st->curve);
+   if (st->curve == 2 && st->directional) return smr_fail(SMR_E_UNSUPPORTED, "draw: explicit Bezier paths (wavy=1) are open paths: no directional fill");
    if (st->curve == 1 && !(st->curve_factor > 0 && st->curve_factor < 100)) return smr_fail(SMR_E_INVAL, "draw: curve_factor %g", st->curve_factor);
    if (st->directional && st->fill_used)
    {
@@ -2902,7 +2914,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    const bool dash_b = st->border_used && dsb.n > 0, dash_o = open_fill && dso.n > 0;
    int2 *tin = nullptr, *tout = nullptr;
    uint8_t *fskip = nullptr;
-   if (st->curve == 1)
+   if (st->curve != 0)
    {
       if (dash_b || dash_o)
          return smr_fail(SMR_E_UNSUPPORTED, "draw: a dashed stroke along a curve (curve=1 with style/bstyle/dash/bdash) is not implemented on the GPU path");
@@ -2911,7 +2923,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SMR_TRY(c->ensure(SMR_BUF_SUMS, ((size_t) n_refs / SCAN_B + 2) * 4, (void **) &sums));
       curve_args_t CA;
       CA.x = b->d_x; CA.y = b->d_y; CA.ref = b->d_ref; CA.pts = pts; CA.way_off = way_off; CA.refway = refway; CA.wayflags = wayflags;
-      CA.n_refs = n_refs; CA.n_ways = n_ways; CA.dpi = c->dpi; CA.sfix = sfix; CA.f = st->curve_factor;
+      CA.n_refs = n_refs; CA.n_ways = n_ways; CA.dpi = c->dpi; CA.sfix = sfix; CA.f = st->curve_factor; CA.knots = st->curve == 2;
       CA.border_used = st->border_used; CA.fill_used = st->fill_used;
       CA.W256 = c->W * 256; CA.H256 = c->H * 256;
       /* _cairo_stroke_style_max_distance_from_path: miter joins, limit 10 -> sqrt(2) * 10 line widths, in device px */
@@ -2927,7 +2939,15 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       k_curve<false><<<blocks(n_refs, 64), 64, 0, s>>>(CA);
       uint32_t total = 0;
       SMR_TRY(count_finish(ccnt, (uint32_t) n_refs, sums, &small[6], &total, s));
-      if (total == 0) return SMR_OK;
+      if (total == 0)
+      {
+         uint32_t stw = 0;
+         SMR_HIP(hipMemcpyAsync(&stw, &small[2], 4, hipMemcpyDeviceToHost, s));
+         SMR_HIP(hipStreamSynchronize(s));
+         if (stw & SMR_ST_KNOTS_CLOSED)
+            return smr_fail(SMR_E_UNSUPPORTED, "draw: a way of explicit Bezier knots (curve=2) must not end in its first ref: such paths are open (the way was not drawn)");
+         return SMR_OK;
+      }
       SMR_TRY(c->ensure(SMR_BUF_FPTS, (size_t) total * sizeof(int2), (void **) &fpts));
       SMR_TRY(c->ensure(SMR_BUF_FTIN, (size_t) total * sizeof(int2), (void **) &tin));
       SMR_TRY(c->ensure(SMR_BUF_FTOUT, (size_t) total * sizeof(int2), (void **) &tout));
@@ -3141,6 +3161,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       if (attempt) return smr_fail(SMR_E_CAPACITY, "draw: row-mask arena of %zu words still too small", mask_cap);
       mask_cap = (size_t) h_small[4] + 65536;
       init_small[0] = h_small[0];
+      init_small[2] = h_small[2] & ~SMR_ST_MASK_ARENA;           /* what the kernels before the set-up reported stays */
       SMR_HIP(hipMemcpyAsync(small, init_small, sizeof(init_small), hipMemcpyHostToDevice, s));
    }
    if (h_small[2] & SMR_ST_ROWCAP)
@@ -3221,6 +3242,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    }
    if (h_small[2] & SMR_ST_CURVE_DEPTH)
       return smr_fail(SMR_E_CAPACITY, "draw: a curve needs more than %d levels of subdivision", SMR_CURVE_STACK);
+   if (h_small[2] & SMR_ST_KNOTS_CLOSED)
+      return smr_fail(SMR_E_UNSUPPORTED, "draw: a way of explicit Bezier knots (curve=2) must not end in its first ref: such paths are open (the way was not drawn)");
    if (h_small[2] & SMR_ST_DEGRADED) smr_g.draw_status |= SMR_DRAW_DEGRADED_ROWS;
    if (h_small[2] & SMR_ST_ROWCAP)
       return smr_fail(SMR_E_CAPACITY, "draw: more than %d edges of one primitive span a vertex-free pixel row inside one tile", SMR_ROWCAP);

@@ -46,6 +46,11 @@ class DrawStyle(C.Structure):
         self.curve, self.curve_factor = 1, factor
         return self
 
+    def set_knots(self):
+        """curve=2: every way's refs are p0 and (c1, c2, p) triples, the path cairo_smr_wavy records (wavy=1)"""
+        self.curve = 2
+        return self
+
 
 class _DrawBatch(C.Structure):
     _fields_ = [("d_x", C.c_void_p), ("d_y", C.c_void_p), ("n_nodes", C.c_int64), ("d_way_off", C.c_void_p),

@@ -37,7 +37,9 @@ def draw_style(sa, st, **kw):
     """oracle Style -> smr_draw_style_t (ctypes mirror)"""
     gs = sa.DrawStyle(st.fill_used, st.border_used, st.fill_col, st.border_col, st.fill_width_mm, st.border_width_mm,
                       st.ignore_open, st.fill_style, st.border_style, 0, kw.get("directional", 0), kw.get("direct", 0))
-    if st.curve:
+    if st.curve == 2:
+        gs.set_knots()
+    elif st.curve:
         gs.set_curve(st.curve_fact)
     return gs.set_dashes([st.border_dash[i] for i in range(st.border_ndash)], [st.fill_dash[i] for i in range(st.fill_ndash)])
 

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 from oracle import pyoracle as po
 from golden_io import draw_style
+from smrender_amd import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -105,9 +106,11 @@ def test_edge_cases(hip):
     d = sa.DeviceArray((4,), np.float64)
     cv.draw(gs, d, d, sa.DeviceArray.from_numpy(np.zeros(1, np.int64)), None, 0, 0)      # nothing to draw
     assert np.all(cv.read() == 0xffffffff)
-    for bad, val in (("fill_style", 4), ("curve", 2)):       # pipe on the fill stroke; wavy=1
+    for bad, val, *rest in (("fill_style", 4), ("directional", 1, "curve", 2)):       # pipe on the fill stroke; explicit knots in a directional rule
         gs2 = sa.DrawStyle(1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
         setattr(gs2, bad, val)
+        if rest:
+            setattr(gs2, *rest)
         with pytest.raises(sa.SmrHipError) as e:       # unsupported styles fail loudly
             cv.draw(gs2, d, d, sa.DeviceArray.from_numpy(np.array([0, 4], np.int64)), None, 1, 4)
         assert e.value.code == -5
@@ -310,4 +313,49 @@ def test_dash_styles_the_gpu_path_refuses(hip):
                S(0, 1, 0, 0, 0, 0.1, 0).with_dash(border_style=S.DASHED, border_dash=(0, 0))):   # libcairo: invalid dash
         with pytest.raises(sa.SmrHipError):
             cv.draw(draw_style(sa, st), *args)
+    cv.close()
+
+
+WAVY_STYLES = {
+    "hairline": po.Style(1, 0, 0xff00ff, 0, 0.0, 0, 0),                    # draw:color=magenta;wavy=yes (rules/available/seamark_area.osm:38)
+    "line_02": po.Style(1, 0, 0xff00ff, 0, 0.2, 0, 0),                     # test/rules/0131.osm: width=.2
+    "border_only": po.Style(0, 1, 0, 0x204060, 0, 0.3, 0),
+    "bordered": po.Style(1, 1, 0x30c0d8f0, 0x000000, 0.3, 0.1, 0),
+}
+
+
+@pytest.mark.parametrize("style", list(WAVY_STYLES))
+@pytest.mark.parametrize("dpi", [300, 600])
+def test_explicit_bezier_paths_bit_exact(hip, style, dpi):
+    """curve=2: the ways are p0 + (c1, c2, p) triples (what cairo_smr_wavy records for wavy=1, src/smrules_cairo.c:752-840);
+    the GPU decomposes and strokes them like libcairo: bit-exact against the oracle (pinned against libcairo in
+    tests/test_oracle_cairo.py::test_explicit_bezier_paths), whole canvas and per band"""
+    sa = hip
+    W, H = 320, 256
+    st = WAVY_STYLES[style].with_knots()
+    ways = synth.synth_wavy_knots(24, W, H, seed=5, wave_px=(6.0, 30.0) if dpi == 300 else (12.0, 60.0))
+    want = po.oracle_scene([(st, ways)], dpi, W, H, 0xffffff)
+    x = np.concatenate([w[0] for w in ways]); y = np.concatenate([w[1] for w in ways])
+    off = np.concatenate([[0], np.cumsum([len(w[0]) for w in ways])]).astype(np.int64)
+    dx, dy, doff = (sa.DeviceArray.from_numpy(a) for a in (x, y, off))
+    cv = sa.Canvas(W, H, dpi, 0xffffff)
+    cv.draw(draw_style(sa, st), dx, dy, doff, None, len(ways), len(x))
+    got = cv.read(); cv.close()
+    assert len(np.unique(got)) > 2
+    assert np.array_equal(got, want), int((got != want).sum())
+    for y0, h in ((0, 100), (100, 156)):
+        cb = sa.Canvas(W, H, dpi, 0xffffff, y0, h)
+        cb.draw(draw_style(sa, st), dx, dy, doff, None, len(ways), len(x))
+        assert np.array_equal(cb.read(), want[y0:y0 + h]); cb.close()
+
+
+def test_explicit_bezier_paths_refuse_closed_ways(hip):
+    sa = hip
+    cv = sa.Canvas(64, 64, 300, 0xffffff)
+    xy = sa.DeviceArray.from_numpy(np.array([5.0, 20, 40, 50, 30, 10]))
+    off = sa.DeviceArray.from_numpy(np.array([0, 7], np.int64))
+    ref = sa.DeviceArray.from_numpy(np.array([0, 1, 2, 3, 4, 5, 0], np.int32))      # first ref == last ref
+    with pytest.raises(sa.SmrHipError) as e:
+        cv.draw(sa.DrawStyle(1, 0, 0, 0, 0.2, 0, 0, 0, 0, 0, 0, 0).set_knots(), xy, xy, off, ref, 1, 7)
+    assert e.value.code == -5
     cv.close()
