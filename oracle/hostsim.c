@@ -98,6 +98,7 @@ void hs_set_rdata(double lon0, double w, double h, double wc, double lath, doubl
    rd_.w = rd_.pgw = w; rd_.h = rd_.pgh = h; rd_.wc = wc; rd_.hc = lat_ru - lat_ll;
    rd_.lath = lath; rd_.lath_len = lath_len; rd_.dpi = dpi;
    rd_.mean_lat = (lat_ll + lat_ru) / 2; rd_.mean_lon = (lon0 + lon_ru) / 2;
+   rd_.mean_lat_len = wc * cos(rd_.mean_lat * M_PI / 180);      /* init_bbox_mll, src/smrender.c:285: wc = mean_lat_len / cos(mean_lat) */
    rd_.proj = PROJ_MERC; rd_.img_scale = 1;
    bgcolor_ = bgcolor;
 }

@@ -215,6 +215,7 @@ struct draw_rule_t
    std::vector<uint32_t> fill_col, border_col;
    /* directional=1: the closed way with the largest |area| decides about the page rectangle (:1091-1109) */
    double max_area = -1; bool max_cw = false; uint32_t max_col = 0;
+   double wavy_deg = 0;                   /* wavy=1: wavy_length in degrees (:632-642) */
 };
 
 /* parse_dash_style, src/smrparse.c:1077-1102: "a:b:c:d" in mm (the host's parser knows the other units); no or
@@ -271,8 +272,28 @@ static int draw_ini(smr_smrule_t *r)
       d->st.curve = 1;
       if (H.get_param("curve_factor", &d->st.curve_factor, r->act) == nullptr) d->st.curve_factor = 0.2;
    }
-   if (H.get_param_bool("wavy", r->act)) d->st.curve = 2;
+   if (H.get_param_bool("wavy", r->act))
+   {
+      /* :632-642: wavy_length is a length on paper (default unit mm) turned into degrees, rdata_unit(&v, U_DEG) =
+       * px * mean_lat_len / w (src/rdata.c:296-327); without the parameter WAVY_LENGTH 0.0015 degrees (:113) */
+      d->st.curve = 2;
+      d->wavy_deg = 0.0015;
+      if ((s = H.get_param("wavy_length", nullptr, r->act)) != nullptr)
+      {
+         double mm = 0;
+         if (H.parse_length_mm_array ? H.parse_length_mm_array(s, &mm, 1) != 1 : (mm = strtod(s, nullptr), false))
+         {
+            plog(SMR_LOG_ERR, "draw: cannot parse wavy_length=%s", s);
+            delete d;
+            return 1;
+         }
+         const struct smr_rdata *rd = H.rdata_get();
+         d->wavy_deg = mm / 25.4 * rd->dpi * rd->mean_lat_len / rd->w;
+      }
+      if (!(d->wavy_deg > 0)) { plog(SMR_LOG_ERR, "draw: wavy_length must be positive"); delete d; return 1; }
+   }
    d->st.directional = H.get_param_bool("directional", r->act);
+   if (d->st.curve == 2) d->st.directional = 0;      /* only the closed ways of a rule are directional, and wavy closed ways are not drawn here */
    d->st.ignore_open = H.get_param_bool("ignore_open", r->act);
    /* DRAW_TRANSPARENT parses but draws solid (cairo_smr_dash has no case for it) */
    if (d->st.fill_style == 3) d->st.fill_style = 0;
@@ -284,10 +305,9 @@ static int draw_ini(smr_smrule_t *r)
    const char *why = nullptr;
    if (d->st.fill_used && (d->st.fill_style == SMR_STYLE_PIPE || d->st.fill_style == SMR_STYLE_ROUNDDOT))
       why = "style=pipe|rounddot (round caps on the fill strokes of open ways)";
-   else if (d->st.curve == 2) why = "wavy=1";
-   else if (d->st.curve == 1 && ((d->st.border_used && (d->st.border_style != 0 || d->st.border_ndash)) ||
+   else if (d->st.curve != 0 && ((d->st.border_used && (d->st.border_style != 0 || d->st.border_ndash)) ||
                                  (d->st.fill_used && (d->st.fill_style != 0 || d->st.fill_ndash))))
-      why = "dashed strokes along curves (curve=1 with style/bstyle/dash/bdash)";
+      why = "dashed strokes along curves (curve=1 or wavy=1 with style/bstyle/dash/bdash)";
    else if (H.get_param("file", nullptr, r->act)) why = "image pattern fill (file=)";
    if (why)
    {
@@ -314,8 +334,97 @@ static int draw_ini(smr_smrule_t *r)
    return 0;
 }
 
+/* coord_diffp, src/smath.c:34-52: bearing (degrees, 0 = north, clockwise, in [0, 360)) and orthodrome distance (degrees) */
+static void wavy_diff(double slat, double slon, double tlat, double tlon, double *bearing, double *dist)
+{
+   /* DEG2RAD(x) is ((x) * M_PI / 180.0), RAD2DEG(x) ((x) * 180.0 / M_PI) (libsmrender/smrender.h:48-49): written out, their rounding is part of the path */
+   const double dlat = tlat - slat;
+   const double dlon = (tlon - slon) * cos(((slat + tlat) / 2.0) * M_PI / 180.0);
+   double b = atan2(dlon, dlat) * 180.0 / M_PI;
+   *dist = acos(sin(slat * M_PI / 180.0) * sin(tlat * M_PI / 180.0) +
+                cos(slat * M_PI / 180.0) * cos(tlat * M_PI / 180.0) * cos((tlon - slon) * M_PI / 180.0)) * 180.0 / M_PI;
+   b = fmod(b, 360.0);
+   *bearing = b < 0 ? b + 360.0 : b;
+}
+
+/* wavy=1 (cairo_smr_wavy, src/smrules_cairo.c:777-840, and wavy, :752-774): the way is resampled every wavy_length degrees,
+ * and every step becomes one curve_to with its control points at -45 and +45 degrees of the step's bearing.  The resampling
+ * is a chain in which every step starts where the last one ended and compares rounded distances: it runs here, on the host,
+ * with the C library's sin/cos/acos/atan2, which are the ones the reference calls (a device libm may differ in the last bit,
+ * and a flipped comparison is a wave more or less).  What goes to the GPU are the knots p0, (c1, c2, p) * n as nodes of a way
+ * of their own (smr_draw_style_t.curve = 2); projection, decomposition and stroking happen there. */
+static int draw_way_wavy(draw_rule_t *d, const smr_osm_way_t *w)
+{
+   if (w->ref_cnt >= 4 && w->ref[0] == w->ref[w->ref_cnt - 1])
+   {
+      plog(SMR_LOG_ERR, "draw: wavy=1 on the closed way %lld is not implemented on the GPU path (the way is not drawn)", (long long) w->obj.id);
+      return 0;
+   }
+   if (d->st.ignore_open) return 0;
+   if (w->ref_cnt < 2)
+   {
+      plog(SMR_LOG_WARN, "ignoring short way %lld (len = %d)", (long long) w->obj.id, w->ref_cnt);
+      return 0;
+   }
+   const size_t first = d->lat.size();
+   auto put = [&](double lat, double lon) { d->ref.push_back((int32_t) d->lat.size()); d->lat.push_back(lat); d->lon.push_back(lon); };
+   auto give_up = [&](int pos)
+   {
+      plog(SMR_LOG_ERR, "node %lld of way %lld das not exit", (long long) w->ref[pos], (long long) w->obj.id);      /* :793, :811 */
+      d->lat.resize(first); d->lon.resize(first); d->ref.resize((size_t) d->way_off.back());
+      return 0;
+   };
+   const smr_osm_node_t *n = (const smr_osm_node_t *) H.get_object(SMR_OSM_NODE, w->ref[0]);
+   if (n == nullptr) return give_up(0);
+   double sc_lat = n->lat, sc_lon = n->lon;
+   put(sc_lat, sc_lon);
+   const double dist = d->wavy_deg;
+   double bearing = 0, pdist = 0;
+   for (int i = 1;;)
+   {
+      if (pdist <= 0)
+      {
+         if (i >= w->ref_cnt) break;
+         if ((n = (const smr_osm_node_t *) H.get_object(SMR_OSM_NODE, w->ref[i])) == nullptr) return give_up(i);
+         i++;
+         const double rest = pdist;
+         wavy_diff(sc_lat, sc_lon, n->lat, n->lon, &bearing, &pdist);
+         pdist += rest;
+      }
+      if (pdist > dist)
+      {
+         const double ic_lat = sc_lat + dist * cos(bearing * M_PI / 180.0);
+         const double ic_lon = sc_lon + dist * sin(bearing * M_PI / 180.0) / cos(((ic_lat + sc_lat) / 2) * M_PI / 180.0);
+         double wb, wd;
+         wavy_diff(sc_lat, sc_lon, ic_lat, ic_lon, &wb, &wd);
+         for (int side = 0; side < 2; side++)
+         {
+            wb += side == 0 ? -45.0 : 90.0;
+            const double la = sc_lat + wd * M_SQRT1_2 * cos(wb * M_PI / 180.0);
+            const double lo = sc_lon + wd * M_SQRT1_2 * sin(wb * M_PI / 180.0) / cos(((la + sc_lat) / 2) * M_PI / 180.0);
+            put(la, lo);
+         }
+         put(ic_lat, ic_lon);
+         sc_lat = ic_lat; sc_lon = ic_lon;
+      }
+      pdist -= dist;
+   }
+   if (d->lat.size() > 0x7fffff00u) { plog(SMR_LOG_ERR, "draw: more than 2^31 nodes in one rule"); return -1; }
+   if (d->lat.size() - first < 4)
+   {
+      /* a way shorter than one wave: cairo_move_to alone, nothing to stroke */
+      d->lat.resize(first); d->lon.resize(first); d->ref.resize((size_t) d->way_off.back());
+      return 0;
+   }
+   d->way_off.push_back((int64_t) d->ref.size());
+   if (d->fill_cs.key) d->fill_col.push_back(color_by_cs(&w->obj, &d->fill_cs));
+   if (d->border_cs.key) d->border_col.push_back(color_by_cs(&w->obj, &d->border_cs));
+   return 0;
+}
+
 static int draw_way(draw_rule_t *d, const smr_osm_way_t *w)
 {
+   if (d->st.curve == 2) return draw_way_wavy(d, w);
    /* is_closed_poly, src/smcoast.c:115-125 */
    const bool closed = w->ref_cnt >= 4 && w->ref[0] == w->ref[w->ref_cnt - 1];
    if (!closed && d->st.ignore_open) return 0;

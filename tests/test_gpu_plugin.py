@@ -83,7 +83,7 @@ def test_draw_relation_members_and_key_colours(chart):
 
 def test_unsupported_draw_styles_are_refused_loudly(chart):
     sa, proj = chart
-    for params in ("color=red;style=rounddot", "color=red;wavy=1", "bcolor=red;curve=1;bstyle=dashed"):
+    for params in ("color=red;style=rounddot", "color=red;wavy=1;style=dashed", "bcolor=red;curve=1;bstyle=dashed"):
         assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, []) == 2001      # "Rule will be ignored"
 
 
@@ -119,6 +119,49 @@ def test_curve_rule_through_the_action_api(chart, params, factor):
     st = po.Style(1, 1, 0x4080c0, 0x000000, 0.3 if "width=0.3" in params else 0, 0.2, 0).with_curve(factor)
     want = po.oracle_scene([(st, oways)], DPI, W, H, 0xfff8e0)
     assert np.array_equal(plugin_canvas(sa), want)
+
+
+@pytest.mark.parametrize("params,width_mm,length_mm", [("color=#ff00ff;wavy=yes", 0.0, None),                    # rules/available/seamark_area.osm:38 (magenta)
+                                                     ("color=#ff00ff;width=.2;wavy=yes;wavy_length=1.5", 0.2, 1.5)])   # test/rules/0131.osm
+def test_wavy_rule_through_the_action_api(chart, params, width_mm, length_mm):
+    """wavy=1 / wavy_length= (act_draw_ini :632-642): the plugin resamples the way on the host as cairo_smr_wavy does (:752-840)
+    and hands the knots to the GPU as explicit Bezier paths; the expected picture takes the knots from the oracle's own
+    restatement (oracle/wavy.c) of the same loop.  A closed way of the rule is refused with an error message and not drawn."""
+    import ctypes as C
+    from smrender_amd import synth
+    sa, proj = chart
+    rng = np.random.default_rng(3)
+    xs, ys, off = [], [], [0]
+    for _ in range(8):                                   # open ways of a few long legs: submarine cables
+        n = int(rng.integers(3, 8))
+        xs.append(rng.uniform(20, W - 20) + np.cumsum(rng.normal(0, 90, n))); ys.append(rng.uniform(20, H - 20) + np.cumsum(rng.normal(0, 90, n)))
+        off.append(off[-1] + n)
+    ring = np.array([100.0, 200, 200, 100, 100]), np.array([100.0, 100, 200, 200, 100])
+    x, y = np.concatenate(xs + [ring[0][:4]]), np.concatenate(ys + [ring[1][:4]])
+    ref = np.concatenate([np.arange(off[-1]), off[-1] + np.array([0, 1, 2, 3, 0])]).astype(np.int32)
+    off = np.array(off + [off[-1] + 5], np.int64)
+    wids, _ = load_ways(sa, proj, (x, y, off, ref))
+    rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, wids)
+    assert rc == 0, sa.lib().smr_hip_last_error()
+    lat, lon = synth.px_to_geo(proj, x, y)
+    dist = 0.0015 if length_mm is None else length_mm / 25.4 * DPI * (proj.wc * np.cos(np.radians((proj.lat_ll + proj.lat_ru) / 2))) / proj.w
+    L = po.orc()
+    L.orc_wavy_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    oways = []
+    for w in range(len(off) - 2):                        # the ring is not drawn
+        la, lo = np.ascontiguousarray(lat[off[w]:off[w + 1]]), np.ascontiguousarray(lon[off[w]:off[w + 1]])
+        ola, olo = np.zeros(4096), np.zeros(4096)
+        m = L.orc_wavy_path(po.P(la), po.P(lo), len(la), dist, po.P(ola), po.P(olo), 4096)
+        assert m >= 1
+        if m >= 4:
+            ox, oy, _, _, _ = po.project(op, ola[:m], olo[:m])
+            oways.append((ox, oy, False))
+    assert len(oways) >= 4
+    want = po.oracle_scene([(po.Style(1, 0, 0xff00ff, 0, width_mm, 0, 0).with_knots(), oways)], DPI, W, H, 0xfff8e0)
+    got = plugin_canvas(sa)
+    assert len(np.unique(got)) > 2
+    assert np.array_equal(got, want), int((got != want).sum())
 
 
 @pytest.mark.parametrize("sea_first", [True, False])

@@ -49,3 +49,31 @@ def test_far_window_pins_replay_scale_quantisation():
     orules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in rules]
     got = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"])
     assert within(got, want, 0) >= 0.999
+
+
+def test_coord_diffp_equals_the_reference():
+    """oracle/wavy.c's orc_coord_diffp against the reference's own src/smath.c (oracle/_ref/libref_smath.so, built where the
+    reference lies): bit-equal bearings and distances; skipped where the reference build is absent"""
+    import ctypes as C, os
+    so = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libref_smath.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_smath.so not built (no reference here)")
+    R, L = C.CDLL(so), po.orc()
+
+    class Coord(C.Structure):
+        _fields_ = [("lat", C.c_double), ("lon", C.c_double)]
+
+    class PCoord(C.Structure):
+        _fields_ = [("bearing", C.c_double), ("dist", C.c_double)]
+    R.coord_diffp.argtypes = [C.POINTER(Coord), C.POINTER(Coord), C.POINTER(PCoord)]
+    L.orc_coord_diffp.argtypes = [C.c_double] * 4 + [C.POINTER(C.c_double)] * 2
+    rng = np.random.default_rng(1)
+    for _ in range(20000):
+        a = Coord(rng.uniform(-80, 80), rng.uniform(-179, 179))
+        s = 10.0 ** rng.uniform(-5, 0.5)
+        b = Coord(a.lat + rng.normal(0, s), a.lon + rng.normal(0, s))
+        pc = PCoord(); brg, dist = C.c_double(), C.c_double()
+        R.coord_diffp(C.byref(a), C.byref(b), C.byref(pc))
+        L.orc_coord_diffp(a.lat, a.lon, b.lat, b.lon, C.byref(brg), C.byref(dist))
+        assert (pc.bearing == brg.value or (np.isnan(pc.bearing) and np.isnan(brg.value))) and \
+               (pc.dist == dist.value or (np.isnan(pc.dist) and np.isnan(dist.value))), (a.lat, a.lon, b.lat, b.lon)
