@@ -1829,6 +1829,7 @@ struct raster_args_t
    uint32_t *tile_ctr;        /* [8 * xcd]: next tile of the XCD's columns, zero at launch */
    int W, band_y0, band_h, TX;
    uint32_t n_tiles;
+   uint32_t chunk;            /* tiles a wavefront takes from its XCD's queue with one atomic */
    int direct;                /* no group layer: primitives composite straight onto the canvas */
 };
 
@@ -1921,7 +1922,9 @@ __device__ void smr_render_edge(raster_lds_t &L, int row, int32_t X0, int32_t dx
 
 #define SMR_RASTER_WAVES 4      /* independent wavefronts per workgroup, one tile at a time each */
 #ifndef SMR_TILE_CHUNK
-#define SMR_TILE_CHUNK 2        /* tiles a wavefront takes from its XCD's queue with one atomic */
+#define SMR_TILE_CHUNK 2        /* tiles a wavefront takes from its XCD's queue with one atomic on a dense chart (C2: 53 entries per
+                                   tile; 1 is 0.5 % faster there); a sparse chart (C3: 0.5 entries per tile, most tiles empty) pays
+                                   for the atomics, not for the tiles: 8 at a time there (raster 5.3 -> 2.2 ms per rule) */
 #endif
 
 /* -DSMR_SECTION_PROFILE: s_memtime stamps around the sections of k_raster, summed per section into
@@ -1978,17 +1981,17 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
    const uint32_t xcd = blockIdx.x & 7u;
    const uint32_t TYt = A.n_tiles / A.TX;
    const uint32_t ncol = ((uint32_t) A.TX + 7u - xcd) >> 3;
-   /* ... and the tiles of an XCD's columns are handed out dynamically, SMR_TILE_CHUNK vertically adjacent ones at a time:
-    * a chart's load per tile varies, and a static share leaves wavefronts idle at the end of the launch */
+   /* ... and the tiles of an XCD's columns are handed out dynamically, A.chunk vertically adjacent ones at a time: a chart's
+    * load per tile varies, and a static share leaves wavefronts idle at the end of the launch */
    const uint32_t ktotal = ncol * TYt;
    uint32_t *const ctr = A.tile_ctr + 8u * xcd;
    for (;;)
    {
    uint32_t k0 = 0;
-   if (lane == 0) k0 = atomicAdd(ctr, (uint32_t) SMR_TILE_CHUNK);
+   if (lane == 0) k0 = atomicAdd(ctr, A.chunk);
    k0 = __builtin_amdgcn_readfirstlane(k0);
    if (k0 >= ktotal) break;
-   const uint32_t k1 = min(k0 + (uint32_t) SMR_TILE_CHUNK, ktotal);
+   const uint32_t k1 = min(k0 + A.chunk, ktotal);
    for (uint32_t kg = k0; kg < k1; kg++)
    {
       const int tx = (int) (xcd + 8u * (kg / TYt)), ty = (int) (kg % TYt);
@@ -3204,6 +3207,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    A.tile_ctr = &small[64];       /* zero since the memset at the top of the pass */
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
+   A.chunk = n_entries >= 8ull * n_tiles ? SMR_TILE_CHUNK : n_entries >= 2ull * n_tiles ? 2 * SMR_TILE_CHUNK : 4 * SMR_TILE_CHUNK;
    A.direct = st->direct != 0;
    {
       /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
