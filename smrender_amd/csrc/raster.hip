@@ -1561,8 +1561,8 @@ __global__ void k_compound_merge(smr_prim_t *prims, int64_t n_ways, uint32_t com
  * More than SMR_ROWCAP such edges: the row is sub-sampled instead (status SMR_ST_DEGRADED: the one place
  * where the result may leave libcairo's arithmetic, by the difference between 15 samples and the exact
  * trapezoid on that row's edge pixels). */
-__global__ __launch_bounds__(64) void k_compound_rows(const smr_edge_t *__restrict__ E, int64_t n_edges, uint32_t *mask,
-                                                      const uint32_t *__restrict__ covered, int H, uint32_t *status)
+__global__ __launch_bounds__(64) void k_compound_rows(const smr_edge_t *__restrict__ edges, const smr_item_t *__restrict__ items, int64_t n_items,
+                                                      uint32_t compound, uint32_t *mask, const uint32_t *__restrict__ covered, int H, uint32_t *status)
 {
    __shared__ int f0[SMR_ROWCAP], f1[SMR_ROWCAP];
    const int r = blockIdx.x, lane = threadIdx.x;
@@ -1570,23 +1570,36 @@ __global__ __launch_bounds__(64) void k_compound_rows(const smr_edge_t *__restri
    if (!((covered[r >> 5] >> (r & 31)) & 1u) || ((mask[r >> 5] >> (r & 31)) & 1u)) return;
    const int rs0 = r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
    uint32_t cnt = 0;
-   for (int64_t base = 0; base < n_edges; base += 64)
+   /* lanes = 64 items at a time: only the members' items whose box meets the row hold a candidate */
+   for (int64_t kb = 0; kb < n_items; kb += 64)
    {
-      const int64_t idx = base + lane;
-      smr_oedge_t o; o.dir = 0; o.ytop = o.ybot = 0;
-      if (idx < n_edges) o = smr_orient(E[idx]);
-      const bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs1;
-      const unsigned long long am = __ballot(act);
-      if (!am) continue;
-      const uint32_t pos = cnt + __popcll(am & ((1ull << lane) - 1ull));
-      if (act && pos < SMR_ROWCAP)
+      bool ov = false;
+      if (kb + lane < n_items)
       {
-         const int64_t ec = 256 - 30ll * o.p1y;
-         const double inv = smr_rcp((double) o.D);
-         f0[pos] = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs0);
-         f1[pos] = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs1);
+         const smr_item_t *it = items + kb + lane;
+         ov = it->cnt_flags != 0 && it->prim == compound && (it->maxy >> 8) >= r && (it->miny >> 8) <= r;
       }
-      cnt += __popcll(am);
+      unsigned long long om = __ballot(ov);
+      while (om)
+      {
+         const int j = __ffsll((long long) om) - 1;
+         om &= om - 1;
+         const uint32_t eo = items[kb + j].edge_off, ec_ = items[kb + j].cnt_flags & 0xffu;
+         smr_oedge_t o; o.dir = 0; o.ytop = o.ybot = 0;
+         if ((uint32_t) lane < ec_) o = smr_orient(edges[(size_t) eo + lane]);
+         const bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs1;
+         const unsigned long long am = __ballot(act);
+         if (!am) continue;
+         const uint32_t pos = cnt + __popcll(am & ((1ull << lane) - 1ull));
+         if (act && pos < SMR_ROWCAP)
+         {
+            const int64_t ec = 256 - 30ll * o.p1y;
+            const double inv = smr_rcp((double) o.D);
+            f0[pos] = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs0);
+            f1[pos] = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs1);
+         }
+         cnt += __popcll(am);
+      }
    }
    __syncthreads();
    bool viol = false;
@@ -3156,7 +3169,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          {
             uint32_t *covered = (uint32_t *) c->buf[SMR_BUF_COVERED].p;
             k_compound_merge<<<blocks(n_ways, TB), TB, 0, s>>>(prims, n_ways, compound, maskbuf, covered);
-            k_compound_rows<<<(unsigned) c->H, 64, 0, s>>>(edges + off_fill, n_refs, maskbuf, covered, c->H, &small[2]);
+            k_compound_rows<<<(unsigned) c->H, 64, 0, s>>>(edges, items, n_items, compound, maskbuf, covered, c->H, &small[2]);
             SMR_HIP(hipGetLastError());
          }
          break;
