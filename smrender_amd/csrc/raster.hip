@@ -1367,15 +1367,23 @@ __global__ __launch_bounds__(256) void k_big_items(const smr_prim_t *__restrict_
    const int lane = threadIdx.x & 63;
    const uint32_t gwave = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4u;
    const uint32_t nbig = biglist[0];
-   uint32_t first = 0;
-   for (uint32_t b = 0; b < nbig; b++)
+   /* every wavefront takes one contiguous run of the items of all long primitives: it meets one or two primitives, whose boxes it
+    * grows with one set of atomics each (dealt round robin, every item brought five atomics on its primitive's accumulator) */
+   uint64_t total = 0;
+   for (uint32_t b = 0; b < nbig; b++) total += (prims[biglist[1 + 2 * b]].edge_cnt + 63u) >> 6;
+   const uint64_t per = (total + nwaves - 1) / nwaves, lo = (uint64_t) gwave * per, hi = min(total, lo + per);
+   uint64_t first = 0;
+   for (uint32_t b = 0; b < nbig && first < hi; b++)
    {
       const smr_prim_t P = prims[biglist[1 + 2 * b]];
       const uint32_t item0 = biglist[2 + 2 * b], nitems = (P.edge_cnt + 63u) >> 6;
+      if (first + nitems <= lo) { first += nitems; continue; }
       const uint32_t item_flags = acc[b].item_flags, prim_id = acc[b].prim_id;
       const bool pieces = (item_flags & SMR_PF_PIECES) != 0;
       const smr_edge_t *E = edges + P.edge_off;
-      for (uint32_t k = (gwave + nwaves - first % nwaves) % nwaves; k < nitems; k += nwaves)
+      int amnx = INT32_MAX, amny = INT32_MAX, amxx = INT32_MIN, amxy = INT32_MIN, abmx = INT32_MIN;
+      const uint32_t k0 = lo > first ? (uint32_t) (lo - first) : 0u, k1 = (uint32_t) min((uint64_t) nitems, hi - first);
+      for (uint32_t k = k0; k < k1; k++)
       {
          const uint32_t idx = k * 64u + (uint32_t) lane;
          smr_edge_t e; e.x1 = e.y1 = e.x2 = e.y2 = 0;
@@ -1397,12 +1405,13 @@ __global__ __launch_bounds__(256) void k_big_items(const smr_prim_t *__restrict_
             it.color = P.color;
             it.minx = bmn; it.miny = mny; it.maxx = bmx; it.maxy = mxy;
             items[item0 + k] = it;
-            if (mnx <= mxx)
-            {
-               atomicMin(&acc[b].minx, mnx); atomicMin(&acc[b].miny, mny); atomicMax(&acc[b].maxx, mxx); atomicMax(&acc[b].maxy, mxy);
-               atomicMax(&acc[b].bin_maxx, bmx);
-            }
          }
+         if (mnx <= mxx) { amnx = min(amnx, mnx); amny = min(amny, mny); amxx = max(amxx, mxx); amxy = max(amxy, mxy); abmx = max(abmx, bmx); }
+      }
+      if (lane == 0 && amnx <= amxx)
+      {
+         atomicMin(&acc[b].minx, amnx); atomicMin(&acc[b].miny, amny); atomicMax(&acc[b].maxx, amxx); atomicMax(&acc[b].maxy, amxy);
+         atomicMax(&acc[b].bin_maxx, abmx);
       }
       first += nitems;
    }
@@ -1445,17 +1454,22 @@ __global__ __launch_bounds__(256) void k_big_vrows(const smr_prim_t *__restrict_
    const int lane = threadIdx.x & 63;
    const uint32_t gwave = blockIdx.x * 4u + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = gridDim.x * 4u;
    const uint32_t nbig = biglist[0];
-   uint32_t first = 0;
-   for (uint32_t b = 0; b < nbig; b++)
+   uint64_t total = 0;                      /* contiguous runs of items per wavefront, as in k_big_items */
+   for (uint32_t b = 0; b < nbig; b++) total += (prims[biglist[1 + 2 * b]].edge_cnt + 63u) >> 6;
+   const uint64_t per = (total + nwaves - 1) / nwaves, lo = (uint64_t) gwave * per, hi = min(total, lo + per);
+   uint64_t first = 0;
+   for (uint32_t b = 0; b < nbig && first < hi; b++)
    {
       const smr_prim_t P = prims[biglist[1 + 2 * b]];
       const uint32_t item0 = biglist[2 + 2 * b], nitems = (P.edge_cnt + 63u) >> 6;
+      if (first + nitems <= lo) { first += nitems; continue; }
       const smr_bigacc_t a = acc[b];
       if (a.valid)
       {
          const smr_edge_t *E = edges + P.edge_off;
          uint32_t *m = mask + P.mask_off;
-         for (uint32_t k = (gwave + nwaves - first % nwaves) % nwaves; k < nitems; k += nwaves)
+         const uint32_t k0 = lo > first ? (uint32_t) (lo - first) : 0u, k1 = (uint32_t) min((uint64_t) nitems, hi - first);
+         for (uint32_t k = k0; k < k1; k++)
          {
             const uint32_t idx = k * 64u + (uint32_t) lane;
             if (idx < P.edge_cnt)
