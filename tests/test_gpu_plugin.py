@@ -292,3 +292,20 @@ def test_cap_same_rule_captions_see_earlier_rectangles(chart):
     cy = np.concatenate([rng.uniform(60, 90, 5), rng.uniform(180, 210, 5), rng.uniform(20, H - 20, 4)])
     changed = run_caption_rule(chart, 91, cx, cy, [f"Name {k}" for k in range(14)], 1.6, "#203040", 0x203040, 1.0)
     assert changed >= 2          # the dependency really changed some angles in this scene
+
+
+def test_every_shipped_draw_rule_is_accepted_or_refused_for_a_documented_reason(chart):
+    """tests/golden/draw_params.txt holds the parameter strings of all `draw` actions of the reference's rulesets and test
+    rules (collected by tests/golden/make_draw_params.py).  act_draw_ini must take every one of them (and _fini must run on an
+    empty rule), except the image-pattern fills (file=), which the GPU path refuses with "Rule will be ignored"."""
+    import os
+    sa, proj = chart
+    lines = [l.rstrip("\n") for l in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "draw_params.txt"))]
+    assert len(lines) >= 80
+    refused = []
+    for params in lines:
+        rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, [])
+        if rc != 0:
+            refused.append(params)
+            assert rc == 2001 and "file=" in params, (params, rc, sa.lib().smr_hip_last_error())
+    assert sorted(refused) == sorted(l for l in lines if "file=" in l)
