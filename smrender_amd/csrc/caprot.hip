@@ -178,12 +178,16 @@ __global__ __launch_bounds__(64) void k_caprot(caprot_args_t A)
       if (!fg_skip || A.fg)
       {
          /* without explicit plane pixels only the columns from fg_x on are opaque (cairo_smr_plane: the left half of an
-          * E/W-aligned caption's plane is clear): the lanes walk those alone, line and column stepped without a division */
-         const int c0 = A.fg ? 0 : A.fg_x, nq = (A.fg_w - c0) * A.fg_h, cw = max(1, A.fg_w - c0);
-         int line = lane / cw, col = lane - line * cw;
-         for (int q = lane; q < nq; q += 64, col += 64)
+          * E/W-aligned caption's plane is clear): the lanes walk those alone ... */
+         /* ... in blocks of 16 columns x 4 lines: rotated onto the canvas a block is a compact patch of a few cache lines, where 64
+          * pixels of one plane line are a 64-px segment that crosses up to 64 of them */
+         const int c0 = A.fg ? 0 : A.fg_x, cw = A.fg_w - c0, nbc = (cw + 15) >> 4, nblk = nbc * ((A.fg_h + 3) >> 2);
+         for (int blk = 0; blk < nblk; blk++)
          {
-            while (col >= cw) { col -= cw; line++; }
+            const int brow = blk / nbc, bcol = blk - brow * nbc;
+            const int line = 4 * brow + (lane >> 4), col = 16 * bcol + (lane & 15);
+            if (col >= cw || line >= A.fg_h) continue;
+            const int q = line * cw + col;
             const int p = line * A.fg_w + c0 + col;
             int psr = sr, psg = sg, psb = sb;
             double plum = lum_s;
