@@ -57,8 +57,10 @@ def measured_traffic(kernel, args):
     corrected as MI355X_MICROARCH.md prescribes); None when the workload differs from the profiled one."""
     if (args.ways, args.size, args.dpi) != (1000000, 16384, 300):
         return None
+    import re
     best = None
-    for f in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+    # the latest set: names sort by their numbers (r01_s5 < r01_s11 < r02_...), not as strings
+    for f in sorted(os.listdir(os.path.join(ROOT, "profiles")), key=lambda n: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", n)]):
         if f.endswith("_hbm_traffic.json"):
             best = os.path.join(ROOT, "profiles", f)
     if best is None:
