@@ -309,3 +309,73 @@ def test_every_shipped_draw_rule_is_accepted_or_refused_for_a_documented_reason(
             refused.append(params)
             assert rc == 2001 and "file=" in params, (params, rc, sa.lib().smr_hip_last_error())
     assert sorted(refused) == sorted(l for l in lines if "file=" in l)
+
+
+REAL_RULES = [   # (parameters as a ruleset would give them, the oracle's style, directional)
+    ("color=#e0e0e0;bcolor=#0000ff;curve=1", po.Style(1, 1, 0xe0e0e0, 0x0000ff, 0, 0, 0).with_curve(0.2), False),            # rules: color=#e0e0e0;bcolor=blue;curve=1
+    ("bcolor=#40FF00FF;bwidth=0.5;bstyle=dashed", po.Style(0, 1, 0, 0x40ff00ff, 0, 0.5, 0).with_dash(border_style=1), False),
+    ("color=#dde7eb;ignore_open=1;directional=1;curve=1", po.Style(1, 0, 0xdde7eb, 0, 0, 0, 1).with_curve(0.2), True),
+    ("color=#ff00ff;width=.2;wavy=yes;wavy_length=1.5", None, False),                                                           # test/rules/0131.osm
+    ("bcolor=#ff00ff;bstyle=pipe;bwidth=0.2", po.Style(0, 1, 0, 0xff00ff, 0, 0.2, 0).with_dash(border_style=4), False),      # pipeline_submarine
+    ("color=#00600000;width=0.3;curve=1", po.Style(1, 0, 0x00600000, 0, 0.3, 0, 0).with_curve(0.2), False),
+]
+
+
+@pytest.mark.parametrize("k", range(len(REAL_RULES)))
+def test_reference_testdata_through_the_action_api(hip, k):
+    """The reference's own test data (test/testdata.osm: 103 nodes, 11 ways, kept as the fixture tests/golden/testdata.osm) on its
+    test chart (test/Makefile:21-23: window 15E34.35:43N44.06:40000, page 50x50 mm, 300 dpi = 590 px), one shipped draw rule at
+    a time applied to every way in bxtree order (negative ids ascending): what the plugin draws equals the oracle's picture of
+    the same ways bit for bit."""
+    import ctypes as C, os
+    import xml.etree.ElementTree as ET
+    sa = hip
+    params, st, directional = REAL_RULES[k]
+    Wc = Hc = 590
+    sa.lib().smr_hip_plugin_reset()
+    proj = sa.Projection.from_window(43.0 + 44.06 / 60, 15.0 + 34.35 / 60, 40000.0, float(Wc), float(Hc), DPI)
+    hs.set_chart(proj, 0xffffff)
+    t = ET.parse(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "testdata.osm")).getroot()
+    base = _next_id[0]; _next_id[0] += 100000
+    # fresh ids per test (the host's tree lives as long as the process), keeping the file's order of negative ids
+    nid = {n.get("id"): base + 50000 + int(n.get("id")) for n in t.findall("node")}
+    hs.add_nodes(list(nid.values()), [float(n.get("lat")) for n in t.findall("node")], [float(n.get("lon")) for n in t.findall("node")])
+    geo = {n.get("id"): (float(n.get("lat")), float(n.get("lon"))) for n in t.findall("node")}
+    ways = sorted(((int(w.get("id")), [nd.get("ref") for nd in w.findall("nd")]) for w in t.findall("way")))
+    wids = []
+    for wid, refs in ways:
+        hs.add_way(base + 50000 + wid, np.array([nid[r] for r in refs], np.int64))
+        wids.append(base + 50000 + wid)
+    try:
+        rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, wids)
+        assert rc == 0, sa.lib().smr_hip_last_error()
+        got = np.empty((Hc, Wc), np.uint32)
+        assert sa.lib().smr_hip_canvas_read(sa.lib().smr_hip_plugin_canvas(), 0, 0, Wc, Hc, got.ctypes.data) == 0
+    finally:
+        sa.lib().smr_hip_plugin_reset()
+    op = po.make_proj(43.0 + 44.06 / 60, 15.0 + 34.35 / 60, 40000.0, float(Wc), float(Hc), DPI)
+    oways = []
+    for wid, refs in ways:
+        la, lo = np.array([geo[r][0] for r in refs]), np.array([geo[r][1] for r in refs])
+        closed = len(refs) >= 4 and refs[0] == refs[-1]
+        if st is None:                                   # wavy: knots from the oracle's restatement of cairo_smr_wavy
+            if closed:
+                continue
+            L = po.orc()
+            L.orc_wavy_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+            dist = 1.5 / 25.4 * DPI * (proj.wc * np.cos(np.radians((proj.lat_ll + proj.lat_ru) / 2))) / proj.w
+            ola, olo = np.zeros(8192), np.zeros(8192)
+            m = L.orc_wavy_path(po.P(np.ascontiguousarray(la)), po.P(np.ascontiguousarray(lo)), len(la), dist, po.P(ola), po.P(olo), 8192)
+            if m < 4:
+                continue
+            la, lo = ola[:m], olo[:m]
+        ox, oy, _, _, _ = po.project(op, la, lo)
+        oways.append((ox, oy, closed))
+    if st is None:
+        want = po.oracle_scene([(po.Style(1, 0, 0xff00ff, 0, 0.2, 0, 0).with_knots(), oways)], DPI, Wc, Hc, 0xffffff)
+    elif directional:
+        want = po.oracle_directional(st, oways, DPI, Wc, Hc, 0xffffff)
+    else:
+        want = po.oracle_scene([(st, oways)], DPI, Wc, Hc, 0xffffff)
+    assert len(np.unique(got)) > 2
+    assert np.array_equal(got, want), int((got != want).sum())
