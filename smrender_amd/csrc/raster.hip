@@ -1736,7 +1736,7 @@ __global__ void k_set_u32(uint32_t *p, const uint32_t *v) { *p = *v; }
 /* per-tile sort of the scattered item indices (ascending = drawing order), then the tile's
  * work stream: one smr_thdr_t per entry with the item header, the tile's bits of the
  * primitive's row mask and the primitive's pixel extents relative to the tile */
-#define SORT_LDS 4096
+#define SORT_LDS 1024
 struct sort_args_t
 {
    const uint32_t *tile_off;
@@ -1750,20 +1750,26 @@ struct sort_args_t
    int TX, band_y0;
 };
 
-__global__ __launch_bounds__(64) void k_tile_sort(sort_args_t A)
+/* SORT_WAVES independent wavefronts per workgroup, one tile each (a chart of 4 M tiles is 4 M one-wave workgroups otherwise,
+ * and their dispatch, not the sorting, takes the time); no workgroup barrier: a wavefront's LDS traffic is in program order */
+#define SORT_WAVES 4
+__global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
 {
-   __shared__ uint32_t s[SORT_LDS];
-   const uint32_t tile = smr_xcd_remap(blockIdx.x, A.n_tiles);
+   __shared__ uint32_t sall[SORT_WAVES][SORT_LDS];
+   const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   uint32_t *s = sall[wv];
+   const uint32_t tile = smr_xcd_remap(blockIdx.x, gridDim.x) * SORT_WAVES + wv;      /* an XCD's workgroups sort neighbouring tiles */
+   if (tile >= A.n_tiles) return;
    const uint32_t beg = A.tile_off[tile], n = A.tile_off[tile + 1] - beg;
    if (n == 0) return;
-   const uint32_t lane = threadIdx.x;
+   const uint32_t lane = threadIdx.x & 63u;
    uint32_t N = 2;
    while (N < n) N <<= 1;
    const bool in_lds = N <= SORT_LDS;
    if (n >= 2 && in_lds)
    {
       for (uint32_t i = lane; i < N; i += 64) s[i] = i < n ? A.entries[beg + i] : 0xffffffffu;
-      __syncthreads();
+      SMR_WAVE_SYNC();
       for (uint32_t k = 2; k <= N; k <<= 1)
       {
          for (uint32_t j = k >> 1; j > 0; j >>= 1)
@@ -1777,7 +1783,7 @@ __global__ __launch_bounds__(64) void k_tile_sort(sort_args_t A)
                   if (a > b) { s[i] = b; s[p] = a; }
                }
             }
-            __syncthreads();
+            SMR_WAVE_SYNC();
          }
       }
    }
@@ -1805,7 +1811,7 @@ __global__ __launch_bounds__(64) void k_tile_sort(sort_args_t A)
                }
             }
             __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
+            SMR_WAVE_SYNC();
          }
       }
    }
@@ -3224,7 +3230,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       sort_args_t SO;
       SO.tile_off = tile_off; SO.entries = entries; SO.items = items; SO.prims = prims; SO.mask = maskbuf; SO.first_prim = &small[1];
       SO.hdrs = hdrs; SO.n_tiles = n_tiles; SO.TX = TX; SO.band_y0 = c->band_y0;
-      k_tile_sort<<<n_tiles, 64, 0, s>>>(SO);
+      k_tile_sort<<<(n_tiles + SORT_WAVES - 1) / SORT_WAVES, 64 * SORT_WAVES, 0, s>>>(SO);
    }
    SMR_HIP(hipGetLastError());
    T.mark(s);                                                   /* 3: binned + sorted */
