@@ -1752,7 +1752,9 @@ struct sort_args_t
 
 /* SORT_WAVES independent wavefronts per workgroup, one tile each (a chart of 4 M tiles is 4 M one-wave workgroups otherwise,
  * and their dispatch, not the sorting, takes the time); no workgroup barrier: a wavefront's LDS traffic is in program order */
+#ifndef SORT_WAVES
 #define SORT_WAVES 4
+#endif
 __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
 {
    __shared__ uint32_t sall[SORT_WAVES][SORT_LDS];
