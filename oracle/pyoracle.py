@@ -295,7 +295,8 @@ def curve_path(xy_pt, closed, factor, explicit=False):
     """cairo_smr_poly_curve (src/smrules_cairo.c:697-749) through the oracle's restatement: start point, [n, 6] curves.
     explicit (style.curve == 2): the points are p0 and (c1, c2, p) triples already (cairo_smr_wavy's path, :752-840)."""
     if explicit:
-        assert not closed
+        if closed:                     # the trailing point (= the first) only marks the way as closed
+            xy_pt = xy_pt[:-1]
         nc = (len(xy_pt) - 1) // 3
         return np.ascontiguousarray(xy_pt[0], np.float64), np.ascontiguousarray(np.asarray(xy_pt[1:1 + 3 * nc], np.float64).reshape(nc, 6))
     xp, yp = np.ascontiguousarray(xy_pt[:, 0]), np.ascontiguousarray(xy_pt[:, 1])

@@ -841,8 +841,10 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
    {
       /* the way's points ARE the path: move_to p0, then one curve_to per (c1, c2, p) triple, as cairo_smr_wavy records them
        * (src/smrules_cairo.c:752-840: cairo_move_to :800, cairo_curve_to :772); the path is never closed */
-      if (closed) { orc_curve_unsupported_ = 1; free(curves); free(xp); return; }
-      nc = (n - 1) / 3;
+      /* a closed way carries one more point, equal to the first: the path stays open (cairo_fill closes it itself, :1009-1013;
+       * the border's cairo_stroke does not) */
+      if (closed && (n - 2) % 3 != 0) { orc_curve_unsupported_ = 1; free(curves); free(xp); return; }
+      nc = ((closed ? n - 1 : n) - 1) / 3;
       start[0] = xp[0]; start[1] = yp[0];
       for (int k = 0; k < nc; k++)
          for (int t = 0; t < 3; t++) { curves[6 * k + 2 * t] = xp[1 + 3 * k + t]; curves[6 * k + 2 * t + 1] = yp[1 + 3 * k + t]; }

@@ -293,7 +293,11 @@ static int draw_ini(smr_smrule_t *r)
       if (!(d->wavy_deg > 0)) { plog(SMR_LOG_ERR, "draw: wavy_length must be positive"); delete d; return 1; }
    }
    d->st.directional = H.get_param_bool("directional", r->act);
-   if (d->st.curve == 2) d->st.directional = 0;      /* only the closed ways of a rule are directional, and wavy closed ways are not drawn here */
+   if (d->st.curve == 2 && d->st.directional)
+   {
+      plog(SMR_LOG_WARN, "draw: directional=1 with wavy=1 is not implemented on the GPU path -> disabling directional mode (every closed way is filled by itself)");
+      d->st.directional = 0;
+   }
    d->st.ignore_open = H.get_param_bool("ignore_open", r->act);
    /* DRAW_TRANSPARENT parses but draws solid (cairo_smr_dash has no case for it) */
    if (d->st.fill_style == 3) d->st.fill_style = 0;
@@ -355,12 +359,10 @@ static void wavy_diff(double slat, double slon, double tlat, double tlon, double
  * of their own (smr_draw_style_t.curve = 2); projection, decomposition and stroking happen there. */
 static int draw_way_wavy(draw_rule_t *d, const smr_osm_way_t *w)
 {
-   if (w->ref_cnt >= 4 && w->ref[0] == w->ref[w->ref_cnt - 1])
-   {
-      plog(SMR_LOG_ERR, "draw: wavy=1 on the closed way %lld is not implemented on the GPU path (the way is not drawn)", (long long) w->obj.id);
-      return 0;
-   }
-   if (d->st.ignore_open) return 0;
+   /* is_closed_poly, src/smcoast.c:115-125.  A closed way is filled (:1009-1013): cairo_fill closes the wavy path, which ends at the
+    * last whole wave before the way's end, with a straight line; the library learns it from one more ref equal to the first */
+   const bool closed = w->ref_cnt >= 4 && w->ref[0] == w->ref[w->ref_cnt - 1];
+   if (!closed && d->st.ignore_open) return 0;
    if (w->ref_cnt < 2)
    {
       plog(SMR_LOG_WARN, "ignoring short way %lld (len = %d)", (long long) w->obj.id, w->ref_cnt);
@@ -416,6 +418,7 @@ static int draw_way_wavy(draw_rule_t *d, const smr_osm_way_t *w)
       d->lat.resize(first); d->lon.resize(first); d->ref.resize((size_t) d->way_off.back());
       return 0;
    }
+   if (closed) d->ref.push_back((int32_t) first);
    d->way_off.push_back((int64_t) d->ref.size());
    if (d->fill_cs.key) d->fill_col.push_back(color_by_cs(&w->obj, &d->fill_cs));
    if (d->border_cs.key) d->border_col.push_back(color_by_cs(&w->obj, &d->border_cs));

@@ -124,7 +124,8 @@ struct curve_args_t
    int dpi; int32_t sfix; double f;
    int border_used, fill_used;
    int knots;                          /* curve=2: the way's refs are p0 and (c1, c2, p) triples, the path cairo_smr_wavy records
-                                          (src/smrules_cairo.c:752-840); never closed */
+                                          (src/smrules_cairo.c:752-840); one more ref equal to the first marks the way as closed
+                                          (filled, :1009-1013): the path itself stays open, cairo_fill closes it with a straight line */
    int32_t W256, H256;                 /* the chart in 24.8 */
    int32_t reach[4];                   /* reach of the border stroke (no fill / open / closed way) and of the open ways' fill stroke, 24.8 */
    uint32_t *cnt;                      /* count pass */
@@ -205,17 +206,18 @@ __global__ void k_curve(curve_args_t A)
       last = p;
       cnt++;
    };
-   if (A.knots && closed && (wf & (2 | 4 | 8)))
+   if (A.knots && closed && (n - 2) % 3 != 0 && (wf & (2 | 4 | 8)))
    {
-      if (j == 0) atomicOr(A.status, SMR_ST_KNOTS_CLOSED);      /* first ref == last ref: not a path this mode draws */
+      if (j == 0) atomicOr(A.status, SMR_ST_KNOTS_CLOSED);      /* a closed knot way is p0, (c1, c2, p) * m, p0 */
    }
+   else if (A.knots && closed && j == n - 1) { }                /* the closing ref only says "closed": cairo_fill closes the path itself */
    else if ((wf & (2 | 4 | 8)) && n >= 2)
    {
       const int64_t npt = closed ? n - 1 : n;
       const int st = closed ? 0 : 1;
       if (j == 0)
       {
-         const int2 p = A.pts[a0 + (A.knots ? 0 : (st - 1 + npt) % npt)];
+         const int2 p = A.pts[a0 + (A.knots ? 0 : (st - 1 + npt) % npt)];      /* (knots: i0..i3 below are unused) */
          last = p;
          sink(p, 0, 0, false);
          if (EMIT) A.fway_off[w] = base;
@@ -2983,7 +2985,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          SMR_HIP(hipMemcpyAsync(&stw, &small[2], 4, hipMemcpyDeviceToHost, s));
          SMR_HIP(hipStreamSynchronize(s));
          if (stw & SMR_ST_KNOTS_CLOSED)
-            return smr_fail(SMR_E_UNSUPPORTED, "draw: a way of explicit Bezier knots (curve=2) must not end in its first ref: such paths are open (the way was not drawn)");
+            return smr_fail(SMR_E_UNSUPPORTED, "draw: a closed way of explicit Bezier knots (curve=2) must be p0, (c1, c2, p) * m, p0 (the way was not drawn)");
          return SMR_OK;
       }
       SMR_TRY(c->ensure(SMR_BUF_FPTS, (size_t) total * sizeof(int2), (void **) &fpts));
@@ -3282,7 +3284,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    if (h_small[2] & SMR_ST_CURVE_DEPTH)
       return smr_fail(SMR_E_CAPACITY, "draw: a curve needs more than %d levels of subdivision", SMR_CURVE_STACK);
    if (h_small[2] & SMR_ST_KNOTS_CLOSED)
-      return smr_fail(SMR_E_UNSUPPORTED, "draw: a way of explicit Bezier knots (curve=2) must not end in its first ref: such paths are open (the way was not drawn)");
+      return smr_fail(SMR_E_UNSUPPORTED, "draw: a closed way of explicit Bezier knots (curve=2) must be p0, (c1, c2, p) * m, p0 (the way was not drawn)");
    if (h_small[2] & SMR_ST_DEGRADED) smr_g.draw_status |= SMR_DRAW_DEGRADED_ROWS;
    if (h_small[2] & SMR_ST_ROWCAP)
       return smr_fail(SMR_E_CAPACITY, "draw: more than %d edges of one primitive span a vertex-free pixel row inside one tile", SMR_ROWCAP);

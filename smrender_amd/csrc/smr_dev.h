@@ -66,7 +66,7 @@ struct __attribute__((aligned(16))) smr_thdr_t
 #define SMR_ST_BUCKET_OVERFLOW 1u
 #define SMR_ST_ROWCAP 2u
 #define SMR_ST_MASK_ARENA 4u
-#define SMR_ST_KNOTS_CLOSED 32u  /* a way of explicit Bezier knots (curve=2) whose first ref is its last */
+#define SMR_ST_KNOTS_CLOSED 32u  /* a closed way of explicit Bezier knots (curve=2) that is not p0, (c1, c2, p) * m, p0 */
 #define SMR_ST_CURVE_DEPTH 16u  /* a Bezier needed more levels of subdivision than the decomposition's stack holds */
 #define SMR_ST_DEGRADED 8u      /* a compound row with more than SMR_ROWCAP spanning edges was sub-sampled */
 

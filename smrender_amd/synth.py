@@ -94,16 +94,22 @@ def synth_coast(n_coast, n_islands, n_rings, W, H, seed=1234, hurst=0.75):
     return pack(ways), pack(rings)
 
 
-def synth_wavy_knots(n_ways, W, H, seed=7, wave_px=(6.0, 30.0)):
+def synth_wavy_knots(n_ways, W, H, seed=7, wave_px=(6.0, 30.0), closed=False):
     """Open ways as explicit Bezier paths of the shape cairo_smr_wavy records (src/smrules_cairo.c:752-840): the way is
     resampled every `d` px and every step is one curve_to whose control points sit at -45 and +45 degrees of the step's
-    bearing, d / sqrt(2) from its start.  Returns [(x, y, False)] with x, y = p0, (c1, c2, p) * n in px."""
+    bearing, d / sqrt(2) from its start.  Returns [(x, y, closed)] with x, y = p0, (c1, c2, p) * n in px; closed: rings, whose
+    knot ways end in one more point equal to p0 (the mark of a closed way; the path itself stays open)."""
     rng = np.random.default_rng(seed)
     ways = []
     for _ in range(n_ways):
         d = rng.uniform(*wave_px)
         n = int(rng.integers(2, 9))
         vx = rng.uniform(0, W) + np.cumsum(rng.normal(0, 4 * d, n)); vy = rng.uniform(0, H) + np.cumsum(rng.normal(0, 4 * d, n))
+        if closed:                   # a ring: the way's last node is its first; the knot way gets one more point = p0 below
+            cx, cy, r = rng.uniform(0.2 * W, 0.8 * W), rng.uniform(0.2 * H, 0.8 * H), rng.uniform(3 * d, 6 * d)
+            n = int(rng.integers(5, 10)); a = np.sort(rng.uniform(0, 2 * np.pi, n - 1)) * rng.choice([-1, 1])
+            vx, vy = cx + r * np.cos(a), cy + r * np.sin(a)
+            vx, vy = np.append(vx, vx[0]), np.append(vy, vy[0])
         xs, ys = [vx[0]], [vy[0]]
         sx, sy, rest = vx[0], vy[0], 0.0
         for i in range(1, n):
@@ -118,5 +124,7 @@ def synth_wavy_knots(n_ways, W, H, seed=7, wave_px=(6.0, 30.0)):
                 seg -= d
             rest = seg
         if len(xs) >= 4:
-            ways.append((np.array(xs), np.array(ys), False))
+            if closed:
+                xs.append(xs[0]); ys.append(ys[0])
+            ways.append((np.array(xs), np.array(ys), closed))
     return ways

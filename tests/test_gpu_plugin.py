@@ -126,7 +126,7 @@ def test_curve_rule_through_the_action_api(chart, params, factor):
 def test_wavy_rule_through_the_action_api(chart, params, width_mm, length_mm):
     """wavy=1 / wavy_length= (act_draw_ini :632-642): the plugin resamples the way on the host as cairo_smr_wavy does (:752-840)
     and hands the knots to the GPU as explicit Bezier paths; the expected picture takes the knots from the oracle's own
-    restatement (oracle/wavy.c) of the same loop.  A closed way of the rule is refused with an error message and not drawn."""
+    restatement (oracle/wavy.c) of the same loop.  The closed way of the rule is filled (cairo_fill closes its open wavy path)."""
     import ctypes as C
     from smrender_amd import synth
     sa, proj = chart
@@ -149,15 +149,18 @@ def test_wavy_rule_through_the_action_api(chart, params, width_mm, length_mm):
     L.orc_wavy_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
     op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
     oways = []
-    for w in range(len(off) - 2):                        # the ring is not drawn
-        la, lo = np.ascontiguousarray(lat[off[w]:off[w + 1]]), np.ascontiguousarray(lon[off[w]:off[w + 1]])
+    for w in range(len(off) - 1):                        # the last way is the ring: its knot way ends in one more point = p0
+        la, lo = np.ascontiguousarray(lat[ref[off[w]:off[w + 1]]]), np.ascontiguousarray(lon[ref[off[w]:off[w + 1]]])
+        ring_w = w == len(off) - 2
         ola, olo = np.zeros(4096), np.zeros(4096)
         m = L.orc_wavy_path(po.P(la), po.P(lo), len(la), dist, po.P(ola), po.P(olo), 4096)
         assert m >= 1
         if m >= 4:
+            if ring_w:
+                ola[m], olo[m] = ola[0], olo[0]; m += 1
             ox, oy, _, _, _ = po.project(op, ola[:m], olo[:m])
-            oways.append((ox, oy, False))
-    assert len(oways) >= 4
+            oways.append((ox, oy, ring_w))
+    assert len(oways) >= 4 and oways[-1][2]
     want = po.oracle_scene([(po.Style(1, 0, 0xff00ff, 0, width_mm, 0, 0).with_knots(), oways)], DPI, W, H, 0xfff8e0)
     got = plugin_canvas(sa)
     assert len(np.unique(got)) > 2
@@ -359,8 +362,6 @@ def test_reference_testdata_through_the_action_api(hip, k):
         la, lo = np.array([geo[r][0] for r in refs]), np.array([geo[r][1] for r in refs])
         closed = len(refs) >= 4 and refs[0] == refs[-1]
         if st is None:                                   # wavy: knots from the oracle's restatement of cairo_smr_wavy
-            if closed:
-                continue
             L = po.orc()
             L.orc_wavy_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
             dist = 1.5 / 25.4 * DPI * (proj.wc * np.cos(np.radians((proj.lat_ll + proj.lat_ru) / 2))) / proj.w
@@ -368,6 +369,8 @@ def test_reference_testdata_through_the_action_api(hip, k):
             m = L.orc_wavy_path(po.P(np.ascontiguousarray(la)), po.P(np.ascontiguousarray(lo)), len(la), dist, po.P(ola), po.P(olo), 8192)
             if m < 4:
                 continue
+            if closed:                                   # a closed way is filled: its knot way ends in one more point = p0
+                ola[m], olo[m] = ola[0], olo[0]; m += 1
             la, lo = ola[:m], olo[:m]
         ox, oy, _, _, _ = po.project(op, la, lo)
         oways.append((ox, oy, closed))

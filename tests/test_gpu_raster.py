@@ -325,27 +325,30 @@ WAVY_STYLES = {
 
 
 @pytest.mark.parametrize("style", list(WAVY_STYLES))
-@pytest.mark.parametrize("dpi", [300, 600])
-def test_explicit_bezier_paths_bit_exact(hip, style, dpi):
+@pytest.mark.parametrize("dpi,closed", [(300, False), (600, False), (300, True)])
+def test_explicit_bezier_paths_bit_exact(hip, style, dpi, closed):
     """curve=2: the ways are p0 + (c1, c2, p) triples (what cairo_smr_wavy records for wavy=1, src/smrules_cairo.c:752-840);
     the GPU decomposes and strokes them like libcairo: bit-exact against the oracle (pinned against libcairo in
     tests/test_oracle_cairo.py::test_explicit_bezier_paths), whole canvas and per band"""
     sa = hip
     W, H = 320, 256
     st = WAVY_STYLES[style].with_knots()
-    ways = synth.synth_wavy_knots(24, W, H, seed=5, wave_px=(6.0, 30.0) if dpi == 300 else (12.0, 60.0))
+    ways = synth.synth_wavy_knots(24, W, H, seed=5, wave_px=(6.0, 30.0) if dpi == 300 else (12.0, 60.0), closed=closed)
     want = po.oracle_scene([(st, ways)], dpi, W, H, 0xffffff)
     x = np.concatenate([w[0] for w in ways]); y = np.concatenate([w[1] for w in ways])
     off = np.concatenate([[0], np.cumsum([len(w[0]) for w in ways])]).astype(np.int64)
-    dx, dy, doff = (sa.DeviceArray.from_numpy(a) for a in (x, y, off))
+    ref = np.arange(len(x), dtype=np.int32)
+    if closed:                       # the closing point of a knot way is the REF of its first node
+        ref[off[1:] - 1] = off[:-1]
+    dx, dy, doff, dref = (sa.DeviceArray.from_numpy(a) for a in (x, y, off, ref))
     cv = sa.Canvas(W, H, dpi, 0xffffff)
-    cv.draw(draw_style(sa, st), dx, dy, doff, None, len(ways), len(x))
+    cv.draw(draw_style(sa, st), dx, dy, doff, dref, len(ways), len(x))
     got = cv.read(); cv.close()
     assert len(np.unique(got)) > 2
     assert np.array_equal(got, want), int((got != want).sum())
     for y0, h in ((0, 100), (100, 156)):
         cb = sa.Canvas(W, H, dpi, 0xffffff, y0, h)
-        cb.draw(draw_style(sa, st), dx, dy, doff, None, len(ways), len(x))
+        cb.draw(draw_style(sa, st), dx, dy, doff, dref, len(ways), len(x))
         assert np.array_equal(cb.read(), want[y0:y0 + h]); cb.close()
 
 

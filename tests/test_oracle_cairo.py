@@ -227,12 +227,14 @@ WAVY_CASES = {
 }
 
 
+@pytest.mark.parametrize("closed", [False, True])
 @pytest.mark.parametrize("case", list(WAVY_CASES))
-def test_explicit_bezier_paths(case):
+def test_explicit_bezier_paths(case, closed):
+    """closed: the way is filled (cairo_fill closes the open wavy path with a straight line), its border strokes the open path"""
     from smrender_amd import synth
     st, bar2, bar0 = WAVY_CASES[case]
     st = st.with_knots()
-    ways = synth.synth_wavy_knots(10, 256, 200, seed=11)
+    ways = synth.synth_wavy_knots(10, 256, 200, seed=11, closed=closed)
     a = po.oracle_scene([(st, ways)], 300, 256, 200, 0xffffff)
     b = po.cairo_scene([(st, ways)], 300, 256, 200, 0xffffff)
     d = po.chan_diff(a, b)
