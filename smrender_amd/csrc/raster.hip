@@ -1078,27 +1078,62 @@ struct smr_rowscan_t
       /* first which edges span the row (a compare per candidate), then their cells in a loop all lanes walk together:
        * the lanes' active edges sit at different places of the list, and evaluating inside the scan would make every
        * lane pay for every other lane's evaluations */
-      for (uint32_t i = 0; i < list_n; i++)
+      /* the rows every list entry spans, once per entry (lanes = entries) instead of once per entry and row; they sit in act1's
+       * storage, which the second phase only writes after the scan is through */
+      int2 *span = reinterpret_cast<int2 *>(&L->act1[0][0]);
+      static_assert(sizeof(L->act1) >= SMR_LONGCAP * sizeof(int2), "act1 holds the list's row spans during the scan");
+      for (uint32_t i = lane; i < list_n; i += 64)
       {
          const int4 le = L->l_edge[i];
          const int ytop = smr_to_grid_y(le.y), ybot = smr_to_grid_y(le.y + le.w);
-         if (mine && !over && ytop <= rs0 && ybot >= rs1)
+         /* rows r with ytop <= 15 r and 15 (r + 1) <= ybot (ytop >= 0 for every row on the chart; rows below 0 do not exist) */
+         span[i] = make_int2(ytop > 0 ? (ytop + SMR_GRID_Y - 1) / SMR_GRID_Y : 0, (ybot >= 0 ? ybot / SMR_GRID_Y : -1) - 1);
+      }
+      SMR_WAVE_SYNC();
+      const int myrow = row0 + r;
+      for (uint32_t i = 0; i < list_n; i++)
+      {
+         const int2 sp = span[i];
+         if (mine && !over && sp.x <= myrow && myrow <= sp.y)
          {
             if (cnt < SMR_ACTCAP) L->act0[lane][cnt++] = (int) i;
             else over = true;
          }
       }
+      SMR_WAVE_SYNC();
       const int kmax = smr_wave_max(over ? 0 : cnt);
       for (int k = 0; k < kmax; k++)
-         if (!over && k < cnt)
+      {
+         const bool on = !over && k < cnt;
+         int4 le = make_int4(0, 0, 0, 1);
+         if (on) le = L->l_edge[L->act0[lane][k]];
+         const int32_t D = 60 * le.w;
+         /* short edges (|dx|, dy < 16 px) evaluate in 32 bits, as in k_raster's crossing loop */
+         if (!__ballot(on && !(abs(le.z) < 4096 && D <= 60 * 4096)))
          {
-            const int4 le = L->l_edge[L->act0[lane][k]];
-            const int32_t D = 60 * le.w;
+            if (on)
+            {
+               const float rf = __builtin_amdgcn_rcpf((float) D);
+               const int c32 = (int) ((uint32_t) rs0 * 512u + 256u - 30u * (uint32_t) le.y);
+               const int n0 = __mul24(2 * le.z, c32) + (D >> 1);
+               auto cell32 = [&](int n) -> int
+               {
+                  const int q = (int) fmaf((float) n, rf, -0.5f);
+                  const int rem = __mul24(q, -D) + n;
+                  return le.x + q + (rem >= D ? 1 : 0) + (rem >> 31);
+               };
+               L->act0[lane][k] = cell32(n0);
+               L->act1[lane][k] = cell32(n0 + __mul24(2 * le.z, 512 * SMR_GRID_Y));
+            }
+         }
+         else if (on)
+         {
             const int64_t ec = 256 - 30ll * le.y;
             const double inv = smr_rcp((double) D);
             L->act0[lane][k] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs0);
             L->act1[lane][k] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs1);
          }
+      }
       bool viol = false;
       if (!over)
          for (int i = 0; i < cnt; i++)
@@ -1292,6 +1327,10 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    RS.row0 = P.row0; RS.nrows = P.nrows; RS.edge_cnt = P.edge_cnt; RS.E = E; RS.L = &L; RS.lmask = lmask; RS.lane = lane;
    RS.status = &A.small[2]; RS.list_n = nlong; RS.mbase = 0;
    RS.items = nitems > 64 ? A.items + item0 : nullptr;
+#ifdef SMR_KO_SETUP
+   if (SMR_KO_SETUP & 1) { }
+   else
+#endif
    if (nlong > SMR_LONGCAP)
    {
       for (int rb = 0; rb < P.nrows; rb += 64) if (RS.build_list(rb)) { RS.window(rb); SMR_WAVE_SYNC(); }
