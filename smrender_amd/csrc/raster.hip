@@ -1006,11 +1006,29 @@ struct smr_rowscan_t
          uint32_t pos = cnt + __popcll(am & ((1ull << lane) - 1ull));
          if (act && pos < SMR_ROWCAP)
          {
-            int64_t q; int32_t rem;
-            smr_edge_x(p1x, p1y, dxs, D, rs0, q, rem);
-            f0[pos] = smr_cell(q, rem, D, dxs);
-            smr_edge_x(p1x, p1y, dxs, D, rs1, q, rem);
-            f1[pos] = smr_cell(q, rem, D, dxs);
+            /* the rounded cells at the top and the bottom of the row (exact either way: 32 bits for a short edge, else the
+             * reciprocal estimate with its integer correction) */
+            if (abs(dxs) < 4096 && D <= 60 * 4096)
+            {
+               const float rf = __builtin_amdgcn_rcpf((float) D);
+               const int c32 = (int) ((uint32_t) rs0 * 512u + 256u - 30u * (uint32_t) p1y);
+               const int n0 = __mul24(2 * dxs, c32) + (D >> 1);
+               auto cell32 = [&](int n) -> int
+               {
+                  const int q = (int) fmaf((float) n, rf, -0.5f);
+                  const int rem = __mul24(q, -D) + n;
+                  return p1x + q + (rem >= D ? 1 : 0) + (rem >> 31);
+               };
+               f0[pos] = cell32(n0);
+               f1[pos] = cell32(n0 + __mul24(2 * dxs, 512 * SMR_GRID_Y));
+            }
+            else
+            {
+               const int64_t ec = 256 - 30ll * p1y;
+               const double inv = smr_rcp((double) D);
+               f0[pos] = smr_edge_cell(ec, 2 * dxs, D, inv, p1x, rs0);
+               f1[pos] = smr_edge_cell(ec, 2 * dxs, D, inv, p1x, rs1);
+            }
          }
          cnt += __popcll(am);
       };
