@@ -976,6 +976,9 @@ struct smr_rowscan_t
     * go to LDS, then every pair is compared */
    __device__ void row_by_wave(int r)
    {
+#ifdef SMR_KO_SETUP
+      if (SMR_KO_SETUP & 2) return;
+#endif
       const int rs0 = (row0 + r) * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
       int *f0 = &L->act0[0][0], *f1 = &L->act1[0][0];
       uint32_t cnt = 0;
@@ -1109,14 +1112,20 @@ struct smr_rowscan_t
       }
       SMR_WAVE_SYNC();
       const int myrow = row0 + r;
-      for (uint32_t i = 0; i < list_n; i++)
+      /* eight spans at a time, read before any append: the appends go to LDS too, and the compiler keeps every later read
+       * behind them */
+      for (uint32_t i0 = 0; i0 < list_n; i0 += 8)
       {
-         const int2 sp = span[i];
-         if (mine && !over && sp.x <= myrow && myrow <= sp.y)
-         {
-            if (cnt < SMR_ACTCAP) L->act0[lane][cnt++] = (int) i;
-            else over = true;
-         }
+         int2 sp[8];
+#pragma unroll
+         for (int u = 0; u < 8; u++) sp[u] = i0 + u < list_n ? span[i0 + u] : make_int2(1, 0);
+#pragma unroll
+         for (int u = 0; u < 8; u++)
+            if (mine && !over && sp[u].x <= myrow && myrow <= sp[u].y)
+            {
+               if (cnt < SMR_ACTCAP) L->act0[lane][cnt++] = (int) (i0 + u);
+               else over = true;
+            }
       }
       SMR_WAVE_SYNC();
       const int kmax = smr_wave_max(over ? 0 : cnt);
@@ -1153,12 +1162,28 @@ struct smr_rowscan_t
          }
       }
       bool viol = false;
+#ifdef SMR_KO_SETUP
+      if (!(SMR_KO_SETUP & 4))
+#endif
       if (!over)
-         for (int i = 0; i < cnt; i++)
+      {
+         /* the lane's cells into registers once (2 cnt reads instead of 2 cnt^2), then every pair */
+         int c0[SMR_ACTCAP], c1[SMR_ACTCAP];
+#pragma unroll
+         for (int i = 0; i < SMR_ACTCAP; i++) { c0[i] = i < cnt ? L->act0[lane][i] : INT32_MAX; c1[i] = i < cnt ? L->act1[lane][i] : INT32_MAX; }
+         /* a slot beyond cnt holds (MAX, MAX): it is never left of anything at the top, and nothing is right of it at the bottom */
+#pragma unroll
+         for (int i = 0; i < SMR_ACTCAP; i++)
          {
-            int a0 = L->act0[lane][i], a1 = L->act1[lane][i];
-            for (int j = 0; j < cnt; j++) if (a0 < L->act0[lane][j] && a1 > L->act1[lane][j]) viol = true;
+            if (i >= kmax) break;                    /* kmax: the wavefront's largest cnt (uniform) */
+#pragma unroll
+            for (int j = 0; j < SMR_ACTCAP; j++)
+            {
+               if (j >= kmax) break;
+               if (i != j && c0[i] < c0[j] && c1[i] > c1[j] && j < cnt) viol = true;
+            }
          }
+      }
       if (mine && viol) atomicOr(&lmask[(r - mbase) >> 5], 1u << (r & 31));
       unsigned long long om = __ballot(over);
       while (om)
