@@ -1757,13 +1757,18 @@ __global__ void k_bin(const smr_item_t *__restrict__ items, int64_t n_items, int
 /* exclusive scan of n uint32 (three small kernels; n up to a few 10 M) */
 #define SCAN_B 1024
 __global__ __launch_bounds__(256) void k_scan_block(const uint32_t *__restrict__ in, uint32_t *__restrict__ out,
-                                                    uint32_t *__restrict__ sums, uint32_t n)
+                                                    uint32_t *__restrict__ sums, uint32_t n, uint32_t *maxv)
 {
    __shared__ uint32_t s[256];
    uint32_t base = blockIdx.x * SCAN_B, t = threadIdx.x;
    uint32_t v[4], tot = 0;
 #pragma unroll
    for (int k = 0; k < 4; k++) { uint32_t i = base + t * 4 + k; v[k] = i < n ? in[i] : 0; tot += v[k]; }
+   if (maxv)                     /* the largest element too (entries of the fullest tile: k_tile_sort's LDS) */
+   {
+      const int m = smr_wave_max((int) max(max(v[0], v[1]), max(v[2], v[3])));
+      if ((t & 63u) == 0 && m > 0) atomicMax(maxv, (uint32_t) m);
+   }
    s[t] = tot;
    __syncthreads();
    for (int d = 1; d < 256; d <<= 1)
@@ -1820,7 +1825,7 @@ __global__ void k_set_u32(uint32_t *p, const uint32_t *v) { *p = *v; }
 /* per-tile sort of the scattered item indices (ascending = drawing order), then the tile's
  * work stream: one smr_thdr_t per entry with the item header, the tile's bits of the
  * primitive's row mask and the primitive's pixel extents relative to the tile */
-#define SORT_LDS 1024
+#define SORT_LDS 4096        /* most entries of a tile sorted in LDS; beyond, the same network runs in global memory */
 struct sort_args_t
 {
    const uint32_t *tile_off;
@@ -1831,6 +1836,7 @@ struct sort_args_t
    const uint32_t *first_prim;
    smr_thdr_t *hdrs;
    uint32_t n_tiles;
+   uint32_t lds_cap;          /* entries of one tile that fit its wavefront's share of LDS (a power of two up to SORT_LDS) */
    int TX, band_y0;
 };
 
@@ -1841,9 +1847,9 @@ struct sort_args_t
 #endif
 __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
 {
-   __shared__ uint32_t sall[SORT_WAVES][SORT_LDS];
+   extern __shared__ uint32_t sall[];              /* [SORT_WAVES][A.lds_cap]: sized for the fullest tile of the launch */
    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-   uint32_t *s = sall[wv];
+   uint32_t *s = sall + (size_t) wv * A.lds_cap;
    const uint32_t tile = smr_xcd_remap(blockIdx.x, gridDim.x) * SORT_WAVES + wv;      /* an XCD's workgroups sort neighbouring tiles */
    if (tile >= A.n_tiles) return;
    const uint32_t beg = A.tile_off[tile], n = A.tile_off[tile + 1] - beg;
@@ -1851,7 +1857,7 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
    const uint32_t lane = threadIdx.x & 63u;
    uint32_t N = 2;
    while (N < n) N <<= 1;
-   const bool in_lds = N <= SORT_LDS;
+   const bool in_lds = N <= A.lds_cap;
    if (n >= 2 && in_lds)
    {
       for (uint32_t i = lane; i < N; i += 64) s[i] = i < n ? A.entries[beg + i] : 0xffffffffu;
@@ -2887,7 +2893,7 @@ __global__ void k_max_u32(const uint32_t *__restrict__ v, int64_t n, uint32_t *_
 static int count_finish(uint32_t *buf, uint32_t n, uint32_t *sums, uint32_t *total_dev, uint32_t *total, hipStream_t s)
 {
    const uint32_t nb = (n + SCAN_B - 1) / SCAN_B;
-   k_scan_block<<<nb, 256, 0, s>>>(buf, buf, sums, n);
+   k_scan_block<<<nb, 256, 0, s>>>(buf, buf, sums, n, nullptr);
    k_scan_sums<<<1, 1024, 0, s>>>(sums, nb, total_dev);
    k_scan_add<<<nb, 256, 0, s>>>(buf, sums, n);
    k_set_u32<<<1, 1, 0, s>>>(&buf[n], total_dev);
@@ -3298,7 +3304,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    SMR_TRY(c->ensure(SMR_BUF_SUMS, (size_t) nb_scan * 4, (void **) &sums));
    SMR_HIP(hipMemsetAsync(counts, 0, (size_t) n_tiles * 4, s));
    k_bin<false><<<blocks(n_items, TB), TB, 0, s>>>(items, n_items, c->W, c->band_y0, c->band_h, TX, counts, nullptr, nullptr);
-   k_scan_block<<<nb_scan, 256, 0, s>>>(counts, tile_off, sums, n_tiles);
+   k_scan_block<<<nb_scan, 256, 0, s>>>(counts, tile_off, sums, n_tiles, &small[7]);
    k_scan_sums<<<1, 1024, 0, s>>>(sums, nb_scan, &small[3]);
    k_scan_add<<<nb_scan, 256, 0, s>>>(tile_off, sums, n_tiles);
    k_set_u32<<<1, 1, 0, s>>>(&tile_off[n_tiles], &small[3]);
@@ -3316,7 +3322,10 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       sort_args_t SO;
       SO.tile_off = tile_off; SO.entries = entries; SO.items = items; SO.prims = prims; SO.mask = maskbuf; SO.first_prim = &small[1];
       SO.hdrs = hdrs; SO.n_tiles = n_tiles; SO.TX = TX; SO.band_y0 = c->band_y0;
-      k_tile_sort<<<(n_tiles + SORT_WAVES - 1) / SORT_WAVES, 64 * SORT_WAVES, 0, s>>>(SO);
+      uint32_t cap = 64;
+      while (cap < h_small[7] && cap < SORT_LDS) cap <<= 1;       /* h_small[7]: entries of the fullest tile (k_scan_block) */
+      SO.lds_cap = cap;
+      k_tile_sort<<<(n_tiles + SORT_WAVES - 1) / SORT_WAVES, 64 * SORT_WAVES, (size_t) SORT_WAVES * cap * 4, s>>>(SO);
    }
    SMR_HIP(hipGetLastError());
    T.mark(s);                                                   /* 3: binned + sorted */

@@ -1,6 +1,7 @@
 """Kernel 2 (edge setup, stroke expansion, binning, wave-per-tile rasterizer) through the
 C-ABI vs the oracle restatement of act_draw + libcairo's tor scan converter.  Integer
 arithmetic end to end, so the bar is bit-exact ARGB."""
+import ctypes as C
 import numpy as np
 import pytest
 from oracle import pyoracle as po
@@ -362,3 +363,38 @@ def test_explicit_bezier_paths_refuse_closed_ways(hip):
         cv.draw(sa.DrawStyle(1, 0, 0, 0, 0.2, 0, 0, 0, 0, 0, 0, 0).set_knots(), xy, xy, off, ref, 1, 7)
     assert e.value.code == -5
     cv.close()
+
+
+@pytest.mark.parametrize("n_ways", [700, 6000])
+def test_many_primitives_on_one_tile(hip, n_ways):
+    """hundreds / thousands of small translucent polygons on the same 64x4-px tiles: the tile's work stream is sorted in LDS sized
+    for the fullest tile of the launch (700 ways) or, beyond 4096 entries, by the same network in global memory (6000 ways);
+    the drawing order decides every pixel"""
+    sa = hip
+    W, H, dpi = 128, 64, 300
+    rng = np.random.default_rng(17)
+    xs, ys, off = [], [], [0]
+    for _ in range(n_ways):
+        cx, cy, r = rng.uniform(8, 56), rng.uniform(8, 20), rng.uniform(2, 6)
+        a = np.sort(rng.uniform(0, 2 * np.pi, 3))
+        x, y = cx + r * np.cos(a), cy + r * np.sin(a)
+        xs.append(np.append(x, x[0])); ys.append(np.append(y, y[0])); off.append(off[-1] + 4)
+    x, y, off = np.concatenate(xs), np.concatenate(ys), np.array(off, np.int64)
+    ref = np.arange(len(x), dtype=np.int32); ref[off[1:] - 1] = off[:-1]
+    cols = (rng.integers(0, 1 << 24, n_ways) | (rng.integers(0x20, 0x70, n_ways) << 24)).astype(np.uint32)      # translucent, all different
+    st = po.Style(1, 0, 0, 0, 0, 0, 0)
+    ways = po.ways_from_arrays(x, y, off, ref)
+    L = po.orc()
+    c = L.orc_canvas_new(0, 0, W, H, dpi, 0xffffff)
+    L.orc_rule_begin(c)
+    for (wx, wy, closed), col in zip(ways, cols):
+        wx = np.ascontiguousarray(wx, np.float64); wy = np.ascontiguousarray(wy, np.float64)
+        L.orc_draw_way(c, C.byref(st), po.P(wx), po.P(wy), len(wx), 1, 1, int(col), 0, 0)
+    L.orc_rule_end(c)
+    want = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (H, W)).copy()
+    L.orc_canvas_free(c)
+    cv = sa.Canvas(W, H, dpi, 0xffffff)
+    cv.draw(draw_style(sa, st), *(sa.DeviceArray.from_numpy(a) for a in (x, y, off, ref)), n_ways, len(ref),
+            d_fill_col=sa.DeviceArray.from_numpy(cols))
+    got = cv.read(); cv.close()
+    assert np.array_equal(got, want), int((got != want).sum())
