@@ -105,7 +105,7 @@ typedef struct
                                                explicit Bezier knots p0, (c1, c2, p) * n: the move_to + curve_to path that cairo_smr_wavy
                                                records for wavy=1 (:752-840; the caller resamples the way); one more ref
                                                equal to the first marks the way as closed (filled: cairo_fill closes the open path itself,
-                                               the border stroke does not); directional rules: SMR_E_UNSUPPORTED */
+                                               the border stroke does not) */
    int32_t directional;                     /* directional=1 with a fill: open ways first, then ALL closed ways of the batch as one
                                                non-zero fill in fill_col (act_draw_fini, src/smrules_cairo.c:1084-1140); the caller
                                                appends the page rectangle (:1103-1109) as one more closed way when it is due */

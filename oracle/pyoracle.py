@@ -223,7 +223,7 @@ def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0, image=None):
         if closed and st.curve:
             # the closed ways as Bezier chains (cairo_smr_poly_curve), decomposed against the image's limits
             xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
-            start, curves = curve_path(xy, True, st.curve_fact)
+            start, curves = curve_path(xy, True, st.curve_fact, st.curve == 2)
             cap = 64 * (len(curves) + 2)
             while True:
                 pts, tin, tout = np.zeros(2 * cap, np.int32), np.zeros(2 * cap, np.int32), np.zeros(2 * cap, np.int32)
@@ -260,7 +260,7 @@ def cairo_directional(st, ways, dpi, W, H, bg):
         if not closed and len(x) >= 2 and not st.ignore_open:
             xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
             if st.curve:
-                start, curves = curve_path(xy, False, st.curve_fact)
+                start, curves = curve_path(xy, False, st.curve_fact, st.curve == 2)
                 L.cd_poly_curve(start[0], start[1], P(curves), len(curves))
             else:
                 L.cd_poly_line(P(xy), len(xy))
@@ -271,7 +271,7 @@ def cairo_directional(st, ways, dpi, W, H, bg):
         if closed:
             xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
             if st.curve:
-                start, curves = curve_path(xy, True, st.curve_fact)
+                start, curves = curve_path(xy, True, st.curve_fact, st.curve == 2)
                 L.cd_poly_curve(start[0], start[1], P(curves), len(curves))
             else:
                 L.cd_poly_line(P(xy), len(xy))

@@ -293,11 +293,6 @@ static int draw_ini(smr_smrule_t *r)
       if (!(d->wavy_deg > 0)) { plog(SMR_LOG_ERR, "draw: wavy_length must be positive"); delete d; return 1; }
    }
    d->st.directional = H.get_param_bool("directional", r->act);
-   if (d->st.curve == 2 && d->st.directional)
-   {
-      plog(SMR_LOG_WARN, "draw: directional=1 with wavy=1 is not implemented on the GPU path -> disabling directional mode (every closed way is filled by itself)");
-      d->st.directional = 0;
-   }
    d->st.ignore_open = H.get_param_bool("ignore_open", r->act);
    /* DRAW_TRANSPARENT parses but draws solid (cairo_smr_dash has no case for it) */
    if (d->st.fill_style == 3) d->st.fill_style = 0;
@@ -380,6 +375,8 @@ static int draw_way_wavy(draw_rule_t *d, const smr_osm_way_t *w)
    if (n == nullptr) return give_up(0);
    double sc_lat = n->lat, sc_lon = n->lon;
    put(sc_lat, sc_lon);
+   /* directional=1: poly_area's shoelace sum over the WAY's nodes (src/smfunc.c:377-432), as in draw_way */
+   double ar = 0, plat = n->lat, plon = n->lon;
    const double dist = d->wavy_deg;
    double bearing = 0, pdist = 0;
    for (int i = 1;;)
@@ -388,6 +385,8 @@ static int draw_way_wavy(draw_rule_t *d, const smr_osm_way_t *w)
       {
          if (i >= w->ref_cnt) break;
          if ((n = (const smr_osm_node_t *) H.get_object(SMR_OSM_NODE, w->ref[i])) == nullptr) return give_up(i);
+         ar += plon * cos(plat * M_PI / 180.0) * n->lat - n->lon * cos(n->lat * M_PI / 180.0) * plat;
+         plat = n->lat; plon = n->lon;
          i++;
          const double rest = pdist;
          wavy_diff(sc_lat, sc_lon, n->lat, n->lon, &bearing, &pdist);
@@ -422,6 +421,11 @@ static int draw_way_wavy(draw_rule_t *d, const smr_osm_way_t *w)
    d->way_off.push_back((int64_t) d->ref.size());
    if (d->fill_cs.key) d->fill_col.push_back(color_by_cs(&w->obj, &d->fill_cs));
    if (d->border_cs.key) d->border_col.push_back(color_by_cs(&w->obj, &d->border_cs));
+   if (closed && d->st.directional && fabs(ar) > d->max_area)
+   {
+      d->max_area = fabs(ar); d->max_cw = ar < 0;
+      d->max_col = d->fill_cs.key ? d->fill_col.back() : d->fill_cs.col;
+   }
    return 0;
 }
 

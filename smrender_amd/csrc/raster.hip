@@ -2964,7 +2964,6 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    if (st->fill_used && (st->fill_style == SMR_STYLE_PIPE || st->fill_style == SMR_STYLE_ROUNDDOT))
       return smr_fail(SMR_E_UNSUPPORTED, "draw: style=pipe|rounddot on the fill of open ways leaves round caps on every later stroke of the rule: not implemented on the GPU path");
    if (st->curve < 0 || st->curve > 2) return smr_fail(SMR_E_INVAL, "draw: curve mode %d", st->curve);
-   if (st->curve == 2 && st->directional) return smr_fail(SMR_E_UNSUPPORTED, "draw: explicit Bezier paths (wavy=1) are open paths: no directional fill");
    if (st->curve == 1 && !(st->curve_factor > 0 && st->curve_factor < 100)) return smr_fail(SMR_E_INVAL, "draw: curve_factor %g", st->curve_factor);
    if (st->directional && st->fill_used)
    {

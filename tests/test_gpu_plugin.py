@@ -199,6 +199,46 @@ def test_directional_rule_with_page_rectangle(chart, sea_first):
     assert ((got[0, 0] & 0xffffff) != 0xfff8e0) == sea_first
 
 
+def test_directional_wavy_rule_with_page_rectangle(chart):
+    """directional=1 together with wavy=1: every closed way (and the page rectangle, which the largest, clockwise way calls for)
+    goes through cairo_smr_wavy as a sub-path of ONE fill (act_draw_fini :1084-1140 -> cairo_smr_poly :926-937)"""
+    import ctypes as C
+    from smrender_amd import synth
+    sa, proj = chart
+    rings = [(np.array([60.0, 320, 320, 60, 60]), np.array([40.0, 40, 260, 260, 40])),          # big, clockwise on the chart (north up)
+             (np.array([120.0, 120, 200, 200, 120]), np.array([100.0, 180, 180, 100, 100])),    # counterclockwise inside it
+             (np.array([230.0, 290, 260, 230]), np.array([90.0, 150, 220, 90]))]
+    x, y = np.concatenate([r[0][:-1] for r in rings]), np.concatenate([r[1][:-1] for r in rings])
+    off, ref = [0], []
+    for r in rings:
+        n = len(r[0]) - 1
+        ref += list(range(off[-1] - len(off) + 1 + 0, off[-1] - len(off) + 1 + n)) + [off[-1] - len(off) + 1]
+        off.append(off[-1] + n + 1)
+    wids, _ = load_ways(sa, proj, (x, y, np.array(off, np.int64), np.array(ref, np.int32)))
+    rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;directional=1;wavy=1;wavy_length=2", wids)
+    assert rc == 0, sa.lib().smr_hip_last_error()
+    lat, lon = synth.px_to_geo(proj, x, y)
+    dist = 2.0 / 25.4 * DPI * (proj.wc * np.cos(np.radians((proj.lat_ll + proj.lat_ru) / 2))) / proj.w
+    L = po.orc()
+    L.orc_wavy_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    geo = [(lat[np.array(ref[off[k]:off[k + 1]])], lon[np.array(ref[off[k]:off[k + 1]])]) for k in range(len(rings))]
+    geo.append((np.array([proj.lat_ru, proj.lat_ll, proj.lat_ll, proj.lat_ru, proj.lat_ru]),
+                np.array([proj.lon0, proj.lon0, proj.lon_ru, proj.lon_ru, proj.lon0])))      # page_way(): NW, SW, SE, NE, NW
+    oways = []
+    for la, lo in geo:
+        ola, olo = np.zeros(8192), np.zeros(8192)
+        m = L.orc_wavy_path(po.P(np.ascontiguousarray(la)), po.P(np.ascontiguousarray(lo)), len(la), dist, po.P(ola), po.P(olo), 8192)
+        assert m >= 4
+        ola[m], olo[m] = ola[0], olo[0]; m += 1
+        ox, oy, _, _, _ = po.project(op, ola[:m], olo[:m])
+        oways.append((ox, oy, True))
+    want = po.oracle_directional(po.Style(1, 0, 0x4080c0, 0, 0, 0, 0).with_knots(), oways, DPI, W, H, 0xfff8e0)
+    got = plugin_canvas(sa)
+    assert np.array_equal(got, want), int((got != want).sum())
+    assert (got[1, 1] & 0xffffff) != 0xfff8e0           # the page rectangle is the outer ring
+
+
 def oracle_caption_tags(img, names, px, py, size_mm, col, weight):
     """cap_coord for every caption of one rule in object order (src/smrules_cairo.c:2202-2392): geometry through
     the real libcairo, find_angle restated (oracle/caprot.c), and the rule's private background copy that

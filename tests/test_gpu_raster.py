@@ -107,14 +107,14 @@ def test_edge_cases(hip):
     d = sa.DeviceArray((4,), np.float64)
     cv.draw(gs, d, d, sa.DeviceArray.from_numpy(np.zeros(1, np.int64)), None, 0, 0)      # nothing to draw
     assert np.all(cv.read() == 0xffffffff)
-    for bad, val, *rest in (("fill_style", 4), ("directional", 1, "curve", 2)):       # pipe on the fill stroke; explicit knots in a directional rule
+    for bad, val, *rest in (("fill_style", 4), ("curve", 3)):       # pipe on the fill stroke; an unknown curve mode
         gs2 = sa.DrawStyle(1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0)
         setattr(gs2, bad, val)
         if rest:
             setattr(gs2, *rest)
         with pytest.raises(sa.SmrHipError) as e:       # unsupported styles fail loudly
             cv.draw(gs2, d, d, sa.DeviceArray.from_numpy(np.array([0, 4], np.int64)), None, 1, 4)
-        assert e.value.code == -5
+        assert e.value.code == (-5 if bad == "fill_style" else -2)
     cv.close()
 
 
@@ -397,4 +397,26 @@ def test_many_primitives_on_one_tile(hip, n_ways):
     cv.draw(draw_style(sa, st), *(sa.DeviceArray.from_numpy(a) for a in (x, y, off, ref)), n_ways, len(ref),
             d_fill_col=sa.DeviceArray.from_numpy(cols))
     got = cv.read(); cv.close()
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_directional_rule_of_knot_ways(hip):
+    """directional=1 with explicit Bezier knots (wavy=1): open knot ways first, then ALL closed knot ways as one non-zero fill,
+    each sub-path closed by the fill itself (act_draw_fini :1084-1140 calls cairo_smr_poly, i.e. cairo_smr_wavy, per way)"""
+    sa = hip
+    W, H, dpi = 320, 256, 300
+    ways = synth.synth_wavy_knots(8, W, H, seed=3, closed=True) + synth.synth_wavy_knots(6, W, H, seed=4)
+    ways[1] = (ways[1][0][::-1].copy(), ways[1][1][::-1].copy(), True)       # one ring the other way round (its knots reversed: still p0 ... p0)
+    st = po.Style(1, 0, 0x4080c0c0, 0, 0.25, 0, 0).with_knots()
+    want = po.oracle_directional(st, ways, dpi, W, H, 0xffffff)
+    x = np.concatenate([w[0] for w in ways]); y = np.concatenate([w[1] for w in ways])
+    off = np.concatenate([[0], np.cumsum([len(w[0]) for w in ways])]).astype(np.int64)
+    ref = np.arange(len(x), dtype=np.int32)
+    for k, w in enumerate(ways):
+        if w[2]:
+            ref[off[k + 1] - 1] = off[k]
+    cv = sa.Canvas(W, H, dpi, 0xffffff)
+    cv.draw(draw_style(sa, st, directional=1), *(sa.DeviceArray.from_numpy(a) for a in (x, y, off, ref)), len(ways), len(x))
+    got = cv.read(); cv.close()
+    assert len(np.unique(got)) > 2
     assert np.array_equal(got, want), int((got != want).sum())

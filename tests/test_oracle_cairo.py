@@ -240,3 +240,15 @@ def test_explicit_bezier_paths(case, closed):
     d = po.chan_diff(a, b)
     assert len(np.unique(a)) > 2
     assert (d <= 2).mean() >= bar2 and (d == 0).mean() >= bar0, ((d > 2).sum(), (d > 0).sum(), d.max())
+
+
+def test_directional_rule_of_explicit_bezier_paths():
+    """directional=1 over closed knot ways (wavy=1): every way a sub-path that cairo_fill closes, ONE non-zero fill"""
+    from smrender_amd import synth
+    ways = synth.synth_wavy_knots(8, 256, 200, seed=3, closed=True)
+    ways[1] = (ways[1][0][::-1].copy(), ways[1][1][::-1].copy(), True)
+    st = po.Style(1, 0, 0x4080c0, 0, 0.25, 0, 0).with_knots()
+    a = po.oracle_directional(st, ways, 300, 256, 200, 0xffffff)
+    b = po.cairo_directional(st, ways, 300, 256, 200, 0xffffff)
+    assert len(np.unique(a)) > 2
+    assert np.array_equal(a, b), int((a != b).sum())
