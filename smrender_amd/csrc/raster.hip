@@ -133,7 +133,13 @@ struct curve_args_t
    int2 *fpts, *tin, *tout; int32_t *frefway; int64_t *fway_off;
    uint8_t *fskip;                     /* 1: the point exists for the border stroke only, 2: the fill arrives here by a line_to (see k_curve) */
    uint32_t *status;
+   /* ill-conditioned control points (see smr_control_points): recorded by the first count pass (fix_n counts them, fix their
+    * slot and inputs), computed on the host with its libm, and looked up by slot (sorted) in the passes that follow */
+   uint32_t *fix_n; struct smr_curvefix_t *fix; uint32_t fix_cnt;
 };
+
+#define SMR_CURVEFIX_CAP 8192u
+struct smr_curvefix_t { int64_t g; double v[8]; };      /* in: gax gay gbx gby lax lay lbx lby; back from the host: c1x c1y c2x c2y */
 
 #define SMR_CURVE_STACK 28
 
@@ -162,8 +168,11 @@ __device__ __forceinline__ double smr_spline_err2(const smr_knots_t &k)      /* 
 
 __device__ __forceinline__ int2 smr_lerp_half(int2 a, int2 b) { return make_int2(a.x + ((b.x - a.x) >> 1), a.y + ((b.y - a.y) >> 1)); }
 
-/* src/bspline_ctrl.c:64-105 */
-__device__ __forceinline__ void smr_control_points(double gax, double gay, double gbx, double gby, double lax, double lay, double lbx, double lby,
+/* src/bspline_ctrl.c:64-105.  Returns true when a control point's direction is the angle of a vector that is all rounding
+ * noise: the segment runs straight back along its neighbour (a way that doubles back, A B A, or nodes mirrored exactly), so
+ * the helper point falls onto the segment's other end and atan2 sees the last bits of cos and sin.  The reference's result
+ * then depends on its libm to the last bit, which the device's does not share: such control points come from the host. */
+__device__ __forceinline__ bool smr_control_points(double gax, double gay, double gbx, double gby, double lax, double lay, double lbx, double lby,
                                                    double f, double &p1x, double &p1y, double &p2x, double &p2y)
 {
    const double lgt = smr_hypot(gbx - lax, gby - lay);
@@ -177,6 +186,26 @@ __device__ __forceinline__ void smr_control_points(double gax, double gay, doubl
    a = atan2(hby - gby, hbx - gbx);
    p2x = lax - lgt * cos(a) * f;
    p2y = lay - lgt * sin(a) * f;
+   const double v1 = (lax - hax) * (lax - hax) + (lay - hay) * (lay - hay), v2 = (hbx - gbx) * (hbx - gbx) + (hby - gby) * (hby - gby);
+   const double lim = 1e-10 * lgt * lgt;
+   return lgt > 0 && (v1 < lim || v2 < lim);
+}
+
+/* the same on the host, with the libm the reference itself would use (expression by expression src/bspline_ctrl.c:64-105) */
+static void smr_control_points_host(const double *v, double f, double *out)
+{
+   const double gax = v[0], gay = v[1], gbx = v[2], gby = v[3], lax = v[4], lay = v[5], lbx = v[6], lby = v[7];
+   const double lgt = hypot(gbx - lax, gby - lay);
+   const double ag = atan2(gby - gay, gbx - gax);
+   const double hax = gbx - lgt * cos(ag), hay = gby - lgt * sin(ag);
+   double a = atan2(lay - hay, lax - hax);
+   out[0] = gbx + lgt * cos(a) * f;
+   out[1] = gby + lgt * sin(a) * f;
+   const double al = atan2(lby - lay, lbx - lax);
+   const double hbx = lax + lgt * cos(al), hby = lay + lgt * sin(al);
+   a = atan2(hby - gby, hbx - gbx);
+   out[2] = lax - lgt * cos(a) * f;
+   out[3] = lay - lgt * sin(a) * f;
 }
 
 template <bool EMIT>
@@ -237,7 +266,25 @@ __global__ void k_curve(curve_args_t A)
          else
          {
             double c1x, c1y, c2x, c2y;
-            smr_control_points(gax, gay, gbx, gby, lax, lay, lbx, lby, A.f, c1x, c1y, c2x, c2y);
+            if (smr_control_points(gax, gay, gbx, gby, lax, lay, lbx, lby, A.f, c1x, c1y, c2x, c2y))
+            {
+               if (A.fix_cnt)
+               {
+                  uint32_t lo = 0, hi = A.fix_cnt;              /* the host's values, by slot */
+                  while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (A.fix[mid].g < g) lo = mid + 1; else hi = mid; }
+                  if (lo < A.fix_cnt && A.fix[lo].g == g) { c1x = A.fix[lo].v[0]; c1y = A.fix[lo].v[1]; c2x = A.fix[lo].v[2]; c2y = A.fix[lo].v[3]; }
+               }
+               else if (!EMIT && A.fix_n)
+               {
+                  const uint32_t k = atomicAdd(A.fix_n, 1u);
+                  if (k < SMR_CURVEFIX_CAP)
+                  {
+                     smr_curvefix_t fx; fx.g = g;
+                     fx.v[0] = gax; fx.v[1] = gay; fx.v[2] = gbx; fx.v[3] = gby; fx.v[4] = lax; fx.v[5] = lay; fx.v[6] = lbx; fx.v[7] = lby;
+                     A.fix[k] = fx;
+                  }
+               }
+            }
             if (st)
             {
                if (i == 1) { c1x = gbx; c1y = gby; }
@@ -3063,9 +3110,35 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       }
       CA.cnt = ccnt; CA.off = nullptr; CA.fpts = nullptr; CA.tin = CA.tout = nullptr; CA.frefway = nullptr; CA.fway_off = nullptr; CA.fskip = nullptr;
       CA.status = &small[2];
+      uint32_t *fixbuf;
+      SMR_TRY(c->ensure(SMR_BUF_CURVEFIX, 16 + (size_t) SMR_CURVEFIX_CAP * sizeof(smr_curvefix_t), (void **) &fixbuf));
+      CA.fix_n = st->curve == 1 ? fixbuf : nullptr; CA.fix = reinterpret_cast<smr_curvefix_t *>(fixbuf + 4); CA.fix_cnt = 0;
+      SMR_HIP(hipMemsetAsync(fixbuf, 0, 16, s));
       k_curve<false><<<blocks(n_refs, 64), 64, 0, s>>>(CA);
       uint32_t total = 0;
       SMR_TRY(count_finish(ccnt, (uint32_t) n_refs, sums, &small[6], &total, s));
+      if (st->curve == 1)
+      {
+         /* control points the device cannot reproduce to the bit (smr_control_points): from the host, then count again */
+         uint32_t nfix = 0;
+         SMR_HIP(hipMemcpyAsync(&nfix, fixbuf, 4, hipMemcpyDeviceToHost, s));
+         SMR_HIP(hipStreamSynchronize(s));
+         if (nfix > SMR_CURVEFIX_CAP)
+            return smr_fail(SMR_E_CAPACITY, "draw: curve=1 with %u segments that run straight back along their neighbours (at most %u per rule)", nfix, SMR_CURVEFIX_CAP);
+         if (nfix)
+         {
+            std::vector<smr_curvefix_t> fx(nfix);
+            SMR_HIP(hipMemcpyAsync(fx.data(), CA.fix, (size_t) nfix * sizeof(smr_curvefix_t), hipMemcpyDeviceToHost, s));
+            SMR_HIP(hipStreamSynchronize(s));
+            for (auto &e : fx) { double o[4]; smr_control_points_host(e.v, st->curve_factor, o); e.v[0] = o[0]; e.v[1] = o[1]; e.v[2] = o[2]; e.v[3] = o[3]; }
+            std::sort(fx.begin(), fx.end(), [](const smr_curvefix_t &a, const smr_curvefix_t &b) { return a.g < b.g; });
+            SMR_HIP(hipMemcpyAsync(CA.fix, fx.data(), (size_t) nfix * sizeof(smr_curvefix_t), hipMemcpyHostToDevice, s));
+            SMR_HIP(hipStreamSynchronize(s));      /* fx leaves scope */
+            CA.fix_cnt = nfix;
+            k_curve<false><<<blocks(n_refs, 64), 64, 0, s>>>(CA);
+            SMR_TRY(count_finish(ccnt, (uint32_t) n_refs, sums, &small[6], &total, s));
+         }
+      }
       if (total == 0)
       {
          uint32_t stw = 0;

@@ -283,6 +283,71 @@ def test_rows_beyond_the_exact_path_are_subsampled_and_reported(hip):
     assert sa.lib().smr_hip_draw_status() == 0
 
 
+def test_soak_scene_with_a_wide_curved_stroke(hip):
+    """The one scene of tools/soak.py's random runs that differed from the oracle (tests/golden/soak_scene4.npz, 31 ways at
+    600 dpi, curve=1): way 9's border is an 11.8 px wide stroke of a tightly curved line whose flattened pieces put 86 edges
+    across the vertex-free pixel row 133, more than the exact whole-row path keeps.  That row of that way is sub-sampled and
+    the library says so; every other pixel of the scene equals the oracle (= libcairo, tests/test_oracle_cairo.py)."""
+    sa = hip
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene4.npz"))
+    x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
+    W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
+    st = po.Style.from_buffer_copy(bytes(d["style"]))
+    want = oracle_of([(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
+    got = gpu_scene(sa, [(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
+    assert sa.lib().smr_hip_draw_status() & 1
+    dd = po.chan_diff(got, want)
+    rows = set(np.argwhere(dd > 0)[:, 0].tolist())
+    assert rows <= {133} and dd.max() <= 4 and (dd > 0).sum() <= 8, report(got, want)
+    # without way 9 the scene is exact (another way's wide stroke still reports a sub-sampled row, whose sub-sampled
+    # coverage happens to equal the exact one)
+    keep = [w for w in range(len(off) - 1) if w != 9]
+    ref2 = np.concatenate([ref[off[w]:off[w + 1]] for w in keep]).astype(np.int32)
+    off2 = np.concatenate([[0], np.cumsum([off[w + 1] - off[w] for w in keep])]).astype(np.int64)
+    want = oracle_of([(st, (x, y, off2, ref2))], dpi, W, H, 0xffffff)
+    got = gpu_scene(sa, [(st, (x, y, off2, ref2))], dpi, W, H, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
+
+
+@pytest.mark.parametrize("scene", ["soak_scene5_16", "soak_scene5_43"])
+def test_soak_scenes_with_segments_that_run_straight_back(hip, scene):
+    """Two more scenes of tools/soak.py (coordinates snapped to half pixels, curve=1): a segment runs exactly back along its
+    neighbour, the helper point of control_points (src/bspline_ctrl.c:64-105) falls onto the segment's other end and the control
+    point's angle is atan2 of rounding noise, i.e. decided by the last bits of the host's libm.  The library takes such control
+    points from the host (smr_control_points / smr_control_points_host)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", scene + ".npz"))
+    x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
+    W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
+    st = po.Style.from_buffer_copy(bytes(d["style"]))
+    want = oracle_of([(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
+    got = gpu_scene(hip, [(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
+
+
+@pytest.mark.parametrize("style", ["border", "fill+border"])
+def test_curved_ways_that_double_back(hip, style):
+    """A B A C ...: ways with a spur, as OSM data has them; every spur makes two ill-conditioned control points"""
+    rng = np.random.default_rng(31)
+    xs, ys, off, ref = [], [], [0], []
+    for w in range(40):
+        n = int(rng.integers(3, 9))
+        px = rng.uniform(10, 290) + np.cumsum(rng.normal(0, 14, n)); py = rng.uniform(10, 190) + np.cumsum(rng.normal(0, 14, n))
+        k = int(rng.integers(1, n - 1))
+        order = list(range(k + 1)) + [k - 1] + list(range(k + 1, n))          # ... k-1, k, k-1, k+1 ...
+        base = sum(len(a) for a in xs)
+        xs.append(px); ys.append(py)
+        ref += [base + o for o in order]
+        off.append(len(ref))
+    x, y = np.concatenate(xs), np.concatenate(ys)
+    arrs = (x, y, np.array(off, np.int64), np.array(ref, np.int32))
+    st = CURVE_STYLES[style].with_curve(0.35)
+    g = gpu_scene(hip, [(st, arrs)], 300, 300, 200, 0xffffff)
+    o = oracle_of([(st, arrs)], 300, 300, 200, 0xffffff)
+    assert np.array_equal(g, o), report(g, o)
+
+
 @pytest.mark.parametrize("case", ["dashed", "dotted", "rounddot", "pipe", "dash4", "hairline-dashed", "fill+dashed-border",
                                   "dashed-fill-stroke", "pipe+fill-closed", "rounddot+dashed-fill"])
 def test_dashed_strokes_bit_exact(hip, case):

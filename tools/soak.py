@@ -10,6 +10,7 @@ from golden_io import draw_style
 sa.init(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 bad = 0
+degraded = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     W, H = int(rng.integers(100, 700)), int(rng.integers(80, 500))
     dpi = int(rng.choice([150, 300, 450, 600, 900]))
@@ -50,6 +51,13 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         cv.draw(draw_style(sa, st), *(sa.DeviceArray.from_numpy(a) for a in (x, y, off, ref)), len(off) - 1, len(ref))
         got = cv.read()
         nd = int((got != want).sum())
+        if nd and sa.lib().smr_hip_draw_status() & 1:
+            # the documented degrade: > 64 row-spanning edges of one primitive, reported by the library
+            d = po.chan_diff(got, want)
+            print("scene", it, "flagged DEGRADED_ROWS: differing px", nd, "in rows", sorted(set(np.argwhere(got != want)[:, 0].tolist())), "max", int(d.max()))
+            degraded += 1
+            if d.max() <= 4:
+                nd = 0
     except sa.SmrHipError as e:
         nd = -1; print("  error:", e)
     cv.close()
@@ -69,4 +77,4 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
             g1 = c1.read(); c1.close()
             if not np.array_equal(g1, wt):
                 print("   way", w, "refs", len(r1), "closed", bool(r1[0] == r1[-1]), "diff px", int((g1 != wt).sum()), np.argwhere(g1 != wt)[:5].tolist())
-print("scenes with differences:", bad)
+print("scenes with differences:", bad, "| scenes with reported sub-sampled rows (within 4 levels):", degraded)
