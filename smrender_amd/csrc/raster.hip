@@ -941,6 +941,7 @@ struct setup_args_t
    uint64_t off_dots;
    const uint32_t *po_border, *po_dots, *po_open;      /* [n_ways+1] piece offsets; NULL: the plain layout */
    const uint32_t *id_off;                             /* [n_ways+1] in 8-slot groups; NULL: way_off */
+   uint32_t scancap;                                   /* spanning edges per row the analysis of a stroke compares (smr_rowscan_t::cap) */
    uint32_t *biglist;                                  /* long primitives, left to the k_big_* kernels ([0] = their number, then (id, first item)) */
    struct smr_bigacc_t *bigacc;                        /* [biglist entry] what those kernels need of them */
 };
@@ -1000,6 +1001,7 @@ __device__ __forceinline__ void smr_setup_edge(const smr_oedge_t &o, int row0, i
    }
 }
 
+#define SMR_SCANCAP (64u * (SMR_ACTCAP + 1))      /* act0 / act1 of setup_lds_t as flat arrays */
 #define SMR_BIG_SLOTS 4096u   /* edge slots from which a primitive with an overflowing row-spanning list goes to k_big_rows */
 
 /* analysis of the vertex-free rows of one primitive: which of them libcairo's scan converter sub-samples after all
@@ -1017,6 +1019,9 @@ struct smr_rowscan_t
    uint32_t list_n;               /* entries of L->l_edge that count; more than SMR_LONGCAP: the list overflowed, scan every slot */
    const smr_item_t *items;       /* the primitive's items (64 slots each, with their boxes), or NULL: build_list skips the items that
                                      cannot reach the window instead of reading every slot of a long primitive once per window */
+   uint32_t cap;                  /* spanning edges per row that row_by_wave compares: SMR_ROWCAP for fills (what k_raster's exact path
+                                     holds of one row in one tile: fill chunks bring every edge left of a tile along), SMR_SCANCAP for
+                                     strokes, whose pieces reach a tile only with the items binned there */
 
    /* one vertex-free row decided by the whole wavefront: lanes walk the candidate edges (the LDS list of row-spanning
     * edges, or every edge slot when that list overflowed), the active ones' cells at the top and the bottom of the row
@@ -1054,7 +1059,7 @@ struct smr_rowscan_t
          unsigned long long am = __ballot(act);
          if (!am) return;
          uint32_t pos = cnt + __popcll(am & ((1ull << lane) - 1ull));
-         if (act && pos < SMR_ROWCAP)
+         if (act && pos < cap)
          {
             /* the rounded cells at the top and the bottom of the row (exact either way: 32 bits for a short edge, else the
              * reciprocal estimate with its integer correction) */
@@ -1108,13 +1113,15 @@ struct smr_rowscan_t
       SMR_WAVE_SYNC();
       bool viol = false;
       /* more spanning edges than the exact full-row path holds: the row is sub-sampled instead (reported) */
-      if (cnt > SMR_ROWCAP) { if (lane == 0) atomicOr(status, SMR_ST_DEGRADED); viol = true; }
-      else if ((uint32_t) lane < cnt)
-      {
-         int a0 = f0[lane], a1 = f1[lane];
-         for (uint32_t j = 0; j < cnt; j++) if (a0 < f0[j] && a1 > f1[j]) viol = true;
-      }
+      if (cnt > cap) { if (lane == 0) atomicOr(status, SMR_ST_DEGRADED); viol = true; }
+      else
+         for (uint32_t i = lane; i < cnt; i += 64)
+         {
+            const int a0 = f0[i], a1 = f1[i];
+            for (uint32_t j = 0; j < cnt; j++) if (a0 < f0[j] && a1 > f1[j]) viol = true;
+         }
       if (__ballot(viol) && lane == 0) lmask[(r - mbase) >> 5] |= 1u << (r & 31);
+      else if (cnt > SMR_ROWCAP && lane == 0) atomicOr(status, SMR_ST_ROWRISK);
       SMR_WAVE_SYNC();
    }
 
@@ -1417,6 +1424,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    RS.row0 = P.row0; RS.nrows = P.nrows; RS.edge_cnt = P.edge_cnt; RS.E = E; RS.L = &L; RS.lmask = lmask; RS.lane = lane;
    RS.status = &A.small[2]; RS.list_n = nlong; RS.mbase = 0;
    RS.items = nitems > 64 ? A.items + item0 : nullptr;
+   RS.cap = pieces ? A.scancap : SMR_ROWCAP;
 #ifdef SMR_KO_SETUP
    if (SMR_KO_SETUP & 1) { }
    else
@@ -1631,7 +1639,8 @@ __global__ __launch_bounds__(256) void k_big_vrows(const smr_prim_t *__restrict_
  * each reads the window's two mask words (vertex rows, written by k_big_vrows), builds the window's list of spanning
  * edges with one pass over the primitive's slots and ORs the rows found crossing back into the arena */
 __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_big_rows(const smr_prim_t *__restrict__ prims, const smr_edge_t *__restrict__ edges,
-                                                                   const smr_item_t *__restrict__ items, const uint32_t *__restrict__ biglist, uint32_t *mask, uint32_t *status)
+                                                                   const smr_item_t *__restrict__ items, const uint32_t *__restrict__ biglist, uint32_t *mask, uint32_t *status,
+                                                                   uint32_t scancap)
 {
    __shared__ setup_lds_t LL[SMR_SETUP_WAVES];
    __shared__ uint32_t wmask[SMR_SETUP_WAVES][2];
@@ -1655,6 +1664,7 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_big_rows(const smr_pri
          RS.row0 = P.row0; RS.nrows = P.nrows; RS.edge_cnt = P.edge_cnt; RS.E = edges + P.edge_off; RS.L = &LL[wv];
          RS.lmask = &wmask[wv][0]; RS.mbase = rb;
          RS.lane = lane; RS.status = status; RS.list_n = 0; RS.items = items + biglist[2 + 2 * b];
+         RS.cap = (P.flags & SMR_PF_PIECES) ? scancap : SMR_ROWCAP;
          const uint32_t before0 = wmask[wv][0], before1 = wmask[wv][1];
          if (RS.build_list(rb)) RS.window(rb);
          SMR_WAVE_SYNC();
@@ -2573,6 +2583,25 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                int rs0 = ysbase + r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
                bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs1;
                unsigned long long am = __ballot(act);
+               if (pieces && rowcnt[r] + __popcll(am) > SMR_ROWCAP)
+               {
+                  /* the row's list is about to overflow: only the pieces (4 aligned lanes) that come near the tile from here
+                   * on.  Any whole piece may stay away: it adds its +1 and its -1 beside the tile (see the flush) */
+                  int pmn = o.dir != 0 ? eminx : INT32_MAX, pmx = o.dir != 0 ? emaxx : INT32_MIN;
+                  pmn = min(pmn, __shfl_xor(pmn, 1)); pmx = max(pmx, __shfl_xor(pmx, 1));
+                  pmn = min(pmn, __shfl_xor(pmn, 2)); pmx = max(pmx, __shfl_xor(pmx, 2));
+                  act = act && pmx >= X0 - 1024 && pmn < X1 + 1024;
+                  /* and not the sides that two neighbouring pieces share: the same edge twice, once down and once up (slot 3 of
+                   * piece k is slot 1 of piece k - 1).  The two sort next to each other and leave the winding as it was */
+                  const int m4 = lane & 3;
+                  int src = m4 == 3 ? lane - 6 : m4 == 1 ? lane + 6 : lane;
+                  if (src < 0 || src > 63) src = lane;
+                  const int t_x = __shfl(o.p1x, src), t_y = __shfl(o.p1y, src), t_dx = __shfl(o.dxs, src), t_D = __shfl(o.D, src);
+                  const int t_dir = __shfl(o.dir, src), t_act = __shfl((int) act, src);
+                  const bool twin = src != lane && act && t_act && t_x == o.p1x && t_y == o.p1y && t_dx == o.dxs && t_D == o.D && t_dir == -o.dir;
+                  act = act && !twin;
+                  am = __ballot(act);
+               }
                if (am)
                {
                   touched = true;
@@ -3306,7 +3335,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       uint32_t *biglist;
       SMR_TRY(c->ensure(SMR_BUF_BIGLIST, ((size_t) n_prims * 2 + 2) * 4, (void **) &biglist));
       SMR_HIP(hipMemsetAsync(biglist, 0, 4, s));
-      SA.biglist = biglist;
+      SA.biglist = biglist; SA.scancap = c->strict_rows ? SMR_ROWCAP : SMR_SCANCAP;
       /* a long primitive has at least SMR_BIG_SLOTS edge slots */
       smr_bigacc_t *bigacc;
       SMR_TRY(c->ensure(SMR_BUF_BIGACC, ((size_t) (n_edges / SMR_BIG_SLOTS) + 2) * sizeof(smr_bigacc_t), (void **) &bigacc));
@@ -3341,7 +3370,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
             k_big_items<<<256 * 4, 256, 0, s>>>(prims, edges, items, biglist, bigacc);
             k_big_finish<<<(nbig + 63) / 64, 64, 0, s>>>(prims, biglist, bigacc, maskbuf, SA.mask_cap, small, c->W, c->H);
             k_big_vrows<<<256 * 4, 256, 0, s>>>(prims, edges, items, biglist, bigacc, maskbuf);
-            k_big_rows<<<256 * 16 / SMR_SETUP_WAVES, 64 * SMR_SETUP_WAVES, 0, s>>>(prims, edges, items, biglist, maskbuf, &small[2]);
+            k_big_rows<<<256 * 16 / SMR_SETUP_WAVES, 64 * SMR_SETUP_WAVES, 0, s>>>(prims, edges, items, biglist, maskbuf, &small[2], c->strict_rows ? SMR_ROWCAP : SMR_SCANCAP);
             SMR_HIP(hipGetLastError());
             SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
             SMR_HIP(hipStreamSynchronize(s));
@@ -3402,6 +3431,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    SMR_HIP(hipGetLastError());
    T.mark(s);                                                   /* 3: binned + sorted */
 
+   const bool risk = (h_small[2] & SMR_ST_ROWRISK) && !c->strict_rows;
+   uint32_t *snapshot = nullptr;
    raster_args_t A;
    A.prims = prims; A.hdrs = hdrs; A.edges = edges; A.tile_off = tile_off;
    A.tile_ctr = &small[64];       /* zero since the memset at the top of the pass */
@@ -3413,6 +3444,13 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
       unsigned nwg = std::min<unsigned>((n_tiles + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES, 256u * 8u);
       nwg = (nwg + 7u) & ~7u;            /* a multiple of the 8 XCDs (k_raster's tile order) */
+      /* rows of strokes with more spanning edges than one tile's exact path holds: should a tile get more than its share of
+       * them after all (SMR_ST_ROWCAP), the pass runs again from this copy with such rows sub-sampled */
+      if (risk)
+      {
+         SMR_TRY(c->ensure(SMR_BUF_SNAPSHOT, (size_t) c->W * c->band_h * 4, (void **) &snapshot));
+         SMR_HIP(hipMemcpyAsync(snapshot, c->pix, (size_t) c->W * c->band_h * 4, hipMemcpyDeviceToDevice, s));
+      }
       k_raster<<<nwg, 64 * SMR_RASTER_WAVES, 0, s>>>(A);
    }
    SMR_HIP(hipGetLastError());
@@ -3448,6 +3486,14 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       return smr_fail(SMR_E_CAPACITY, "draw: a curve needs more than %d levels of subdivision", SMR_CURVE_STACK);
    if (h_small[2] & SMR_ST_KNOTS_CLOSED)
       return smr_fail(SMR_E_UNSUPPORTED, "draw: a closed way of explicit Bezier knots (curve=2) must be p0, (c1, c2, p) * m, p0 (the way was not drawn)");
+   if ((h_small[2] & SMR_ST_ROWCAP) && risk && !(h_small[2] & (SMR_ST_CURVE_DEPTH | SMR_ST_KNOTS_CLOSED | SMR_ST_BUCKET_OVERFLOW)))
+   {
+      SMR_HIP(hipMemcpyAsync(c->pix, snapshot, (size_t) c->W * c->band_h * 4, hipMemcpyDeviceToDevice, s));
+      c->strict_rows = 1;
+      const int rc = draw_pass(c, st, b, mode);
+      c->strict_rows = 0;
+      return rc;
+   }
    if (h_small[2] & SMR_ST_DEGRADED) smr_g.draw_status |= SMR_DRAW_DEGRADED_ROWS;
    if (h_small[2] & SMR_ST_ROWCAP)
       return smr_fail(SMR_E_CAPACITY, "draw: more than %d edges of one primitive span a vertex-free pixel row inside one tile", SMR_ROWCAP);

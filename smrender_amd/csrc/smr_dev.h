@@ -68,6 +68,8 @@ struct __attribute__((aligned(16))) smr_thdr_t
 #define SMR_ST_MASK_ARENA 4u
 #define SMR_ST_KNOTS_CLOSED 32u  /* a closed way of explicit Bezier knots (curve=2) that is not p0, (c1, c2, p) * m, p0 */
 #define SMR_ST_CURVE_DEPTH 16u  /* a Bezier needed more levels of subdivision than the decomposition's stack holds */
+#define SMR_ST_ROWRISK 64u      /* a stroke's vertex-free row with more than SMR_ROWCAP spanning edges was found free of crossings: it takes the
+                                   exact whole-row path, which holds SMR_ROWCAP of them per tile (draw_pass keeps a copy of the canvas) */
 #define SMR_ST_DEGRADED 8u      /* a compound row with more than SMR_ROWCAP spanning edges was sub-sampled */
 
 __device__ __forceinline__ int smr_to_grid_y(int32_t y) { return (int) ((15ll * y + 128) >> 8); }

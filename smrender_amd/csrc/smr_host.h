@@ -30,7 +30,7 @@ int smr_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)
 
 enum { SMR_BUF_PTS, SMR_BUF_WAYFLAGS, SMR_BUF_SMALL, SMR_BUF_PRIMS, SMR_BUF_EDGES, SMR_BUF_WAYPIX, SMR_BUF_COUNTS,
        SMR_BUF_TILEOFF, SMR_BUF_SUMS, SMR_BUF_ENTRIES, SMR_BUF_CAP0, SMR_BUF_CAP1, SMR_BUF_REFWAY, SMR_BUF_ITEMS, SMR_BUF_MASK, SMR_BUF_HDRS, SMR_BUF_COVERED, SMR_BUF_DASH, SMR_BUF_PEN,
-       SMR_BUF_CURVE_CNT, SMR_BUF_FPTS, SMR_BUF_FTIN, SMR_BUF_FTOUT, SMR_BUF_FREFWAY, SMR_BUF_FWAYOFF, SMR_BUF_FSKIP, SMR_BUF_BIGLIST, SMR_BUF_BIGACC, SMR_BUF_CURVEFIX, SMR_BUF_MAX };
+       SMR_BUF_CURVE_CNT, SMR_BUF_FPTS, SMR_BUF_FTIN, SMR_BUF_FTOUT, SMR_BUF_FREFWAY, SMR_BUF_FWAYOFF, SMR_BUF_FSKIP, SMR_BUF_BIGLIST, SMR_BUF_BIGACC, SMR_BUF_CURVEFIX, SMR_BUF_SNAPSHOT, SMR_BUF_MAX };
 
 struct smr_devbuf_t { void *p = nullptr; size_t cap = 0; };
 
@@ -42,6 +42,7 @@ struct smr_canvas
    uint32_t *halo_above = nullptr, *halo_below = nullptr;     /* neighbour rows for the caption scan */
    int n_above = 0, n_below = 0;
    smr_devbuf_t buf[SMR_BUF_MAX];      /* grow-only work buffers, reused across draw calls */
+   int strict_rows = 0;                /* draw_pass's second attempt: rows beyond SMR_ROWCAP spanning edges are sub-sampled (and reported) */
    uint64_t last_n_edges = 0;          /* edge slots of the last draw pass (smr_hip_debug_edges) */
 
    int ensure(int id, size_t bytes, void **out)

@@ -284,10 +284,10 @@ def test_rows_beyond_the_exact_path_are_subsampled_and_reported(hip):
 
 
 def test_soak_scene_with_a_wide_curved_stroke(hip):
-    """The one scene of tools/soak.py's random runs that differed from the oracle (tests/golden/soak_scene4.npz, 31 ways at
+    """The first scene of tools/soak.py's random runs that differed from the oracle (tests/golden/soak_scene4.npz, 31 ways at
     600 dpi, curve=1): way 9's border is an 11.8 px wide stroke of a tightly curved line whose flattened pieces put 86 edges
-    across the vertex-free pixel row 133, more than the exact whole-row path keeps.  That row of that way is sub-sampled and
-    the library says so; every other pixel of the scene equals the oracle (= libcairo, tests/test_oracle_cairo.py)."""
+    across the vertex-free pixel row 133.  The row analysis of a stroke compares up to SMR_SCANCAP (576) spanning edges, and a
+    tile whose list of one row fills up keeps only the pieces near it: exact, and nothing to report."""
     sa = hip
     import os
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene4.npz"))
@@ -296,18 +296,26 @@ def test_soak_scene_with_a_wide_curved_stroke(hip):
     st = po.Style.from_buffer_copy(bytes(d["style"]))
     want = oracle_of([(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
     got = gpu_scene(sa, [(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
+    assert sa.lib().smr_hip_draw_status() == 0
+
+
+def test_soak_scene_whose_tiles_overflow_runs_again_with_reported_rows(hip):
+    """tests/golden/soak_scene1_37.npz (900 dpi, a 39 px wide curved stroke): vertex-free rows with hundreds of spanning edges
+    pass the row analysis, but one 64-px tile would have to hold more than SMR_ROWCAP of them.  draw_pass restores the canvas
+    from its copy and runs again with such rows sub-sampled: no error, the rows are reported, the picture stays within a few
+    levels of the oracle on a few pixels."""
+    sa = hip
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene1_37.npz"))
+    x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
+    W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
+    st = po.Style.from_buffer_copy(bytes(d["style"]))
+    want = oracle_of([(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
+    got = gpu_scene(sa, [(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
     assert sa.lib().smr_hip_draw_status() & 1
     dd = po.chan_diff(got, want)
-    rows = set(np.argwhere(dd > 0)[:, 0].tolist())
-    assert rows <= {133} and dd.max() <= 4 and (dd > 0).sum() <= 8, report(got, want)
-    # without way 9 the scene is exact (another way's wide stroke still reports a sub-sampled row, whose sub-sampled
-    # coverage happens to equal the exact one)
-    keep = [w for w in range(len(off) - 1) if w != 9]
-    ref2 = np.concatenate([ref[off[w]:off[w + 1]] for w in keep]).astype(np.int32)
-    off2 = np.concatenate([[0], np.cumsum([off[w + 1] - off[w] for w in keep])]).astype(np.int64)
-    want = oracle_of([(st, (x, y, off2, ref2))], dpi, W, H, 0xffffff)
-    got = gpu_scene(sa, [(st, (x, y, off2, ref2))], dpi, W, H, 0xffffff)
-    assert np.array_equal(got, want), report(got, want)
+    assert dd.max() <= 12 and (dd > 0).mean() < 0.02, report(got, want)
 
 
 @pytest.mark.parametrize("scene", ["soak_scene5_16", "soak_scene5_43"])
