@@ -10,6 +10,7 @@ from golden_io import draw_style
 sa.init(0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 bad = 0
+DASH = len(sys.argv) > 3 and sys.argv[3] == "dash"
 degraded = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     W, H = int(rng.integers(100, 700)), int(rng.integers(80, 500))
@@ -42,8 +43,17 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     fc = int(rng.integers(0, 1 << 24)) | (int(rng.integers(0, 0x60)) << 24 if rng.uniform() < 0.4 else 0)
     bc = int(rng.integers(0, 1 << 24)) | (int(rng.integers(0, 0x60)) << 24 if rng.uniform() < 0.4 else 0)
     st = po.Style(fu, bu, fc, bc, float(rng.choice([0, 0.1, 0.3, 0.8])), float(rng.choice([0, 0.08, 0.2, 0.5])), 0)
-    if rng.uniform() < 0.3:
+    kind = rng.uniform()
+    if kind < 0.3:
         st = st.with_curve(float(rng.choice([0.2, 0.35])))
+    elif kind < 0.5 and DASH:
+        # dashed / dotted borders (and dashed fill strokes of open ways); round caps stay with the border (a solid fill stroke
+        # after round caps is refused, tests/test_gpu_raster.py)
+        S = po.Style
+        bs = int(rng.choice([S.DASHED, S.DOTTED])) if bu else 0
+        fs = int(rng.choice([0, S.DASHED, S.DOTTED])) if fu else 0
+        bd = tuple(float(v) for v in rng.uniform(1, 8, 2)) if rng.uniform() < 0.5 else None
+        st = st.with_dash(border_style=bs, fill_style=fs, border_dash=bd)
     ways = po.ways_from_arrays(x, y, off, ref)
     want = po.oracle_scene([(st, ways)], dpi, W, H, 0xffffff)
     cv = sa.Canvas(W, H, dpi, 0xffffff)
@@ -73,7 +83,10 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
             wy = po.ways_from_arrays(x, y, o1, r1)
             wt = po.oracle_scene([(st, wy)], dpi, W, H, 0xffffff)
             c1 = sa.Canvas(W, H, dpi, 0xffffff)
-            c1.draw(draw_style(sa, st), *(sa.DeviceArray.from_numpy(a) for a in (x, y, o1, np.ascontiguousarray(r1))), 1, len(r1))
+            try:
+                c1.draw(draw_style(sa, st), *(sa.DeviceArray.from_numpy(a) for a in (x, y, o1, np.ascontiguousarray(r1))), 1, len(r1))
+            except sa.SmrHipError as e:
+                print("   way", w, "error:", e); c1.close(); continue
             g1 = c1.read(); c1.close()
             if not np.array_equal(g1, wt):
                 print("   way", w, "refs", len(r1), "closed", bool(r1[0] == r1[-1]), "diff px", int((g1 != wt).sum()), np.argwhere(g1 != wt)[:5].tolist())
