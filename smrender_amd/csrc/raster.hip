@@ -2275,7 +2275,6 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             const smr_edge_t *E = A.edges;
 
             /* ---- sub-sampled rows: crossings -> spans -> cells ---- */
-            if (__ballot(ovf) && lane == 0) atomicOr(A.status, SMR_ST_BUCKET_OVERFLOW);
             const bool mine = lane < SMR_NSUB && ((partial >> my_row) & 1u);
             auto add_span = [&](int x1, int x2)
             {
@@ -2294,7 +2293,24 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
 #endif
             if (mine && pieces)
             {
-               if (cl <= cr) push_interval(cl, cr);
+               /* the interval still open takes the stored ones it meets along and goes straight to the cells: it needs no
+                * room in the list (pushed there, a full list dropped it after the overflow had been looked at) */
+               if (cl <= cr)
+               {
+                  for (int i = 0; i < cnt;)
+                  {
+                     const int ia = bk[2 * i], ib = bk[2 * i + 1];
+                     if (ia <= cr && cl <= ib)
+                     {
+                        cl = min(cl, ia); cr = max(cr, ib);
+                        cnt--;
+                        bk[2 * i] = bk[2 * cnt]; bk[2 * i + 1] = bk[2 * cnt + 1];
+                        i = 0;
+                     }
+                     else i++;
+                  }
+                  add_span(cl, cr);
+               }
                for (int i = 0; i < cnt; i++) add_span(bk[2 * i], bk[2 * i + 1]);
             }
             else if (mine)
@@ -2323,6 +2339,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                if (xstart >= 0) add_span(xstart, SMR_TW * 256);
             }
 
+            if (__ballot(ovf) && lane == 0) atomicOr(A.status, SMR_ST_BUCKET_OVERFLOW);
             TICK(1);      /* flush: spans of the sub-sampled rows */
             /* ---- rows that take libcairo's exact full-row path ---- */
             uint32_t fullrows = 0;
@@ -2788,6 +2805,10 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                            }
                         }
                      }
+#ifdef SMR_DEBUG_PIECE
+                     if (tx == SMR_DEBUG_PIECE && ysbase == SMR_DEBUG_YS && lane >= 15 && lane < 30)
+                        printf("lane %d piece slot %u lo %d hi %d small %d cl %d cr %d cnt %d\n", lane, it.edge_off + j, lo - X0, hi - X0, (int) ((smallmask >> j) & 1ull), cl, cr, cnt);
+#endif
                      if (mine && lo < hi && hi > X0 && lo < X1)
                      {
                         const int l = (lo < X0 ? X0 : lo) - X0, r = (hi > X1 ? X1 : hi) - X0;

@@ -318,14 +318,13 @@ def test_soak_scene_whose_tiles_overflow_runs_again_with_reported_rows(hip):
     assert dd.max() <= 12 and (dd > 0).mean() < 0.02, report(got, want)
 
 
-@pytest.mark.xfail(reason="open: one pixel of a dotted fill stroke with 1-px dots differs (GPU alpha 220, oracle 254)", strict=False)
 def test_soak_scene_with_one_pixel_dots(hip):
     """tests/golden/soak_scene21_2.npz, way 17 (tools/soak.py 21 60 dash): a dotted fill stroke (style=dotted, no border, so the
-    dots are one device pixel long) at 600 dpi.  The edge slots equal the oracle's (tools/soak_edges.py), the picture differs in
-    ONE pixel, where the last dot of the way overlaps the dots around a vertex of the way: two of the 15 sub-rows of that pixel
-    row lose the last dot's interval, and only when the dot began in the strip of four rows above (the same way moved up by ten
-    rows is exact, tools/soak_shift.py).  Kept as an expected failure until the cause in k_raster's piece path is found
-    (DESIGN.md 4.1)."""
+    dots are one device pixel long) at 600 dpi puts 17 dots on two sub-rows of one tile, two more than a sub-row's list holds.
+    The interval still open at the flush used to be pushed into the full list after the overflow flag had been read, and was
+    dropped without a word (one pixel at alpha 220 instead of 254).  Now it goes straight to the cells, and an overflow during
+    the flush is reported like any other."""
+    sa = hip
     import os
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene21_2.npz"))
     x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
@@ -333,7 +332,11 @@ def test_soak_scene_with_one_pixel_dots(hip):
     st = po.Style.from_buffer_copy(bytes(d["style"]))
     r1 = np.ascontiguousarray(ref[off[17]:off[18]]); o1 = np.array([0, len(r1)], np.int64)
     want = oracle_of([(st, (x, y, o1, r1))], dpi, W, H, 0xffffff)
-    got = gpu_scene(hip, [(st, (x, y, o1, r1))], dpi, W, H, 0xffffff)
+    try:
+        got = gpu_scene(sa, [(st, (x, y, o1, r1))], dpi, W, H, 0xffffff)
+    except sa.SmrHipError as e:          # the loud limit is acceptable, a wrong pixel is not
+        assert e.code == -6
+        return
     assert np.array_equal(got, want), report(got, want)
 
 
