@@ -2430,7 +2430,9 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                   }
                }
                const int wincl = wsum + dir;
-               const bool is_end = onr && ((((uint32_t) wincl & mask) == 0 && (!has_succ || succ_c0 != c0)) || !has_succ);
+               /* (no "the last edge closes whatever is open": the paths are closed, so a span still open after the tile's last
+                * edge ends at an edge of an item right of the tile, which is not binned here: it covers the rest of the tile) */
+               const bool is_end = onr && ((uint32_t) wincl & mask) == 0 && (!has_succ || succ_c0 != c0);
                const bool is_start = onr && (!has_pred || (((uint32_t) wsum & mask) == 0 && pred_c0 != c0));
                /* every span-boundary edge adds its exact trapezoid coverage to the cells it crosses inside
                 * the tile (libcairo's cell_list_render_edge; the per-cell y steps are floors of one
@@ -2525,7 +2527,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
 #pragma unroll
                for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(wsum, d); if (lane >= d) wsum += t; }
                bool last = (uint32_t) lane + 1 == n;
-               bool is_end = on && ((((uint32_t) wsum & mask) == 0 && (last || c0n != c0)) || last);
+               bool is_end = on && ((uint32_t) wsum & mask) == 0 && (last || c0n != c0);
                int prev_end = __shfl_up((int) is_end, 1);
                bool is_start = on && (lane == 0 || prev_end);
                if (is_start) smr_render_edge(L, r, X0, dxs, D, q0, r0, q1, r1, +1);

@@ -340,6 +340,21 @@ def test_soak_scene_with_one_pixel_dots(hip):
     assert np.array_equal(got, want), report(got, want)
 
 
+def test_soak_scene_with_a_span_that_ends_right_of_the_tile(hip):
+    """tests/golden/soak_scene38_49.npz (tools/soak.py 38 60), way 35: a curved closed fill of 223 edges (four items).  In the
+    vertex-free row 276 the span starts at x = 41 and ends at x = 230, at an edge of the first item, whose box lies right of
+    the tile 64..127 and is not binned there.  The exact whole-row path used to close the span at the tile's last edge (the
+    oracle's rule for unbalanced input, which closed paths never are): 58 px of the row were left white."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene38_49.npz"))
+    x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
+    W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
+    st = po.Style.from_buffer_copy(bytes(d["style"]))
+    want = oracle_of([(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
+    got = gpu_scene(hip, [(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
+
+
 @pytest.mark.parametrize("scene", ["soak_scene5_16", "soak_scene5_43"])
 def test_soak_scenes_with_segments_that_run_straight_back(hip, scene):
     """Two more scenes of tools/soak.py (coordinates snapped to half pixels, curve=1): a segment runs exactly back along its

@@ -8,7 +8,8 @@ import smrender_amd as sa
 from oracle import pyoracle as po
 from golden_io import draw_style
 sa.init(0)
-rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+rng = np.random.default_rng(SEED)
 bad = 0
 DASH = len(sys.argv) > 3 and sys.argv[3] == "dash"
 degraded = 0
@@ -75,7 +76,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         bad += 1
         print("scene", it, "W,H,dpi", W, H, dpi, "ways", n_ways, "seg", round(seg, 1), "style", fu, bu, st.curve, "DIFF", nd)
         os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
-        np.savez(os.path.join(R, "gpurun_out", f"soak_fail_{it}.npz"), x=x, y=y, off=off, ref=ref, W=W, H=H, dpi=dpi, style=bytes(st),
+        np.savez(os.path.join(R, "gpurun_out", f"soak_fail_s{SEED}_{it}.npz"), x=x, y=y, off=off, ref=ref, W=W, H=H, dpi=dpi, style=bytes(st),
                  got=got if nd > 0 else np.zeros(1), want=want)
         # which ways: one at a time
         for w in range(len(off) - 1):
