@@ -11,7 +11,8 @@ sa.init(0)
 SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 rng = np.random.default_rng(SEED)
 bad = 0
-DASH = len(sys.argv) > 3 and sys.argv[3] == "dash"
+DASH = len(sys.argv) > 3 and "dash" in sys.argv[3]
+BIG = len(sys.argv) > 3 and "big" in sys.argv[3]
 degraded = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     W, H = int(rng.integers(100, 700)), int(rng.integers(80, 500))
@@ -21,9 +22,11 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     xs, ys, off, ref = [], [], [0], []
     for w in range(n_ways):
         n = int(rng.integers(2, 20))
+        if BIG and rng.uniform() < 0.25:
+            n = int(rng.integers(60, 400))             # fills and strokes of several items
         closed = rng.uniform() < 0.5 and n >= 4
         if closed:
-            r = seg * n / 6.3 * rng.uniform(0.5, 1.5)
+            r = min(seg * n / 6.3, 0.6 * max(W, H)) * rng.uniform(0.5, 1.5)
             a = np.sort(rng.uniform(0, 2 * np.pi, n - 1)) * rng.choice([-1, 1])
             cx, cy = rng.uniform(-20, W + 20), rng.uniform(-20, H + 20)
             x, y = cx + r * rng.uniform(0.6, 1.0, n - 1) * np.cos(a), cy + r * rng.uniform(0.6, 1.0, n - 1) * np.sin(a)
