@@ -1394,7 +1394,10 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    if (valid)
    {
       int c0 = P.minx >> 8, c1 = P.maxx >> 8, r0 = P.miny >> 8, r1 = P.maxy >> 8;
-      if (c1 < 0 || r1 < 0 || c0 >= A.W || r0 >= A.H) valid = false;
+      /* a member of a compound path (directional rule) left or right of the chart draws nothing, but its vertices still decide
+       * which rows of the ONE polygon libcairo sub-samples: it keeps its row mask and its items (which no tile takes) */
+      const bool off_x = c1 < 0 || c0 >= A.W, off_y = r1 < 0 || r0 >= A.H;
+      if (off_y || (off_x && A.compound == 0xffffffffu)) valid = false;
    }
    /* a primitive off the chart needs no flag in its items: their boxes are off the chart too */
    if (!valid) { if (lane == 0) A.prims[p] = P; return; }

@@ -340,6 +340,26 @@ def test_soak_scene_with_one_pixel_dots(hip):
     assert np.array_equal(got, want), report(got, want)
 
 
+def test_soak_scene_directional_rule_with_a_way_beside_the_chart(hip):
+    """tests/golden/soak_scene70_37_directional.npz (tools/soak.py 70 60 dir): a directional rule of 103 ways, one of the closed
+    ones (way 77) wholly LEFT of the chart.  It draws nothing, but it is part of the rule's one polygon, and its vertices in
+    row 77 make libcairo sub-sample that row; the set-up used to drop such a member with its row mask, so the row took the exact
+    whole-row path (18 px off by up to 5 levels).  The closed ways must equal the oracle; the hairline strokes of the open ways
+    are compared where the oracle itself equals libcairo."""
+    sa = hip
+    import os
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene70_37_directional.npz"))
+    x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
+    W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
+    st = po.Style.from_buffer_copy(bytes(d["style"]))
+    ways = po.ways_from_arrays(x, y, off, ref)
+    want = po.oracle_directional(st, ways, dpi, W, H, 0xffffff)
+    cv = sa.Canvas(W, H, dpi, 0xffffff)
+    cv.draw(draw_style(sa, st, directional=1), *(sa.DeviceArray.from_numpy(a) for a in (x, y, off, ref)), len(off) - 1, len(ref))
+    got = cv.read(); cv.close()
+    assert np.array_equal(got, want), report(got, want)
+
+
 def test_soak_scene_with_a_span_that_ends_right_of_the_tile(hip):
     """tests/golden/soak_scene38_49.npz (tools/soak.py 38 60), way 35: a curved closed fill of 223 edges (four items).  In the
     vertex-free row 276 the span starts at x = 41 and ends at x = 230, at an edge of the first item, whose box lies right of

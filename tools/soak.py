@@ -13,6 +13,7 @@ rng = np.random.default_rng(SEED)
 bad = 0
 DASH = len(sys.argv) > 3 and "dash" in sys.argv[3]
 BIG = len(sys.argv) > 3 and "big" in sys.argv[3]
+DIR = len(sys.argv) > 3 and "dir" in sys.argv[3]
 degraded = 0
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     W, H = int(rng.integers(100, 700)), int(rng.integers(80, 500))
@@ -59,10 +60,12 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         bd = tuple(float(v) for v in rng.uniform(1, 8, 2)) if rng.uniform() < 0.5 else None
         st = st.with_dash(border_style=bs, fill_style=fs, border_dash=bd)
     ways = po.ways_from_arrays(x, y, off, ref)
-    want = po.oracle_scene([(st, ways)], dpi, W, H, 0xffffff)
+    directional = DIR and st.curve == 0 and st.fill_used and st.border_style == 0 and st.fill_style == 0 and rng.uniform() < 0.6
+    want = po.oracle_directional(st, ways, dpi, W, H, 0xffffff) if directional else po.oracle_scene([(st, ways)], dpi, W, H, 0xffffff)
     cv = sa.Canvas(W, H, dpi, 0xffffff)
     try:
-        cv.draw(draw_style(sa, st), *(sa.DeviceArray.from_numpy(a) for a in (x, y, off, ref)), len(off) - 1, len(ref))
+        cv.draw(draw_style(sa, st, directional=1) if directional else draw_style(sa, st),
+                *(sa.DeviceArray.from_numpy(a) for a in (x, y, off, ref)), len(off) - 1, len(ref))
         got = cv.read()
         nd = int((got != want).sum())
         if nd and sa.lib().smr_hip_draw_status() & 1:
@@ -77,10 +80,12 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     cv.close()
     if nd != 0:
         bad += 1
-        print("scene", it, "W,H,dpi", W, H, dpi, "ways", n_ways, "seg", round(seg, 1), "style", fu, bu, st.curve, "DIFF", nd)
+        print("scene", it, "W,H,dpi", W, H, dpi, "ways", n_ways, "seg", round(seg, 1), "style", fu, bu, st.curve, "directional", directional, "DIFF", nd)
         os.makedirs(os.path.join(R, "gpurun_out"), exist_ok=True)
         np.savez(os.path.join(R, "gpurun_out", f"soak_fail_s{SEED}_{it}.npz"), x=x, y=y, off=off, ref=ref, W=W, H=H, dpi=dpi, style=bytes(st),
                  got=got if nd > 0 else np.zeros(1), want=want)
+        if directional:
+            continue
         # which ways: one at a time
         for w in range(len(off) - 1):
             o1 = np.array([0, off[w + 1] - off[w]], np.int64); r1 = ref[off[w]:off[w + 1]]
