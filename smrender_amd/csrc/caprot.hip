@@ -326,24 +326,24 @@ static uint32_t cap_color_pixel(uint32_t c)
    return ((d2s(a) >> 8) << 24) | ((d2s(r * a) >> 8) << 16) | ((d2s(g * a) >> 8) << 8) | (d2s(b * a) >> 8);
 }
 
-extern "C" int smr_hip_caprot(smr_canvas_t *c, const smr_cap_batch_t *b, double *d_angle, double *d_dv)
+/* what both entry points check and derive from a batch */
+static int caprot_geometry(smr_canvas_t *c, const smr_cap_batch_t *b, double *d_angle, int *n_steps, int *r, size_t *lds)
 {
-   SMR_NEED_INIT();
    if (!c || !b || !d_angle) return smr_fail(SMR_E_INVAL, "caprot: NULL argument");
    if (b->n < 0 || b->fg_w <= 0 || b->fg_h <= 0 || b->fg_x < 0 || b->fg_x > b->fg_w)
       return smr_fail(SMR_E_INVAL, "caprot: bad plane geometry");
-   if (b->n == 0) return SMR_OK;
-   if (!b->d_cx || !b->d_cy) return smr_fail(SMR_E_INVAL, "caprot: missing caption coordinates");
-   int n_steps, r;
-   SMR_TRY(smr_hip_caprot_steps(b->fg_w, b->fg_h, c->dpi, &n_steps, &r));
-   if (n_steps < 1) return smr_fail(SMR_E_INVAL, "caprot: plane too small (num_steps = %d)", n_steps);
-   size_t lds = (((size_t) (n_steps + 256) * 8 + 15) & ~(size_t) 15) + (size_t) (b->fg_w - (b->d_fg ? 0 : b->fg_x)) * b->fg_h * 4;
-   if (lds > 64 * 1024)
-      return smr_fail(SMR_E_CAPACITY, "caprot: plane of %dx%d px needs %zu bytes of LDS (limit 65536)", b->fg_w, b->fg_h, lds);
+   if (b->n > 0 && (!b->d_cx || !b->d_cy)) return smr_fail(SMR_E_INVAL, "caprot: missing caption coordinates");
+   SMR_TRY(smr_hip_caprot_steps(b->fg_w, b->fg_h, c->dpi, n_steps, r));
+   if (*n_steps < 1) return smr_fail(SMR_E_INVAL, "caprot: plane too small (num_steps = %d)", *n_steps);
+   *lds = (((size_t) (*n_steps + 256) * 8 + 15) & ~(size_t) 15) + (size_t) (b->fg_w - (b->d_fg ? 0 : b->fg_x)) * b->fg_h * 4;
+   if (*lds > 64 * 1024)
+      return smr_fail(SMR_E_CAPACITY, "caprot: plane of %dx%d px needs %zu bytes of LDS (limit 65536)", b->fg_w, b->fg_h, *lds);
+   return SMR_OK;
+}
 
-   /* per-batch tables with the host libm: angles accumulate like dv_sample's loop (:1842) */
-   std::vector<smr_rotmat_t> mats(n_steps);
-   std::vector<double> ang(n_steps), wfac(n_steps);
+/* per-batch tables with the host libm: angles accumulate like dv_sample's loop (:1842) */
+static void caprot_tables(const smr_cap_batch_t *b, int n_steps, int r, smr_rotmat_t *mats, double *ang, double *wfac)
+{
    double a = 0, phase = b->phase_deg * M_PI / 180.0;
    for (int i = 0; i < n_steps; a += M_2PI / n_steps, i++)
    {
@@ -351,15 +351,13 @@ extern "C" int smr_hip_caprot(smr_canvas_t *c, const smr_cap_batch_t *b, double 
       rot_matrix(b->fg_w, b->fg_h, r, r, a, &mats[i]);
       wfac[i] = 1.0 - (1.0 - fabs(b->weight)) * (1.0 - cos(a * 2.0 + phase)) / 2.0;      /* dv_weight :1819 */
    }
-   hipStream_t s = smr_g.stream;
-   smr_rotmat_t *d_m; double *d_t;
-   SMR_TRY(c->ensure(SMR_BUF_CAP0, sizeof(smr_rotmat_t) * n_steps, (void **) &d_m));
-   SMR_TRY(c->ensure(SMR_BUF_CAP1, sizeof(double) * 2 * n_steps, (void **) &d_t));
-   SMR_HIP(hipMemcpyAsync(d_m, mats.data(), sizeof(smr_rotmat_t) * n_steps, hipMemcpyHostToDevice, s));
-   SMR_HIP(hipMemcpyAsync(d_t, ang.data(), sizeof(double) * n_steps, hipMemcpyHostToDevice, s));
-   SMR_HIP(hipMemcpyAsync(d_t + n_steps, wfac.data(), sizeof(double) * n_steps, hipMemcpyHostToDevice, s));
-   SMR_HIP(hipStreamSynchronize(s));      /* the host vectors go out of scope below */
+}
 
+/* the launch itself; d_m / d_ang / d_wfac: the per-batch tables in device memory, already on their way on the stream */
+static int caprot_launch(smr_canvas_t *c, const smr_cap_batch_t *b, double *d_angle, double *d_dv, int n_steps, int r, size_t lds,
+                         const smr_rotmat_t *d_m, const double *d_ang, const double *d_wfac, bool timed)
+{
+   hipStream_t s = smr_g.stream;
    caprot_args_t A;
    A.canvas = c->pix; A.W = c->W; A.H = c->H; A.band_y0 = c->band_y0; A.band_h = c->band_h;
    A.halo_above = c->halo_above; A.halo_below = c->halo_below; A.n_above = c->n_above; A.n_below = c->n_below;
@@ -375,13 +373,86 @@ extern "C" int smr_hip_caprot(smr_canvas_t *c, const smr_cap_batch_t *b, double 
    A.cx = b->d_cx; A.cy = b->d_cy; A.n = b->n;
    A.fg_w = b->fg_w; A.fg_h = b->fg_h; A.fg_x = b->fg_x; A.r = r; A.num_steps = n_steps;
    A.fg_pix = cap_color_pixel(b->col); A.fg = b->d_fg; A.weight = b->weight;
-   A.mats = d_m; A.ang = d_t; A.wfac = d_t + n_steps;
+   A.mats = d_m; A.ang = d_ang; A.wfac = d_wfac;
    A.out_angle = d_angle; A.out_dv = d_dv;
-   smr_timer_t T(smr_g.profiling);
+   smr_timer_t T(timed && smr_g.profiling);
    T.mark(s);
    k_caprot<<<(unsigned) b->n, 64, lds, s>>>(A);
    SMR_HIP(hipGetLastError());
    T.mark(s);
-   if (smr_g.profiling) smr_g.last.caprot_ms = T.ms(0, 1);
+   if (timed && smr_g.profiling) smr_g.last.caprot_ms = T.ms(0, 1);
    return SMR_OK;
+}
+
+extern "C" int smr_hip_caprot(smr_canvas_t *c, const smr_cap_batch_t *b, double *d_angle, double *d_dv)
+{
+   SMR_NEED_INIT();
+   int n_steps, r; size_t lds;
+   SMR_TRY(caprot_geometry(c, b, d_angle, &n_steps, &r, &lds));
+   if (b->n == 0) return SMR_OK;
+   std::vector<smr_rotmat_t> mats(n_steps);
+   std::vector<double> ang(n_steps), wfac(n_steps);
+   caprot_tables(b, n_steps, r, mats.data(), ang.data(), wfac.data());
+   hipStream_t s = smr_g.stream;
+   smr_rotmat_t *d_m; double *d_t;
+   SMR_TRY(c->ensure(SMR_BUF_CAP0, sizeof(smr_rotmat_t) * n_steps, (void **) &d_m));
+   SMR_TRY(c->ensure(SMR_BUF_CAP1, sizeof(double) * 2 * n_steps, (void **) &d_t));
+   SMR_HIP(hipMemcpyAsync(d_m, mats.data(), sizeof(smr_rotmat_t) * n_steps, hipMemcpyHostToDevice, s));
+   SMR_HIP(hipMemcpyAsync(d_t, ang.data(), sizeof(double) * n_steps, hipMemcpyHostToDevice, s));
+   SMR_HIP(hipMemcpyAsync(d_t + n_steps, wfac.data(), sizeof(double) * n_steps, hipMemcpyHostToDevice, s));
+   SMR_HIP(hipStreamSynchronize(s));      /* the host vectors go out of scope below */
+   return caprot_launch(c, b, d_angle, d_dv, n_steps, r, lds, d_m, d_t, d_t + n_steps, true);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* smr_hip_caprot_noalloc: the same scan for callers that cannot allocate (code under HIP  */
+/* graph capture, tight serving loops, harnesses that forbid hipMalloc).  The scan's only   */
+/* scratch, the per-batch tables (rotation matrices, angles, weight factors), lives in a    */
+/* file-scope device array instead of the canvas's grow-only buffers; the host copies are   */
+/* file-scope too.  Each GPU holds its own copy of the array at its own address: the        */
+/* address is asked for once per device (smr_caprot_scratch_setup, called by smr_hip_init    */
+/* with that device current) and only that pointer is ever handed to a kernel or a copy.     */
+/* ------------------------------------------------------------------------------------ */
+struct smr_caprot_tables_t
+{
+   smr_rotmat_t mats[SMR_CAPROT_NOALLOC_MAX_STEPS];
+   double ang[SMR_CAPROT_NOALLOC_MAX_STEPS], wfac[SMR_CAPROT_NOALLOC_MAX_STEPS];
+};
+static __device__ __align__(256) unsigned char scratch[sizeof(smr_caprot_tables_t)];      /* 48 KiB per GPU, until the process ends */
+#define SMR_MAX_DEVICES 64
+static smr_caprot_tables_t *scratch_ptr[SMR_MAX_DEVICES];      /* per device: the array's address ON that device */
+static smr_caprot_tables_t scratch_host;                       /* the tables on their way to the device */
+
+int smr_caprot_scratch_setup(int device)
+{
+   if (device < 0 || device >= SMR_MAX_DEVICES) return smr_fail(SMR_E_INVAL, "caprot_noalloc: device %d (at most %d)", device, SMR_MAX_DEVICES);
+   if (scratch_ptr[device]) return SMR_OK;
+   void *p = nullptr;
+   SMR_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+   if (!p) return smr_fail(SMR_E_HIP, "caprot_noalloc: hipGetSymbolAddress returned NULL");
+   scratch_ptr[device] = static_cast<smr_caprot_tables_t *>(p);
+   return SMR_OK;
+}
+
+extern "C" int smr_hip_caprot_noalloc(smr_canvas_t *c, const smr_cap_batch_t *b, double *d_angle, double *d_dv)
+{
+   SMR_NEED_INIT();
+   int n_steps, r; size_t lds;
+   SMR_TRY(caprot_geometry(c, b, d_angle, &n_steps, &r, &lds));
+   if (n_steps > SMR_CAPROT_NOALLOC_MAX_STEPS)
+      return smr_fail(SMR_E_CAPACITY, "caprot_noalloc: %d trial angles, the static tables hold %d (use smr_hip_caprot)", n_steps,
+                      SMR_CAPROT_NOALLOC_MAX_STEPS);
+   if (b->n == 0) return SMR_OK;
+   smr_caprot_tables_t *d = smr_g.device >= 0 && smr_g.device < SMR_MAX_DEVICES ? scratch_ptr[smr_g.device] : nullptr;
+   if (!d) return smr_fail(SMR_E_NODEVICE, "caprot_noalloc: no scratch address for device %d (smr_hip_init)", smr_g.device);
+   hipStream_t s = smr_g.stream;
+   /* the previous call's copies have left scratch_host: every call ends with the kernel enqueued behind them, and syncs here first */
+   SMR_HIP(hipStreamSynchronize(s));
+   caprot_tables(b, n_steps, r, scratch_host.mats, scratch_host.ang, scratch_host.wfac);
+   /* every word the kernel reads ([0, n_steps) of each table) is rewritten: nothing of the last call's contents is used */
+   SMR_HIP(hipMemcpyAsync(d->mats, scratch_host.mats, sizeof(smr_rotmat_t) * n_steps, hipMemcpyHostToDevice, s));
+   SMR_HIP(hipMemcpyAsync(d->ang, scratch_host.ang, sizeof(double) * n_steps, hipMemcpyHostToDevice, s));
+   SMR_HIP(hipMemcpyAsync(d->wfac, scratch_host.wfac, sizeof(double) * n_steps, hipMemcpyHostToDevice, s));
+   SMR_HIP(hipStreamSynchronize(s));      /* pageable source: the copies are staged before scratch_host may change */
+   return caprot_launch(c, b, d_angle, d_dv, n_steps, r, lds, d->mats, d->ang, d->wfac, false);
 }

@@ -33,6 +33,7 @@ extern "C" int smr_hip_init(int device)
       if (smr_g.stream) { hipStreamDestroy(smr_g.stream); smr_g.stream = nullptr; }
       SMR_HIP(hipStreamCreateWithFlags(&smr_g.stream, hipStreamNonBlocking));
    }
+   SMR_TRY(smr_caprot_scratch_setup(device));      /* with `device` current: every GPU has its own copy of the array */
    smr_g.device = device;
    smr_g.init = true;
    memset(&smr_g.last, 0, sizeof(smr_g.last));

@@ -24,6 +24,9 @@ extern smr_global_t smr_g;
 
 int smr_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 
+/* caprot.hip: the address, on the CURRENT device, of the static scratch array of smr_hip_caprot_noalloc (once per device) */
+int smr_caprot_scratch_setup(int device);
+
 #define SMR_NEED_INIT() do { if (!smr_g.init) return smr_fail(SMR_E_NODEVICE, "libsmr_hip: smr_hip_init() has not succeeded (no GPU, no work: there is no CPU fallback)"); } while (0)
 #define SMR_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return smr_fail(SMR_E_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); } while (0)
 #define SMR_TRY(call) do { int r_ = (call); if (r_ != SMR_OK) return r_; } while (0)

@@ -75,7 +75,7 @@ EXPORTS = [
     "smr_hip_proj_from_window", "smr_hip_set_projection", "smr_hip_project", "smr_hip_unproject",
     "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_read", "smr_hip_canvas_device",
     "smr_hip_canvas_set_halo", "smr_hip_canvas_clone",
-    "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
+    "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
     "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
     "act_draw_ini", "act_draw_main", "act_draw_fini", "act_cap_ini", "act_cap_main", "act_cap_fini",
@@ -109,6 +109,7 @@ def lib():
         L.smr_hip_draw.argtypes = [C.c_void_p, C.POINTER(DrawStyle), C.POINTER(_DrawBatch)]
         L.smr_hip_debug_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.smr_hip_caprot.argtypes = [C.c_void_p, C.POINTER(_CapBatch), C.c_void_p, C.c_void_p]
+        L.smr_hip_caprot_noalloc.argtypes = [C.c_void_p, C.POINTER(_CapBatch), C.c_void_p, C.c_void_p]
         L.smr_hip_caprot_steps.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.smr_hip_timings.argtypes = [C.POINTER(Timings)]
         L.smr_hip_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
@@ -232,6 +233,11 @@ class Canvas:
     def caprot(self, d_cx, d_cy, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_angle, d_dv=None, d_fg=None):
         b = _CapBatch(d_cx.ptr, d_cy.ptr, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_fg.ptr if d_fg else None)
         _chk(lib().smr_hip_caprot(self.h, C.byref(b), d_angle.ptr, d_dv.ptr if d_dv else None))
+
+    def caprot_noalloc(self, d_cx, d_cy, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_angle, d_dv=None, d_fg=None):
+        """smr_hip_caprot_noalloc: the same scan with its tables in the library's static device array (no hipMalloc)"""
+        b = _CapBatch(d_cx.ptr, d_cy.ptr, n, fg_w, fg_h, fg_x, col, phase_deg, weight, d_fg.ptr if d_fg else None)
+        _chk(lib().smr_hip_caprot_noalloc(self.h, C.byref(b), d_angle.ptr, d_dv.ptr if d_dv else None))
 
     def clone(self):
         """device copy (act_cap's auto_sfc)"""
