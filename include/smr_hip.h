@@ -140,6 +140,10 @@ int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_bat
  * 15-row grid instead, so their anti-aliasing may differ from libcairo's by a few levels.  No counterpart in the
  * reference (libcairo has no such limit); the plugin logs a warning. */
 #define SMR_DRAW_DEGRADED_ROWS 1u
+/* SMR_DRAW_SECOND_PASS (informational, nothing is lost): some 64x4-px tile held more edge crossings on one sub-scanline than
+ * the rasterizer's on-chip lists (30 crossings of a fill, 15 disjoint intervals of a stroke) and was rendered by the second
+ * raster pass, whose lists live in device memory; the pixels are the same */
+#define SMR_DRAW_SECOND_PASS 2u
 uint32_t smr_hip_draw_status(void);
 
 /* ---- caption auto-rotation: replaces find_angle ----------------------------------------

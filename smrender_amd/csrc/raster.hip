@@ -2016,6 +2016,29 @@ struct raster_args_t
    uint32_t n_tiles;
    uint32_t chunk;            /* tiles a wavefront takes from its XCD's queue with one atomic */
    int direct;                /* no group layer: primitives composite straight onto the canvas */
+   /* tiles whose crossing lists overflow in the fast instantiation write nothing and queue here; the second instantiation
+    * (k_raster<true>) renders them from lists in global memory that hold every edge slot binned to the tile */
+   uint32_t *ovf_list;        /* [n_tiles] */
+   uint32_t *ovf_cnt;         /* [0] tiles queued, [1] most entries of one of them */
+   uint32_t ovf_n;            /* k_raster<true>: tiles in the list */
+   uint32_t *big_bucket;      /* k_raster<true>: [wavefront][big_cap][64 lanes] */
+   uint32_t big_cap;          /* entries per sub-row (a crossing takes one, an interval two) */
+};
+
+/* a sub-row's list of crossings (fills) or disjoint intervals (strokes): LDS in the fast instantiation, global memory (through
+ * the L2: a wavefront reads back what it wrote) in the one for overflowed tiles */
+template <bool BIG> struct smr_bucket_t;
+template <> struct smr_bucket_t<false>
+{
+   uint16_t *p;
+   __device__ __forceinline__ int get(int i) const { return p[i]; }
+   __device__ __forceinline__ void set(int i, int v) const { p[i] = (uint16_t) v; }
+};
+template <> struct smr_bucket_t<true>
+{
+   uint32_t *p;               /* entry i of this lane at p[64 * i] */
+   __device__ __forceinline__ int get(int i) const { return (int) __hip_atomic_load(&p[(size_t) i << 6], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+   __device__ __forceinline__ void set(int i, int v) const { __hip_atomic_store(&p[(size_t) i << 6], (uint32_t) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 };
 
 struct raster_lds_t
@@ -2106,6 +2129,7 @@ __device__ void smr_render_edge(raster_lds_t &L, int row, int32_t X0, int32_t dx
 }
 
 #define SMR_RASTER_WAVES 4      /* independent wavefronts per workgroup, one tile at a time each */
+#define SMR_BIG_SLOTS_MAX (1u << 20)      /* most edge slots of one tile (entries x 64) the second pass's lists are sized for */
 #ifndef SMR_TILE_CHUNK
 #define SMR_TILE_CHUNK 2        /* tiles a wavefront takes from its XCD's queue with one atomic on a dense chart (C2: 53 entries per
                                    tile; 1 is 0.5 % faster there); a sparse chart (C3: 0.5 entries per tile, most tiles empty) pays
@@ -2133,6 +2157,7 @@ __device__ void smr_render_edge(raster_lds_t &L, int row, int32_t X0, int32_t dx
 #ifndef SMR_RASTER_WPE
 #define SMR_RASTER_WPE 4
 #endif
+template <bool BIG>
 __attribute__((amdgpu_waves_per_eu(SMR_RASTER_WPE, SMR_RASTER_WPE)))
 __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t A)
 {
@@ -2144,7 +2169,10 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
    const int lane = threadIdx.x & 63;
    const unsigned long long lt_mask = (1ull << lane) - 1ull;
    const int my_row = lane / SMR_GRID_Y;               /* sub-row lane -> pixel row (lanes 60..63 idle) */
-   uint16_t *bk = L.bucket[lane < SMR_NSUB ? lane : 0];
+   smr_bucket_t<BIG> bk;
+   if constexpr (BIG) bk.p = A.big_bucket + (size_t) (blockIdx.x * SMR_RASTER_WAVES + wave) * A.big_cap * 64u + lane;
+   else bk.p = L.bucket[lane < SMR_NSUB ? lane : 0];
+   const int BK = BIG ? (int) A.big_cap : SMR_BK;      /* entries a sub-row's list holds */
 
 #pragma unroll
    for (int r = 0; r < SMR_TH; r++) { L.cover[r][lane] = 0; L.uarea[r][lane] = 0; }
@@ -2169,18 +2197,19 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
    /* ... and the tiles of an XCD's columns are handed out dynamically, A.chunk vertically adjacent ones at a time: a chart's
     * load per tile varies, and a static share leaves wavefronts idle at the end of the launch */
    const uint32_t ktotal = ncol * TYt;
-   uint32_t *const ctr = A.tile_ctr + 8u * xcd;
+   uint32_t *const ctr = BIG ? A.tile_ctr : A.tile_ctr + 8u * xcd;
    for (;;)
    {
    uint32_t k0 = 0;
-   if (lane == 0) k0 = atomicAdd(ctr, A.chunk);
+   if (lane == 0) k0 = atomicAdd(ctr, BIG ? 1u : A.chunk);
    k0 = __builtin_amdgcn_readfirstlane(k0);
-   if (k0 >= ktotal) break;
-   const uint32_t k1 = min(k0 + A.chunk, ktotal);
+   if (k0 >= (BIG ? A.ovf_n : ktotal)) break;
+   const uint32_t k1 = BIG ? k0 + 1u : min(k0 + A.chunk, ktotal);
    for (uint32_t kg = k0; kg < k1; kg++)
    {
-      const int tx = (int) (xcd + 8u * (kg / TYt)), ty = (int) (kg % TYt);
-      const uint32_t tile = (uint32_t) ty * A.TX + tx;
+      /* the overflowed tiles come from the list (one queue: they are few), the others from the XCD's columns */
+      const uint32_t tile = BIG ? A.ovf_list[kg] : (uint32_t) (kg % TYt) * A.TX + (xcd + 8u * (kg / TYt));
+      const int tx = (int) (tile % (uint32_t) A.TX), ty = (int) (tile / (uint32_t) A.TX);
       const uint32_t beg = A.tile_off[tile], end = A.tile_off[tile + 1];
       if (beg == end) continue;
       COUNT(0);
@@ -2203,22 +2232,23 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
       int cnt = 0, lw = 0;
       int cl = 1, cr = 0;            /* stroke pieces: the interval being grown (empty while cl > cr), tile-relative 24.8 */
       bool ovf = false, touched = false;
+      bool tile_bad = false;         /* a list of this tile overflowed: what it holds from there on is not the tile */
       /* merge [l, r] into the lane's list of disjoint covered intervals (LDS bucket) */
       auto push_interval = [&](int l, int r)
       {
          for (int i = 0; i < cnt;)
          {
-            int ia = bk[2 * i], ib = bk[2 * i + 1];
+            int ia = bk.get(2 * i), ib = bk.get(2 * i + 1);
             if (ia <= r && l <= ib)
             {
                l = min(l, ia); r = max(r, ib);
                cnt--;
-               bk[2 * i] = bk[2 * cnt]; bk[2 * i + 1] = bk[2 * cnt + 1];
+               bk.set(2 * i, bk.get(2 * cnt)); bk.set(2 * i + 1, bk.get(2 * cnt + 1));
                i = 0;
             }
             else i++;
          }
-         if (2 * cnt + 2 <= SMR_BK) { bk[2 * cnt] = (uint16_t) l; bk[2 * cnt + 1] = (uint16_t) r; cnt++; }
+         if (2 * cnt + 2 <= BK) { bk.set(2 * cnt, l); bk.set(2 * cnt + 1, r); cnt++; }
          else ovf = true;
       };
 
@@ -2302,38 +2332,39 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                {
                   for (int i = 0; i < cnt;)
                   {
-                     const int ia = bk[2 * i], ib = bk[2 * i + 1];
+                     const int ia = bk.get(2 * i), ib = bk.get(2 * i + 1);
                      if (ia <= cr && cl <= ib)
                      {
                         cl = min(cl, ia); cr = max(cr, ib);
                         cnt--;
-                        bk[2 * i] = bk[2 * cnt]; bk[2 * i + 1] = bk[2 * cnt + 1];
+                        bk.set(2 * i, bk.get(2 * cnt)); bk.set(2 * i + 1, bk.get(2 * cnt + 1));
                         i = 0;
                      }
                      else i++;
                   }
                   add_span(cl, cr);
                }
-               for (int i = 0; i < cnt; i++) add_span(bk[2 * i], bk[2 * i + 1]);
+               for (int i = 0; i < cnt; i++) add_span(bk.get(2 * i), bk.get(2 * i + 1));
             }
             else if (mine)
             {
                for (int i = 1; i < cnt; i++)
                {
-                  uint16_t v = bk[i];
+                  const int v = bk.get(i);
                   int k = i - 1;
-                  while (k >= 0 && (bk[k] >> 1) > (v >> 1)) { bk[k + 1] = bk[k]; k--; }
-                  bk[k + 1] = v;
+                  while (k >= 0 && (bk.get(k) >> 1) > (v >> 1)) { bk.set(k + 1, bk.get(k)); k--; }
+                  bk.set(k + 1, v);
                }
                int winding = lw;
                int xstart = (((uint32_t) winding & mask) != 0) ? 0 : -1;
                for (int i = 0; i < cnt; i++)
                {
-                  int xend = bk[i] >> 1;
-                  winding += (bk[i] & 1) ? 1 : -1;
+                  const int bv = bk.get(i);
+                  int xend = bv >> 1;
+                  winding += (bv & 1) ? 1 : -1;
                   if (((uint32_t) winding & mask) == 0)
                   {
-                     if (i + 1 < cnt && (bk[i + 1] >> 1) == xend) continue;
+                     if (i + 1 < cnt && (bk.get(i + 1) >> 1) == xend) continue;
                      if (xstart >= 0) add_span(xstart, xend);
                      xstart = -1;
                   }
@@ -2342,7 +2373,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                if (xstart >= 0) add_span(xstart, SMR_TW * 256);
             }
 
-            if (__ballot(ovf) && lane == 0) atomicOr(A.status, SMR_ST_BUCKET_OVERFLOW);
+            if (__ballot(ovf)) tile_bad = true;
             TICK(1);      /* flush: spans of the sub-sampled rows */
             /* ---- rows that take libcairo's exact full-row path ---- */
             uint32_t fullrows = 0;
@@ -2719,7 +2750,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                            if (cell < X0) lw += (win >> 16) ? 1 : -1;
                            else if (cell < X1)
                            {
-                              if (cnt < SMR_BK) bk[cnt++] = (uint16_t) (((cell - X0) << 1) | (win >> 16));
+                              if (cnt < BK) { bk.set(cnt, ((cell - X0) << 1) | (win >> 16)); cnt++; }
                               else ovf = true;
                            }
                         }
@@ -2735,7 +2766,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                         if (cell < X0) lw += (win >> 16) ? 1 : -1;
                         else if (cell < X1)
                         {
-                           if (cnt < SMR_BK) bk[cnt++] = (uint16_t) (((cell - X0) << 1) | (win >> 16));
+                           if (cnt < BK) { bk.set(cnt, ((cell - X0) << 1) | (win >> 16)); cnt++; }
                            else ovf = true;
                         }
                      }
@@ -2829,6 +2860,21 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
       }
 
       TICK(7);
+      if (tile_bad)
+      {
+         /* nothing of this tile is written: the fast instantiation hands it to the second one, which has room for every
+          * edge slot binned here; should that one run out all the same, the pass fails (and the host restores the canvas) */
+         if (lane == 0)
+         {
+            if constexpr (BIG) atomicOr(A.status, SMR_ST_BUCKET_OVERFLOW);
+            else
+            {
+               A.ovf_list[atomicAdd(&A.ovf_cnt[0], 1u)] = tile;
+               atomicMax(&A.ovf_cnt[1], end - beg);
+            }
+         }
+         continue;
+      }
       /* pop_group_to_source + paint: layer OVER canvas */
       const int px = tx * SMR_TW + lane;
       if (px < A.W)
@@ -3080,6 +3126,14 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
    return draw_pass(c, st, b, SMR_PASS_NORMAL);      /* directional without a fill is not directional (:681-685) */
 }
 
+/* most edge slots of one tile the second raster pass is given lists for; SMR_HIP_DEBUG_BIG_SLOTS lowers it so that a test can
+ * reach the pass's clean failure (a real chart would need a 64x4-px tile with 16 384 entries) */
+static uint64_t big_slots_max()
+{
+   const char *e = getenv("SMR_HIP_DEBUG_BIG_SLOTS");
+   return e && *e ? strtoull(e, nullptr, 10) : (uint64_t) SMR_BIG_SLOTS_MAX;
+}
+
 static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, int mode)
 {
    if (b->n_ways < 0 || b->n_refs < 0 || b->n_ways > 0x7ffffff0ll / 2 || b->n_refs > 0x7fffffffll)
@@ -3127,7 +3181,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    }
    k_way_info<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, b->d_ref, n_ways, st->border_used, st->fill_used,
                                                 st->ignore_open, mode, wayflags, &small[0], &small[5]);
-   uint32_t h_small[8];
+   uint32_t h_small[16];         /* [8] tiles left to k_raster<true>, [9] most entries of one of them, [10] that kernel's queue */
    SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
    const bool open_fill = h_small[0] != 0;
@@ -3438,6 +3492,11 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
    const uint32_t n_entries = h_small[3];
+   /* what the geometry kernels refused is reported before a pixel is touched */
+   if (h_small[2] & SMR_ST_CURVE_DEPTH)
+      return smr_fail(SMR_E_CAPACITY, "draw: a curve needs more than %d levels of subdivision", SMR_CURVE_STACK);
+   if (h_small[2] & SMR_ST_KNOTS_CLOSED)
+      return smr_fail(SMR_E_UNSUPPORTED, "draw: a closed way of explicit Bezier knots (curve=2) must be p0, (c1, c2, p) * m, p0 (the way was not drawn)");
    uint32_t *entries;
    SMR_TRY(c->ensure(SMR_BUF_ENTRIES, ((size_t) n_entries + 1) * 4, (void **) &entries));
    SMR_HIP(hipMemsetAsync(counts, 0, (size_t) n_tiles * 4, s));
@@ -3457,8 +3516,13 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    SMR_HIP(hipGetLastError());
    T.mark(s);                                                   /* 3: binned + sorted */
 
-   const bool risk = (h_small[2] & SMR_ST_ROWRISK) && !c->strict_rows;
+   /* A copy of the canvas is taken when the pass may have to be undone: rows of strokes with more spanning edges than one
+    * tile's exact path holds (below), and a tile with so many entries that its lists might not fit the second
+    * instantiation's memory (h_small[7]: entries of the fullest tile, 64 edge slots each) */
+   const bool risk = ((h_small[2] & SMR_ST_ROWRISK) && !c->strict_rows) || (uint64_t) h_small[7] * 64u > big_slots_max();
    uint32_t *snapshot = nullptr;
+   uint32_t *ovf_list;
+   SMR_TRY(c->ensure(SMR_BUF_OVFLIST, (size_t) n_tiles * 4, (void **) &ovf_list));
    raster_args_t A;
    A.prims = prims; A.hdrs = hdrs; A.edges = edges; A.tile_off = tile_off;
    A.tile_ctr = &small[64];       /* zero since the memset at the top of the pass */
@@ -3466,6 +3530,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    A.n_tiles = n_tiles;
    A.chunk = n_entries >= 8ull * n_tiles ? SMR_TILE_CHUNK : n_entries >= 2ull * n_tiles ? 2 * SMR_TILE_CHUNK : 4 * SMR_TILE_CHUNK;
    A.direct = st->direct != 0;
+   A.ovf_list = ovf_list; A.ovf_cnt = &small[8]; A.ovf_n = 0; A.big_bucket = nullptr; A.big_cap = 0;
    {
       /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
       unsigned nwg = std::min<unsigned>((n_tiles + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES, 256u * 8u);
@@ -3477,12 +3542,36 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          SMR_TRY(c->ensure(SMR_BUF_SNAPSHOT, (size_t) c->W * c->band_h * 4, (void **) &snapshot));
          SMR_HIP(hipMemcpyAsync(snapshot, c->pix, (size_t) c->W * c->band_h * 4, hipMemcpyDeviceToDevice, s));
       }
-      k_raster<<<nwg, 64 * SMR_RASTER_WAVES, 0, s>>>(A);
+      k_raster<false><<<nwg, 64 * SMR_RASTER_WAVES, 0, s>>>(A);
    }
    SMR_HIP(hipGetLastError());
-   T.mark(s);                                                   /* 4: rastered */
    SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
+   if (h_small[8])
+   {
+      /* tiles with more crossings on a sub-row than the fast instantiation's LDS lists hold (one-pixel dots, scribbles): again,
+       * with lists in global memory sized for every edge slot binned to the fullest of them, so that this run cannot overflow */
+      const uint64_t cap = (uint64_t) h_small[9] * 64u;
+      if (cap > big_slots_max())
+      {
+         SMR_HIP(hipMemcpyAsync(c->pix, snapshot, (size_t) c->W * c->band_h * 4, hipMemcpyDeviceToDevice, s));      /* taken above: h_small[7] >= h_small[9] */
+         SMR_HIP(hipStreamSynchronize(s));
+         return smr_fail(SMR_E_CAPACITY, "draw: a tile with %u entries overflowed its crossing lists (the second pass holds %u edge slots per tile); "
+                         "the canvas is as before the rule", h_small[9], (unsigned) big_slots_max());
+      }
+      const size_t per_wave = (size_t) cap * 64 * 4;
+      size_t nwave = std::min<size_t>({ (size_t) 512, (size_t) h_small[8], std::max<size_t>(1, ((size_t) 256 << 20) / per_wave) });
+      const unsigned nwg = (unsigned) ((nwave + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES);
+      uint32_t *big;
+      SMR_TRY(c->ensure(SMR_BUF_BIGBUCKET, per_wave * nwg * SMR_RASTER_WAVES, (void **) &big));
+      smr_g.draw_status |= SMR_DRAW_SECOND_PASS;
+      A.ovf_n = h_small[8]; A.big_bucket = big; A.big_cap = (uint32_t) cap; A.tile_ctr = &small[10];
+      k_raster<true><<<nwg, 64 * SMR_RASTER_WAVES, 0, s>>>(A);
+      SMR_HIP(hipGetLastError());
+      SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
+      SMR_HIP(hipStreamSynchronize(s));
+   }
+   T.mark(s);                                                   /* 4: rastered */
 #ifdef SMR_COUNT_PROFILE
    {
       unsigned long long pr[24];
@@ -3508,22 +3597,28 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       t.edges_ms = T.ms(0, 1); t.prims_ms = T.ms(1, 2); t.bin_ms = T.ms(2, 3); t.raster_ms = T.ms(3, 4); t.total_ms = T.ms(0, 4);
       t.n_prims = (uint64_t) n_prims; t.n_edges = n_edges; t.n_tile_refs = n_entries; t.n_tiles = n_tiles;
    }
-   if (h_small[2] & SMR_ST_CURVE_DEPTH)
-      return smr_fail(SMR_E_CAPACITY, "draw: a curve needs more than %d levels of subdivision", SMR_CURVE_STACK);
-   if (h_small[2] & SMR_ST_KNOTS_CLOSED)
-      return smr_fail(SMR_E_UNSUPPORTED, "draw: a closed way of explicit Bezier knots (curve=2) must be p0, (c1, c2, p) * m, p0 (the way was not drawn)");
-   if ((h_small[2] & SMR_ST_ROWCAP) && risk && !(h_small[2] & (SMR_ST_CURVE_DEPTH | SMR_ST_KNOTS_CLOSED | SMR_ST_BUCKET_OVERFLOW)))
+   if (h_small[2] & (SMR_ST_ROWCAP | SMR_ST_BUCKET_OVERFLOW))
    {
-      SMR_HIP(hipMemcpyAsync(c->pix, snapshot, (size_t) c->W * c->band_h * 4, hipMemcpyDeviceToDevice, s));
-      c->strict_rows = 1;
-      const int rc = draw_pass(c, st, b, mode);
-      c->strict_rows = 0;
-      return rc;
+      /* a tile's exact whole-row path met more spanning edges than it holds (only where the set-up reported the risk, so the
+       * copy exists): the canvas goes back to what it was, and the pass runs again with such rows sub-sampled */
+      if (snapshot)
+      {
+         SMR_HIP(hipMemcpyAsync(c->pix, snapshot, (size_t) c->W * c->band_h * 4, hipMemcpyDeviceToDevice, s));
+         SMR_HIP(hipStreamSynchronize(s));
+      }
+      if ((h_small[2] & SMR_ST_ROWCAP) && !(h_small[2] & SMR_ST_BUCKET_OVERFLOW) && snapshot && !c->strict_rows)
+      {
+         c->strict_rows = 1;
+         const int rc = draw_pass(c, st, b, mode);
+         c->strict_rows = 0;
+         return rc;
+      }
+      if (h_small[2] & SMR_ST_ROWCAP)
+         return smr_fail(SMR_E_CAPACITY, "draw: more than %d edges of one primitive span a vertex-free pixel row inside one tile%s", SMR_ROWCAP,
+                         snapshot ? "; the canvas is as before the rule" : "");
+      /* cannot happen: the second pass's lists hold every edge slot of the tile */
+      return smr_fail(SMR_E_HIP, "draw: internal: the crossing lists of the second raster pass overflowed%s", snapshot ? "; the canvas is as before the rule" : "");
    }
    if (h_small[2] & SMR_ST_DEGRADED) smr_g.draw_status |= SMR_DRAW_DEGRADED_ROWS;
-   if (h_small[2] & SMR_ST_ROWCAP)
-      return smr_fail(SMR_E_CAPACITY, "draw: more than %d edges of one primitive span a vertex-free pixel row inside one tile", SMR_ROWCAP);
-   if (h_small[2] & SMR_ST_BUCKET_OVERFLOW)
-      return smr_fail(SMR_E_CAPACITY, "draw: more than %d edge crossings on one sub-scanline inside a 64-px tile", SMR_BK);
    return SMR_OK;
 }

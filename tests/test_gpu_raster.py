@@ -320,10 +320,11 @@ def test_soak_scene_whose_tiles_overflow_runs_again_with_reported_rows(hip):
 
 def test_soak_scene_with_one_pixel_dots(hip):
     """tests/golden/soak_scene21_2.npz, way 17 (tools/soak.py 21 60 dash): a dotted fill stroke (style=dotted, no border, so the
-    dots are one device pixel long) at 600 dpi puts 17 dots on two sub-rows of one tile, two more than a sub-row's list holds.
-    The interval still open at the flush used to be pushed into the full list after the overflow flag had been read, and was
-    dropped without a word (one pixel at alpha 220 instead of 254).  Now it goes straight to the cells, and an overflow during
-    the flush is reported like any other."""
+    dots are one device pixel long) at 600 dpi puts 17 dots on two sub-rows of one tile, two more than a sub-row's list in LDS
+    holds.  (The interval still open at the flush used to be pushed into the full list after the overflow flag had been read, and
+    was dropped without a word: one pixel at alpha 220 instead of 254.)  A tile whose lists overflow writes nothing and is rendered
+    again by the second instantiation of k_raster, whose lists in global memory hold every edge slot binned to it: bit-exact, for
+    the way alone and for the whole scene."""
     sa = hip
     import os
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene21_2.npz"))
@@ -331,12 +332,81 @@ def test_soak_scene_with_one_pixel_dots(hip):
     W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
     st = po.Style.from_buffer_copy(bytes(d["style"]))
     r1 = np.ascontiguousarray(ref[off[17]:off[18]]); o1 = np.array([0, len(r1)], np.int64)
-    want = oracle_of([(st, (x, y, o1, r1))], dpi, W, H, 0xffffff)
-    try:
-        got = gpu_scene(sa, [(st, (x, y, o1, r1))], dpi, W, H, 0xffffff)
-    except sa.SmrHipError as e:          # the loud limit is acceptable, a wrong pixel is not
-        assert e.code == -6
-        return
+    for arrs in ((x, y, o1, r1), (x, y, off, ref)):
+        want = oracle_of([(st, arrs)], dpi, W, H, 0xffffff)
+        got = gpu_scene(sa, [(st, arrs)], dpi, W, H, 0xffffff)
+        assert np.array_equal(got, want), report(got, want)
+
+
+def _comb(teeth, x0, pitch, width, y_top, y_bot, W):
+    """a closed comb: `teeth` slanted teeth of `width` px every `pitch` px, joined by a bar below them"""
+    xs, ys = [], []
+    for k in range(teeth):
+        a = x0 + k * pitch
+        xs += [a, a + 0.35 * width, a + 1.35 * width, a + width]; ys += [y_bot, y_top, y_top, y_bot]
+    xs += [x0 + teeth * pitch, x0 - 1.0]; ys += [y_bot + 6.3, y_bot + 6.3]
+    x, y = np.array(xs), np.array(ys)
+    n = len(x)
+    return x, y, np.array([0, n + 1], np.int64), np.append(np.arange(n), 0).astype(np.int32)
+
+
+@pytest.mark.parametrize("style", ["fill", "fill+border", "hairline"])
+def test_tiles_with_more_crossings_than_the_lds_lists_hold_are_rendered_by_the_second_pass(hip, style):
+    """26 teeth inside one 64-px tile: 52 crossings of the fill, or (16 teeth) 32 disjoint stroke intervals, on every sub-row,
+    where the fast instantiation's lists hold 30 / 15.  No error, no reported row, every pixel the oracle's; the tiles beside
+    (drawn by the fast instantiation) and a second, ordinary rule on top come out right as well."""
+    sa = hip
+    W, H = 200, 64
+    # (a stroke of 26 teeth would put 104 edges across the vertex-free rows of one tile, beyond the exact path's 64: 16 teeth)
+    comb = _comb(26 if style == "fill" else 16, 66.2, 2.37, 1.1, 7.3, 41.8, W)
+    st = STYLES[style]
+    cv = sa.Canvas(W, H, 300, 0xffffff)
+    dev = lambda arrs: [sa.DeviceArray.from_numpy(a) for a in (arrs[0], arrs[1], arrs[2].astype(np.int64), arrs[3].astype(np.int32))]
+    cv.draw(draw_style(sa, st), *dev(comb), 1, len(comb[3]))
+    assert sa.lib().smr_hip_draw_status() == 2          # SMR_DRAW_SECOND_PASS and nothing else
+    over = po.synth_ways(12, W, H, seed=3)
+    cv.draw(draw_style(sa, STYLES["translucent"]), *dev(over), len(over[2]) - 1, len(over[3]))
+    assert sa.lib().smr_hip_draw_status() == 0
+    got = cv.read(); cv.close()
+    want = oracle_of([(st, comb), (STYLES["translucent"], over)], 300, W, H, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
+
+
+def test_scribble_that_used_to_end_in_the_crossing_limit(hip):
+    """a random walk of 400 short segments over a 40-px patch, stroked 1.3 px wide: dozens of disjoint intervals per sub-row
+    (tools/soak.py ... big ended in SMR_E_CAPACITY for such ways in round 1)"""
+    rng = np.random.default_rng(77)
+    n = 400
+    x = 100 + np.cumsum(rng.normal(0, 6, n)); y = 60 + np.cumsum(rng.normal(0, 6, n))
+    x = 80 + np.abs((x - 80) % 80 - 40); y = 40 + np.abs((y - 40) % 80 - 40)           # folded back into the patch
+    arrs = (x, y, np.array([0, n], np.int64), np.arange(n, dtype=np.int32))
+    st = po.Style(0, 1, 0, 0x102030, 0, 0.11, 0)
+    want = oracle_of([(st, arrs)], 300, 200, 140, 0xffffff)
+    got = gpu_scene(hip, [(st, arrs)], 300, 200, 140, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
+
+
+def test_a_pass_that_cannot_be_finished_leaves_the_canvas_as_it_was(hip, monkeypatch):
+    """The second pass sizes its lists for every edge slot of the fullest overflowed tile, up to 2^20 slots (a tile with 16 384
+    entries); beyond, the rule fails with SMR_E_CAPACITY and the canvas is restored from the copy taken before the pass.
+    SMR_HIP_DEBUG_BIG_SLOTS lowers the limit so that the comb reaches it."""
+    sa = hip
+    W, H = 200, 64
+    cv = sa.Canvas(W, H, 300, 0xffffff)
+    base = po.synth_ways(12, W, H, seed=3)
+    dev = lambda arrs: [sa.DeviceArray.from_numpy(a) for a in (arrs[0], arrs[1], arrs[2].astype(np.int64), arrs[3].astype(np.int32))]
+    cv.draw(draw_style(sa, STYLES["fill+border"]), *dev(base), len(base[2]) - 1, len(base[3]))
+    before = cv.read()
+    comb = _comb(26, 66.2, 2.37, 1.1, 7.3, 41.8, W)
+    monkeypatch.setenv("SMR_HIP_DEBUG_BIG_SLOTS", "32")
+    with pytest.raises(sa.SmrHipError) as e:
+        cv.draw(draw_style(sa, STYLES["fill"]), *dev(comb), 1, len(comb[3]))
+    assert e.value.code == -6 and "as before the rule" in str(e.value)
+    assert np.array_equal(cv.read(), before)
+    monkeypatch.delenv("SMR_HIP_DEBUG_BIG_SLOTS")
+    cv.draw(draw_style(sa, STYLES["fill"]), *dev(comb), 1, len(comb[3]))          # and the same rule goes through without the limit
+    want = oracle_of([(STYLES["fill+border"], base), (STYLES["fill"], comb)], 300, W, H, 0xffffff)
+    got = cv.read(); cv.close()
     assert np.array_equal(got, want), report(got, want)
 
 
