@@ -14,6 +14,10 @@ def load(d, name):
             if r["Counter_Name"] != name:
                 continue
             k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("void "):
+                k = k[5:]
+            if k == "k_raster<false>":      # the fast instantiation is THE rasterizer; k_raster<true> only re-renders overflowed tiles
+                k = "k_raster"
             tot[k] += float(r["Counter_Value"]); n[k] += 1
     return tot, n
 
