@@ -86,6 +86,13 @@ int smr_hip_canvas_read(smr_canvas_t *c, int x, int y, int w, int h, uint32_t *h
  * keeps device copies until the next call (n = 0 drops them).  The exchange itself is the caller's
  * (smrender_amd/dist.py: send/recv over RCCL). */
 int smr_hip_canvas_set_halo(smr_canvas_t *c, const uint32_t *above, int n_above, const uint32_t *below, int n_below);
+/* the same with the strips in DEVICE memory (e.g. the receive buffers of a device-to-device send/recv): no host round trip */
+int smr_hip_canvas_set_halo_device(smr_canvas_t *c, const uint32_t *d_above, int n_above, const uint32_t *d_below, int n_below);
+/* A second canvas whose band is this band plus its halo strips, pixels copied: the rule-private background of a banded
+ * caption rule (act_cap's auto_sfc, src/smrules_cairo.c:2455-2460).  The rectangles of finished captions (:2376-2382), the
+ * neighbouring ranks' included, are drawn onto it with smr_hip_draw (direct = 1); smr_hip_caprot on it scans the captions
+ * anchored in the ORIGINAL band's rows. */
+int smr_hip_canvas_extend(smr_canvas_t *c, smr_canvas_t **out);
 /* device pointer + row stride (pixels) of the band, for zero-copy consumers */
 int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *stride_px);
 

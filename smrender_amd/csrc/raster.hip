@@ -29,15 +29,20 @@ __device__ __forceinline__ int64_t smr_find_way(const int64_t *__restrict__ way_
 }
 
 __global__ void k_dev_points(const double *__restrict__ x, const double *__restrict__ y,
-                             const int32_t *__restrict__ ref, int64_t n_refs, int dpi, int32_t sfix,
+                             const int32_t *__restrict__ ref, int64_t n_refs, int64_t n_nodes, int dpi, int32_t sfix,
                              const int64_t *__restrict__ way_off, int64_t n_ways,
-                             int2 *__restrict__ pts, int32_t *__restrict__ refway)
+                             int2 *__restrict__ pts, int32_t *__restrict__ refway, uint32_t *__restrict__ status)
 {
    int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    int64_t stride = (int64_t) gridDim.x * blockDim.x;
    for (; g < n_refs; g += stride)
    {
       int64_t node = ref ? (int64_t) ref[g] : g;
+      /* a ref outside the node arrays: reported (SMR_E_INVAL before anything is drawn), and nothing is read out of bounds */
+      if (node < 0 || node >= n_nodes) { atomicOr(status, SMR_ST_BADBATCH); node = 0; }
+      /* the edge arithmetic is exact while |coordinates| < 2^20 px (smr_edge_cell); a node further off the chart (or not a
+       * number) is reported instead of wrapping around in the 24.8 conversion below */
+      if (!(fabs(x[node]) < 1048576.0) || !(fabs(y[node]) < 1048576.0)) atomicOr(status, SMR_ST_FARAWAY);
       double xp = x[node] * 72 / dpi, yp = y[node] * 72 / dpi;      /* rdata_px_unit(.., U_PT) */
       int32_t fx = (int32_t) rint(xp * 256.0), fy = (int32_t) rint(yp * 256.0);
       int2 p;
@@ -54,13 +59,20 @@ enum { SMR_PASS_NORMAL = 0, SMR_PASS_OPEN = 1, SMR_PASS_COMPOUND = 2 };
  * (src/smrules_cairo.c:962-966), ignore_open (:1030-1033); decides which of the two
  * primitives of the way exist.  wayflags: bit0 closed, bit1 border prim, bit2 fill polygon,
  * bit3 fill-as-stroke (open way) */
-__global__ void k_way_info(const int64_t *__restrict__ way_off, const int32_t *__restrict__ ref, int64_t n_ways,
+__global__ void k_way_info(const int64_t *__restrict__ way_off, const int32_t *__restrict__ ref, int64_t n_ways, int64_t n_refs,
                            int border_used, int fill_used, int ignore_open, int mode, uint8_t *__restrict__ wayflags,
-                           uint32_t *__restrict__ any_open_fill, uint32_t *__restrict__ first_stroked)
+                           uint32_t *__restrict__ any_open_fill, uint32_t *__restrict__ first_stroked, uint32_t *__restrict__ status)
 {
    int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    if (w >= n_ways) return;
    int64_t a = way_off[w], b = way_off[w + 1];
+   /* the way table must start at 0, ascend and end at n_refs: every kernel downstream indexes the refs through it */
+   if (a < 0 || b < a || b > n_refs || (w == 0 && a != 0) || (w == n_ways - 1 && b != n_refs))
+   {
+      atomicOr(status, SMR_ST_BADBATCH);
+      wayflags[w] = 0;
+      return;
+   }
    int64_t n = b - a;
    int closed = 0;
    if (n >= 4)
@@ -2940,6 +2952,7 @@ extern "C" int smr_hip_canvas_clone(smr_canvas_t *c, smr_canvas_t **out)
    if (!c || !out) return smr_fail(SMR_E_INVAL, "canvas_clone: NULL");
    smr_canvas_t *n = new smr_canvas_t();
    n->W = c->W; n->H = c->H; n->dpi = c->dpi; n->band_y0 = c->band_y0; n->band_h = c->band_h; n->bg = c->bg;
+   n->own_y0 = c->own_y0; n->own_h = c->own_h;
    size_t bytes = (size_t) c->W * c->band_h * 4;
    if (hipMalloc(&n->pix, bytes) != hipSuccess) { delete n; return smr_fail(SMR_E_NOMEM, "canvas_clone: hipMalloc %zu bytes", bytes); }
    SMR_HIP(hipMemcpyAsync(n->pix, c->pix, bytes, hipMemcpyDeviceToDevice, smr_g.stream));
@@ -3003,6 +3016,58 @@ extern "C" int smr_hip_canvas_set_halo(smr_canvas_t *c, const uint32_t *above, i
       SMR_HIP(hipMemcpy(c->halo_below, below, bytes, hipMemcpyHostToDevice));
       c->n_below = n_below;
    }
+   return SMR_OK;
+}
+
+/* the same with the strips already in device memory (what a device-to-device exchange over RCCL delivers): no host round trip */
+extern "C" int smr_hip_canvas_set_halo_device(smr_canvas_t *c, const uint32_t *d_above, int n_above, const uint32_t *d_below, int n_below)
+{
+   SMR_NEED_INIT();
+   if (!c || n_above < 0 || n_below < 0 || (n_above && !d_above) || (n_below && !d_below) || n_above > c->band_y0 ||
+       n_below > c->H - c->band_y0 - c->band_h)
+      return smr_fail(SMR_E_INVAL, "canvas_set_halo_device: bad strip (above %d, below %d rows)", n_above, n_below);
+   hipStream_t s = smr_g.stream;
+   SMR_HIP(hipStreamSynchronize(s));
+   if (c->halo_above) { hipFree(c->halo_above); c->halo_above = nullptr; }
+   if (c->halo_below) { hipFree(c->halo_below); c->halo_below = nullptr; }
+   c->n_above = c->n_below = 0;
+   if (n_above)
+   {
+      const size_t bytes = (size_t) n_above * c->W * 4;
+      if (hipMalloc(&c->halo_above, bytes) != hipSuccess) return smr_fail(SMR_E_NOMEM, "canvas_set_halo_device: hipMalloc %zu bytes", bytes);
+      SMR_HIP(hipMemcpyAsync(c->halo_above, d_above, bytes, hipMemcpyDeviceToDevice, s));
+      c->n_above = n_above;
+   }
+   if (n_below)
+   {
+      const size_t bytes = (size_t) n_below * c->W * 4;
+      if (hipMalloc(&c->halo_below, bytes) != hipSuccess) return smr_fail(SMR_E_NOMEM, "canvas_set_halo_device: hipMalloc %zu bytes", bytes);
+      SMR_HIP(hipMemcpyAsync(c->halo_below, d_below, bytes, hipMemcpyDeviceToDevice, s));
+      c->n_below = n_below;
+   }
+   SMR_HIP(hipStreamSynchronize(s));      /* the caller may reuse its strips */
+   return SMR_OK;
+}
+
+/* band + halo strips as ONE canvas band [band_y0 - n_above, band_y0 + band_h + n_below): the rule-private background copy of a
+ * banded caption rule (act_cap's auto_sfc, src/smrules_cairo.c:2455-2460).  Rectangles of finished captions (:2376-2382), the
+ * neighbours' included, are drawn onto it like onto any band, halo rows and all; smr_hip_caprot on it scans the captions
+ * whose anchor lies in the ORIGINAL band's rows, which is what its halo check then looks at. */
+extern "C" int smr_hip_canvas_extend(smr_canvas_t *c, smr_canvas_t **out)
+{
+   SMR_NEED_INIT();
+   if (!c || !out) return smr_fail(SMR_E_INVAL, "canvas_extend: NULL");
+   smr_canvas_t *n = new smr_canvas_t();
+   n->W = c->W; n->H = c->H; n->dpi = c->dpi; n->bg = c->bg;
+   n->band_y0 = c->band_y0 - c->n_above; n->band_h = c->band_h + c->n_above + c->n_below;
+   n->own_y0 = c->own_y0 >= 0 ? c->own_y0 : c->band_y0; n->own_h = c->own_y0 >= 0 ? c->own_h : c->band_h;
+   const size_t row = (size_t) c->W * 4;
+   if (hipMalloc(&n->pix, row * n->band_h) != hipSuccess) { delete n; return smr_fail(SMR_E_NOMEM, "canvas_extend: hipMalloc %zu bytes", row * n->band_h); }
+   hipStream_t s = smr_g.stream;
+   if (c->n_above) SMR_HIP(hipMemcpyAsync(n->pix, c->halo_above, row * c->n_above, hipMemcpyDeviceToDevice, s));
+   SMR_HIP(hipMemcpyAsync(n->pix + (size_t) c->n_above * c->W, c->pix, row * c->band_h, hipMemcpyDeviceToDevice, s));
+   if (c->n_below) SMR_HIP(hipMemcpyAsync(n->pix + (size_t) (c->n_above + c->band_h) * c->W, c->halo_below, row * c->n_below, hipMemcpyDeviceToDevice, s));
+   *out = n;
    return SMR_OK;
 }
 
@@ -3140,6 +3205,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       return smr_fail(SMR_E_INVAL, "draw: batch too large (n_ways %lld, n_refs %lld)", (long long) b->n_ways, (long long) b->n_refs);
    if (b->n_ways == 0 || b->n_refs == 0 || (!st->fill_used && !st->border_used)) return SMR_OK;
    if (!b->d_x || !b->d_y || !b->d_way_off) return smr_fail(SMR_E_INVAL, "draw: missing device arrays");
+   if (b->n_nodes <= 0 || (!b->d_ref && b->n_refs > b->n_nodes))
+      return smr_fail(SMR_E_INVAL, "draw: n_nodes %lld does not cover the refs (n_refs %lld%s)", (long long) b->n_nodes, (long long) b->n_refs, b->d_ref ? "" : ", identity refs");
 
    hipStream_t s = smr_g.stream;
    /* dash arrays in pt: cairo_smr_dash (:898-923) scales the multipliers by the BORDER width, also for the fill */
@@ -3177,14 +3244,20 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    int32_t sfix = (int32_t) nearbyint((double) c->dpi / 72 * 256.0);
    {
       unsigned nb = blocks(n_refs, TB); if (nb > 65536u * 4) nb = 65536u * 4;
-      k_dev_points<<<nb, TB, 0, s>>>(b->d_x, b->d_y, b->d_ref, n_refs, c->dpi, sfix, b->d_way_off, n_ways, pts, refway);
+      k_dev_points<<<nb, TB, 0, s>>>(b->d_x, b->d_y, b->d_ref, n_refs, b->n_nodes, c->dpi, sfix, b->d_way_off, n_ways, pts, refway, &small[2]);
    }
-   k_way_info<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, b->d_ref, n_ways, st->border_used, st->fill_used,
-                                                st->ignore_open, mode, wayflags, &small[0], &small[5]);
+   k_way_info<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, b->d_ref, n_ways, n_refs, st->border_used, st->fill_used,
+                                                st->ignore_open, mode, wayflags, &small[0], &small[5], &small[2]);
    uint32_t h_small[16];         /* [8] tiles left to k_raster<true>, [9] most entries of one of them, [10] that kernel's queue */
    SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
    const bool open_fill = h_small[0] != 0;
+   /* the batch itself is checked on the device, by the two kernels that read it first; nothing has been drawn yet */
+   if (h_small[2] & SMR_ST_BADBATCH)
+      return smr_fail(SMR_E_INVAL, "draw: bad batch: d_way_off must start at 0, ascend and end at n_refs (%lld), every ref must lie in [0, n_nodes = %lld)",
+                      (long long) b->n_refs, (long long) b->n_nodes);
+   if (h_small[2] & SMR_ST_FARAWAY)
+      return smr_fail(SMR_E_CAPACITY, "draw: a node of the batch lies 2^20 px or more from the chart's origin (or is not a number); the rule was not drawn");
 
    double hw_nofill = mm2wu(st->border_width_mm, c->dpi) / 2;
    double hw_open = (mm2wu(2 * st->border_width_mm, c->dpi) + mm2wu(st->fill_width_mm, c->dpi)) / 2;

@@ -44,6 +44,7 @@ struct smr_canvas
    uint32_t *pix = nullptr;
    uint32_t *halo_above = nullptr, *halo_below = nullptr;     /* neighbour rows for the caption scan */
    int n_above = 0, n_below = 0;
+   int own_y0 = -1, own_h = 0;         /* smr_hip_canvas_extend: the rows whose captions this canvas scans (-1: the band itself) */
    smr_devbuf_t buf[SMR_BUF_MAX];      /* grow-only work buffers, reused across draw calls */
    int strict_rows = 0;                /* draw_pass's second attempt: rows beyond SMR_ROWCAP spanning edges are sub-sampled (and reported) */
    uint64_t last_n_edges = 0;          /* edge slots of the last draw pass (smr_hip_debug_edges) */

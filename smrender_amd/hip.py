@@ -74,7 +74,7 @@ EXPORTS = [
     "smr_hip_init", "smr_hip_shutdown", "smr_hip_last_error", "smr_hip_device_name",
     "smr_hip_proj_from_window", "smr_hip_set_projection", "smr_hip_project", "smr_hip_unproject",
     "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_read", "smr_hip_canvas_device",
-    "smr_hip_canvas_set_halo", "smr_hip_canvas_clone",
+    "smr_hip_canvas_set_halo", "smr_hip_canvas_set_halo_device", "smr_hip_canvas_extend", "smr_hip_canvas_clone",
     "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
     "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
@@ -105,6 +105,8 @@ def lib():
         L.smr_hip_canvas_read.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.smr_hip_canvas_clone.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.smr_hip_canvas_set_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.smr_hip_canvas_set_halo_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.smr_hip_canvas_extend.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.smr_hip_canvas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.smr_hip_draw.argtypes = [C.c_void_p, C.POINTER(DrawStyle), C.POINTER(_DrawBatch)]
         L.smr_hip_debug_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -224,6 +226,7 @@ class Canvas:
         h = C.c_void_p()
         _chk(lib().smr_hip_canvas_create(W, H, dpi, bgcolor, self.band_y0, self.band_h, C.byref(h)))
         self.h = h.value
+        self._n_above = self._n_below = 0
 
     def draw(self, style, d_x, d_y, d_way_off, d_ref, n_ways, n_refs, d_fill_col=None, d_border_col=None):
         b = _DrawBatch(d_x.ptr, d_y.ptr, int(np.prod(d_x.shape)), d_way_off.ptr, d_ref.ptr if d_ref else None,
@@ -245,6 +248,7 @@ class Canvas:
         _chk(lib().smr_hip_canvas_clone(self.h, C.byref(h)))
         o = Canvas.__new__(Canvas)
         o.W, o.H, o.dpi, o.band_y0, o.band_h, o.h = self.W, self.H, self.dpi, self.band_y0, self.band_h, h.value
+        o._n_above, o._n_below = self._n_above, self._n_below
         return o
 
     def set_halo(self, above=None, below=None):
@@ -253,6 +257,40 @@ class Canvas:
         b = None if below is None else np.ascontiguousarray(below, np.uint32)
         _chk(lib().smr_hip_canvas_set_halo(self.h, a.ctypes.data if a is not None else None, 0 if a is None else a.shape[0],
                                            b.ctypes.data if b is not None else None, 0 if b is None else b.shape[0]))
+        self._n_above, self._n_below = 0 if a is None else a.shape[0], 0 if b is None else b.shape[0]
+
+    def set_halo_device(self, d_above, n_above, d_below, n_below):
+        """the same from DEVICE pointers (ints): the receive buffers of a device-to-device exchange"""
+        _chk(lib().smr_hip_canvas_set_halo_device(self.h, d_above, n_above, d_below, n_below))
+        self._n_above, self._n_below = n_above, n_below
+
+    def extend(self):
+        """band + halo strips as one canvas: the private background of a banded caption rule (smr_hip_canvas_extend)"""
+        h = C.c_void_p()
+        _chk(lib().smr_hip_canvas_extend(self.h, C.byref(h)))
+        o = Canvas.__new__(Canvas)
+        o.W, o.H, o.dpi, o.h = self.W, self.H, self.dpi, h.value
+        o.band_y0, o.band_h = self.band_y0 - self._n_above, self.band_h + self._n_above + self._n_below
+        o._n_above = o._n_below = 0
+        return o
+
+    def device_ptr(self):
+        """(device address of the band's first pixel, row stride in pixels)"""
+        p, st = C.c_void_p(), C.c_int()
+        _chk(lib().smr_hip_canvas_device(self.h, C.byref(p), C.byref(st)))
+        return p.value, st.value
+
+    def device_rows(self, row0, nrows):
+        """rows [row0, row0 + nrows) of the band as a torch int32 tensor VIEW of the device memory (no copy)"""
+        import torch
+        ptr, stride = self.device_ptr()
+
+        class _View:
+            pass
+        v = _View()
+        v.__cuda_array_interface__ = {"shape": (nrows, self.W), "typestr": "<i4", "data": (ptr + 4 * stride * row0, False),
+                                      "version": 2, "strides": None}
+        return torch.as_tensor(v, device="cuda")
 
     def debug_edges(self):
         """edge slots of the last draw pass, int32 [n, 4] (diagnostics)"""

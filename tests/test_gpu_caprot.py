@@ -47,6 +47,9 @@ def make_canvas(sa, W, H, bg, style):
     (64, 20, 0, 0x203040, 0.0, 0.7, 0xffffff),       # centred, weighted ellipse (test/rules/0180.osm: weight=0.7)
     (48, 10, 24, 0xffffff, 90.0, -0.5, 0xc0d0e0),    # negative weight inverts the metric (:1817-1818)
     (40, 12, 20, 0x000000, 0.0, 1.0, 0x10ffffff),    # background alpha byte 0xdf: (A & 0x7f) = 95 <= 101 -> "transparent" by the 0x7f-mask quirk (:1692)
+    (270, 20, 135, 0x000000, 0.0, 1.0, 0xffffff),    # BASELINE.json C4 at its own shape: 270x20 plane, 271-px cut-out, 72 angles (45 blocks, 4 wavefronts)
+    (320, 44, 0, 0x102030, 0.0, 0.7, 0xffffff),      # 220 blocks of 16x4 px: 7 wavefronts per caption, 32 blocks each
+    (2100, 1, 0, 0x000000, 0.0, 1.0, 0xffffff),      # one line of 132 blocks: 5 wavefronts, the last blocks ragged
 ])
 def test_angles_match_oracle(hip, fg_w, fg_h, fg_x, col, phase, weight, bg):
     sa = hip
@@ -55,13 +58,14 @@ def test_angles_match_oracle(hip, fg_w, fg_h, fg_x, col, phase, weight, bg):
     cv = make_canvas(sa, W, H, bg, st)
     img = cv.read()
     rng = np.random.default_rng(fg_w)
-    n_cap = 48
+    n_cap = 48 if fg_w < 300 else 10
     cx = rng.uniform(-5, W + 5, n_cap)
     cy = rng.uniform(-5, H + 5, n_cap)
     cx[:4] = [0.0, W, W / 2 + 0.5, 17.25]
     cy[:4] = [0.0, H, H / 2 + 0.5, 290.75]
     want, want_dv, n, r = oracle_angles(img, cx, cy, fg_w, fg_h, fg_x, col, 300, phase, weight)
     assert sa.caprot_steps(fg_w, fg_h, 300) == (n, r)
+    assert (fg_w, fg_h) != (270, 20) or (n, r) == (72, 271)
     d_ang = sa.DeviceArray((n_cap,), np.float64)
     d_dv = sa.DeviceArray((n_cap, n), np.float64)
     cv.caprot(sa.DeviceArray.from_numpy(cx), sa.DeviceArray.from_numpy(cy), n_cap, fg_w, fg_h, fg_x, col, phase, weight,

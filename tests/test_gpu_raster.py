@@ -620,3 +620,37 @@ def test_directional_rule_of_knot_ways(hip):
     got = cv.read(); cv.close()
     assert len(np.unique(got)) > 2
     assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_bad_batches_are_refused_before_anything_is_drawn(hip):
+    """smr_hip_draw checks the device-side batch itself (the way table starts at 0, ascends, ends at n_refs; every ref inside
+    the node arrays; no node 2^20 px or more away, where the 24.8 edge arithmetic would wrap): SMR_E_INVAL / SMR_E_CAPACITY,
+    the canvas untouched, and the next good rule draws as if nothing had happened."""
+    sa = hip
+    W, H = 96, 80
+    x, y, off, ref = po.synth_ways(6, W, H, seed=2)
+    off = off.astype(np.int64); ref = ref.astype(np.int32)
+    cv = sa.Canvas(W, H, 300, 0xffffff)
+    gs = draw_style(sa, STYLES["fill+border"])
+    D = sa.DeviceArray.from_numpy
+    bad_ref = ref.copy(); bad_ref[7] = len(x) + 5
+    neg_ref = ref.copy(); neg_ref[0] = -1
+    bad_off = off.copy(); bad_off[2], bad_off[3] = off[3], off[2]            # not ascending
+    short_off = off.copy(); short_off[-1] -= 1                                # does not end at n_refs
+    late_off = off.copy(); late_off[0] = 1                                    # does not start at 0
+    far_x = x.copy(); far_x[3] = 2.0 ** 21
+    nan_y = y.copy(); nan_y[5] = np.nan
+    cases = [(x, y, off, bad_ref, -2), (x, y, off, neg_ref, -2), (x, y, bad_off, ref, -2), (x, y, short_off, ref, -2),
+             (x, y, late_off, ref, -2), (far_x, y, off, ref, -6), (x, nan_y, off, ref, -6)]
+    for cx, cy, co, cr, code in cases:
+        with pytest.raises(sa.SmrHipError) as e:
+            cv.draw(gs, D(cx), D(cy), D(co), D(cr), len(co) - 1, len(cr))
+        assert e.value.code == code, str(e.value)
+        assert np.all(cv.read() == 0xffffffff)
+    with pytest.raises(sa.SmrHipError) as e:          # identity refs beyond the node arrays: caught on the host
+        cv.draw(gs, D(x[:5]), D(y[:5]), D(np.array([0, 8], np.int64)), None, 1, 8)
+    assert e.value.code == -2
+    cv.draw(gs, D(x), D(y), D(off), D(ref), len(off) - 1, len(ref))
+    got = cv.read(); cv.close()
+    want = oracle_of([(STYLES["fill+border"], (x, y, off, ref))], 300, W, H, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
