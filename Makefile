@@ -8,7 +8,7 @@ OBJS := $(patsubst %,build/%.o,$(notdir $(SRCS)))
 
 all: smrender_amd/libsmr_hip.so oracle
 
-build/%.hip.o: $(CSRC)/%.hip $(CSRC)/smr_dev.h $(CSRC)/smr_host.h include/smr_hip.h
+build/%.hip.o: $(CSRC)/%.hip $(CSRC)/smr_dev.h $(CSRC)/smr_host.h $(CSRC)/raster_cross.inc include/smr_hip.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -194,7 +194,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    stage = {k: 0.0 for k in ("proj_ms", "edges_ms", "prims_ms", "bin_ms", "raster_ms")}
+    stage = {k: 0.0 for k in ("proj_ms", "edges_ms", "prims_ms", "cover_ms", "bin_ms", "raster_ms")}
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -255,7 +255,8 @@ def main():
                        "canvas_total": [W, H * n_bands], "partition": f"{world} row band(s), one per GPU"},
             "nodes_per_s": round(n_nodes / (stage["proj_ms"] * 1e-3), 1) if stage["proj_ms"] > 0 else None,
             "stage_ms": {k: round(v, 3) for k, v in stage.items()},
-            "counts": {"prims": tm["n_prims"], "edge_slots": tm["n_edges"], "tile_refs": tm["n_tile_refs"], "tiles": tm["n_tiles"]},
+            "counts": {"prims": tm["n_prims"], "edge_slots": tm["n_edges"], "tile_refs": tm["n_tile_refs"], "tiles": tm["n_tiles"],
+                       "cover_prims": tm["n_cover_prims"], "cover_left": tm["n_cover_left"], "deltas": tm["n_deltas"]},
             "roofline": {"kernel": "k_raster", "bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5), "traffic": measured_traffic("k_raster", args),
                          "algorithmic_bytes": alg_bytes},

@@ -195,6 +195,9 @@ typedef struct
    float proj_ms, edges_ms, prims_ms, bin_ms, raster_ms, caprot_ms, total_ms;   /* draw: edge generation, primitive set-up,
                                                                                  binning + sort, raster */
    uint64_t n_prims, n_edges, n_tile_refs, n_tiles;
+   float cover_ms;                                /* draw: scan conversion of the small primitives, primitive by primitive (k_cover) */
+   uint32_t n_cover_prims, n_cover_left;          /* primitives k_cover handled / had to leave to the tile rasterizer */
+   uint32_t n_deltas;                             /* coverage cells k_cover wrote */
 } smr_timings_t;
 int smr_hip_set_profiling(int on);
 int smr_hip_timings(smr_timings_t *t);

@@ -1327,7 +1327,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    const bool pieces = role != 2 || (wf & 8);
    smr_prim_t P;
    P.edge_off = 0; P.edge_cnt = 0; P.color = 0; P.minx = P.miny = INT32_MAX; P.maxx = P.maxy = INT32_MIN;
-   P.flags = 0; P.mask_off = 0; P.row0 = 0; P.nrows = 0;
+   P.flags = 0; P.mask_off = 0; P.row0 = 0; P.nrows = 0; P.drow_off = 0; P.pad_[0] = P.pad_[1] = P.pad_[2] = 0;
    int64_t nitems = 0;
    if (on)
    {
@@ -1787,7 +1787,7 @@ __global__ void k_compound_init(smr_prim_t *prims, uint32_t compound, uint64_t e
    smr_prim_t P;
    P.edge_off = edge_off; P.edge_cnt = edge_cnt; P.color = color;
    P.minx = P.miny = INT32_MAX; P.maxx = P.maxy = INT32_MIN;
-   P.flags = SMR_PF_VALID | SMR_PF_MULTI; P.mask_off = 0; P.row0 = 0; P.nrows = H;
+   P.flags = SMR_PF_VALID | SMR_PF_MULTI; P.mask_off = 0; P.row0 = 0; P.nrows = H; P.drow_off = 0; P.pad_[0] = P.pad_[1] = P.pad_[2] = 0;
    prims[compound] = P;
 }
 
@@ -1894,6 +1894,7 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t *__restrict__ out, co
 
 __global__ void k_set_u32(uint32_t *p, const uint32_t *v) { *p = *v; }
 
+
 /* per-tile sort of the scattered item indices (ascending = drawing order), then the tile's
  * work stream: one smr_thdr_t per entry with the item header, the tile's bits of the
  * primitive's row mask and the primitive's pixel extents relative to the tile */
@@ -1909,7 +1910,8 @@ struct sort_args_t
    smr_thdr_t *hdrs;
    uint32_t n_tiles;
    uint32_t lds_cap;          /* entries of one tile that fit its wavefront's share of LDS (a power of two up to SORT_LDS) */
-   int TX, band_y0;
+   int TX, band_y0, band_h;
+   const uint2 *drows;        /* k_cover's row table (primitives with SMR_PF_DELTA) */
 };
 
 /* SORT_WAVES independent wavefronts per workgroup, one tile each (a chart of 4 M tiles is 4 M one-wave workgroups otherwise,
@@ -2006,7 +2008,25 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
       }
       h.rowbits = bits;
       h.colmin = (P.minx >> 8) - col0; h.colmax = (P.maxx >> 8) - col0;
-      h.pad_ = 0;
+      h.dcounts = 0;
+      if (P.flags & SMR_PF_DELTA)
+      {
+         /* k_cover has the primitive's cells: the entry names those of the tile's four rows (consecutive in the arena: the
+          * passes of k_cover start on tile rows) */
+         const int dr0 = max(P.row0, A.band_y0), dn = min(P.row0 + P.nrows, A.band_y0 + A.band_h) - dr0;
+         uint32_t start = 0xffffffffu, counts = 0;
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++)
+         {
+            const int rr = row0 + r - dr0;
+            if (rr >= 0 && rr < dn)
+            {
+               const uint2 d = A.drows[P.drow_off + (uint32_t) rr];
+               if (d.y) { start = min(start, d.x); counts |= d.y << (8 * r); }
+            }
+         }
+         h.edge_off = counts ? start : 0u; h.dcounts = counts; h.cnt_flags |= SMR_PF_DELTA << 8;
+      }
       A.hdrs[beg + i] = h;
       if (in_lds && n >= 2) A.entries[beg + i] = idx;
    }
@@ -2033,6 +2053,7 @@ struct raster_args_t
    uint32_t *ovf_list;        /* [n_tiles] */
    uint32_t *ovf_cnt;         /* [0] tiles queued, [1] most entries of one of them */
    uint32_t ovf_n;            /* k_raster<true>: tiles in the list */
+   const smr_delta_t *deltas; /* k_cover's cells (entries with SMR_PF_DELTA) */
    uint32_t *big_bucket;      /* k_raster<true>: [wavefront][big_cap][64 lanes] */
    uint32_t big_cap;          /* entries per sub-row (a crossing takes one, an interval two) */
 };
@@ -2284,7 +2305,14 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
          {
             const int j = (int) (k - bbase);
             const uint32_t eo = __builtin_amdgcn_readlane(hb0.x, j), cf = __builtin_amdgcn_readlane(hb0.z, j);
-            if ((uint32_t) lane < (cf & 0xffu)) e = A.edges[(size_t) eo + lane];
+            if (cf & (SMR_PF_DELTA << 8))
+            {
+               /* the first 64 cells of the tile's rows instead of edge slots */
+               const uint32_t dc = __builtin_amdgcn_readlane(hb1.w, j);
+               const uint32_t tot = (dc & 0xffu) + ((dc >> 8) & 0xffu) + ((dc >> 16) & 0xffu) + (dc >> 24);
+               if ((uint32_t) lane < tot) { const smr_delta_t d = A.deltas[(size_t) eo + lane]; e.x1 = d.x; e.y1 = d.ca; }
+            }
+            else if ((uint32_t) lane < (cf & 0xffu)) e = A.edges[(size_t) eo + lane];
          }
          return e;
       };
@@ -2297,7 +2325,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
          const smr_edge_t my_edge = edge1;
          smr_item_t it;
          it.prim = 0xffffffffu; it.cnt_flags = 0; it.edge_off = 0; it.color = 0;
-         uint32_t it_rowbits = 0; int it_colmin = 0, it_colmax = -1;
+         uint32_t it_rowbits = 0, it_dcounts = 0; int it_colmin = 0, it_colmax = -1;
          if (ei < end)
          {
             const int j = (int) (ei - bbase);
@@ -2305,6 +2333,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             it.cnt_flags = __builtin_amdgcn_readlane(hb0.z, j); it.color = __builtin_amdgcn_readlane(hb0.w, j);
             it_rowbits = __builtin_amdgcn_readlane(hb1.x, j);
             it_colmin = (int) __builtin_amdgcn_readlane(hb1.y, j); it_colmax = (int) __builtin_amdgcn_readlane(hb1.z, j);
+            it_dcounts = __builtin_amdgcn_readlane(hb1.w, j);
             if (ei + 1 == bbase + 64) { bbase += 64; load_batch(); }
             edge1 = load_edge(ei + 1);
          }
@@ -2627,7 +2656,31 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             for (int r = 0; r < SMR_TH; r++) rowcnt[r] = 0;
             partial = it_rowbits & 0xfu; cur_rowin = (it_rowbits >> 4) & 0xfu;
             cur_colmin = it_colmin; cur_colmax = it_colmax; cur_first = (it.cnt_flags >> 16) & 1u;
+            if (cur_flags & SMR_PF_DELTA)
+            {
+               /* k_cover has run the scan converter over this primitive: the cells of the tile's rows, ascending x row by row,
+                * go into the tile's accumulators (every cell once: plain stores; the covers left of the tile add up) */
+               COUNT(18);
+               partial = 0;                  /* nothing for the flush to convert */
+               const uint32_t c0 = it_dcounts & 0xffu, c1 = c0 + ((it_dcounts >> 8) & 0xffu), c2 = c1 + ((it_dcounts >> 16) & 0xffu), tot = c2 + (it_dcounts >> 24);
+               touched = tot != 0;
+               for (uint32_t base = 0; base < tot; base += 64)
+               {
+                  const uint32_t i = base + lane;
+                  int dx = my_edge.x1, dca = my_edge.y1;
+                  if (base && i < tot) { const smr_delta_t d = A.deltas[(size_t) it.edge_off + i]; dx = d.x; dca = d.ca; }
+                  if (i < tot)
+                  {
+                     const int row = (i >= c0 ? 1 : 0) + (i >= c1 ? 1 : 0) + (i >= c2 ? 1 : 0);
+                     const int ix = dx - tx * SMR_TW;
+                     if (ix < 0) atomicAdd(&L.left[row], smr_delta_cover(dca));
+                     else if (ix < SMR_TW) { L.cover[row][ix] = smr_delta_cover(dca); L.uarea[row][ix] = smr_delta_area(dca); }
+                  }
+               }
+               SMR_WAVE_SYNC();
+            }
          }
+         if (cur_flags & SMR_PF_DELTA) continue;       /* (further items of the same primitive bring nothing) */
 
          /* ================= one item: up to 64 edge slots, one per lane ================= */
          const uint32_t icnt = it.cnt_flags & 0xffu;
@@ -2679,196 +2732,13 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
          }
 
          TICK(4);         /* orient + full-row bookkeeping */
-         /* sub-sampled rows; lane = sub-row */
-         if (partial)
-         {
-            const bool mine = lane < SMR_NSUB && ((partial >> my_row) & 1u);
-            unsigned long long om = __ballot(inband);
-            if (pieces)
-            {
-               /* a piece (4 aligned lanes) is needed when any of its edges meets the strip and
-                * its x-extent meets the tile */
-               int32_t pmax = o.dir != 0 ? emaxx : INT32_MIN;
-               pmax = max(pmax, __shfl_xor(pmax, 1)); pmax = max(pmax, __shfl_xor(pmax, 2));
-               unsigned long long right = __ballot(pmax > X0);
-               om = om & right;
-               om |= om >> 1; om |= om >> 2;            /* gather the piece's bits into its first lane */
-               om &= 0x1111111111111111ull;
-            }
-            if (om)
-            {
-               touched = true;
-               COUNT(10);
-               /* per-edge constants of the fast exact evaluation, broadcast by v_readlane */
-               const int64_t e_c = 256 - 30ll * o.p1y;
-               const int e_clo = (int) (uint32_t) e_c, e_chi = (int) (e_c >> 32);
-               const int e_dxs2 = 2 * o.dxs;
-               /* 1/D for the quotient estimates: short edges (nearly all of a chart of small polygons) need it in fp32 only */
-               int e_small = (o.dir == 0 || (abs(o.dxs) < 4096 && o.D <= 60 * 4096)) ? 1 : 0;
-               const unsigned long long smalledge = __ballot(e_small != 0);               /* fills: edge by edge */
-               double e_inv = 0.0;
-               float e_invf;
-               if (~smalledge) { e_inv = smr_rcp((double) o.D); e_invf = (float) e_inv; }
-               else e_invf = __builtin_amdgcn_rcpf((float) o.D);
-               const int e_ilo = (int) (uint32_t) __double_as_longlong(e_inv), e_ihi = (int) (__double_as_longlong(e_inv) >> 32);
-               /* sub-row window of the edge relative to the tile, [0, 60]; empty for empty slots */
-               const int e_t0 = o.dir == 0 ? 64 : min(max(o.ytop - ysbase, 0), 64), e_t1 = o.dir == 0 ? 0 : min(max(o.ybot - ysbase, 0), 64);
-               const int e_win = e_t0 | (e_t1 << 8) | ((o.dir > 0 ? 1 : 0) << 16);
-               const int e_rcpf = __float_as_int(e_invf);
-               /* the 32-bit path's form of the same edge: with ys = ysbase + lane the numerator of the ROUNDED cell,
-                * dxs2 * (512 * ys + c) + D / 2, is e_A * lane + e_B (wrapping arithmetic: the true values are small whenever
-                * the piece meets the strip); window and D share one word: first sub-row (6 bits), sub-rows (7), D (18) */
-               const int e_c32 = (int) ((uint32_t) ysbase * 512u + 256u - 30u * (uint32_t) o.p1y);
-               const int e_A = o.dxs * 1024;
-               const int e_B = (int) ((uint32_t) e_dxs2 * (uint32_t) e_c32 + (uint32_t) (o.D >> 1));
-               const int e_W = e_t0 < e_t1 ? (e_t0 | ((e_t1 - e_t0) << 6) | (o.D << 13)) : (o.D << 13);
-               /* pieces: the windows of the piece's four edges side by side in its lanes (two words), and -D */
-               const int e_w13 = e_W & 0x1fff;
-               const int e_W01 = __builtin_amdgcn_update_dpp(0, e_w13, 0x00, 0xf, 0xf, false) | (__builtin_amdgcn_update_dpp(0, e_w13, 0x55, 0xf, 0xf, false) << 13);
-               const int e_W23 = __builtin_amdgcn_update_dpp(0, e_w13, 0xaa, 0xf, 0xf, false) | (__builtin_amdgcn_update_dpp(0, e_w13, 0xff, 0xf, 0xf, false) << 13);
-               const int e_nD = -o.D;
-               /* a piece takes the 32-bit path when each of its edges is empty or short in x and y */
-               e_small &= __shfl_xor(e_small, 1); e_small &= __shfl_xor(e_small, 2);      /* no short-circuit: every lane shuffles */
-               const unsigned long long smallmask = pieces ? __ballot(e_small != 0) : smalledge;
-               TICK(5);   /* per-edge constants */
-#ifdef SMR_KO
-               if (SMR_KO & 4) om = 0;
-#endif
-               while (om)
-               {
-                  const int j = __ffsll((long long) om) - 1;
-                  om &= om - 1;
-                  if (!pieces)
-                  {
-                     const int win = __builtin_amdgcn_readlane(e_win, j);
-                     if (__builtin_amdgcn_readlane(emaxx, j) < X0)
-                     {
-                        COUNT(13);
-                        /* the edge lies left of the tile: every crossing is, so only its winding counts */
-                        if (mine && lane >= (win & 0xff) && lane < ((win >> 8) & 0xff)) lw += (win >> 16) ? 1 : -1;
-                     }
-                     else if ((smallmask >> j) & 1ull)
-                     {
-                        COUNT(14);
-                        /* a short edge: the 32-bit evaluation of the piece path below */
-                        const uint32_t Wd = (uint32_t) __builtin_amdgcn_readlane(e_W, j);
-                        const int D = (int) (Wd >> 13);
-                        const int n = __mul24(__builtin_amdgcn_readlane(e_A, j), lane) + __builtin_amdgcn_readlane(e_B, j);
-                        const int q = (int) fmaf((float) n, __int_as_float(__builtin_amdgcn_readlane(e_rcpf, j)), -0.5f);
-                        const int rem = __mul24(q, -D) + n;
-                        const int cell = __builtin_amdgcn_readlane(o.p1x, j) + q + (rem >= D ? 1 : 0) + (rem >> 31);
-                        if (mine && (uint32_t) (lane - (int) (Wd & 63u)) < ((Wd >> 6) & 127u))
-                        {
-                           if (cell < X0) lw += (win >> 16) ? 1 : -1;
-                           else if (cell < X1)
-                           {
-                              if (cnt < BK) { bk.set(cnt, ((cell - X0) << 1) | (win >> 16)); cnt++; }
-                              else ovf = true;
-                           }
-                        }
-                     }
-                     else if (mine && lane >= (win & 0xff) && lane < ((win >> 8) & 0xff))
-                     {
-                        COUNT(15);
-                        const int64_t c = ((int64_t) __builtin_amdgcn_readlane(e_chi, j) << 32) | (uint32_t) __builtin_amdgcn_readlane(e_clo, j);
-                        const double inv = __longlong_as_double(((long long) __builtin_amdgcn_readlane(e_ihi, j) << 32) |
-                                                                (uint32_t) __builtin_amdgcn_readlane(e_ilo, j));
-                        int32_t cell = smr_edge_cell(c, __builtin_amdgcn_readlane(e_dxs2, j), __builtin_amdgcn_readlane(o.D, j), inv,
-                                                     __builtin_amdgcn_readlane(o.p1x, j), my_ys);
-                        if (cell < X0) lw += (win >> 16) ? 1 : -1;
-                        else if (cell < X1)
-                        {
-                           if (cnt < BK) { bk.set(cnt, ((cell - X0) << 1) | (win >> 16)); cnt++; }
-                           else ovf = true;
-                        }
-                     }
-                  }
-                  else
-                  {
-                     /* convex piece: its two crossings bound one covered interval; the stroke is
-                      * the union of the intervals of all pieces (every piece winds the same way) */
-                     int32_t lo = INT32_MAX, hi = INT32_MIN;
-                     if ((smallmask >> j) & 1ull) COUNT(11); else COUNT(12);
-                     if ((smallmask >> j) & 1ull)
-                     {
-                        /* all four edges are short (|dx|, dy < 16 px): the numerator fits 32 bits, the quotient 13, so 24-bit
-                         * multiplies and one fp32 estimate (within 1 of the floor on either side, corrected through the exact
-                         * remainder) give floor((n + D/2) / D) = the rounded cell; branch-free.
-                         * A sub-row meets two edges of a convex piece, its left and its right one: every lane picks its
-                         * two among the four from their windows and fetches their constants with ds_bpermute (the LDS
-                         * crossbar, no VALU work) instead of evaluating all four and masking two away. */
-                        const uint32_t W01 = (uint32_t) __builtin_amdgcn_readlane(e_W01, j), W23 = (uint32_t) __builtin_amdgcn_readlane(e_W23, j);
-                        const bool i0 = (uint32_t) (lane - (int) (W01 & 63u)) < ((W01 >> 6) & 127u);
-                        const bool i1 = (uint32_t) (lane - (int) ((W01 >> 13) & 63u)) < ((W01 >> 19) & 127u);
-                        const bool i2 = (uint32_t) (lane - (int) (W23 & 63u)) < ((W23 >> 6) & 127u);
-                        const bool i3 = (uint32_t) (lane - (int) ((W23 >> 13) & 63u)) < ((W23 >> 19) & 127u);
-                        const unsigned long long m0 = __ballot(i0), m1 = __ballot(i1), m2 = __ballot(i2), m3 = __ballot(i3);
-                        if (!((m0 & m1 & (m2 | m3)) | (m2 & m3 & (m0 | m1))))
-                        {
-                           auto cell_of = [&](int idx) -> int
-                           {
-                              const int ad = (j + idx) << 2;
-                              const int D_ = __builtin_amdgcn_ds_bpermute(ad, e_nD);
-                              const int n = __mul24(__builtin_amdgcn_ds_bpermute(ad, e_A), lane) + __builtin_amdgcn_ds_bpermute(ad, e_B);
-                              const int q = (int) fmaf((float) n, __int_as_float(__builtin_amdgcn_ds_bpermute(ad, e_rcpf)), -0.5f);
-                              const int rem = __mul24(q, D_) + n;
-                              return __builtin_amdgcn_ds_bpermute(ad, o.p1x) + q + (rem + D_ >= 0 ? 1 : 0) + (rem >> 31);
-                           };
-                           const int ca = cell_of(i0 ? 0 : i1 ? 1 : i2 ? 2 : 3), cb = cell_of(i3 ? 3 : i2 ? 2 : i1 ? 1 : 0);
-                           if (i0 || i1 || i2 || i3) { lo = min(ca, cb); hi = max(ca, cb); }
-                        }
-                        else
-                        {
-                           /* more than two edges on one sub-row (a degenerate piece): all four */
-#pragma unroll
-                           for (int k = 0; k < 4; k++)
-                           {
-                              const int jj = j + k;
-                              const uint32_t Wd = (uint32_t) __builtin_amdgcn_readlane(e_W, jj);
-                              const int D = (int) (Wd >> 13);
-                              const int n = __mul24(__builtin_amdgcn_readlane(e_A, jj), lane) + __builtin_amdgcn_readlane(e_B, jj);
-                              const int q = (int) fmaf((float) n, __int_as_float(__builtin_amdgcn_readlane(e_rcpf, jj)), -0.5f);
-                              const int rem = __mul24(q, -D) + n;
-                              const int cell = __builtin_amdgcn_readlane(o.p1x, jj) + q + (rem >= D ? 1 : 0) + (rem >> 31);
-                              const bool in = (uint32_t) (lane - (int) (Wd & 63u)) < ((Wd >> 6) & 127u);
-                              lo = in ? min(lo, cell) : lo; hi = in ? max(hi, cell) : hi;
-                           }
-                        }
-                     }
-                     else
-                     {
-#pragma unroll
-                        for (int k = 0; k < 4; k++)
-                        {
-                           const int jj = j + k;
-                           const int win = __builtin_amdgcn_readlane(e_win, jj);
-                           if (mine && lane >= (win & 0xff) && lane < ((win >> 8) & 0xff))
-                           {
-                              const int64_t c = ((int64_t) __builtin_amdgcn_readlane(e_chi, jj) << 32) | (uint32_t) __builtin_amdgcn_readlane(e_clo, jj);
-                              const double inv = __longlong_as_double(((long long) __builtin_amdgcn_readlane(e_ihi, jj) << 32) |
-                                                                      (uint32_t) __builtin_amdgcn_readlane(e_ilo, jj));
-                              int32_t cell = smr_edge_cell(c, __builtin_amdgcn_readlane(e_dxs2, jj), __builtin_amdgcn_readlane(o.D, jj), inv,
-                                                           __builtin_amdgcn_readlane(o.p1x, jj), my_ys);
-                              lo = min(lo, cell); hi = max(hi, cell);
-                           }
-                        }
-                     }
-#ifdef SMR_DEBUG_PIECE
-                     if (tx == SMR_DEBUG_PIECE && ysbase == SMR_DEBUG_YS && lane >= 15 && lane < 30)
-                        printf("lane %d piece slot %u lo %d hi %d small %d cl %d cr %d cnt %d\n", lane, it.edge_off + j, lo - X0, hi - X0, (int) ((smallmask >> j) & 1ull), cl, cr, cnt);
-#endif
-                     if (mine && lo < hi && hi > X0 && lo < X1)
-                     {
-                        const int l = (lo < X0 ? X0 : lo) - X0, r = (hi > X1 ? X1 : hi) - X0;
-                        if (cl > cr) { cl = l; cr = r; }
-                        else if (l <= cr && cl <= r) { cl = min(cl, l); cr = max(cr, r); }
-                        else { push_interval(cl, cr); cl = l; cr = r; }
-                     }
-                  }
-               }
-               TICK(6);   /* crossing loop */
-            }
-         }
+#define XTICK(i) TICK(i)
+#define XCOUNT(i) COUNT(i)
+#define XCOUNTN(i, n) COUNTN(i, n)
+#include "raster_cross.inc"
+#undef XTICK
+#undef XCOUNT
+#undef XCOUNTN
       }
 
       TICK(7);
@@ -2911,6 +2781,439 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
 #ifdef SMR_COUNT_PROFILE
    if (lane == 0) for (int i = 0; i < 24; i++) atomicAdd((unsigned long long *) (A.status + 190) + i, cnts[i]);
 #endif
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* coverage of small primitives, one wavefront per primitive                              */
+/* ------------------------------------------------------------------------------------ */
+/* A chart of many small polygons pays in k_raster for every (item, tile) pair: header, orientation, per-edge constants, the
+ * flush's fixed parts and the blend, with two or three edges per pair that matter (C2: 55.8 M pairs, 650 VALU instructions
+ * each).  Coverage does not depend on tiles: libcairo's scan converter accumulates (cover, area) per pixel row and cell, and a
+ * tile needs of a primitive's row only those cells: the ones inside it, and the sum of the covers left of it.  So for every
+ * primitive that is small enough (at most SMR_CV_MAXSLOTS edge slots, 126 px wide) ONE wavefront runs the scan converter over
+ * the primitive's own rows, four at a time with k_raster's own crossing loop (raster_cross.inc: lanes = the 60 sub-rows), and
+ * writes per row the cells that are not zero (smr_delta_t, ascending x); k_raster's work for such a primitive in a tile is to
+ * read the rows' cells and to composite.
+ * Anything that does not fit (lists, arenas, cell range) leaves the primitive to k_raster's own path: never an error. */
+#define SMR_CV_WC 128                              /* cells per row, one guard cell on either side included */
+#define SMR_CV_SL 16                               /* edges spanning one vertex-free row */
+#define SMR_CV_MAXSLOTS 1024u
+#define SMR_CV_MAXGROUPS (SMR_CV_MAXSLOTS / 64u)
+#define SMR_CV_WAVES 4
+#define SMR_CV_DBLOCK 4096u                        /* deltas a wavefront takes from the arena with one atomic */
+#define SMR_CV_RBLOCK 1024u                        /* row-table entries likewise */
+#define SMR_CV_CHUNK 8u                            /* primitives a wavefront takes from the queue with one atomic */
+
+struct cover_args_t
+{
+   smr_prim_t *prims;
+   uint32_t n_prims;
+   const smr_edge_t *edges;
+   const uint32_t *mask;
+   smr_delta_t *deltas;
+   uint32_t delta_cap;
+   uint2 *drows;              /* per (primitive, row): first delta, number of deltas */
+   uint32_t drow_cap;
+   uint32_t *ctr;             /* [0] next primitive [1] deltas taken [2] rows taken [3] primitives done [4] primitives left to k_raster */
+   int band_y0, band_h;
+};
+
+struct cover_lds_t
+{
+   int cell[SMR_TH][SMR_CV_WC];
+   uint16_t bucket[SMR_NSUB][SMR_BKS];
+   int redge[SMR_TH][SMR_CV_SL][5];
+   int gy[SMR_CV_MAXGROUPS][2];      /* sub-row extent of each group of 64 edge slots */
+};
+
+__global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
+{
+   __shared__ cover_lds_t LL[SMR_CV_WAVES];
+   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+   cover_lds_t &L = LL[wave];
+   const int lane = threadIdx.x & 63;
+   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+   const int my_row = lane / SMR_GRID_Y;
+   smr_bucket_t<false> bk;
+   bk.p = L.bucket[lane < SMR_NSUB ? lane : 0];
+   const int BK = SMR_BK;
+#pragma unroll
+   for (int r = 0; r < SMR_TH; r++) { L.cell[r][lane] = 0; L.cell[r][lane + 64] = 0; }
+   SMR_WAVE_SYNC();
+   uint32_t dpos = 0, dleft = 0, rpos = 0, rleft = 0;      /* this wavefront's blocks of the two arenas */
+   uint32_t n_done = 0, n_left = 0;
+
+   for (;;)
+   {
+   uint32_t p0 = 0;
+   if (lane == 0) p0 = atomicAdd(&A.ctr[0], SMR_CV_CHUNK);
+   p0 = __builtin_amdgcn_readfirstlane(p0);
+   if (p0 >= A.n_prims) break;
+   const uint32_t p1 = min(p0 + SMR_CV_CHUNK, A.n_prims);
+   for (uint32_t p = p0; p < p1; p++)
+   {
+      const smr_prim_t P = A.prims[p];
+      if (!(P.flags & SMR_PF_VALID) || P.edge_cnt == 0) continue;
+      const int cx0 = (P.minx >> 8) - 1;                   /* cell 0 is a guard: the exact rows reach half a sub-row beyond an edge's ends */
+      const int wp = (P.maxx >> 8) - cx0 + 2;
+      const int dr0 = max(P.row0, A.band_y0), dr1 = min(P.row0 + P.nrows, A.band_y0 + A.band_h);
+      if (dr1 <= dr0) continue;
+      if (P.edge_cnt > SMR_CV_MAXSLOTS || wp > SMR_CV_WC) { n_left++; continue; }
+#ifdef SMR_CV_ONLY
+      if (((P.flags & SMR_PF_PIECES) != 0) != (SMR_CV_ONLY == 2)) { n_left++; continue; }
+#endif
+      const int dn = dr1 - dr0;
+      const int32_t X0 = cx0 * 256, X1 = X0 + SMR_CV_WC * 256;
+      const smr_edge_t *E = A.edges + P.edge_off;
+      const uint32_t ngroups = (P.edge_cnt + 63u) >> 6;
+      const uint32_t wmask = (P.flags & SMR_PF_EVENODD) ? 1u : ~0u;
+      const bool pieces = (P.flags & SMR_PF_PIECES) != 0;
+      bool bad = false;                                    /* uniform */
+
+      /* the primitive's rows in the row table */
+      uint32_t rbase;
+      if ((uint32_t) dn > rleft)
+      {
+         const uint32_t take = (uint32_t) dn > SMR_CV_RBLOCK / 4 ? (uint32_t) dn : SMR_CV_RBLOCK;
+         uint32_t b = 0;
+         if (lane == 0) b = atomicAdd(&A.ctr[2], take);
+         b = __builtin_amdgcn_readfirstlane(b);
+         if ((uint64_t) b + take > A.drow_cap) { n_left++; continue; }
+         if (take == (uint32_t) dn) rbase = b;
+         else { rpos = b; rleft = take; rbase = rpos; rpos += dn; rleft -= dn; }
+      }
+      else { rbase = rpos; rpos += dn; rleft -= dn; }
+
+      /* one group of 64 slots stays in registers; of several, each group's sub-row extent decides which strips read it */
+      smr_edge_t e0; e0.x1 = e0.y1 = e0.x2 = e0.y2 = 0;
+      if ((uint32_t) lane < P.edge_cnt) e0 = E[lane];
+      if (ngroups > 1)
+      {
+         for (uint32_t g = 0; g < ngroups; g++)
+         {
+            const uint32_t idx = g * 64u + lane;
+            smr_edge_t e; e.x1 = e.y1 = e.x2 = e.y2 = 0;
+            if (g == 0) e = e0; else if (idx < P.edge_cnt) e = E[idx];
+            const smr_oedge_t o = smr_orient(e);
+            const int lo = smr_wave_min(o.dir != 0 ? o.ytop : INT32_MAX), hi = smr_wave_max(o.dir != 0 ? o.ybot : INT32_MIN);
+            if (lane == 0) { L.gy[g][0] = lo; L.gy[g][1] = hi; }
+         }
+         SMR_WAVE_SYNC();
+      }
+
+      const int cr_first = A.band_y0 + ((dr0 - A.band_y0) & ~(SMR_TH - 1));
+      for (int crow = cr_first; crow < dr1 && !bad; crow += SMR_TH)
+      {
+         /* the strip's rows: sub-sampled (bit of the row mask set), exact (clear), or not the primitive's */
+         uint32_t partial, full_bits;
+         {
+            const int row = crow + lane;
+            const bool inside = lane < SMR_TH && row >= dr0 && row < dr1;
+            bool sub = false;
+            if (inside) { const int rr = row - P.row0; sub = (A.mask[P.mask_off + ((uint32_t) rr >> 5)] >> (rr & 31)) & 1u; }
+            partial = (uint32_t) __ballot(inside && sub); full_bits = (uint32_t) __ballot(inside && !sub);
+         }
+         const int ysbase = crow * SMR_GRID_Y;
+         const int my_ys = ysbase + lane;
+         uint32_t rowcnt[SMR_TH] = { 0, 0, 0, 0 };
+         int cnt = 0, lw = 0, cl = 1, cr = 0;
+         bool ovf = false, touched = false;
+         auto push_interval = [&](int l, int r)
+         {
+            for (int i = 0; i < cnt;)
+            {
+               int ia = bk.get(2 * i), ib = bk.get(2 * i + 1);
+               if (ia <= r && l <= ib)
+               {
+                  l = min(l, ia); r = max(r, ib);
+                  cnt--;
+                  bk.set(2 * i, bk.get(2 * cnt)); bk.set(2 * i + 1, bk.get(2 * cnt + 1));
+                  i = 0;
+               }
+               else i++;
+            }
+            if (2 * cnt + 2 <= BK) { bk.set(2 * cnt, l); bk.set(2 * cnt + 1, r); cnt++; }
+            else ovf = true;
+         };
+         /* the groups that meet the strip */
+         uint32_t gm = 1u;
+         if (ngroups > 1)
+         {
+            bool meets = false;
+            if ((uint32_t) lane < ngroups) meets = L.gy[lane][0] < ysbase + SMR_NSUB && L.gy[lane][1] > ysbase;
+            gm = (uint32_t) __ballot(meets);
+         }
+         struct { uint32_t edge_off; } it; it.edge_off = 0;
+         const int tx = 0;
+         (void) tx; (void) it; (void) lw; (void) touched;
+         while (gm)
+         {
+            const uint32_t g = (uint32_t) __ffs((int) gm) - 1u;
+            gm &= gm - 1u;
+            smr_edge_t my_edge = e0;
+            if (g) { my_edge.x1 = my_edge.y1 = my_edge.x2 = my_edge.y2 = 0; const uint32_t idx = g * 64u + lane; if (idx < P.edge_cnt) my_edge = E[idx]; }
+            const smr_oedge_t o = smr_orient(my_edge);
+            const int32_t emaxx = o.p1x + (o.dxs > 0 ? o.dxs : 0);
+            const bool inband = o.dir != 0 && o.ytop < ysbase + SMR_NSUB && o.ybot > ysbase;
+            it.edge_off = g * 64u;
+            /* exact rows: who spans them */
+            uint32_t fb = full_bits;
+#ifdef SMR_CV_KO
+            if (SMR_CV_KO & 16) fb = 0;
+#endif
+            while (fb)
+            {
+               const int r = __ffs((int) fb) - 1;
+               fb &= fb - 1;
+               const int rs0 = ysbase + r * SMR_GRID_Y;
+               const bool act = o.dir != 0 && o.ytop <= rs0 && o.ybot >= rs0 + SMR_GRID_Y;
+               const unsigned long long am = __ballot(act);
+               if (!am) continue;
+               const uint32_t cntr = r == 0 ? rowcnt[0] : r == 1 ? rowcnt[1] : r == 2 ? rowcnt[2] : rowcnt[3];
+               const uint32_t pos = cntr + __popcll(am & lt_mask);
+               if (act && pos < SMR_CV_SL) { int *re = L.redge[r][pos]; re[0] = o.p1x; re[1] = o.p1y; re[2] = o.dxs; re[3] = o.D; re[4] = o.dir; }
+               if (cntr + __popcll(am) > SMR_CV_SL) bad = true;
+#pragma unroll
+               for (int k = 0; k < SMR_TH; k++) rowcnt[k] += k == r ? (uint32_t) __popcll(am) : 0u;
+            }
+#ifdef SMR_CV_KO
+            if (SMR_CV_KO & 1) continue;
+#endif
+#define XTICK(i) do { } while (0)
+#define XCOUNT(i) do { } while (0)
+#define XCOUNTN(i, n) do { } while (0)
+#include "raster_cross.inc"
+#undef XTICK
+#undef XCOUNT
+#undef XCOUNTN
+         }
+
+         /* ---- sub-sampled rows: crossings -> spans -> cells; lane = sub-row (k_raster's flush) ---- */
+#ifdef SMR_CV_KO
+         if (SMR_CV_KO & 2) cnt = 0, cl = 1, cr = 0;
+         if (SMR_CV_KO & 4) full_bits = 0;
+#endif
+         if (partial)
+         {
+            const bool mine = lane < SMR_NSUB && ((partial >> my_row) & 1u);
+            auto add_span = [&](int x1, int x2)
+            {
+               if (x1 == x2) return;
+               const int ix1 = x1 >> 8, ix2 = x2 >> 8, fx1 = x1 & 255, fx2 = x2 & 255;
+               if (ix2 >= SMR_CV_WC) { ovf = true; return; }
+               if (ix1 != ix2)
+               {
+                  atomicAdd(&L.cell[my_row][ix1], smr_delta_pack(1, 2 * fx1));
+                  atomicAdd(&L.cell[my_row][ix2], smr_delta_pack(-1, -2 * fx2));
+               }
+               else atomicAdd(&L.cell[my_row][ix1], smr_delta_pack(0, 2 * (fx1 - fx2)));
+            };
+            if (mine && pieces)
+            {
+               if (cl <= cr)
+               {
+                  for (int i = 0; i < cnt;)
+                  {
+                     const int ia = bk.get(2 * i), ib = bk.get(2 * i + 1);
+                     if (ia <= cr && cl <= ib)
+                     {
+                        cl = min(cl, ia); cr = max(cr, ib);
+                        cnt--;
+                        bk.set(2 * i, bk.get(2 * cnt)); bk.set(2 * i + 1, bk.get(2 * cnt + 1));
+                        i = 0;
+                     }
+                     else i++;
+                  }
+                  add_span(cl, cr);
+               }
+               for (int i = 0; i < cnt; i++) add_span(bk.get(2 * i), bk.get(2 * i + 1));
+            }
+            else if (mine)
+            {
+               for (int i = 1; i < cnt; i++)
+               {
+                  const int v = bk.get(i);
+                  int k = i - 1;
+                  while (k >= 0 && (bk.get(k) >> 1) > (v >> 1)) { bk.set(k + 1, bk.get(k)); k--; }
+                  bk.set(k + 1, v);
+               }
+               int winding = 0, xstart = -1;
+               for (int i = 0; i < cnt; i++)
+               {
+                  const int bv = bk.get(i);
+                  const int xend = bv >> 1;
+                  winding += (bv & 1) ? 1 : -1;
+                  if (((uint32_t) winding & wmask) == 0)
+                  {
+                     if (i + 1 < cnt && (bk.get(i + 1) >> 1) == xend) continue;
+                     if (xstart >= 0) add_span(xstart, xend);
+                     xstart = -1;
+                  }
+                  else if (xstart < 0) xstart = xend;
+               }
+            }
+         }
+         if (__ballot(ovf)) bad = true;
+         SMR_WAVE_SYNC();
+
+         /* ---- exact rows: lane = (row, edge slot), all four rows at once (k_raster's form of libcairo's cell_list_render_edge) ---- */
+         if (full_bits && !bad)
+         {
+            const int grp = lane >> 4, es = lane & 15, row = grp;
+            const uint32_t my_n = grp == 0 ? rowcnt[0] : grp == 1 ? rowcnt[1] : grp == 2 ? rowcnt[2] : rowcnt[3];
+            uint32_t nmax = 0;
+#pragma unroll
+            for (int k = 0; k < SMR_TH; k++) if ((full_bits >> k) & 1u) nmax = max(nmax, rowcnt[k]);
+            const bool onr = ((full_bits >> row) & 1u) && (uint32_t) es < my_n;
+            const int rs0 = ysbase + row * SMR_GRID_Y;
+            int32_t c0 = 0, c1 = 0, dir = 0, D = 1, q1 = 0, r1 = 0, q2 = 0, r2 = 0, dxs = 0;
+            if (onr)
+            {
+               const int *re = L.redge[row][es];
+               const int p1x = re[0], p1y = re[1];
+               dxs = re[2]; D = re[3]; dir = re[4];
+               const int64_t ec = 256 - 30ll * p1y;
+               const double inv = smr_rcp((double) D);
+               smr_edge_qr(ec, 2 * dxs, D, inv, rs0, q1, r1);
+               smr_edge_qr(ec, 2 * dxs, D, inv, rs0 + SMR_GRID_Y, q2, r2);
+               const int64_t nn = (int64_t) dxs * 1024;
+               int64_t dq = (int64_t) trunc((double) nn * inv);
+               int64_t dr = nn - dq * D;
+               if (nn >= 0) { if (dr < 0) { dq--; dr += D; } else if (dr >= D) { dq++; dr -= D; } }
+               else { if (dr > 0) { dq++; dr -= D; } else if (dr <= -(int64_t) D) { dq--; dr += D; } }
+               const int32_t hq = (int32_t) (dq / 2), hr = (int32_t) (dr / 2);
+               q1 += p1x; q2 += p1x;
+               c0 = q1 + (r1 >= (D >> 1) ? 1 : 0); c1 = q2 + (r2 >= (D >> 1) ? 1 : 0);
+               /* step back from the sample location (half a sub-row) to the row boundary */
+               q1 -= hq; r1 -= hr;
+               if (r1 < 0) { --q1; r1 += D; } else if (r1 >= D) { ++q1; r1 -= D; }
+               q2 -= hq; r2 -= hr;
+               if (r2 < 0) { --q2; r2 += D; } else if (r2 >= D) { ++q2; r2 -= D; }
+               q1 -= X0; q2 -= X0;
+            }
+            /* position in the row's (cell, next cell) order, winding before me, neighbours' cells */
+            int wsum = 0, pred_c0 = INT32_MIN, succ_c0 = INT32_MAX;
+            bool has_pred = false, has_succ = false;
+            for (uint32_t j = 0; j < nmax; j++)
+            {
+               const int src = (lane & 48) + (int) j;
+               const int kc0 = __shfl(c0, src), kc1 = __shfl(c1, src), kdir = __shfl(dir, src);
+               if (j < my_n && (int) j != es)
+               {
+                  const bool before = kc0 < c0 || (kc0 == c0 && (kc1 < c1 || (kc1 == c1 && (int) j < es)));
+                  if (before) { wsum += kdir; pred_c0 = max(pred_c0, kc0); has_pred = true; }
+                  else { succ_c0 = min(succ_c0, kc0); has_succ = true; }
+               }
+            }
+            const int wincl = wsum + dir;
+            /* every edge of the primitive is here, so libcairo's own rule applies: a span starts at the first edge after the
+             * last span's end and ends where the winding returns to zero and the next edge lies in another cell, at the
+             * row's last edge at the latest */
+            const bool is_start = onr && (!has_pred || (((uint32_t) wsum & wmask) == 0 && pred_c0 != c0));
+            const bool is_end = onr && !is_start && (!has_succ || (((uint32_t) wincl & wmask) == 0 && succ_c0 != c0));
+            bool oob = false;
+            if (is_start || is_end)
+            {
+               const int sgn = is_start ? 1 : -1;
+               int ix1 = (int) (q1 >> 8), ix2 = (int) (q2 >> 8), fx1 = q1 & 255, fx2 = q2 & 255;
+               if (ix1 == ix2)
+               {
+                  if ((uint32_t) ix1 >= (uint32_t) SMR_CV_WC) oob = true;
+                  else atomicAdd(&L.cell[row][ix1], smr_delta_pack(sgn * SMR_GRID_Y, sgn * (fx1 + fx2) * SMR_GRID_Y));
+               }
+               else
+               {
+                  int32_t qa = q1, ra = r1, qb = q2, rb = r2;
+                  if (ix2 < ix1)
+                  {
+                     int t = ix1; ix1 = ix2; ix2 = t;
+                     t = fx1; fx1 = fx2; fx2 = t;
+                     qa = q2; ra = r2; qb = q1; rb = r1;
+                  }
+                  if (ix1 < 0 || ix2 >= SMR_CV_WC) oob = true;
+                  else
+                  {
+                     const int64_t dx = (int64_t) (qb - qa) * D + (rb - ra);
+                     const int64_t tmp0 = ((int64_t) (256 - fx1) * D - ra) * SMR_GRID_Y;
+                     const int64_t step = (int64_t) (SMR_GRID_Y * 256) * D;
+                     const double inv = smr_rcp(smr_i64_to_f64(dx));
+                     auto Y = [&](int cell) -> int
+                     {
+                        const int64_t n = tmp0 + (int64_t) (cell - ix1) * step;
+                        int y = (int) (smr_i64_to_f64(n) * inv);
+                        int64_t rem = n - (int64_t) y * dx;
+                        if (rem < 0) y--; else if (rem >= dx) y++;
+                        return y;
+                     };
+                     int ylast = 0;
+                     for (int k = ix1; k <= ix2; k++)
+                     {
+                        const int yhi = k == ix2 ? SMR_GRID_Y : Y(k);
+                        const int cov = yhi - ylast;
+                        const int fac = k == ix1 ? 256 + fx1 : k == ix2 ? fx2 : 256;
+                        if (cov) atomicAdd(&L.cell[row][k], smr_delta_pack(sgn * cov, sgn * cov * fac));
+                        ylast = yhi;
+                     }
+                  }
+               }
+            }
+            if (__ballot(oob)) bad = true;
+         }
+         SMR_WAVE_SYNC();
+
+         /* ---- the cells that are not zero, row by row, ascending x ---- */
+         uint32_t cnt_r[SMR_TH], ntot = 0;
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++)
+         {
+            cnt_r[r] = 0;
+            if (!(((partial | full_bits) >> r) & 1u)) continue;
+            for (int xb = 0; xb < wp; xb += 64) cnt_r[r] += (uint32_t) __popcll(__ballot(xb + lane < wp && L.cell[r][xb + lane] != 0));
+            if (cnt_r[r] > 255u) bad = true;
+            ntot += cnt_r[r];
+         }
+         uint32_t dbase = 0;
+         if (!bad && ntot)
+         {
+            if (ntot > dleft)
+            {
+               const uint32_t take = ntot > SMR_CV_DBLOCK / 4 ? ntot : SMR_CV_DBLOCK;
+               uint32_t b = 0;
+               if (lane == 0) b = atomicAdd(&A.ctr[1], take);
+               b = __builtin_amdgcn_readfirstlane(b);
+               if ((uint64_t) b + take > A.delta_cap) bad = true;
+               else if (take == ntot) dbase = b;
+               else { dpos = b; dleft = take; dbase = dpos; dpos += ntot; dleft -= ntot; }
+            }
+            else { dbase = dpos; dpos += ntot; dleft -= ntot; }
+         }
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++)
+         {
+            if (!(((partial | full_bits) >> r) & 1u)) continue;
+            uint32_t run = dbase;
+            for (int xb = 0; xb < wp; xb += 64)
+            {
+               const int v = xb + lane < wp ? L.cell[r][xb + lane] : 0;
+               const unsigned long long nz = __ballot(v != 0);
+               if (v != 0)
+               {
+                  L.cell[r][xb + lane] = 0;
+                  if (!bad) { smr_delta_t d; d.x = cx0 + xb + lane; d.ca = v; A.deltas[run + __popcll(nz & lt_mask)] = d; }
+               }
+               run += (uint32_t) __popcll(nz);
+            }
+            if (!bad && lane == 0) A.drows[rbase + (uint32_t) (crow + r - dr0)] = make_uint2(dbase, cnt_r[r]);
+            dbase = run;
+         }
+         SMR_WAVE_SYNC();
+      }
+      if (bad) { n_left++; continue; }
+      if (lane == 0) { A.prims[p].flags = P.flags | SMR_PF_DELTA; A.prims[p].drow_off = rbase; }
+      n_done++;
+   }
+   }
+   if (lane == 0) { if (n_done) atomicAdd(&A.ctr[3], n_done); if (n_left) atomicAdd(&A.ctr[4], n_left); }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -3193,6 +3496,13 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
 
 /* most edge slots of one tile the second raster pass is given lists for; SMR_HIP_DEBUG_BIG_SLOTS lowers it so that a test can
  * reach the pass's clean failure (a real chart would need a 64x4-px tile with 16 384 entries) */
+/* SMR_HIP_COVER=0 leaves every primitive to k_raster's own scan conversion (diagnostics, A/B timing) */
+static bool smr_cover_enabled()
+{
+   const char *e = getenv("SMR_HIP_COVER");
+   return !(e && *e == '0');
+}
+
 static uint64_t big_slots_max()
 {
    const char *e = getenv("SMR_HIP_DEBUG_BIG_SLOTS");
@@ -3550,6 +3860,32 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       return smr_fail(SMR_E_CAPACITY, "draw: more than %d edges of one primitive span a vertex-free pixel row", SMR_ROWCAP);
    T.mark(s);                                                   /* 2: primitives set up */
 
+   /* coverage of the small primitives, primitive by primitive (k_cover): what it manages carries SMR_PF_DELTA from here on.
+    * Not for a compound (its members' items carry the compound's id), not on the second attempt of a pass */
+   smr_delta_t *deltas = nullptr;
+   uint2 *drows = nullptr;
+   uint32_t *cvctr = &small[40];
+   if (mode != SMR_PASS_COMPOUND && !c->strict_rows && smr_cover_enabled())
+   {
+      const uint64_t stroke_slots = n_edges - (st->fill_used ? (uint64_t) n_refs : 0);
+      /* cells per edge slot, measured on C2: 2 for strokes, 6 for fills; the row table: the primitive's rows.  An arena that
+       * runs out leaves the remaining primitives to k_raster's own path */
+      uint64_t dcap = 3 * stroke_slots + (st->fill_used ? 8ull * (uint64_t) n_refs : 0) + (1u << 20);
+      uint64_t rcap = 64ull * (uint64_t) n_prims + (1u << 20);
+      if (dcap > 0xfffffff0ull) dcap = 0xfffffff0ull;
+      if (rcap > 0xfffffff0ull) rcap = 0xfffffff0ull;
+      SMR_TRY(c->ensure(SMR_BUF_DELTAS, (size_t) dcap * sizeof(smr_delta_t), (void **) &deltas));
+      SMR_TRY(c->ensure(SMR_BUF_DROWS, (size_t) rcap * sizeof(uint2), (void **) &drows));
+      cover_args_t CV;
+      CV.prims = prims; CV.n_prims = (uint32_t) n_prims; CV.edges = edges; CV.mask = maskbuf;
+      CV.deltas = deltas; CV.delta_cap = (uint32_t) dcap; CV.drows = drows; CV.drow_cap = (uint32_t) rcap;
+      CV.ctr = cvctr; CV.band_y0 = c->band_y0; CV.band_h = c->band_h;
+      const unsigned nwg = (unsigned) std::min<int64_t>((n_prims + SMR_CV_CHUNK * SMR_CV_WAVES - 1) / (SMR_CV_CHUNK * SMR_CV_WAVES), 256 * 5);
+      k_cover<<<nwg, 64 * SMR_CV_WAVES, 0, s>>>(CV);
+      SMR_HIP(hipGetLastError());
+   }
+   T.mark(s);                                                   /* 3: small primitives covered */
+
    /* binning */
    uint32_t *counts, *tile_off, *sums;
    const uint32_t nb_scan = (n_tiles + SCAN_B - 1) / SCAN_B;
@@ -3580,14 +3916,14 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    {
       sort_args_t SO;
       SO.tile_off = tile_off; SO.entries = entries; SO.items = items; SO.prims = prims; SO.mask = maskbuf; SO.first_prim = &small[1];
-      SO.hdrs = hdrs; SO.n_tiles = n_tiles; SO.TX = TX; SO.band_y0 = c->band_y0;
+      SO.hdrs = hdrs; SO.n_tiles = n_tiles; SO.TX = TX; SO.band_y0 = c->band_y0; SO.band_h = c->band_h; SO.drows = drows;
       uint32_t cap = 64;
       while (cap < h_small[7] && cap < SORT_LDS) cap <<= 1;       /* h_small[7]: entries of the fullest tile (k_scan_block) */
       SO.lds_cap = cap;
       k_tile_sort<<<(n_tiles + SORT_WAVES - 1) / SORT_WAVES, 64 * SORT_WAVES, (size_t) SORT_WAVES * cap * 4, s>>>(SO);
    }
    SMR_HIP(hipGetLastError());
-   T.mark(s);                                                   /* 3: binned + sorted */
+   T.mark(s);                                                   /* 4: binned + sorted */
 
    /* A copy of the canvas is taken when the pass may have to be undone: rows of strokes with more spanning edges than one
     * tile's exact path holds (below), and a tile with so many entries that its lists might not fit the second
@@ -3603,7 +3939,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    A.n_tiles = n_tiles;
    A.chunk = n_entries >= 8ull * n_tiles ? SMR_TILE_CHUNK : n_entries >= 2ull * n_tiles ? 2 * SMR_TILE_CHUNK : 4 * SMR_TILE_CHUNK;
    A.direct = st->direct != 0;
-   A.ovf_list = ovf_list; A.ovf_cnt = &small[8]; A.ovf_n = 0; A.big_bucket = nullptr; A.big_cap = 0;
+   A.ovf_list = ovf_list; A.ovf_cnt = &small[8]; A.ovf_n = 0; A.big_bucket = nullptr; A.big_cap = 0; A.deltas = deltas;
    {
       /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
       unsigned nwg = std::min<unsigned>((n_tiles + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES, 256u * 8u);
@@ -3644,7 +3980,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
       SMR_HIP(hipStreamSynchronize(s));
    }
-   T.mark(s);                                                   /* 4: rastered */
+   T.mark(s);                                                   /* 5: rastered */
 #ifdef SMR_COUNT_PROFILE
    {
       unsigned long long pr[24];
@@ -3667,8 +4003,11 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    if (smr_g.profiling)
    {
       smr_timings_t &t = smr_g.last;
-      t.edges_ms = T.ms(0, 1); t.prims_ms = T.ms(1, 2); t.bin_ms = T.ms(2, 3); t.raster_ms = T.ms(3, 4); t.total_ms = T.ms(0, 4);
+      t.edges_ms = T.ms(0, 1); t.prims_ms = T.ms(1, 2); t.cover_ms = T.ms(2, 3); t.bin_ms = T.ms(3, 4); t.raster_ms = T.ms(4, 5); t.total_ms = T.ms(0, 5);
       t.n_prims = (uint64_t) n_prims; t.n_edges = n_edges; t.n_tile_refs = n_entries; t.n_tiles = n_tiles;
+      uint32_t cv[5] = { 0, 0, 0, 0, 0 };
+      if (deltas) hipMemcpy(cv, cvctr, sizeof(cv), hipMemcpyDeviceToHost);
+      t.n_deltas = cv[1]; t.n_cover_prims = cv[3]; t.n_cover_left = cv[4];
    }
    if (h_small[2] & (SMR_ST_ROWCAP | SMR_ST_BUCKET_OVERFLOW))
    {

@@ -66,7 +66,8 @@ class _CapBatch(C.Structure):
 class Timings(C.Structure):
     _fields_ = [("proj_ms", C.c_float), ("edges_ms", C.c_float), ("prims_ms", C.c_float), ("bin_ms", C.c_float),
                 ("raster_ms", C.c_float), ("caprot_ms", C.c_float), ("total_ms", C.c_float),
-                ("n_prims", C.c_uint64), ("n_edges", C.c_uint64), ("n_tile_refs", C.c_uint64), ("n_tiles", C.c_uint64)]
+                ("n_prims", C.c_uint64), ("n_edges", C.c_uint64), ("n_tile_refs", C.c_uint64), ("n_tiles", C.c_uint64),
+                ("cover_ms", C.c_float), ("n_cover_prims", C.c_uint32), ("n_cover_left", C.c_uint32), ("n_deltas", C.c_uint32)]
 
 
 # every symbol include/smr_hip.h declares (tests/test_abi.py checks the list against the header)
