@@ -919,6 +919,16 @@ __global__ void k_color_pixels(const uint32_t *__restrict__ col, int64_t n, uint
  * ascend in drawing order (way, border before fill, chunk).                               */
 /* ------------------------------------------------------------------------------------ */
 #ifndef SMR_LONGCAP
+/* k_cover (below): which primitives it takes, and what its arenas must hold for them (k_prim_setup adds it up) */
+#define SMR_CV_WC 128                              /* cells per row, one guard cell on either side included */
+#define SMR_CV_SL 16                               /* edges spanning one vertex-free row */
+#define SMR_CV_MAXSLOTS 1024u
+#define SMR_CV_MAXGROUPS (SMR_CV_MAXSLOTS / 64u)
+#define SMR_CV_WAVES 4
+#define SMR_CV_DBLOCK 4096u                        /* alpha words a wavefront takes from the arena with one atomic */
+#define SMR_CV_RBLOCK 1024u                        /* strip-table entries likewise */
+#define SMR_CV_CHUNK 8u                            /* primitives a wavefront takes from the queue with one atomic */
+
 #define SMR_LONGCAP 256      /* edges spanning a whole pixel row, kept in LDS per primitive */
 #endif
 #define SMR_ACTCAP 8         /* active edges per vertex-free row in the lane-per-row analysis */
@@ -954,6 +964,7 @@ struct setup_args_t
    const uint32_t *po_border, *po_dots, *po_open;      /* [n_ways+1] piece offsets; NULL: the plain layout */
    const uint32_t *id_off;                             /* [n_ways+1] in 8-slot groups; NULL: way_off */
    uint32_t scancap;                                   /* spanning edges per row the analysis of a stroke compares (smr_rowscan_t::cap) */
+   int band_y0, band_h;                                /* this canvas's rows (k_cover's arenas are sized for them) */
    uint32_t *biglist;                                  /* long primitives, left to the k_big_* kernels ([0] = their number, then (id, first item)) */
    struct smr_bigacc_t *bigacc;                        /* [biglist entry] what those kernels need of them */
 };
@@ -1313,7 +1324,8 @@ struct smr_rowscan_t
 #define SMR_MASK_BLOCK 2048u   /* words a wavefront takes from the mask arena with one atomic */
 
 __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const int64_t p, const int lane, setup_lds_t &L, uint32_t *lmask,
-                                                   uint32_t &arena_pos, uint32_t &arena_left, uint32_t &first_valid)
+                                                   uint32_t &arena_pos, uint32_t &arena_left, uint32_t &first_valid,
+                                                   unsigned long long &need_alpha, uint32_t &need_strips)
 {
    const int64_t w = p / A.K;
    const int kind = (int) (p - w * A.K);
@@ -1476,6 +1488,18 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    P.mask_off = moff;
    if (lane == 0) A.prims[p] = P;
    first_valid = min(first_valid, A.compound != 0xffffffffu ? A.compound : (uint32_t) p);
+   /* what k_cover will need for this primitive at most: one alpha word per column of its box and strip of four rows */
+   if (A.compound == 0xffffffffu && P.edge_cnt <= SMR_CV_MAXSLOTS)
+   {
+      const int wp = (P.maxx >> 8) - (P.minx >> 8) + 3;
+      const int dr0 = max(P.row0, A.band_y0), dr1 = min(P.row0 + P.nrows, A.band_y0 + A.band_h);
+      if (wp <= SMR_CV_WC && dr1 > dr0)
+      {
+         const int first = A.band_y0 + ((dr0 - A.band_y0) & ~(SMR_TH - 1));
+         const uint32_t nstrips = (uint32_t) ((dr1 - 1 - first) >> 2) + 1u;
+         need_alpha += (unsigned long long) nstrips * (uint32_t) wp; need_strips += nstrips;
+      }
+   }
 }
 
 #ifndef SMR_SETUP_WAVES
@@ -1490,7 +1514,8 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_
    extern __shared__ uint32_t lmask_all[];         /* [SMR_SETUP_WAVES][mask_words] */
    __shared__ setup_lds_t LL[SMR_SETUP_WAVES];
    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      /* uniform: keeps the loop control in SGPRs */
-   uint32_t arena_pos = 0, arena_left = 0, first_valid = 0xffffffffu;
+   uint32_t arena_pos = 0, arena_left = 0, first_valid = 0xffffffffu, need_strips = 0;
+   unsigned long long need_alpha = 0;
    /* XCD x takes the chunks x, x + 8, ... of `chunk` consecutive primitives (workgroups b and b+8 share an XCD), one chunk per
     * atomic: borders cost several times what fills do and a contour line thousands of times what an island does, so a static
     * share leaves most wavefronts waiting for the slowest */
@@ -1506,11 +1531,12 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_prim_setup(setup_args_
       const int64_t p1 = min(p0 + chunk, nprim);
       for (int64_t p = p0; p < p1; p++)
       {
-         smr_prim_setup_one(A, p, lane, LL[wv], lmask_all + (size_t) wv * mask_words, arena_pos, arena_left, first_valid);
+         smr_prim_setup_one(A, p, lane, LL[wv], lmask_all + (size_t) wv * mask_words, arena_pos, arena_left, first_valid, need_alpha, need_strips);
          SMR_WAVE_SYNC();
       }
    }
    if (lane == 0 && first_valid != 0xffffffffu) atomicMin(&A.small[1], first_valid);
+   if (lane == 0 && need_strips) { atomicAdd(&A.small[11], need_strips); atomicAdd((unsigned long long *) (A.small + 12), need_alpha); }
 }
 
 /* ---- long primitives, step 1: items and boxes.  The items of all long primitives are dealt round robin to the wavefronts
@@ -1911,7 +1937,7 @@ struct sort_args_t
    uint32_t n_tiles;
    uint32_t lds_cap;          /* entries of one tile that fit its wavefront's share of LDS (a power of two up to SORT_LDS) */
    int TX, band_y0, band_h;
-   const uint2 *drows;        /* k_cover's row table (primitives with SMR_PF_DELTA) */
+   const uint2 *drows;        /* k_cover's strip table (primitives with SMR_PF_DELTA) */
 };
 
 /* SORT_WAVES independent wavefronts per workgroup, one tile each (a chart of 4 M tiles is 4 M one-wave workgroups otherwise,
@@ -2011,21 +2037,13 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
       h.dcounts = 0;
       if (P.flags & SMR_PF_DELTA)
       {
-         /* k_cover has the primitive's cells: the entry names those of the tile's four rows (consecutive in the arena: the
-          * passes of k_cover start on tile rows) */
-         const int dr0 = max(P.row0, A.band_y0), dn = min(P.row0 + P.nrows, A.band_y0 + A.band_h) - dr0;
-         uint32_t start = 0xffffffffu, counts = 0;
-#pragma unroll
-         for (int r = 0; r < SMR_TH; r++)
-         {
-            const int rr = row0 + r - dr0;
-            if (rr >= 0 && rr < dn)
-            {
-               const uint2 d = A.drows[P.drow_off + (uint32_t) rr];
-               if (d.y) { start = min(start, d.x); counts |= d.y << (8 * r); }
-            }
-         }
-         h.edge_off = counts ? start : 0u; h.dcounts = counts; h.cnt_flags |= SMR_PF_DELTA << 8;
+         /* k_cover has the primitive's alpha: the entry names the words of the tile's strip (k_cover's strips start on tile rows) */
+         const int dr0 = max(P.row0, A.band_y0), dr1 = min(P.row0 + P.nrows, A.band_y0 + A.band_h);
+         const int first = A.band_y0 + ((dr0 - A.band_y0) & ~(SMR_TH - 1));
+         const int sidx = (row0 - first) >> 2, nstrips = ((dr1 - 1 - first) >> 2) + 1;
+         uint2 d = make_uint2(0u, 0u);
+         if (row0 >= first && sidx < nstrips) d = A.drows[P.drow_off + (uint32_t) sidx];
+         h.edge_off = d.x; h.dcounts = d.y; h.cnt_flags |= SMR_PF_DELTA << 8;
       }
       A.hdrs[beg + i] = h;
       if (in_lds && n >= 2) A.entries[beg + i] = idx;
@@ -2053,7 +2071,7 @@ struct raster_args_t
    uint32_t *ovf_list;        /* [n_tiles] */
    uint32_t *ovf_cnt;         /* [0] tiles queued, [1] most entries of one of them */
    uint32_t ovf_n;            /* k_raster<true>: tiles in the list */
-   const smr_delta_t *deltas; /* k_cover's cells (entries with SMR_PF_DELTA) */
+   const uint32_t *alpha;     /* k_cover's alpha words (entries with SMR_PF_DELTA) */
    uint32_t *big_bucket;      /* k_raster<true>: [wavefront][big_cap][64 lanes] */
    uint32_t big_cap;          /* entries per sub-row (a crossing takes one, an interval two) */
 };
@@ -2307,10 +2325,11 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             const uint32_t eo = __builtin_amdgcn_readlane(hb0.x, j), cf = __builtin_amdgcn_readlane(hb0.z, j);
             if (cf & (SMR_PF_DELTA << 8))
             {
-               /* the first 64 cells of the tile's rows instead of edge slots */
-               const uint32_t dc = __builtin_amdgcn_readlane(hb1.w, j);
-               const uint32_t tot = (dc & 0xffu) + ((dc >> 8) & 0xffu) + ((dc >> 16) & 0xffu) + (dc >> 24);
-               if ((uint32_t) lane < tot) { const smr_delta_t d = A.deltas[(size_t) eo + lane]; e.x1 = d.x; e.y1 = d.ca; }
+               /* this column's alpha word of the strip instead of an edge slot; the other items of a primitive bring nothing */
+               const uint32_t info = __builtin_amdgcn_readlane(hb1.w, j);
+               const bool again = j > 0 && __builtin_amdgcn_readlane(hb0.y, j) == __builtin_amdgcn_readlane(hb0.y, j - 1);
+               const uint32_t i = (uint32_t) (tx * SMR_TW + lane - smr_strip_x0(info));
+               if (!again && i < smr_strip_n(info)) e.x1 = (int32_t) A.alpha[(size_t) eo + i];
             }
             else if ((uint32_t) lane < (cf & 0xffu)) e = A.edges[(size_t) eo + lane];
          }
@@ -2325,7 +2344,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
          const smr_edge_t my_edge = edge1;
          smr_item_t it;
          it.prim = 0xffffffffu; it.cnt_flags = 0; it.edge_off = 0; it.color = 0;
-         uint32_t it_rowbits = 0, it_dcounts = 0; int it_colmin = 0, it_colmax = -1;
+         uint32_t it_rowbits = 0; int it_colmin = 0, it_colmax = -1;
          if (ei < end)
          {
             const int j = (int) (ei - bbase);
@@ -2333,7 +2352,6 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             it.cnt_flags = __builtin_amdgcn_readlane(hb0.z, j); it.color = __builtin_amdgcn_readlane(hb0.w, j);
             it_rowbits = __builtin_amdgcn_readlane(hb1.x, j);
             it_colmin = (int) __builtin_amdgcn_readlane(hb1.y, j); it_colmax = (int) __builtin_amdgcn_readlane(hb1.z, j);
-            it_dcounts = __builtin_amdgcn_readlane(hb1.w, j);
             if (ei + 1 == bbase + 64) { bbase += 64; load_batch(); }
             edge1 = load_edge(ei + 1);
          }
@@ -2658,26 +2676,23 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             cur_colmin = it_colmin; cur_colmax = it_colmax; cur_first = (it.cnt_flags >> 16) & 1u;
             if (cur_flags & SMR_PF_DELTA)
             {
-               /* k_cover has run the scan converter over this primitive: the cells of the tile's rows, ascending x row by row,
-                * go into the tile's accumulators (every cell once: plain stores; the covers left of the tile add up) */
+               /* k_cover has run the scan converter over this primitive: the lane holds its column's alpha of the four rows */
                COUNT(18);
-               partial = 0;                  /* nothing for the flush to convert */
-               const uint32_t c0 = it_dcounts & 0xffu, c1 = c0 + ((it_dcounts >> 8) & 0xffu), c2 = c1 + ((it_dcounts >> 16) & 0xffu), tot = c2 + (it_dcounts >> 24);
-               touched = tot != 0;
-               for (uint32_t base = 0; base < tot; base += 64)
+               partial = 0;
+               const uint32_t a4 = (uint32_t) my_edge.x1;
+               if (__ballot(a4 != 0))
                {
-                  const uint32_t i = base + lane;
-                  int dx = my_edge.x1, dca = my_edge.y1;
-                  if (base && i < tot) { const smr_delta_t d = A.deltas[(size_t) it.edge_off + i]; dx = d.x; dca = d.ca; }
-                  if (i < tot)
+                  const uint32_t spix = cur_color;
+                  const bool lerp = (spix >> 24) == 255u || (cur_first && !A.direct);
+#pragma unroll
+                  for (int r = 0; r < SMR_TH; r++)
                   {
-                     const int row = (i >= c0 ? 1 : 0) + (i >= c1 ? 1 : 0) + (i >= c2 ? 1 : 0);
-                     const int ix = dx - tx * SMR_TW;
-                     if (ix < 0) atomicAdd(&L.left[row], smr_delta_cover(dca));
-                     else if (ix < SMR_TW) { L.cover[row][ix] = smr_delta_cover(dca); L.uarea[row][ix] = smr_delta_area(dca); }
+                     const uint32_t a = (a4 >> (8 * r)) & 255u;
+                     if (!__ballot(a != 0)) continue;
+                     if (lerp && !__ballot(a != 255u && a != 0)) layer[r] = a ? spix : layer[r];      /* no edge pixel on the row */
+                     else if (a) layer[r] = lerp ? smr_blend_lerp(spix, a, layer[r]) : smr_blend_over_mask(spix, a, layer[r]);
                   }
                }
-               SMR_WAVE_SYNC();
             }
          }
          if (cur_flags & SMR_PF_DELTA) continue;       /* (further items of the same primitive bring nothing) */
@@ -2792,29 +2807,21 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
  * tile needs of a primitive's row only those cells: the ones inside it, and the sum of the covers left of it.  So for every
  * primitive that is small enough (at most SMR_CV_MAXSLOTS edge slots, 126 px wide) ONE wavefront runs the scan converter over
  * the primitive's own rows, four at a time with k_raster's own crossing loop (raster_cross.inc: lanes = the 60 sub-rows), and
- * writes per row the cells that are not zero (smr_delta_t, ascending x); k_raster's work for such a primitive in a tile is to
- * read the rows' cells and to composite.
+ * turns the cells into alpha right there (prefix sum of cover, libcairo's area-to-alpha, the primitive's pixel extents): per strip
+ * one word per column with the four rows' alpha.  k_raster's work for such a primitive in a tile is to read its column's word and
+ * to blend.
  * Anything that does not fit (lists, arenas, cell range) leaves the primitive to k_raster's own path: never an error. */
-#define SMR_CV_WC 128                              /* cells per row, one guard cell on either side included */
-#define SMR_CV_SL 16                               /* edges spanning one vertex-free row */
-#define SMR_CV_MAXSLOTS 1024u
-#define SMR_CV_MAXGROUPS (SMR_CV_MAXSLOTS / 64u)
-#define SMR_CV_WAVES 4
-#define SMR_CV_DBLOCK 4096u                        /* deltas a wavefront takes from the arena with one atomic */
-#define SMR_CV_RBLOCK 1024u                        /* row-table entries likewise */
-#define SMR_CV_CHUNK 8u                            /* primitives a wavefront takes from the queue with one atomic */
-
 struct cover_args_t
 {
    smr_prim_t *prims;
    uint32_t n_prims;
    const smr_edge_t *edges;
    const uint32_t *mask;
-   smr_delta_t *deltas;
-   uint32_t delta_cap;
-   uint2 *drows;              /* per (primitive, row): first delta, number of deltas */
+   uint32_t *alpha;           /* per strip of four rows and column: the rows' alpha, one byte each */
+   uint32_t alpha_cap;
+   uint2 *drows;              /* per (primitive, strip): first alpha word, smr_strip_pack(first column, words) */
    uint32_t drow_cap;
-   uint32_t *ctr;             /* [0] next primitive [1] deltas taken [2] rows taken [3] primitives done [4] primitives left to k_raster */
+   uint32_t *ctr;             /* [0] next primitive [1] alpha words taken [2] strips taken [3] primitives done [4] primitives left to k_raster */
    int band_y0, band_h;
 };
 
@@ -2862,7 +2869,6 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
 #ifdef SMR_CV_ONLY
       if (((P.flags & SMR_PF_PIECES) != 0) != (SMR_CV_ONLY == 2)) { n_left++; continue; }
 #endif
-      const int dn = dr1 - dr0;
       const int32_t X0 = cx0 * 256, X1 = X0 + SMR_CV_WC * 256;
       const smr_edge_t *E = A.edges + P.edge_off;
       const uint32_t ngroups = (P.edge_cnt + 63u) >> 6;
@@ -2870,19 +2876,21 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
       const bool pieces = (P.flags & SMR_PF_PIECES) != 0;
       bool bad = false;                                    /* uniform */
 
-      /* the primitive's rows in the row table */
+      /* the primitive's strips in the strip table */
+      const int cr_first = A.band_y0 + ((dr0 - A.band_y0) & ~(SMR_TH - 1));
+      const uint32_t nstrips = (uint32_t) ((dr1 - 1 - cr_first) >> 2) + 1u;
       uint32_t rbase;
-      if ((uint32_t) dn > rleft)
+      if (nstrips > rleft)
       {
-         const uint32_t take = (uint32_t) dn > SMR_CV_RBLOCK / 4 ? (uint32_t) dn : SMR_CV_RBLOCK;
+         const uint32_t take = nstrips > SMR_CV_RBLOCK / 4 ? nstrips : SMR_CV_RBLOCK;
          uint32_t b = 0;
          if (lane == 0) b = atomicAdd(&A.ctr[2], take);
          b = __builtin_amdgcn_readfirstlane(b);
          if ((uint64_t) b + take > A.drow_cap) { n_left++; continue; }
-         if (take == (uint32_t) dn) rbase = b;
-         else { rpos = b; rleft = take; rbase = rpos; rpos += dn; rleft -= dn; }
+         if (take == nstrips) rbase = b;
+         else { rpos = b; rleft = take; rbase = rpos; rpos += nstrips; rleft -= nstrips; }
       }
-      else { rbase = rpos; rpos += dn; rleft -= dn; }
+      else { rbase = rpos; rpos += nstrips; rleft -= nstrips; }
 
       /* one group of 64 slots stays in registers; of several, each group's sub-row extent decides which strips read it */
       smr_edge_t e0; e0.x1 = e0.y1 = e0.x2 = e0.y2 = 0;
@@ -2901,7 +2909,6 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
          SMR_WAVE_SYNC();
       }
 
-      const int cr_first = A.band_y0 + ((dr0 - A.band_y0) & ~(SMR_TH - 1));
       for (int crow = cr_first; crow < dr1 && !bad; crow += SMR_TH)
       {
          /* the strip's rows: sub-sampled (bit of the row mask set), exact (clear), or not the primitive's */
@@ -3161,52 +3168,70 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
          }
          SMR_WAVE_SYNC();
 
-         /* ---- the cells that are not zero, row by row, ascending x ---- */
-         uint32_t cnt_r[SMR_TH], ntot = 0;
+         /* ---- cells -> alpha (k_raster's flush: prefix sum of cover, area, libcairo's extents), the four rows of a column in
+          * one word; lane = column, two sweeps for a primitive wider than 64 cells ---- */
+         uint32_t a4[2] = { 0u, 0u };
 #pragma unroll
          for (int r = 0; r < SMR_TH; r++)
          {
-            cnt_r[r] = 0;
             if (!(((partial | full_bits) >> r) & 1u)) continue;
-            for (int xb = 0; xb < wp; xb += 64) cnt_r[r] += (uint32_t) __popcll(__ballot(xb + lane < wp && L.cell[r][xb + lane] != 0));
-            if (cnt_r[r] > 255u) bad = true;
-            ntot += cnt_r[r];
-         }
-         uint32_t dbase = 0;
-         if (!bad && ntot)
-         {
-            if (ntot > dleft)
+            int carry = 0;
+#pragma unroll
+            for (int h = 0; h < 2; h++)
             {
-               const uint32_t take = ntot > SMR_CV_DBLOCK / 4 ? ntot : SMR_CV_DBLOCK;
-               uint32_t b = 0;
-               if (lane == 0) b = atomicAdd(&A.ctr[1], take);
-               b = __builtin_amdgcn_readfirstlane(b);
-               if ((uint64_t) b + take > A.delta_cap) bad = true;
-               else if (take == ntot) dbase = b;
-               else { dpos = b; dleft = take; dbase = dpos; dpos += ntot; dleft -= ntot; }
+               if (h == 1 && wp <= 64) continue;
+               const int i = h * 64 + lane;
+               const int v = L.cell[r][i];
+               if (!__ballot(v != 0) && carry == 0) continue;
+               if (v) L.cell[r][i] = 0;
+               int c = smr_delta_cover(v);
+               const int ua = smr_delta_area(v);
+               c = (__ballot(c != 0) ? smr_wave_scan(c) : 0) + carry;
+               carry = __builtin_amdgcn_readlane(c, 63);
+               const int area = c * 512 - ua;
+               int a = (area + (area << 4) + 256) >> 9;
+               a = a < 0 ? 0 : a > 255 ? 255 : a;
+               if (i < 1 || i > wp - 2) a = 0;           /* libcairo composites inside the primitive's pixel extents only */
+               a4[h] |= (uint32_t) a << (8 * r);
             }
-            else { dbase = dpos; dpos += ntot; dleft -= ntot; }
          }
-#pragma unroll
-         for (int r = 0; r < SMR_TH; r++)
          {
-            if (!(((partial | full_bits) >> r) & 1u)) continue;
-            uint32_t run = dbase;
-            for (int xb = 0; xb < wp; xb += 64)
+            const unsigned long long m0 = __ballot(a4[0] != 0), m1 = __ballot(a4[1] != 0);
+            uint2 entry = make_uint2(0u, 0u);
+            if ((m0 | m1) && !bad)
             {
-               const int v = xb + lane < wp ? L.cell[r][xb + lane] : 0;
-               const unsigned long long nz = __ballot(v != 0);
-               if (v != 0)
+               const int xlo = m0 ? __ffsll((long long) m0) - 1 : 63 + __ffsll((long long) m1);
+               const int xhi = m1 ? 127 - __clzll((long long) m1) : 63 - __clzll((long long) m0);
+               const uint32_t n = (uint32_t) (xhi - xlo + 1);
+               uint32_t abase = 0;
+               if (n > dleft)
                {
-                  L.cell[r][xb + lane] = 0;
-                  if (!bad) { smr_delta_t d; d.x = cx0 + xb + lane; d.ca = v; A.deltas[run + __popcll(nz & lt_mask)] = d; }
+                  uint32_t b = 0;
+                  if (lane == 0) b = atomicAdd(&A.ctr[1], SMR_CV_DBLOCK);
+                  b = __builtin_amdgcn_readfirstlane(b);
+                  if ((uint64_t) b + SMR_CV_DBLOCK > A.alpha_cap) bad = true;
+                  else { dpos = b; dleft = SMR_CV_DBLOCK; }
                }
-               run += (uint32_t) __popcll(nz);
+               if (!bad)
+               {
+                  abase = dpos; dpos += n; dleft -= n;
+                  if (lane >= xlo && lane <= xhi) A.alpha[abase + (uint32_t) (lane - xlo)] = a4[0];
+                  if (lane + 64 >= xlo && lane + 64 <= xhi) A.alpha[abase + (uint32_t) (lane + 64 - xlo)] = a4[1];
+                  entry = make_uint2(abase, smr_strip_pack(cx0 + xlo, (int) n));
+               }
             }
-            if (!bad && lane == 0) A.drows[rbase + (uint32_t) (crow + r - dr0)] = make_uint2(dbase, cnt_r[r]);
-            dbase = run;
+            if (!bad && lane == 0) A.drows[rbase + (uint32_t) ((crow - cr_first) >> 2)] = entry;
          }
          SMR_WAVE_SYNC();
+      }
+      if (bad)
+      {
+         /* cells of the strip that failed may be left */
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++) { L.cell[r][lane] = 0; L.cell[r][lane + 64] = 0; }
+         SMR_WAVE_SYNC();
+         n_left++;
+         continue;
       }
       if (bad) { n_left++; continue; }
       if (lane == 0) { A.prims[p].flags = P.flags | SMR_PF_DELTA; A.prims[p].drow_off = rbase; }
@@ -3798,6 +3823,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       uint32_t *biglist;
       SMR_TRY(c->ensure(SMR_BUF_BIGLIST, ((size_t) n_prims * 2 + 2) * 4, (void **) &biglist));
       SMR_HIP(hipMemsetAsync(biglist, 0, 4, s));
+      SA.band_y0 = c->band_y0; SA.band_h = c->band_h;
       SA.biglist = biglist; SA.scancap = c->strict_rows ? SMR_ROWCAP : SMR_SCANCAP;
       /* a long primitive has at least SMR_BIG_SLOTS edge slots */
       smr_bigacc_t *bigacc;
@@ -3817,6 +3843,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       /* at least 8 takes per wavefront before the chunks grow: few primitives (a chart's 50 contour lines) go one by one */
       const int setup_chunk = (int) std::max<int64_t>(1, std::min<int64_t>(SMR_SETUP_CHUNK, n_prims / ((int64_t) setup_wg * SMR_SETUP_WAVES * 8)));
       SMR_HIP(hipMemsetAsync(small + 128, 0, 256, s));           /* the set-up's queues start at zero on every attempt */
+      SMR_HIP(hipMemsetAsync(small + 11, 0, 12, s));             /* and so does its tally of what k_cover will need */
       k_prim_setup<<<setup_wg, 64 * SMR_SETUP_WAVES, (size_t) mask_words * 4 * SMR_SETUP_WAVES, s>>>(SA, mask_words, setup_chunk);
       SMR_HIP(hipGetLastError());
       SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
@@ -3862,25 +3889,26 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
 
    /* coverage of the small primitives, primitive by primitive (k_cover): what it manages carries SMR_PF_DELTA from here on.
     * Not for a compound (its members' items carry the compound's id), not on the second attempt of a pass */
-   smr_delta_t *deltas = nullptr;
+   uint32_t *alpha = nullptr;
    uint2 *drows = nullptr;
    uint32_t *cvctr = &small[40];
-   if (mode != SMR_PASS_COMPOUND && !c->strict_rows && smr_cover_enabled())
+   if (mode != SMR_PASS_COMPOUND && !c->strict_rows && smr_cover_enabled() && h_small[11])
    {
-      const uint64_t stroke_slots = n_edges - (st->fill_used ? (uint64_t) n_refs : 0);
-      /* cells per edge slot, measured on C2: 2 for strokes, 6 for fills; the row table: the primitive's rows.  An arena that
-       * runs out leaves the remaining primitives to k_raster's own path */
-      uint64_t dcap = 3 * stroke_slots + (st->fill_used ? 8ull * (uint64_t) n_refs : 0) + (1u << 20);
-      uint64_t rcap = 64ull * (uint64_t) n_prims + (1u << 20);
-      if (dcap > 0xfffffff0ull) dcap = 0xfffffff0ull;
+      /* k_prim_setup has added up what the eligible primitives need at most (h_small[11] strips, h_small[12..13] alpha words);
+       * on top of it the blocks the wavefronts take and do not use up.  An arena that runs out (beyond 2^32 words) leaves the
+       * remaining primitives to k_raster's own path */
+      const unsigned nwg = (unsigned) std::min<int64_t>((n_prims + SMR_CV_CHUNK * SMR_CV_WAVES - 1) / (SMR_CV_CHUNK * SMR_CV_WAVES), 256 * 5);
+      uint64_t need_a = (uint64_t) h_small[12] | ((uint64_t) h_small[13] << 32);
+      uint64_t acap = need_a + (uint64_t) nwg * SMR_CV_WAVES * SMR_CV_DBLOCK + 65536;
+      uint64_t rcap = (uint64_t) h_small[11] + (uint64_t) nwg * SMR_CV_WAVES * SMR_CV_RBLOCK + 65536;
+      if (acap > 0xfffffff0ull) acap = 0xfffffff0ull;
       if (rcap > 0xfffffff0ull) rcap = 0xfffffff0ull;
-      SMR_TRY(c->ensure(SMR_BUF_DELTAS, (size_t) dcap * sizeof(smr_delta_t), (void **) &deltas));
+      SMR_TRY(c->ensure(SMR_BUF_DELTAS, (size_t) acap * 4, (void **) &alpha));
       SMR_TRY(c->ensure(SMR_BUF_DROWS, (size_t) rcap * sizeof(uint2), (void **) &drows));
       cover_args_t CV;
       CV.prims = prims; CV.n_prims = (uint32_t) n_prims; CV.edges = edges; CV.mask = maskbuf;
-      CV.deltas = deltas; CV.delta_cap = (uint32_t) dcap; CV.drows = drows; CV.drow_cap = (uint32_t) rcap;
+      CV.alpha = alpha; CV.alpha_cap = (uint32_t) acap; CV.drows = drows; CV.drow_cap = (uint32_t) rcap;
       CV.ctr = cvctr; CV.band_y0 = c->band_y0; CV.band_h = c->band_h;
-      const unsigned nwg = (unsigned) std::min<int64_t>((n_prims + SMR_CV_CHUNK * SMR_CV_WAVES - 1) / (SMR_CV_CHUNK * SMR_CV_WAVES), 256 * 5);
       k_cover<<<nwg, 64 * SMR_CV_WAVES, 0, s>>>(CV);
       SMR_HIP(hipGetLastError());
    }
@@ -3939,7 +3967,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    A.n_tiles = n_tiles;
    A.chunk = n_entries >= 8ull * n_tiles ? SMR_TILE_CHUNK : n_entries >= 2ull * n_tiles ? 2 * SMR_TILE_CHUNK : 4 * SMR_TILE_CHUNK;
    A.direct = st->direct != 0;
-   A.ovf_list = ovf_list; A.ovf_cnt = &small[8]; A.ovf_n = 0; A.big_bucket = nullptr; A.big_cap = 0; A.deltas = deltas;
+   A.ovf_list = ovf_list; A.ovf_cnt = &small[8]; A.ovf_n = 0; A.big_bucket = nullptr; A.big_cap = 0; A.alpha = alpha;
    {
       /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
       unsigned nwg = std::min<unsigned>((n_tiles + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES, 256u * 8u);
@@ -4006,7 +4034,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       t.edges_ms = T.ms(0, 1); t.prims_ms = T.ms(1, 2); t.cover_ms = T.ms(2, 3); t.bin_ms = T.ms(3, 4); t.raster_ms = T.ms(4, 5); t.total_ms = T.ms(0, 5);
       t.n_prims = (uint64_t) n_prims; t.n_edges = n_edges; t.n_tile_refs = n_entries; t.n_tiles = n_tiles;
       uint32_t cv[5] = { 0, 0, 0, 0, 0 };
-      if (deltas) hipMemcpy(cv, cvctr, sizeof(cv), hipMemcpyDeviceToHost);
+      if (alpha) hipMemcpy(cv, cvctr, sizeof(cv), hipMemcpyDeviceToHost);
       t.n_deltas = cv[1]; t.n_cover_prims = cv[3]; t.n_cover_left = cv[4];
    }
    if (h_small[2] & (SMR_ST_ROWCAP | SMR_ST_BUCKET_OVERFLOW))

@@ -30,23 +30,26 @@ struct __attribute__((aligned(16))) smr_prim_t
    uint32_t mask_off;        /* first word of the row mask in the mask arena */
    int32_t row0, nrows;      /* chart rows the mask covers; bit set = the row is sub-sampled (an edge starts or
                                 ends inside it, or edges cross in it), clear = libcairo's exact full-row path */
-   uint32_t drow_off;        /* SMR_PF_DELTA: first entry of the primitive's rows in the row table of k_cover */
+   uint32_t drow_off;        /* SMR_PF_DELTA: first entry of the primitive's strips in the strip table of k_cover */
    uint32_t pad_[3];
 };
 #define SMR_PF_VALID 1u
 #define SMR_PF_EVENODD 2u
 #define SMR_PF_PIECES 4u     /* every 4 aligned edge slots form one closed convex piece, all wound alike (strokes) */
 #define SMR_PF_MULTI 8u      /* the primitive has more than one item */
-#define SMR_PF_DELTA 16u     /* k_cover has worked out the primitive's coverage: per chart row the cells that differ from their left
-                                neighbour (smr_delta_t); k_raster only composites */
+#define SMR_PF_DELTA 16u     /* k_cover has worked out the primitive's coverage: per strip of four chart rows the alpha of every column
+                                (the four rows of a column in one word); k_raster only composites */
 
-/* one cell of a primitive's coverage of one chart row: cover and area as libcairo's tor scan converter accumulates them per
- * cell (cover in sub-rows, area in 1/512 cell units), packed as cover * 2^20 + area: |cover| <= 15 * 30 crossings and
- * |area| <= 15 * 30 * 510 by the limits of k_cover's lists, so both fit and the sum unpacks without loss */
-struct __attribute__((aligned(8))) smr_delta_t { int32_t x; int32_t ca; };
+/* k_cover accumulates per cell what libcairo's tor scan converter does: cover in sub-rows and area in 1/512 cell units, packed
+ * as cover * 2^20 + area in one word for the LDS atomics: |cover| <= 15 * 30 crossings and |area| <= 15 * 30 * 510 by the
+ * limits of k_cover's lists, so both fit and the sum unpacks without loss */
 __device__ __forceinline__ int smr_delta_area(int ca) { return (ca << 12) >> 12; }
 __device__ __forceinline__ int smr_delta_cover(int ca) { return (ca - smr_delta_area(ca)) >> 20; }
 __device__ __forceinline__ int smr_delta_pack(int dcover, int darea) { return (int) (((uint32_t) dcover << 20) + (uint32_t) darea); }
+/* one strip of a covered primitive: its alpha words start at column x0 (may be left of the chart) and there are n of them */
+__device__ __forceinline__ uint32_t smr_strip_pack(int x0, int n) { return (uint32_t) (x0 + 256) | ((uint32_t) n << 20); }
+__device__ __forceinline__ int smr_strip_x0(uint32_t info) { return (int) (info & 0xfffffu) - 256; }
+__device__ __forceinline__ uint32_t smr_strip_n(uint32_t info) { return info >> 20; }
 
 /* one item = up to 64 consecutive edge slots of one primitive: the unit that is binned to
  * tiles and that one wavefront loads with one 16-byte access per lane */
@@ -71,7 +74,7 @@ struct __attribute__((aligned(16))) smr_thdr_t
    uint32_t rowbits;         /* bits 0..3: the tile's rows that are sub-sampled for this primitive (row mask);
                                 bits 4..7: the tile's rows inside the primitive's pixel extents */
    int32_t colmin, colmax;   /* tile columns inside the primitive's pixel extents (may be outside 0..63) */
-   uint32_t dcounts;         /* SMR_PF_DELTA: deltas of the tile's four rows, one byte each; edge_off is then the first of them */
+   uint32_t dcounts;         /* SMR_PF_DELTA: smr_strip_pack of the tile's strip of the primitive; edge_off is then its first alpha word */
 };
 
 /* status word bits reported back to the host */
