@@ -924,7 +924,9 @@ __global__ void k_color_pixels(const uint32_t *__restrict__ col, int64_t n, uint
 #define SMR_CV_SL 16                               /* edges spanning one vertex-free row */
 #define SMR_CV_MAXSLOTS 1024u
 #define SMR_CV_MAXGROUPS (SMR_CV_MAXSLOTS / 64u)
+#ifndef SMR_CV_WAVES
 #define SMR_CV_WAVES 4
+#endif
 #define SMR_CV_DBLOCK 4096u                        /* alpha words a wavefront takes from the arena with one atomic */
 #define SMR_CV_RBLOCK 1024u                        /* strip-table entries likewise */
 #define SMR_CV_CHUNK 8u                            /* primitives a wavefront takes from the queue with one atomic */
@@ -2831,7 +2833,19 @@ struct cover_lds_t
    uint16_t bucket[SMR_NSUB][SMR_BKS];
    int redge[SMR_TH][SMR_CV_SL][5];
    int gy[SMR_CV_MAXGROUPS][2];      /* sub-row extent of each group of 64 edge slots */
+   int own[64];
 };
+
+__device__ __forceinline__ int smr_wave_scan_max(int v)
+{
+   v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x111, 0xf, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x112, 0xf, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x114, 0xf, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x118, 0xf, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x142, 0xa, 0xf, false));
+   v = max(v, __builtin_amdgcn_update_dpp(INT32_MIN, v, 0x143, 0xc, 0xf, false));
+   return v;
+}
 
 __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
 {
@@ -2849,6 +2863,12 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
    SMR_WAVE_SYNC();
    uint32_t dpos = 0, dleft = 0, rpos = 0, rleft = 0;      /* this wavefront's blocks of the two arenas */
    uint32_t n_done = 0, n_left = 0;
+#ifdef SMR_CV_PROFILE
+   unsigned long long cvp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, cvt = __builtin_amdgcn_s_memtime();
+#define CVTICK(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); cvp[i] += t_ - cvt; cvt = t_; } while (0)
+#else
+#define CVTICK(i) do { } while (0)
+#endif
 
    for (;;)
    {
@@ -2909,6 +2929,7 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
          SMR_WAVE_SYNC();
       }
 
+      CVTICK(0);
       for (int crow = cr_first; crow < dr1 && !bad; crow += SMR_TH)
       {
          /* the strip's rows: sub-sampled (bit of the row mask set), exact (clear), or not the primitive's */
@@ -2950,6 +2971,7 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
             if ((uint32_t) lane < ngroups) meets = L.gy[lane][0] < ysbase + SMR_NSUB && L.gy[lane][1] > ysbase;
             gm = (uint32_t) __ballot(meets);
          }
+         CVTICK(1);
          struct { uint32_t edge_off; } it; it.edge_off = 0;
          const int tx = 0;
          (void) tx; (void) it; (void) lw; (void) touched;
@@ -2983,6 +3005,7 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
 #pragma unroll
                for (int k = 0; k < SMR_TH; k++) rowcnt[k] += k == r ? (uint32_t) __popcll(am) : 0u;
             }
+            CVTICK(2);
 #ifdef SMR_CV_KO
             if (SMR_CV_KO & 1) continue;
 #endif
@@ -2993,6 +3016,7 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
 #undef XTICK
 #undef XCOUNT
 #undef XCOUNTN
+            CVTICK(3);
          }
 
          /* ---- sub-sampled rows: crossings -> spans -> cells; lane = sub-row (k_raster's flush) ---- */
@@ -3062,6 +3086,7 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
          }
          if (__ballot(ovf)) bad = true;
          SMR_WAVE_SYNC();
+         CVTICK(4);
 
          /* ---- exact rows: lane = (row, edge slot), all four rows at once (k_raster's form of libcairo's cell_list_render_edge) ---- */
          if (full_bits && !bad)
@@ -3074,22 +3099,47 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
             const bool onr = ((full_bits >> row) & 1u) && (uint32_t) es < my_n;
             const int rs0 = ysbase + row * SMR_GRID_Y;
             int32_t c0 = 0, c1 = 0, dir = 0, D = 1, q1 = 0, r1 = 0, q2 = 0, r2 = 0, dxs = 0;
+            smr_oedge_t o; o.p1x = o.p1y = o.dxs = 0; o.D = 1; o.dir = 0;
+            if (onr) { const int *re = L.redge[row][es]; o.p1x = re[0]; o.p1y = re[1]; o.dxs = re[2]; o.D = re[3]; o.dir = re[4]; }
+            /* short edges (|dx|, dy < 16 px: every edge of a chart of small polygons) evaluate in 32 bits, as in the crossing loop */
+            const bool allshort = !__ballot(onr && !(abs(o.dxs) < 4096 && o.D <= 60 * 4096));
             if (onr)
             {
-               const int *re = L.redge[row][es];
-               const int p1x = re[0], p1y = re[1];
-               dxs = re[2]; D = re[3]; dir = re[4];
-               const int64_t ec = 256 - 30ll * p1y;
-               const double inv = smr_rcp((double) D);
-               smr_edge_qr(ec, 2 * dxs, D, inv, rs0, q1, r1);
-               smr_edge_qr(ec, 2 * dxs, D, inv, rs0 + SMR_GRID_Y, q2, r2);
-               const int64_t nn = (int64_t) dxs * 1024;
-               int64_t dq = (int64_t) trunc((double) nn * inv);
-               int64_t dr = nn - dq * D;
-               if (nn >= 0) { if (dr < 0) { dq--; dr += D; } else if (dr >= D) { dq++; dr -= D; } }
-               else { if (dr > 0) { dq++; dr -= D; } else if (dr <= -(int64_t) D) { dq--; dr += D; } }
-               const int32_t hq = (int32_t) (dq / 2), hr = (int32_t) (dr / 2);
-               q1 += p1x; q2 += p1x;
+               dxs = o.dxs; D = o.D; dir = o.dir;
+               int32_t hq, hr;
+               if (allshort)
+               {
+                  const float rf = __builtin_amdgcn_rcpf((float) o.D);
+                  /* floor(n / D) and the remainder: truncating fp32 estimate within 1 of the floor, exact correction */
+                  auto qr32 = [&](int n) -> int2
+                  {
+                     const int qe = (int) fmaf((float) n, rf, -0.5f);
+                     const int rr = __mul24(qe, -o.D) + n;
+                     const int adj = (rr >= o.D ? 1 : 0) + (rr >> 31);
+                     return make_int2(qe + adj, rr - __mul24(adj, o.D));
+                  };
+                  const int c32 = (int) ((uint32_t) rs0 * 512u + 256u - 30u * (uint32_t) o.p1y);
+                  const int n1 = __mul24(2 * o.dxs, c32);
+                  const int2 A1 = qr32(n1), A2 = qr32(n1 + __mul24(2 * o.dxs, 512 * SMR_GRID_Y));
+                  q1 = A1.x; r1 = A1.y; q2 = A2.x; r2 = A2.y;
+                  const int nn = o.dxs * 1024;
+                  const int2 A3 = qr32(abs(nn));
+                  hq = nn < 0 ? -(A3.x >> 1) : (A3.x >> 1); hr = nn < 0 ? -(A3.y >> 1) : (A3.y >> 1);
+               }
+               else
+               {
+                  const int64_t ec = 256 - 30ll * o.p1y;
+                  const double inv = smr_rcp((double) D);
+                  smr_edge_qr(ec, 2 * dxs, D, inv, rs0, q1, r1);
+                  smr_edge_qr(ec, 2 * dxs, D, inv, rs0 + SMR_GRID_Y, q2, r2);
+                  const int64_t nn = (int64_t) dxs * 1024;
+                  int64_t dq = (int64_t) trunc((double) nn * inv);
+                  int64_t dr = nn - dq * D;
+                  if (nn >= 0) { if (dr < 0) { dq--; dr += D; } else if (dr >= D) { dq++; dr -= D; } }
+                  else { if (dr > 0) { dq++; dr -= D; } else if (dr <= -(int64_t) D) { dq--; dr += D; } }
+                  hq = (int32_t) (dq / 2); hr = (int32_t) (dr / 2);
+               }
+               q1 += o.p1x; q2 += o.p1x;
                c0 = q1 + (r1 >= (D >> 1) ? 1 : 0); c1 = q2 + (r2 >= (D >> 1) ? 1 : 0);
                /* step back from the sample location (half a sub-row) to the row boundary */
                q1 -= hq; r1 -= hr;
@@ -3118,71 +3168,89 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
              * row's last edge at the latest */
             const bool is_start = onr && (!has_pred || (((uint32_t) wsum & wmask) == 0 && pred_c0 != c0));
             const bool is_end = onr && !is_start && (!has_succ || (((uint32_t) wincl & wmask) == 0 && succ_c0 != c0));
+            /* the cells every span-boundary edge crosses: one lane per (edge, cell) (an edge crossing many cells kept its whole
+             * wavefront waiting while it walked them) */
             bool oob = false;
+            int ncell = 0, sgn = 0, ix1 = 0, ix2 = 0, fx1 = 0, fx2 = 0;
+            int64_t dx = 1, tmp0 = 0;
             if (is_start || is_end)
             {
-               const int sgn = is_start ? 1 : -1;
-               int ix1 = (int) (q1 >> 8), ix2 = (int) (q2 >> 8), fx1 = q1 & 255, fx2 = q2 & 255;
-               if (ix1 == ix2)
-               {
-                  if ((uint32_t) ix1 >= (uint32_t) SMR_CV_WC) oob = true;
-                  else atomicAdd(&L.cell[row][ix1], smr_delta_pack(sgn * SMR_GRID_Y, sgn * (fx1 + fx2) * SMR_GRID_Y));
-               }
+               sgn = is_start ? 1 : -1;
+               ix1 = (int) (q1 >> 8); ix2 = (int) (q2 >> 8); fx1 = q1 & 255; fx2 = q2 & 255;
+               const bool sw = ix2 < ix1;
+               const int32_t qa = sw ? q2 : q1, ra = sw ? r2 : r1, qb = sw ? q1 : q2, rb = sw ? r1 : r2;
+               if (sw) { int t = ix1; ix1 = ix2; ix2 = t; t = fx1; fx1 = fx2; fx2 = t; }
+               if (ix1 < 0 || ix2 >= SMR_CV_WC) oob = true;
                else
                {
-                  int32_t qa = q1, ra = r1, qb = q2, rb = r2;
-                  if (ix2 < ix1)
-                  {
-                     int t = ix1; ix1 = ix2; ix2 = t;
-                     t = fx1; fx1 = fx2; fx2 = t;
-                     qa = q2; ra = r2; qb = q1; rb = r1;
-                  }
-                  if (ix1 < 0 || ix2 >= SMR_CV_WC) oob = true;
-                  else
-                  {
-                     const int64_t dx = (int64_t) (qb - qa) * D + (rb - ra);
-                     const int64_t tmp0 = ((int64_t) (256 - fx1) * D - ra) * SMR_GRID_Y;
-                     const int64_t step = (int64_t) (SMR_GRID_Y * 256) * D;
-                     const double inv = smr_rcp(smr_i64_to_f64(dx));
-                     auto Y = [&](int cell) -> int
-                     {
-                        const int64_t n = tmp0 + (int64_t) (cell - ix1) * step;
-                        int y = (int) (smr_i64_to_f64(n) * inv);
-                        int64_t rem = n - (int64_t) y * dx;
-                        if (rem < 0) y--; else if (rem >= dx) y++;
-                        return y;
-                     };
-                     int ylast = 0;
-                     for (int k = ix1; k <= ix2; k++)
-                     {
-                        const int yhi = k == ix2 ? SMR_GRID_Y : Y(k);
-                        const int cov = yhi - ylast;
-                        const int fac = k == ix1 ? 256 + fx1 : k == ix2 ? fx2 : 256;
-                        if (cov) atomicAdd(&L.cell[row][k], smr_delta_pack(sgn * cov, sgn * cov * fac));
-                        ylast = yhi;
-                     }
-                  }
+                  ncell = ix2 - ix1 + 1;
+                  if (ncell > 1) { dx = (int64_t) (qb - qa) * D + (rb - ra); tmp0 = ((int64_t) (256 - fx1) * D - ra) * SMR_GRID_Y; }
                }
             }
             if (__ballot(oob)) bad = true;
+            const int incl = smr_wave_scan(ncell), excl = incl - ncell;
+            const int total = bad ? 0 : __builtin_amdgcn_readlane(incl, 63);
+            for (int base = 0; base < total; base += 64)
+            {
+               L.own[lane] = INT32_MIN;
+               SMR_WAVE_SYNC();
+               if (ncell > 0)
+               {
+                  const int first = excl - base;
+                  if (first >= 0 && first < 64) L.own[first] = lane;
+                  else if (first < 0 && incl > base) L.own[0] = lane;
+               }
+               SMR_WAVE_SYNC();
+               const int own = smr_wave_scan_max(L.own[lane]);
+               const bool valid = base + lane < total;
+               const int src = valid ? own : lane, ad = src << 2;
+               const int o_ix1 = __builtin_amdgcn_ds_bpermute(ad, ix1), o_ix2 = __builtin_amdgcn_ds_bpermute(ad, ix2);
+               const int o_fx1 = __builtin_amdgcn_ds_bpermute(ad, fx1), o_fx2 = __builtin_amdgcn_ds_bpermute(ad, fx2);
+               const int o_sgn = __builtin_amdgcn_ds_bpermute(ad, sgn), o_D = __builtin_amdgcn_ds_bpermute(ad, D);
+               const int o_excl = __builtin_amdgcn_ds_bpermute(ad, excl);
+               const int64_t o_dx = ((int64_t) __builtin_amdgcn_ds_bpermute(ad, (int) (dx >> 32)) << 32) | (uint32_t) __builtin_amdgcn_ds_bpermute(ad, (int) (uint32_t) dx);
+               const int64_t o_tmp0 = ((int64_t) __builtin_amdgcn_ds_bpermute(ad, (int) (tmp0 >> 32)) << 32) | (uint32_t) __builtin_amdgcn_ds_bpermute(ad, (int) (uint32_t) tmp0);
+               const int o_row = src >> 4;
+               const int k = o_ix1 + (base + lane - o_excl);
+               const bool multi = valid && o_ix1 != o_ix2;
+               const int64_t step = (int64_t) (SMR_GRID_Y * 256) * o_D;
+               const double inv = smr_rcp(smr_i64_to_f64(multi ? o_dx : 1));
+               /* y (in sub-rows) at which the edge crosses the right boundary of cell `cell` */
+               auto Y = [&](int cell) -> int
+               {
+                  const int64_t n = o_tmp0 + (int64_t) (cell - o_ix1) * step;
+                  int y = (int) (smr_i64_to_f64(n) * inv);
+                  int64_t rem = n - (int64_t) y * o_dx;
+                  if (rem < 0) y--; else if (rem >= o_dx) y++;
+                  return y;
+               };
+               const int yhi = (!multi || k == o_ix2) ? SMR_GRID_Y : Y(k);
+               int ylo = __shfl_up(yhi, 1);                 /* the lane before holds the cell before, except at a batch's start */
+               if (multi && k > o_ix1 && lane == 0) ylo = Y(k - 1);
+               if (!multi || k == o_ix1) ylo = 0;
+               if (valid)
+               {
+                  const int cov = yhi - ylo;
+                  const int fac = !multi ? o_fx1 + o_fx2 : k == o_ix1 ? 256 + o_fx1 : k == o_ix2 ? o_fx2 : 256;
+                  if (cov) atomicAdd(&L.cell[o_row][k], smr_delta_pack(o_sgn * cov, o_sgn * cov * fac));
+               }
+            }
          }
          SMR_WAVE_SYNC();
 
+         CVTICK(5);
          /* ---- cells -> alpha (k_raster's flush: prefix sum of cover, area, libcairo's extents), the four rows of a column in
           * one word; lane = column, two sweeps for a primitive wider than 64 cells ---- */
-         uint32_t a4[2] = { 0u, 0u };
+         uint32_t a4lo = 0u, a4hi = 0u;
 #pragma unroll
          for (int r = 0; r < SMR_TH; r++)
          {
             if (!(((partial | full_bits) >> r) & 1u)) continue;
             int carry = 0;
-#pragma unroll
-            for (int h = 0; h < 2; h++)
+            auto sweep = [&](const int i, uint32_t &a4)
             {
-               if (h == 1 && wp <= 64) continue;
-               const int i = h * 64 + lane;
                const int v = L.cell[r][i];
-               if (!__ballot(v != 0) && carry == 0) continue;
+               if (!__ballot(v != 0) && carry == 0) return;
                if (v) L.cell[r][i] = 0;
                int c = smr_delta_cover(v);
                const int ua = smr_delta_area(v);
@@ -3192,11 +3260,13 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
                int a = (area + (area << 4) + 256) >> 9;
                a = a < 0 ? 0 : a > 255 ? 255 : a;
                if (i < 1 || i > wp - 2) a = 0;           /* libcairo composites inside the primitive's pixel extents only */
-               a4[h] |= (uint32_t) a << (8 * r);
-            }
+               a4 |= (uint32_t) a << (8 * r);
+            };
+            sweep(lane, a4lo);
+            if (wp > 64) sweep(lane + 64, a4hi);
          }
          {
-            const unsigned long long m0 = __ballot(a4[0] != 0), m1 = __ballot(a4[1] != 0);
+            const unsigned long long m0 = __ballot(a4lo != 0), m1 = __ballot(a4hi != 0);
             uint2 entry = make_uint2(0u, 0u);
             if ((m0 | m1) && !bad)
             {
@@ -3215,14 +3285,15 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
                if (!bad)
                {
                   abase = dpos; dpos += n; dleft -= n;
-                  if (lane >= xlo && lane <= xhi) A.alpha[abase + (uint32_t) (lane - xlo)] = a4[0];
-                  if (lane + 64 >= xlo && lane + 64 <= xhi) A.alpha[abase + (uint32_t) (lane + 64 - xlo)] = a4[1];
+                  if (lane >= xlo && lane <= xhi) A.alpha[abase + (uint32_t) (lane - xlo)] = a4lo;
+                  if (lane + 64 >= xlo && lane + 64 <= xhi) A.alpha[abase + (uint32_t) (lane + 64 - xlo)] = a4hi;
                   entry = make_uint2(abase, smr_strip_pack(cx0 + xlo, (int) n));
                }
             }
             if (!bad && lane == 0) A.drows[rbase + (uint32_t) ((crow - cr_first) >> 2)] = entry;
          }
          SMR_WAVE_SYNC();
+         CVTICK(6);
       }
       if (bad)
       {
@@ -3239,6 +3310,9 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
    }
    }
    if (lane == 0) { if (n_done) atomicAdd(&A.ctr[3], n_done); if (n_left) atomicAdd(&A.ctr[4], n_left); }
+#ifdef SMR_CV_PROFILE
+   if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd((unsigned long long *) (A.ctr + 6) + i, cvp[i]);
+#endif
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -3897,7 +3971,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       /* k_prim_setup has added up what the eligible primitives need at most (h_small[11] strips, h_small[12..13] alpha words);
        * on top of it the blocks the wavefronts take and do not use up.  An arena that runs out (beyond 2^32 words) leaves the
        * remaining primitives to k_raster's own path */
-      const unsigned nwg = (unsigned) std::min<int64_t>((n_prims + SMR_CV_CHUNK * SMR_CV_WAVES - 1) / (SMR_CV_CHUNK * SMR_CV_WAVES), 256 * 5);
+      const unsigned nwg = (unsigned) std::min<int64_t>((n_prims + SMR_CV_CHUNK * SMR_CV_WAVES - 1) / (SMR_CV_CHUNK * SMR_CV_WAVES), 256 * 20 / SMR_CV_WAVES);
       uint64_t need_a = (uint64_t) h_small[12] | ((uint64_t) h_small[13] << 32);
       uint64_t acap = need_a + (uint64_t) nwg * SMR_CV_WAVES * SMR_CV_DBLOCK + 65536;
       uint64_t rcap = (uint64_t) h_small[11] + (uint64_t) nwg * SMR_CV_WAVES * SMR_CV_RBLOCK + 65536;
@@ -4036,6 +4110,16 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       uint32_t cv[5] = { 0, 0, 0, 0, 0 };
       if (alpha) hipMemcpy(cv, cvctr, sizeof(cv), hipMemcpyDeviceToHost);
       t.n_deltas = cv[1]; t.n_cover_prims = cv[3]; t.n_cover_left = cv[4];
+#ifdef SMR_CV_PROFILE
+      {
+         unsigned long long pr[8]; double tot = 0;
+         hipMemcpy(pr, cvctr + 6, sizeof(pr), hipMemcpyDeviceToHost);
+         for (int i = 0; i < 8; i++) tot += (double) pr[i];
+         fprintf(stderr, "k_cover sections (prim head, strip head, group, crossing, spans, exact rows, alpha):");
+         for (int i = 0; i < 7; i++) fprintf(stderr, " %d:%.1f%%", i, 100.0 * (double) pr[i] / tot);
+         fprintf(stderr, "\n");
+      }
+#endif
    }
    if (h_small[2] & (SMR_ST_ROWCAP | SMR_ST_BUCKET_OVERFLOW))
    {
