@@ -1940,6 +1940,7 @@ struct sort_args_t
    uint32_t lds_cap;          /* entries of one tile that fit its wavefront's share of LDS (a power of two up to SORT_LDS) */
    int TX, band_y0, band_h;
    const uint2 *drows;        /* k_cover's strip table (primitives with SMR_PF_DELTA) */
+   uint32_t *tile_cnt;        /* [n_tiles] entries of the tile's work stream (entries that bring nothing are left out) */
 };
 
 /* SORT_WAVES independent wavefronts per workgroup, one tile each (a chart of 4 M tiles is 4 M one-wave workgroups otherwise,
@@ -1955,8 +1956,8 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
    const uint32_t tile = smr_xcd_remap(blockIdx.x, gridDim.x) * SORT_WAVES + wv;      /* an XCD's workgroups sort neighbouring tiles */
    if (tile >= A.n_tiles) return;
    const uint32_t beg = A.tile_off[tile], n = A.tile_off[tile + 1] - beg;
-   if (n == 0) return;
    const uint32_t lane = threadIdx.x & 63u;
+   if (n == 0) { if (lane == 0) A.tile_cnt[tile] = 0; return; }
    uint32_t N = 2;
    while (N < n) N <<= 1;
    const bool in_lds = N <= A.lds_cap;
@@ -2013,14 +2014,20 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
    const int tx = tile % A.TX, ty = tile / A.TX;
    const int row0 = A.band_y0 + ty * SMR_TH, col0 = tx * SMR_TW;
    const uint32_t first_prim = *A.first_prim;
-   for (uint32_t i = lane; i < n; i += 64)
+   const unsigned long long lt_mask = (1ull << lane) - 1ull;
+   uint32_t kept = 0, last_prim = 0xffffffffu;
+   for (uint32_t i0 = 0; i0 < n; i0 += 64)
    {
-      uint32_t idx;
-      if (n < 2) idx = A.entries[beg + i];
+      const uint32_t i = i0 + lane;
+      const bool valid = i < n;
+      uint32_t idx = 0;
+      if (!valid) idx = 0;
+      else if (n < 2) idx = A.entries[beg + i];
       else if (in_lds) idx = s[i];
       else idx = __hip_atomic_load(&A.entries[beg + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const smr_item_t it = A.items[idx];
-      const smr_prim_t P = A.prims[it.prim];
+      smr_item_t it; it.edge_off = 0; it.prim = 0xfffffffeu; it.cnt_flags = 0; it.color = 0; it.minx = it.miny = it.maxx = it.maxy = 0;
+      smr_prim_t P; P.flags = 0; P.row0 = 0; P.nrows = 0; P.mask_off = 0; P.minx = P.miny = P.maxx = P.maxy = 0; P.drow_off = 0;
+      if (valid) { it = A.items[idx]; P = A.prims[it.prim]; }
       smr_thdr_t h;
       h.edge_off = it.edge_off; h.prim = it.prim; h.color = it.color;
       h.cnt_flags = it.cnt_flags | (it.prim == first_prim ? 1u << 16 : 0u);
@@ -2030,26 +2037,37 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
       {
          int rr = row0 + r - P.row0;
          uint32_t bit = 1;      /* rows outside the mask hold no edge of the primitive */
-         if (rr >= 0 && rr < P.nrows) bit = (A.mask[P.mask_off + ((uint32_t) rr >> 5)] >> (rr & 31)) & 1u;
+         if (valid && rr >= 0 && rr < P.nrows) bit = (A.mask[P.mask_off + ((uint32_t) rr >> 5)] >> (rr & 31)) & 1u;
          bits |= bit << r;
          if (row0 + r >= (P.miny >> 8) && row0 + r <= (P.maxy >> 8)) bits |= 16u << r;
       }
       h.rowbits = bits;
       h.colmin = (P.minx >> 8) - col0; h.colmax = (P.maxx >> 8) - col0;
       h.dcounts = 0;
-      if (P.flags & SMR_PF_DELTA)
+      bool keep = valid;
+      /* the primitive of the entry before this one in the tile's order */
+      uint32_t prev = __shfl_up(it.prim, 1);
+      if (lane == 0) prev = last_prim;
+      last_prim = __shfl(it.prim, 63);
+      if (valid && (P.flags & SMR_PF_DELTA))
       {
-         /* k_cover has the primitive's alpha: the entry names the words of the tile's strip (k_cover's strips start on tile rows) */
+         /* k_cover has the primitive's alpha: the entry names the words of the tile's strip (k_cover's strips start on tile rows).
+          * One entry per primitive and tile does, and none where the strip has nothing for the tile's columns */
          const int dr0 = max(P.row0, A.band_y0), dr1 = min(P.row0 + P.nrows, A.band_y0 + A.band_h);
          const int first = A.band_y0 + ((dr0 - A.band_y0) & ~(SMR_TH - 1));
          const int sidx = (row0 - first) >> 2, nstrips = ((dr1 - 1 - first) >> 2) + 1;
          uint2 d = make_uint2(0u, 0u);
          if (row0 >= first && sidx < nstrips) d = A.drows[P.drow_off + (uint32_t) sidx];
          h.edge_off = d.x; h.dcounts = d.y; h.cnt_flags |= SMR_PF_DELTA << 8;
+         const int x0 = smr_strip_x0(d.y), nw = (int) smr_strip_n(d.y);
+         if (it.prim == prev || nw == 0 || x0 + nw <= col0 || x0 >= col0 + SMR_TW) keep = false;
       }
-      A.hdrs[beg + i] = h;
-      if (in_lds && n >= 2) A.entries[beg + i] = idx;
+      const unsigned long long km = __ballot(keep);
+      if (keep) A.hdrs[beg + kept + (uint32_t) __popcll(km & lt_mask)] = h;
+      kept += (uint32_t) __popcll(km);
+      if (valid && in_lds && n >= 2) A.entries[beg + i] = idx;
    }
+   if (lane == 0) A.tile_cnt[tile] = kept;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -2061,6 +2079,7 @@ struct raster_args_t
    const smr_thdr_t *hdrs;    /* per-tile sorted work stream (k_tile_sort) */
    const smr_edge_t *edges;
    const uint32_t *tile_off;
+   const uint32_t *tile_cnt;  /* entries of each tile's work stream (k_tile_sort leaves out what brings nothing) */
    uint32_t *canvas;          /* band pixels, stride W */
    uint32_t *status;
    uint32_t *tile_ctr;        /* [8 * xcd]: next tile of the XCD's columns, zero at launch */
@@ -2263,7 +2282,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
       /* the overflowed tiles come from the list (one queue: they are few), the others from the XCD's columns */
       const uint32_t tile = BIG ? A.ovf_list[kg] : (uint32_t) (kg % TYt) * A.TX + (xcd + 8u * (kg / TYt));
       const int tx = (int) (tile % (uint32_t) A.TX), ty = (int) (tile / (uint32_t) A.TX);
-      const uint32_t beg = A.tile_off[tile], end = A.tile_off[tile + 1];
+      const uint32_t beg = A.tile_off[tile], end = beg + A.tile_cnt[tile];
       if (beg == end) continue;
       COUNT(0);
       const int32_t X0 = tx * SMR_TW * 256, X1 = X0 + SMR_TW * 256;
@@ -2327,11 +2346,10 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
             const uint32_t eo = __builtin_amdgcn_readlane(hb0.x, j), cf = __builtin_amdgcn_readlane(hb0.z, j);
             if (cf & (SMR_PF_DELTA << 8))
             {
-               /* this column's alpha word of the strip instead of an edge slot; the other items of a primitive bring nothing */
+               /* this column's alpha word of the strip instead of an edge slot */
                const uint32_t info = __builtin_amdgcn_readlane(hb1.w, j);
-               const bool again = j > 0 && __builtin_amdgcn_readlane(hb0.y, j) == __builtin_amdgcn_readlane(hb0.y, j - 1);
                const uint32_t i = (uint32_t) (tx * SMR_TW + lane - smr_strip_x0(info));
-               if (!again && i < smr_strip_n(info)) e.x1 = (int32_t) A.alpha[(size_t) eo + i];
+               if (i < smr_strip_n(info)) e.x1 = (int32_t) A.alpha[(size_t) eo + i];
             }
             else if ((uint32_t) lane < (cf & 0xffu)) e = A.edges[(size_t) eo + lane];
          }
@@ -4014,11 +4032,13 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    k_bin<true><<<blocks(n_items, TB), TB, 0, s>>>(items, n_items, c->W, c->band_y0, c->band_h, TX, counts, tile_off, entries);
    SMR_HIP(hipGetLastError());
    smr_thdr_t *hdrs;
+   uint32_t *tile_cnt;
+   SMR_TRY(c->ensure(SMR_BUF_TILECNT, (size_t) n_tiles * 4, (void **) &tile_cnt));
    SMR_TRY(c->ensure(SMR_BUF_HDRS, ((size_t) n_entries + 1) * sizeof(smr_thdr_t), (void **) &hdrs));
    {
       sort_args_t SO;
       SO.tile_off = tile_off; SO.entries = entries; SO.items = items; SO.prims = prims; SO.mask = maskbuf; SO.first_prim = &small[1];
-      SO.hdrs = hdrs; SO.n_tiles = n_tiles; SO.TX = TX; SO.band_y0 = c->band_y0; SO.band_h = c->band_h; SO.drows = drows;
+      SO.hdrs = hdrs; SO.n_tiles = n_tiles; SO.TX = TX; SO.band_y0 = c->band_y0; SO.band_h = c->band_h; SO.drows = drows; SO.tile_cnt = tile_cnt;
       uint32_t cap = 64;
       while (cap < h_small[7] && cap < SORT_LDS) cap <<= 1;       /* h_small[7]: entries of the fullest tile (k_scan_block) */
       SO.lds_cap = cap;
@@ -4035,7 +4055,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    uint32_t *ovf_list;
    SMR_TRY(c->ensure(SMR_BUF_OVFLIST, (size_t) n_tiles * 4, (void **) &ovf_list));
    raster_args_t A;
-   A.prims = prims; A.hdrs = hdrs; A.edges = edges; A.tile_off = tile_off;
+   A.prims = prims; A.hdrs = hdrs; A.edges = edges; A.tile_off = tile_off; A.tile_cnt = tile_cnt;
    A.tile_ctr = &small[64];       /* zero since the memset at the top of the pass */
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
