@@ -55,7 +55,7 @@ def measured_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/<round>_hbm_traffic.json,
     collected by tools/profile_round.sh in separate rocprofv3 --pmc runs of this same command and
     corrected as MI355X_MICROARCH.md prescribes); None when the workload differs from the profiled one."""
-    if (args.ways, args.size, args.dpi) != (1000000, 16384, 300):
+    if (args.ways, args.size, args.dpi) != (1000000, 16384, 300) or args.strong:
         return None
     import re
     best = None
@@ -158,6 +158,9 @@ def main():
     ap.add_argument("--cpu-window", type=int, default=3072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-charts", action="store_true", help="skip the 32k target and the C3-like chart (reported outside the timed region)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: ONE chart of --strong-size^2 px (north_star's 32k target: 1 M ways / 10 M nodes) "
+                                                          "split into one row band per GPU; value = the chart's Mpx / max-over-ranks time")
+    ap.add_argument("--strong-size", type=int, default=32768)
     args = ap.parse_args()
 
     from smrender_amd import dist as smrdist
@@ -167,9 +170,24 @@ def main():
 
     W, H = args.size, args.size
     n_bands = world
-    x_px, y_px, way_off, ref = make_band(args, rank, n_bands)
-    # chart: W x (H * n_bands) px; window chosen so that the chart spans ~1.4 deg at 45N
-    proj = sa.Projection.from_window(45.0, 15.0, 100000.0 * (W / 16384.0), float(W), float(H * n_bands), args.dpi)
+    if args.strong:
+        # ONE chart, every rank a row band of it: the ways whose stroke-inflated extent meets the band (identical arithmetic
+        # on both sides of a boundary, no pixel exchange for draw: DESIGN 6)
+        S = args.strong_size
+        W = S
+        x_all, y_all, off_all, ref_all = synth.synth_ways(args.ways, S, S, seed=4242, mean_nodes=10)
+        band_list = smrdist.bands(S, world)
+        band_y0, H = band_list[rank]
+        keep = smrdist.ways_for_band(y_all, off_all, ref_all, band_y0, H, smrdist.stroke_margin_px(0.0, 25.4 / args.dpi, args.dpi))
+        x_px, y_px, way_off, ref = synth.select_ways(x_all, y_all, off_all, ref_all, keep)
+        way_off, ref = way_off.astype(np.int64), ref.astype(np.int32)
+        chart_h = S
+        del x_all, y_all, off_all, ref_all
+    else:
+        x_px, y_px, way_off, ref = make_band(args, rank, n_bands)
+        band_y0, chart_h = rank * H, H * n_bands
+    # chart: W x chart_h px; window chosen so that the chart spans ~1.4 deg at 45N
+    proj = sa.Projection.from_window(45.0, 15.0, 100000.0 * (W / 16384.0), float(W), float(chart_h), args.dpi)
     sa.set_projection(proj)
     lat, lon = synth.px_to_geo(proj, x_px, y_px)
     n_nodes, n_ways, n_refs = len(lat), len(way_off) - 1, len(ref)
@@ -179,7 +197,7 @@ def main():
     d_x, d_y = sa.DeviceArray((len(lat),), np.float64), sa.DeviceArray((len(lat),), np.float64)
     d_off, d_ref = sa.DeviceArray.from_numpy(way_off), sa.DeviceArray.from_numpy(ref)
     style = sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / args.dpi, 0, 0, 0, 0, 0, 0)
-    cv = sa.Canvas(W, H * n_bands, args.dpi, 0xffffff, rank * H, H)
+    cv = sa.Canvas(W, chart_h, args.dpi, 0xffffff, band_y0, H)
     sa.set_profiling(True)
 
     def step():
@@ -211,15 +229,23 @@ def main():
     if args.captions > 0:
         fg_w, fg_h, fg_x = 270, 20, 135            # E-aligned 2 mm caption at 300 dpi -> 72 angles, 271 px cut-out
         n_steps, r_px = sa.caprot_steps(fg_w, fg_h, args.dpi)
+        halo_path = None
         if world > 1:
             halo = r_px // 2 + 2
-            above, below = grp.exchange_halo(cv.read(0, 0, W, halo), cv.read(0, H - halo, W, halo), halo)
-            cv.set_halo(above, below)
+            try:
+                # strips straight from the canvas band in HBM over RCCL into device buffers (no host round trip)
+                grp.exchange_halo_device(cv, halo)
+                halo_path = "device"
+            except Exception as e:      # noqa: BLE001  (first contact with a real multi-GPU node: fall back, say so)
+                print(f"rank {rank}: device halo exchange failed ({e}); host-staged exchange", file=sys.stderr)
+                above, below = grp.exchange_halo(cv.read(0, 0, W, min(halo, H)), cv.read(0, max(0, H - halo), W, min(halo, H)), halo)
+                cv.set_halo(above, below)
+                halo_path = "host"
         rng = np.random.default_rng(4321 + rank)
         side = int(np.ceil(np.sqrt(args.captions)))
         gx, gy = np.meshgrid(np.arange(side), np.arange(side))
         cx = ((gx.ravel()[:args.captions] + rng.uniform(0.2, 0.8, args.captions)) * W / side)
-        cy = ((gy.ravel()[:args.captions] + rng.uniform(0.2, 0.8, args.captions)) * H / side) + rank * H
+        cy = ((gy.ravel()[:args.captions] + rng.uniform(0.2, 0.8, args.captions)) * H / side) + band_y0
         d_cx, d_cy = sa.DeviceArray.from_numpy(cx), sa.DeviceArray.from_numpy(cy)
         d_ang = sa.DeviceArray((args.captions,), np.float64)
         cv.caprot(d_cx, d_cy, args.captions, fg_w, fg_h, fg_x, 0x000000, 0.0, 1.0, d_ang)      # warm-up
@@ -233,11 +259,11 @@ def main():
                "caprot_ms": round(cap_ms, 3), "captions_per_s": round(args.captions * world / (cap_ms * 1e-3), 1),
                "roofline": {"kernel": "k_caprot", "bound": "hbm", "achieved": round(cap_bytes / (cap_ms * 1e-3) / 1e9, 2),
                             "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(cap_bytes / (cap_ms * 1e-3) / HBM_PEAK, 5)},
-               "distinct_angles": int(len(np.unique(ang)))}
+               "distinct_angles": int(len(np.unique(ang))), "halo_exchange": halo_path}
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        mpx = W * H * n_bands / 1e6
+        mpx = W * chart_h / 1e6
         stage = {k: v / args.steps for k, v in stage.items()}
         # SURVEY 8d, per draw pass on one band: every canvas pixel stored once, every projected vertex and every style record read
         # once.  The pass is two kernels now: k_cover (scan conversion, primitive by primitive: reads vertices and records) and
@@ -254,12 +280,14 @@ def main():
             "unit": "Mpx/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
             "dtype": "i64 fixed 24.8 (raster) + f64 (projection)", "data": "synthetic",
-            "config": {"workload": f"C2: {args.ways} closed ways x ~32 nodes (non-zero winding), fill #4080c0 + 2 px AA border, "
-                                   f"{W}x{H} px canvas per GPU @ {args.dpi} dpi",
+            "config": {"workload": (f"north_star target: {args.ways} closed ways x ~10 nodes, fill #4080c0 + 2 px AA border, ONE {W}x{chart_h} px chart @ {args.dpi} dpi"
+                                    if args.strong else
+                                    f"C2: {args.ways} closed ways x ~32 nodes (non-zero winding), fill #4080c0 + 2 px AA border, "
+                                    f"{W}x{H} px canvas per GPU @ {args.dpi} dpi"),
                        "ways_per_gpu": n_ways, "refs_per_gpu": n_refs, "nodes_per_gpu": n_nodes,
-                       "canvas_total": [W, H * n_bands], "partition": f"{world} row band(s), one per GPU"},
+                       "canvas_total": [W, chart_h], "partition": f"{world} row band(s), one per GPU"},
             "nodes_per_s": round(n_nodes / (stage["proj_ms"] * 1e-3), 1) if stage["proj_ms"] > 0 else None,
             "stage_ms": {k: round(v, 3) for k, v in stage.items()},
             "counts": {"prims": tm["n_prims"], "edge_slots": tm["n_edges"], "tile_refs": tm["n_tile_refs"], "tiles": tm["n_tiles"],

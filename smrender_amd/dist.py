@@ -200,11 +200,12 @@ class Group:
         counts[self.rank] = top.shape[0]
         dist.all_reduce(counts)
         ops, bufs = [], {}
-        if self.rank > 0 and counts[self.rank - 1] > 0:
+        # (both sides of a boundary decide alike: a pair exchanges only if both have rows)
+        if self.rank > 0 and counts[self.rank - 1] > 0 and counts[self.rank] > 0:
             bufs["above"] = torch.empty((int(counts[self.rank - 1]), canvas.W), dtype=torch.int32, device=self.device)
             ops.append(dist.P2POp(dist.isend, top, self.rank - 1))
             ops.append(dist.P2POp(dist.irecv, bufs["above"], self.rank - 1))
-        if self.rank < self.world - 1 and counts[self.rank + 1] > 0:
+        if self.rank < self.world - 1 and counts[self.rank + 1] > 0 and counts[self.rank] > 0:
             bufs["below"] = torch.empty((int(counts[self.rank + 1]), canvas.W), dtype=torch.int32, device=self.device)
             ops.append(dist.P2POp(dist.isend, bottom, self.rank + 1))
             ops.append(dist.P2POp(dist.irecv, bufs["below"], self.rank + 1))

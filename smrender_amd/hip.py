@@ -282,8 +282,12 @@ class Canvas:
         return p.value, st.value
 
     def device_rows(self, row0, nrows):
-        """rows [row0, row0 + nrows) of the band as a torch int32 tensor VIEW of the device memory (no copy)"""
+        """rows [row0, row0 + nrows) of the band as a torch int32 tensor VIEW of the device memory (no copy).
+        torch must have been imported BEFORE the library initialised HIP (smrender_amd.dist.Group does so): torch ships a HIP
+        runtime of its own, and of two runtimes in one process only the first sees the GPU."""
         import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("device_rows: torch sees no GPU (import torch before smrender_amd.init(): two HIP runtimes in one process)")
         ptr, stride = self.device_ptr()
 
         class _View:

@@ -14,6 +14,10 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def hip():
     """The product library on cuda:0 -- fails loudly if the .so or the GPU is missing."""
+    try:
+        import torch      # noqa: F401  (before the library: two HIP runtimes in one process, the one loaded first owns the GPU;
+    except ImportError:   #  tests that view canvas memory as torch tensors need torch's to be that one)
+        pass
     import smrender_amd as sa
     sa.init(0)
     yield sa

@@ -141,3 +141,67 @@ def test_bands_with_halo_match_full_canvas(hip):
         cv.close()
     full.close()
     assert np.array_equal(got, want)
+
+
+def test_device_halo_and_extended_background_match_full_canvas(hip):
+    """the device-to-device form of the halo hand-over (smr_hip_canvas_set_halo_device: what a send/recv over RCCL delivers) and
+    the banded caption rule's private background (smr_hip_canvas_extend: band + halo rows as one canvas onto which the
+    rectangles of finished captions are drawn, src/smrules_cairo.c:2376-2382): angles equal the single-canvas ones, before
+    and after a rectangle that straddles the band boundary"""
+    sa = hip
+    W, H = 300, 240
+    st = sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0, 0, 0, 0, 0, 0)
+    x, y, off, ref = po.synth_ways(int(W * H / 900), W, H, seed=17)
+    dev = [sa.DeviceArray.from_numpy(a) for a in (x, y, off, ref)]
+    full = sa.Canvas(W, H, 300, 0xffffff)
+    full.draw(st, dev[0], dev[1], dev[2], dev[3], len(off) - 1, len(ref))
+    img = full.read()
+    rng = np.random.default_rng(5)
+    n_cap = 50
+    cx, cy = rng.uniform(0, W, n_cap), rng.uniform(0, H - 0.01, n_cap)
+    fg_w, fg_h, fg_x = 70, 12, 35
+    n, r = sa.caprot_steps(fg_w, fg_h, 300)
+    halo = r // 2 + 2
+    from smrender_amd import dist
+    bl = dist.bands(H, 2)
+    # a rectangle across the boundary between the two bands, drawn without a group layer like auto_ctx's fills
+    by = bl[1][0]
+    rx = np.array([100.0, 180.0, 180.0, 100.0]); ry = np.array([by - 6.0, by - 6.0, by + 7.0, by + 7.0])
+    roff = np.array([0, 5], np.int64); rref = np.array([0, 1, 2, 3, 0], np.int32)
+    rst = sa.DrawStyle(1, 0, 0x203040, 0, 0.0, 0.0, 0, 0, 0, 0, 0, 1)
+    rdev = [sa.DeviceArray.from_numpy(a) for a in (rx, ry, roff, rref)]
+
+    def scan(cv, idx):
+        d = sa.DeviceArray((max(len(idx), 1),), np.float64)
+        cv.caprot(sa.DeviceArray.from_numpy(cx[idx]), sa.DeviceArray.from_numpy(cy[idx]), len(idx), fg_w, fg_h, fg_x, 0, 0.0, 1.0, d)
+        sa.sync()
+        return d.numpy()[:len(idx)]
+
+    everyone = np.arange(n_cap)
+    want0 = scan(full, everyone)
+    bg = full.clone()
+    bg.draw(rst, rdev[0], rdev[1], rdev[2], rdev[3], 1, 5)
+    want1 = scan(bg, everyone)
+    assert (want0 != want1).sum() >= 1          # the rectangle is seen by somebody
+    got0, got1 = np.full(n_cap, np.nan), np.full(n_cap, np.nan)
+    for y0, h in bl:
+        cv = sa.Canvas(W, H, 300, 0xffffff, y0, h)
+        cv.draw(st, dev[0], dev[1], dev[2], dev[3], len(off) - 1, len(ref))
+        a0, b1 = max(0, y0 - halo), min(H, y0 + h + halo)
+        d_above = sa.DeviceArray.from_numpy(np.ascontiguousarray(img[a0:y0])) if y0 > a0 else None
+        d_below = sa.DeviceArray.from_numpy(np.ascontiguousarray(img[y0 + h:b1])) if b1 > y0 + h else None
+        cv.set_halo_device(d_above.ptr if d_above else None, y0 - a0, d_below.ptr if d_below else None, b1 - y0 - h)
+        mine = np.nonzero((np.floor(cy) >= y0) & (np.floor(cy) < y0 + h))[0]
+        got0[mine] = scan(cv, mine)
+        # the strips a rank sends are views of its band's device memory (no copy): what the RCCL send reads
+        view = cv.device_rows(h - 5, 5)
+        assert view.is_cuda and np.array_equal(view.cpu().numpy().view(np.uint32), img[y0 + h - 5:y0 + h])
+        ext = cv.extend()
+        assert (ext.band_y0, ext.band_h) == (a0, b1 - a0)
+        assert np.array_equal(ext.read(), img[a0:b1])
+        ext.draw(rst, rdev[0], rdev[1], rdev[2], rdev[3], 1, 5)
+        got1[mine] = scan(ext, mine)
+        ext.close(); cv.close()
+    full.close(); bg.close()
+    assert np.array_equal(got0, want0)
+    assert np.array_equal(got1, want1)
