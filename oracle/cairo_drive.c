@@ -214,6 +214,29 @@ int cd_render(double dpi, int x0, int y0, int W, int H, uint32_t *out)
    return e;
 }
 
+/* cairo_smr_cut_out (src/smrules_cairo.c:1511-1533): the r x r pt window of the chart around (x, y) pt as find_angle takes it --
+ * the recording replayed at dpi/72 with the translation (-x + r/2, -y + r/2) pt, i.e. at a sub-pixel offset whenever the
+ * anchor is not on the pixel grid.  out holds n x n pixels, n = round(r * dpi / 72) (returned). */
+int cd_cut_out(double x_pt, double y_pt, double r_pt, double dpi, uint32_t *out, int cap)
+{
+   int n = (int) round(r_pt * dpi / 72);
+   if (n <= 0 || n * n > cap) return -1;
+   cairo_surface_t *img = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, n, n);
+   if (p_cairo_surface_status(img)) return -1;
+   cairo_t *ctx = p_cairo_create(img);
+   p_cairo_scale(ctx, dpi / 72, dpi / 72);
+   p_cairo_set_source_surface(ctx, sfc_, -x_pt + r_pt / 2, -y_pt + r_pt / 2);
+   p_cairo_paint(ctx);
+   int e = p_cairo_status(ctx);
+   p_cairo_destroy(ctx);
+   p_cairo_surface_flush(img);
+   unsigned char *d = p_cairo_image_surface_get_data(img);
+   int stride = p_cairo_image_surface_get_stride(img);
+   for (int y = 0; y < n; y++) memcpy(out + (size_t) y * n, d + (size_t) y * stride, (size_t) n * 4);
+   p_cairo_surface_destroy(img);
+   return e ? -1 : n;
+}
+
 /* direct (no recording surface) variant used for micro-probes: draw a polygon in
  * device px straight onto an image */
 int cd_direct_fill(const double *xy, int n, uint32_t col, uint32_t bg, int W, int H, uint32_t *out)

@@ -1,0 +1,68 @@
+"""The caption scan's cut-out: libsmr_hip crops the rendered canvas at the rounded centre, the reference replays its recording
+at a sub-pixel offset (cairo_smr_cut_out, src/smrules_cairo.c:1511-1533).  tests/golden/cutout_subpixel.npz
+(tests/golden/make_cutout_vectors.py, generated where libcairo 1.16 is) holds, for 2 x 2000 captions with non-integer anchors
+on a C2-like chart, find_angle on libcairo's own sub-pixel cut-out (`ref`), on the crop of libcairo's render (`conv`) and on
+the crop of the oracle's render (`gpu`).  What is pinned here: the GPU path reproduces `gpu` bit for bit; `gpu` equals `conv`
+(the GPU's pixels are libcairo's as far as the scan can tell); and the measured share of %.1f autoangle tags that the crop
+convention changes against the reference's cut-out (11-13 %), which DESIGN.md 2 states as the known deviation."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+from oracle import pyoracle as po
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "cutout_subpixel.npz"))
+W, H, DPI = int(G["W"]), int(G["H"]), int(G["dpi"])
+
+
+def tags(a):
+    return np.array(["%.1f" % (v * 180 / np.pi) for v in a])
+
+
+def scene():
+    return po.synth_ways(int(G["n_ways"]), W, H, seed=int(G["seed"])), po.Style(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / DPI, 0)
+
+
+def test_measured_deviation_of_the_crop_convention():
+    for tag in ("c4", "small"):
+        ref, conv, gpu = G[tag + "_ref"], G[tag + "_conv"], G[tag + "_gpu"]
+        assert np.array_equal(conv, gpu)                       # the renders differ in no pixel the scan notices
+        share = float((tags(ref) != tags(gpu)).mean())
+        assert 0.08 < share < 0.14, share                       # the documented deviation: 11.1 % / 12.6 %
+        d = np.abs(ref - gpu); d = np.minimum(d, 2 * np.pi - d)
+        assert np.median(d[d > 1e-3]) <= np.deg2rad(7.6)        # mostly one scan step (360 / num_steps)
+
+
+def test_oracle_reproduces_the_stored_crop_angles():
+    """first 150 captions of each plane through the oracle here (CPU): the fixture is the oracle's, not a stale file"""
+    (x, y, off, ref), st = scene()
+    L = po.orc()
+    img = po.oracle_scene([(st, po.ways_from_arrays(x, y, off, ref))], DPI, W, H, 0xffffff)
+    crnd = lambda v: int(np.sign(v) * np.floor(abs(v) + 0.5))
+    for tag in ("c4", "small"):
+        fw, fh, fx = (int(v) for v in G[tag + "_plane"])
+        r = C.c_int(); steps = L.orc_num_steps(fw, fh, DPI, C.byref(r)); r = r.value
+        fg = np.zeros((fh, fw), np.uint32); L.orc_make_plane(po.P(fg), fw, fh, fx, 0)
+        for k in range(150):
+            ox, oy = crnd(G[tag + "_cx"][k] - r / 2.0), crnd(G[tag + "_cy"][k] - r / 2.0)
+            cut = np.ascontiguousarray(img[oy:oy + r, ox:ox + r])
+            assert L.orc_find_angle(po.P(cut), r, po.P(fg), fw, fh, steps, 0.0, 1.0, None) == G[tag + "_gpu"][k], (tag, k)
+
+
+@pytest.mark.gpu
+def test_gpu_scan_at_c4_shape_equals_the_stored_angles(hip):
+    """2 x 2000 captions (270x20 plane / 271-px cut-out / 72 angles, and 90x14) on the GPU: bit-equal to the oracle's angles"""
+    sa = hip
+    (x, y, off, ref), _ = scene()
+    cv = sa.Canvas(W, H, DPI, 0xffffff)
+    cv.draw(sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / DPI, 0, 0, 0, 0, 0, 0),
+            *(sa.DeviceArray.from_numpy(a) for a in (x, y, off.astype(np.int64), ref.astype(np.int32))), len(off) - 1, len(ref))
+    for tag in ("c4", "small"):
+        fw, fh, fx = (int(v) for v in G[tag + "_plane"])
+        cx, cy = G[tag + "_cx"], G[tag + "_cy"]
+        d = sa.DeviceArray((len(cx),), np.float64)
+        cv.caprot(sa.DeviceArray.from_numpy(cx), sa.DeviceArray.from_numpy(cy), len(cx), fw, fh, fx, 0, 0.0, 1.0, d)
+        sa.sync()
+        got = d.numpy()
+        assert np.array_equal(got, G[tag + "_gpu"]), int((got != G[tag + "_gpu"]).sum())
+    cv.close()
