@@ -103,6 +103,52 @@ void hs_set_rdata(double lon0, double w, double h, double wc, double lath, doubl
    bgcolor_ = bgcolor;
 }
 
+/* is_closed_poly (src/smcoast.c:115-125), poly_area (src/smfunc.c:377-432) and the chart's area in both units
+ * (src/rdata.c:452-461): what act_cap's closed-way branch asks the executable for (cap_way, src/smrules_cairo.c:2395-2444).
+ * Restated: the shoelace sum over (lon * cos(lat), lat), the centroid from the same terms, nautical square miles
+ * (60 nm per degree: 3600 / 2 = 1800).  tests/test_plugin_host.py checks it against an independent shoelace in numpy. */
+int is_closed_poly(const osm_way_t *w)
+{
+   return w->ref_cnt >= 4 && w->ref[0] == w->ref[w->ref_cnt - 1];
+}
+
+int poly_area(const osm_way_t *w, struct coord *center, double *area)
+{
+   if (center == NULL && area == NULL) return 0;
+   if (!is_closed_poly(w)) return -1;
+   const osm_node_t *a, *b = (const osm_node_t *) get_object(OSM_NODE, w->ref[0]);
+   if (b == NULL) return -1;
+   double sum = 0, clat = 0, clon = 0;
+   for (int i = 1; i < w->ref_cnt; i++)
+   {
+      a = b;
+      if ((b = (const osm_node_t *) get_object(OSM_NODE, w->ref[i])) == NULL) return -1;
+      const double xa = a->lon * cos(a->lat * M_PI / 180), xb = b->lon * cos(b->lat * M_PI / 180);
+      const double f = xa * b->lat - xb * a->lat;
+      clon += (xa + xb) * f;
+      clat += (a->lat + b->lat) * f;
+      sum += f;
+   }
+   clat /= 3.0 * sum;
+   clon /= 3.0 * sum * cos(clat * M_PI / 180);
+   if (center != NULL) { center->lat = clat; center->lon = clon; }
+   if (area != NULL) *area = sum * 1800.0;
+   return 0;
+}
+
+/* test access: centroid and area of a way in the object tree */
+int hs_poly_area(long long way_id, double *out)
+{
+   const osm_way_t *w = (const osm_way_t *) get_object(OSM_WAY, way_id);
+   struct coord c; double ar;
+   if (w == NULL || poly_area(w, &c, &ar)) return -1;
+   out[0] = c.lat; out[1] = c.lon; out[2] = ar;
+   return 0;
+}
+
+double rdata_square_mm(void) { return (rd_.w * 25.4 / rd_.dpi) * (rd_.h * 25.4 / rd_.dpi); }
+double rdata_square_nm(void) { return rd_.mean_lat_len * rd_.hc * 3600; }
+
 /* page_way(), src/smcoast.c:105-108: the way init_corner_brg (:804-841) builds from the corners of the
  * bounding box, refs = NW, SW, SE, NE, NW (counterclockwise on the chart) */
 static osm_way_t *page_way_;

@@ -30,6 +30,9 @@ def host():
         L.hs_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.hs_get_tag.restype = C.c_char_p
         L.hs_get_tag.argtypes = [C.c_int, C.c_int64, C.c_char_p]
+        L.hs_poly_area.argtypes = [C.c_longlong, C.c_void_p]
+        L.rdata_square_mm.restype = C.c_double
+        L.rdata_square_nm.restype = C.c_double
         _hs = L
     return _hs
 
@@ -70,3 +73,10 @@ def add_rel(rid, ways):
 def get_tag(obj_type, oid, key):
     v = host().hs_get_tag(obj_type, int(oid), key.encode())
     return None if v is None else v.decode()
+
+
+def poly_area(wid):
+    """(centroid lat, centroid lon, area in square nautical miles) of a closed way, as the host's poly_area sees it"""
+    out = np.zeros(3)
+    assert host().hs_poly_area(int(wid), out.ctypes.data) == 0
+    return tuple(out)

@@ -422,3 +422,44 @@ def test_reference_testdata_through_the_action_api(hip, k):
         want = po.oracle_scene([(st, oways)], DPI, Wc, Hc, 0xffffff)
     assert len(np.unique(got)) > 2
     assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_cap_on_closed_ways_uses_the_centroid(chart):
+    """cap_way (src/smrules_cairo.c:2395-2444): a closed way is captioned at poly_area's centroid; open ways are passed
+    over.  The host is the miniature one with the reference's libsmrender; the centroid comes from ITS poly_area."""
+    sa, proj = chart
+    from smrender_amd import synth
+    if po.cairo() is None:
+        pytest.skip("libcairo (text extents) not loadable")
+    wids, _ = load_ways(sa, proj, po.synth_ways(90, W, H, seed=83))
+    assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", wids) == 0
+    img = plugin_canvas(sa)
+    # six named closed ways and two named open ones
+    rng = np.random.default_rng(12)
+    names, cap_ids, cen = [], [], []
+    for k in range(8):
+        n = 7
+        ccx, ccy = rng.uniform(60, W - 60), rng.uniform(60, H - 60)
+        a = np.sort(rng.uniform(0, 2 * np.pi, n))
+        x, y = ccx + 25 * rng.uniform(0.6, 1.0, n) * np.cos(a), ccy + 25 * rng.uniform(0.6, 1.0, n) * np.sin(a)
+        lat, lon = synth.px_to_geo(proj, x, y)
+        base = _next_id[0]; _next_id[0] += n + 2
+        ids = base + np.arange(n)
+        hs.add_nodes(ids, lat, lon)
+        closed = k < 6
+        hs.add_way(base + n, np.append(ids, ids[0]) if closed else ids, f"name=Area {k}")
+        cap_ids.append(base + n)
+        if closed:
+            names.append(f"Area {k}")
+            clat, clon, _ = hs.poly_area(base + n)
+            cen.append((clat, clon))
+    params = "key=name;size=2.0;angle=auto;color=black;halign=east;font=serif;weight=1.0"
+    assert hs.apply_rule(sa.lib(), "cap", hs.OSM_WAY, params, cap_ids) == 0, sa.lib().smr_hip_last_error()
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    px, py, _, _, _ = po.project(op, np.array([c[0] for c in cen]), np.array([c[1] for c in cen]))
+    want, _ = oracle_caption_tags(img, names, px, py, 2.0, 0x000000, 1.0)
+    for k in range(6):
+        assert hs.get_tag(hs.OSM_WAY, cap_ids[k], "name:autoangle") == want[k][0], k
+        assert hs.get_tag(hs.OSM_WAY, cap_ids[k], "name:autoalign") == want[k][1], k
+    for k in (6, 7):
+        assert hs.get_tag(hs.OSM_WAY, cap_ids[k], "name:autoangle") is None          # open ways get no caption

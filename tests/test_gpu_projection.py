@@ -64,6 +64,25 @@ def test_project_world_range_and_roundtrip(hip):
     assert np.max(np.abs(d_lat2.numpy() - lat)) < 1e-9
 
 
+def test_unproject_matches_oracle(hip):
+    """k_unproject (pxf2geo, src/rdata.c:68-72) against the oracle's restatement point by point, not only through the round
+    trip: arbitrary pixel positions, on and beside the chart"""
+    import ctypes as C
+    sa = hip
+    p, op = _setup(sa, 43.9, 15.5, 20000.0, 2480.3, 3507.9, 300)
+    rng = np.random.default_rng(21)
+    n = 50000
+    x, y = rng.uniform(-500, 3000, n), rng.uniform(-500, 4000, n)
+    d_lon, d_lat = sa.DeviceArray((n,), np.float64), sa.DeviceArray((n,), np.float64)
+    sa.unproject(sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), d_lon, d_lat)
+    glon, glat = d_lon.numpy(), d_lat.numpy()
+    lo, la = C.c_double(), C.c_double()
+    L = po.orc()
+    for i in range(0, n, 7):
+        L.orc_pxf2geo(C.byref(op), x[i], y[i], C.byref(lo), C.byref(la))
+        assert abs(glon[i] - lo.value) <= 1e-12 * max(1.0, abs(lo.value)) and abs(glat[i] - la.value) <= 1e-12 * max(1.0, abs(la.value)), i
+
+
 def test_project_rejects_misaligned_arrays(hip):
     sa = hip
     d = sa.DeviceArray((8,), np.float64)
