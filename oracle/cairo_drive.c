@@ -67,6 +67,7 @@ FN(void, cairo_set_operator, (cairo_t*, int))
 FN(int, cairo_status, (cairo_t*))
 FN(int, cairo_surface_status, (cairo_surface_t*))
 FN(const char*, cairo_version_string, (void))
+FN(int, cairo_surface_write_to_png, (cairo_surface_t*, const char*))
 typedef struct { double x_bearing, y_bearing, width, height, x_advance, y_advance; } cairo_text_extents_t;
 typedef struct { double ascent, descent, height, max_x_advance, max_y_advance; } cairo_font_extents_t;
 FN(void*, cairo_font_options_create, (void))
@@ -102,7 +103,7 @@ int cd_init(const char *path)
    LOAD(cairo_set_line_width); LOAD(cairo_set_line_cap); LOAD(cairo_set_dash);
    LOAD(cairo_stroke); LOAD(cairo_fill); LOAD(cairo_scale); LOAD(cairo_translate);
    LOAD(cairo_rotate); LOAD(cairo_save); LOAD(cairo_restore); LOAD(cairo_set_operator);
-   LOAD(cairo_status); LOAD(cairo_surface_status); LOAD(cairo_version_string);
+   LOAD(cairo_status); LOAD(cairo_surface_status); LOAD(cairo_version_string); LOAD(cairo_surface_write_to_png);
    LOAD(cairo_font_options_create); LOAD(cairo_font_options_set_hint_metrics); LOAD(cairo_set_font_options);
    LOAD(cairo_font_options_destroy); LOAD(cairo_select_font_face); LOAD(cairo_set_font_size);
    LOAD(cairo_font_extents); LOAD(cairo_text_extents);
@@ -210,6 +211,22 @@ int cd_render(double dpi, int x0, int y0, int W, int H, uint32_t *out)
    int stride = p_cairo_image_surface_get_stride(img);
    for (int y = 0; y < H; y++)
       memcpy(out + (size_t) y * W, d + (size_t) y * stride, (size_t) W * 4);
+   p_cairo_surface_destroy(img);
+   return e;
+}
+
+/* save_main_image's PNG branch (src/smrules_cairo.c:388-412): replay the chart into a W x H ARGB32 image and write it as PNG
+ * (timing anchor of tools/cpu_anchor.py; the page rotation of :405 is the identity for an unrotated chart) */
+int cd_save_png(double dpi, int W, int H, const char *path)
+{
+   cairo_surface_t *img = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, W, H);
+   if (p_cairo_surface_status(img)) return -1;
+   cairo_t *dst = p_cairo_create(img);
+   p_cairo_scale(dst, dpi / 72, dpi / 72);
+   p_cairo_set_source_surface(dst, sfc_, 0, 0);
+   p_cairo_paint(dst);
+   p_cairo_destroy(dst);
+   int e = p_cairo_surface_write_to_png(img, path);
    p_cairo_surface_destroy(img);
    return e;
 }

@@ -98,9 +98,12 @@ static plugin_t P;
 
 extern "C" smr_canvas_t *smr_hip_plugin_canvas(void) { return P.canvas; }
 
+static void pool_release(void);
+
 extern "C" int smr_hip_plugin_reset(void)
 {
    if (P.canvas) smr_hip_canvas_destroy(P.canvas);
+   pool_release();
    P = plugin_t();
    return SMR_OK;
 }
@@ -175,6 +178,34 @@ struct dbuf_t
    }
    int alloc(size_t bytes) { return smr_hip_malloc(&p, bytes ? bytes : 16) == SMR_OK ? 0 : -1; }
 };
+
+/* the draw rules' device arrays (lat, lon, x, y, way table, refs, per-way colours): grow-only and kept from rule to rule -- a
+ * chart has hundreds of draw rules, and six hipMalloc/hipFree pairs per rule cost more than the drawing of a small one */
+struct pool_t { void *p = nullptr; size_t cap = 0; };
+static pool_t pool_[8];
+static void *pool_get(int i, size_t bytes)
+{
+   if (bytes < 16) bytes = 16;
+   if (pool_[i].cap < bytes)
+   {
+      if (pool_[i].p) smr_hip_free(pool_[i].p);
+      pool_[i].p = nullptr; pool_[i].cap = 0;
+      const size_t want = bytes + bytes / 4 + 256;
+      if (smr_hip_malloc(&pool_[i].p, want) != SMR_OK) return nullptr;
+      pool_[i].cap = want;
+   }
+   return pool_[i].p;
+}
+static void *pool_put(int i, const void *h, size_t bytes)
+{
+   void *p = pool_get(i, bytes);
+   if (p && bytes && smr_hip_memcpy_h2d(p, h, bytes) != SMR_OK) return nullptr;
+   return p;
+}
+static void pool_release(void)
+{
+   for (pool_t &b : pool_) { if (b.p) smr_hip_free(b.p); b.p = nullptr; b.cap = 0; }
+}
 
 /* struct col_spec, src/smrender_dev.h:176-180 + parse_col_spec src/smrparse.c:261-267 */
 struct col_spec_t { uint32_t col = 0; const char *key = nullptr; };
@@ -527,22 +558,22 @@ static int draw_fini(smr_smrule_t *r)
    {
       size_t n = d->lat.size();
       if (n & 1) { d->lat.push_back(d->lat.back()); d->lon.push_back(d->lon.back()); n++; }
-      dbuf_t lat, lon, x, y, off, ref, fc, bc;
-      bool ok = lat.put(d->lat.data(), n * 8) == 0 && lon.put(d->lon.data(), n * 8) == 0 && x.alloc(n * 8) == 0 &&
-                y.alloc(n * 8) == 0 && off.put(d->way_off.data(), d->way_off.size() * 8) == 0 &&
-                ref.put(d->ref.data(), d->ref.size() * 4) == 0;
-      if (ok && d->fill_cs.key) ok = fc.put(d->fill_col.data(), d->fill_col.size() * 4) == 0;
-      if (ok && d->border_cs.key) ok = bc.put(d->border_col.data(), d->border_col.size() * 4) == 0;
-      if (ok) ok = smr_hip_project((const double *) lat.p, (const double *) lon.p, (int64_t) n, (double *) x.p, (double *) y.p,
+      void *lat = pool_put(0, d->lat.data(), n * 8), *lon = pool_put(1, d->lon.data(), n * 8), *x = pool_get(2, n * 8), *y = pool_get(3, n * 8);
+      void *off = pool_put(4, d->way_off.data(), d->way_off.size() * 8), *ref = pool_put(5, d->ref.data(), d->ref.size() * 4);
+      void *fc = nullptr, *bc = nullptr;
+      bool ok = lat && lon && x && y && off && ref;
+      if (ok && d->fill_cs.key) ok = (fc = pool_put(6, d->fill_col.data(), d->fill_col.size() * 4)) != nullptr;
+      if (ok && d->border_cs.key) ok = (bc = pool_put(7, d->border_col.data(), d->border_col.size() * 4)) != nullptr;
+      if (ok) ok = smr_hip_project((const double *) lat, (const double *) lon, (int64_t) n, (double *) x, (double *) y,
                                    nullptr, nullptr, nullptr) == SMR_OK;
       if (ok)
       {
          smr_draw_batch_t b;
          memset(&b, 0, sizeof(b));
-         b.d_x = (const double *) x.p; b.d_y = (const double *) y.p; b.n_nodes = (int64_t) n;
-         b.d_way_off = (const int64_t *) off.p; b.d_ref = (const int32_t *) ref.p; b.n_ways = n_ways; b.n_refs = n_refs;
-         b.d_way_fill_col = d->fill_cs.key ? (const uint32_t *) fc.p : nullptr;
-         b.d_way_border_col = d->border_cs.key ? (const uint32_t *) bc.p : nullptr;
+         b.d_x = (const double *) x; b.d_y = (const double *) y; b.n_nodes = (int64_t) n;
+         b.d_way_off = (const int64_t *) off; b.d_ref = (const int32_t *) ref; b.n_ways = n_ways; b.n_refs = n_refs;
+         b.d_way_fill_col = (const uint32_t *) fc;
+         b.d_way_border_col = (const uint32_t *) bc;
          ok = smr_hip_draw(P.canvas, &d->st, &b) == SMR_OK;
       }
       if (ok) ok = smr_hip_sync() == SMR_OK;
