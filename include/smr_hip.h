@@ -93,6 +93,13 @@ int smr_hip_canvas_set_halo_device(smr_canvas_t *c, const uint32_t *d_above, int
  * neighbouring ranks' included, are drawn onto it with smr_hip_draw (direct = 1); smr_hip_caprot on it scans the captions
  * anchored in the ORIGINAL band's rows. */
 int smr_hip_canvas_extend(smr_canvas_t *c, smr_canvas_t **out);
+/* Images painted OVER the canvas, in order: what the host's libcairo / FreeType / rsvg rasterise and the reference records into
+ * its chart -- the glyphs of a caption (cairo_show_text, src/smrules_cairo.c:2384-2388) and the symbols of act_img
+ * (img_place, :2754-2826) -- so that the device canvas holds the whole chart.  `pixels` is host memory,
+ * premultiplied ARGB32; item k is the w x h image at pixels + offset (row stride w) whose top-left pixel lands on chart
+ * pixel (x, y); parts outside the band are clipped.  Items are composited one after the other (later over earlier). */
+typedef struct { int32_t x, y, w, h; uint64_t offset; } smr_blit_t;
+int smr_hip_canvas_blit(smr_canvas_t *c, const uint32_t *pixels, uint64_t n_pixels, const smr_blit_t *items, int n_items);
 /* device pointer + row stride (pixels) of the band, for zero-copy consumers */
 int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *stride_px);
 

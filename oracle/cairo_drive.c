@@ -363,6 +363,94 @@ int cd_caption_geometry(const char *font, double size_mm, const char *text, doub
    return 0;
 }
 
+/* cap_coord's drawing part (src/smrules_cairo.c:2215-2217, :2363, :2384-2388) on the CURRENT RULE's context (between
+ * cd_rule_begin and cd_rule_end, like cap.ctx inside its pushed group): save, translate to the anchor, rotate, move_to the
+ * aligned origin, show_text, restore; font set-up as in cd_caption_geometry */
+int cd_show_caption(const char *font, double size_mm, const char *text, double x_pt, double y_pt, double angle,
+                    double ox_pt, double oy_pt, uint32_t col)
+{
+   if (!rule_) return -1;
+   static void (*show_text)(cairo_t*, const char*);
+   if (!show_text) show_text = (void (*)(cairo_t*, const char*)) dlsym(lib_, "cairo_show_text");
+   if (!show_text) return -2;
+   cairo_t *ctx = rule_;
+   p_cairo_save(ctx);
+   void *fo = p_cairo_font_options_create();
+   p_cairo_font_options_set_hint_metrics(fo, 1);
+   p_cairo_set_font_options(ctx, fo);
+   p_cairo_font_options_destroy(fo);
+   void *(*fc_parse)(const unsigned char*) = (void *(*)(const unsigned char*)) dlsym(RTLD_DEFAULT, "FcNameParse");
+   void (*fc_destroy)(void*) = (void (*)(void*)) dlsym(RTLD_DEFAULT, "FcPatternDestroy");
+   void *(*ft_face)(void*) = (void *(*)(void*)) dlsym(lib_, "cairo_ft_font_face_create_for_pattern");
+   void (*set_face)(cairo_t*, void*) = (void (*)(cairo_t*, void*)) dlsym(lib_, "cairo_set_font_face");
+   void (*face_destroy)(void*) = (void (*)(void*)) dlsym(lib_, "cairo_font_face_destroy");
+   void *pat;
+   if (fc_parse && fc_destroy && ft_face && set_face && face_destroy && (pat = fc_parse((const unsigned char*) font)) != NULL)
+   {
+      void *cfc = ft_face(pat);
+      fc_destroy(pat);
+      set_face(ctx, cfc);
+      face_destroy(cfc);
+   }
+   else
+      p_cairo_select_font_face(ctx, font, 0, 0);
+   p_cairo_set_font_size(ctx, size_mm * 72 / 25.4);
+   set_color(ctx, col);
+   p_cairo_translate(ctx, x_pt, y_pt);
+   p_cairo_rotate(ctx, angle);
+   p_cairo_move_to(ctx, ox_pt, oy_pt);
+   show_text(ctx, text);
+   p_cairo_restore(ctx);
+   return p_cairo_status(ctx);
+}
+
+/* the same caption drawn the way libsmr_hip's plugin does it: straight onto a w x h image whose pixel (0, 0) is chart pixel
+ * (ix0, iy0), no recording surface in between (probe: does the recording + replay change the glyphs?) */
+int cd_caption_direct(const char *font, double size_mm, const char *text, double x_pt, double y_pt, double angle,
+                      double ox_pt, double oy_pt, uint32_t col, double dpi, int ix0, int iy0, int w, int h, uint32_t *out)
+{
+   cairo_surface_t *img = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, w, h);
+   cairo_t *save = rule_;
+   rule_ = p_cairo_create(img);
+   p_cairo_translate(rule_, -ix0, -iy0);
+   p_cairo_scale(rule_, dpi / 72, dpi / 72);
+   int e = cd_show_caption(font, size_mm, text, x_pt, y_pt, angle, ox_pt, oy_pt, col);
+   p_cairo_destroy(rule_);
+   rule_ = save;
+   p_cairo_surface_flush(img);
+   unsigned char *d = p_cairo_image_surface_get_data(img);
+   int stride = p_cairo_image_surface_get_stride(img);
+   for (int y = 0; y < h; y++) memcpy(out + (size_t) y * w, d + (size_t) y * stride, (size_t) w * 4);
+   p_cairo_surface_destroy(img);
+   return e;
+}
+
+/* ... and through a recording surface of its own (chart extents in pt, like the reference's), replayed at dpi/72 into the image */
+int cd_caption_recorded(const char *font, double size_mm, const char *text, double x_pt, double y_pt, double angle,
+                        double ox_pt, double oy_pt, uint32_t col, double dpi, int ix0, int iy0, int w, int h, uint32_t *out)
+{
+   cairo_surface_t *rec = p_cairo_recording_surface_create(CAIRO_CONTENT_COLOR_ALPHA, &ext_);
+   cairo_t *save = rule_;
+   rule_ = p_cairo_create(rec);
+   int e = cd_show_caption(font, size_mm, text, x_pt, y_pt, angle, ox_pt, oy_pt, col);
+   p_cairo_destroy(rule_);
+   rule_ = save;
+   cairo_surface_t *img = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, w, h);
+   cairo_t *dst = p_cairo_create(img);
+   p_cairo_translate(dst, -ix0, -iy0);
+   p_cairo_scale(dst, dpi / 72, dpi / 72);
+   p_cairo_set_source_surface(dst, rec, 0, 0);
+   p_cairo_paint(dst);
+   p_cairo_destroy(dst);
+   p_cairo_surface_flush(img);
+   unsigned char *d = p_cairo_image_surface_get_data(img);
+   int stride = p_cairo_image_surface_get_stride(img);
+   for (int y = 0; y < h; y++) memcpy(out + (size_t) y * w, d + (size_t) y * stride, (size_t) w * 4);
+   p_cairo_surface_destroy(img);
+   p_cairo_surface_destroy(rec);
+   return e;
+}
+
 /* cairo_smr_plane, src/smrules_cairo.c:1536-1558.  out must hold round(w*dpi/72) x round(h*dpi/72) pixels */
 int cd_plane(int w_pt, int h_pt, int x_pt, uint32_t col, int dpi, uint32_t *out)
 {

@@ -144,6 +144,7 @@ def cairo():
         L.cd_caption_geometry.argtypes = [C.c_char_p, C.c_double, C.c_char_p, C.c_double, C.c_double, C.c_int,
                                           C.c_double, C.c_double, C.c_void_p]
         L.cd_last_metrics.argtypes = [C.c_void_p]
+        L.cd_show_caption.argtypes = [C.c_char_p, C.c_double, C.c_char_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_uint32]
         L.cd_plane.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_void_p]
         _cd = L
     return _cd or None
@@ -327,8 +328,9 @@ def _cairo_curve_way(L, st, xy, closed, dpi):
             L.cd_fill(st.fill_col)
 
 
-def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None):
-    """Same scene through the real libcairo with the reference's call sequence."""
+def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None, before_render=None):
+    """Same scene through the real libcairo with the reference's call sequence.  before_render(L): further rules recorded
+    through the driver (captions: cd_rule_begin, cd_show_caption ..., cd_rule_end) before the chart is replayed."""
     L = cairo()
     fw = (full_w or (x0 + W)) * 72 / dpi
     fh = (full_h or (y0 + H)) * 72 / dpi
@@ -365,6 +367,8 @@ def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None):
                 else:
                     L.cd_fill(st.fill_col)
         L.cd_rule_end()
+    if before_render is not None:
+        before_render(L)
     out = np.zeros((H, W), np.uint32)
     assert L.cd_render(float(dpi), x0, y0, W, H, P(out)) == 0
     return out

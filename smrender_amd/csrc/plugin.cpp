@@ -617,6 +617,12 @@ struct cairo_api_t
    void (*set_source_rgba)(void *, double, double, double, double);
    void (*rectangle)(void *, double, double, double, double);
    void (*fill)(void *);
+   void (*translate)(void *, double, double);
+   void (*rotate)(void *, double);
+   void (*move_to)(void *, double, double);
+   void (*show_text)(void *, const char *);
+   void (*set_source_surface)(void *, void *, double, double);
+   void (*paint)(void *);
    /* optional: fontconfig face like the reference's CAIRO_HAS_FC_FONT branch (:1345-1354) */
    void *(*ft_font_face_create_for_pattern)(void *);
    void (*set_font_face)(void *, void *);
@@ -648,6 +654,8 @@ static int cairo_load(void)
    CR_LOAD(set_font_size, "cairo_set_font_size"); CR_LOAD(font_extents, "cairo_font_extents"); CR_LOAD(text_extents, "cairo_text_extents");
    CR_LOAD(scale, "cairo_scale"); CR_LOAD(set_source_rgba, "cairo_set_source_rgba"); CR_LOAD(rectangle, "cairo_rectangle");
    CR_LOAD(fill, "cairo_fill");
+   CR_LOAD(translate, "cairo_translate"); CR_LOAD(rotate, "cairo_rotate"); CR_LOAD(move_to, "cairo_move_to"); CR_LOAD(show_text, "cairo_show_text");
+   CR_LOAD(set_source_surface, "cairo_set_source_surface"); CR_LOAD(paint, "cairo_paint");
    *(void **) (&CR.ft_font_face_create_for_pattern) = dlsym(CR.lib, "cairo_ft_font_face_create_for_pattern");
    *(void **) (&CR.set_font_face) = dlsym(CR.lib, "cairo_set_font_face");
    *(void **) (&CR.font_face_destroy) = dlsym(CR.lib, "cairo_font_face_destroy");
@@ -667,6 +675,8 @@ struct cap_item_t
    uint32_t col;
    short pos;
    double tw, hgt, ascent;    /* tx.width + tx.x_bearing, max(tx.height, ascent + descent), fe.ascent: the auto_ctx rectangle */
+   double size_mm, descent;   /* for the glyphs */
+   std::string text;
 };
 
 struct cap_rule_t
@@ -678,6 +688,7 @@ struct cap_rule_t
    double size = 0, xoff = 0, yoff = 0, phase = 0, weight = 1;
    double min_auto_size = 0.5, max_auto_size = 12.0, min_area_size = 8.0, auto_scale = 0.2;   /* src/smrender_dev.h:107-110 */
    const char *halignkey = nullptr, *valignkey = nullptr;
+   int hide = 0;
    void *sfc = nullptr, *ctx = nullptr;
    std::vector<cap_item_t> items;
 };
@@ -705,6 +716,25 @@ static int alignment(const smr_action_t *act)      /* parse_alignment, src/smrpa
    if ((s = H.get_param("halign", nullptr, act)) != nullptr) pos |= alignment_str(s) & (SMR_POS_E | SMR_POS_W);
    if ((s = H.get_param("valign", nullptr, act)) != nullptr) pos |= alignment_str(s) & (SMR_POS_N | SMR_POS_S);
    return pos;
+}
+
+/* the font of a caption context: hint metrics off, a fontconfig face when libcairo has it (act_cap_ini :1335-1357) */
+static void cap_font(void *ctx, const char *font)
+{
+   void *fo = CR.font_options_create();
+   CR.font_options_set_hint_metrics(fo, 1 /* CAIRO_HINT_METRICS_OFF */);
+   CR.set_font_options(ctx, fo);
+   CR.font_options_destroy(fo);
+   void *pat = nullptr;
+   if (CR.FcNameParse && CR.FcPatternDestroy && CR.ft_font_face_create_for_pattern && CR.set_font_face && CR.font_face_destroy &&
+       (pat = CR.FcNameParse((const unsigned char *) font)) != nullptr)
+   {
+      void *cfc = CR.ft_font_face_create_for_pattern(pat);
+      CR.FcPatternDestroy(pat);
+      CR.set_font_face(ctx, cfc);
+      CR.font_face_destroy(cfc);
+   }
+   else CR.select_font_face(ctx, font, 0, 0);
 }
 
 static int cap_ini(smr_smrule_t *r)
@@ -752,6 +782,7 @@ static int cap_ini(smr_smrule_t *r)
    if (cap->weight > 1.0) cap->weight = 1.0;
    else if (cap->weight < -1.0) cap->weight = -1.0;
    (void) H.get_param("phase", &cap->phase, r->act);
+   cap->hide = H.get_param_bool("hide", r->act);
    cap->pos = (short) alignment(r->act);
    if ((cap->halignkey = H.get_param("alignkey", nullptr, r->act)) != nullptr)
    {
@@ -784,20 +815,7 @@ static int cap_ini(smr_smrule_t *r)
    cr_rectangle_t ext = { 0, 0, P.proj.w * 72 / P.dpi, P.proj.h * 72 / P.dpi };
    cap->sfc = CR.recording_surface_create(0x3000, &ext);
    cap->ctx = CR.create(cap->sfc);
-   void *fo = CR.font_options_create();
-   CR.font_options_set_hint_metrics(fo, 1 /* CAIRO_HINT_METRICS_OFF */);
-   CR.set_font_options(cap->ctx, fo);
-   CR.font_options_destroy(fo);
-   void *pat = nullptr;
-   if (CR.FcNameParse && CR.FcPatternDestroy && CR.ft_font_face_create_for_pattern && CR.set_font_face && CR.font_face_destroy &&
-       (pat = CR.FcNameParse((const unsigned char *) cap->font)) != nullptr)
-   {
-      void *cfc = CR.ft_font_face_create_for_pattern(pat);
-      CR.FcPatternDestroy(pat);
-      CR.set_font_face(cap->ctx, cfc);
-      CR.font_face_destroy(cfc);
-   }
-   else CR.select_font_face(cap->ctx, cap->font, 0, 0);
+   cap_font(cap->ctx, cap->font);
    r->data = cap;
    return 0;
 }
@@ -820,6 +838,7 @@ static int cap_collect(cap_rule_t *cap, double size_mm, double lat, double lon, 
    it.pos = (cap->pos & 0xc) ? (short) ((cap->pos & 0xfff0) | SMR_POS_E) : cap->pos;
    it.col = color_by_cs(o, &cap->cs);
    it.tw = tx.width + tx.x_bearing; it.hgt = fmax(tx.height, fe.ascent + fe.descent); it.ascent = fe.ascent;
+   it.size_mm = size_mm; it.descent = fe.descent; it.text = buf;
    /* cairo_smr_plane(int w, int h, int x, int col): the double arguments are truncated to int pt (:1536, :2272, :2277) */
    if (cap->pos & 0xc) { it.pw = (int) (width * 2); it.ph = (int) height; it.px = (int) width; }
    else { it.pw = (int) width; it.ph = (int) height; it.px = 0; }
@@ -946,6 +965,78 @@ static void cap_levels(const std::vector<double> &cx, const std::vector<double> 
       n_levels = std::max(n_levels, lv + 1);
       grid[{ gx, gy }].push_back(i);
    }
+}
+
+/* cairo_show_text of every caption (cap_coord :2363-2388: translate to the anchor, rotate, move_to the aligned origin, show_text),
+ * rasterised by the host's libcairo + FreeType into a small image per caption on the chart's own pixel grid and painted OVER
+ * the device canvas in object order (smr_hip_canvas_blit): glyph outlines stay on the host, the pixels land on the device */
+static int cap_draw_glyphs(const cap_rule_t *cap, const std::vector<double> &cx, const std::vector<double> &cy,
+                           const std::vector<double> &angle, const std::vector<short> &final_pos)
+{
+   std::vector<uint32_t> pixels;
+   std::vector<smr_blit_t> items;
+   const double sc = (double) P.dpi / 72.0;
+   const int W = (int) round(P.proj.w), Hh = (int) round(P.proj.h);
+   auto flush = [&]() -> int
+   {
+      if (items.empty()) return SMR_OK;
+      const int rc = smr_hip_canvas_blit(P.canvas, pixels.data(), pixels.size(), items.data(), (int) items.size());
+      pixels.clear(); items.clear();
+      return rc;
+   };
+   for (size_t i = 0; i < cap->items.size(); i++)
+   {
+      const cap_item_t &it = cap->items[i];
+      if (it.size_mm == 0.0 || it.text.empty()) continue;
+      const double a = angle[i], ca = cos(a), sa = sin(a);
+      double ox, oy;
+      pos_offset(final_pos[i], it.tw, it.hgt, cap->xoff, cap->yoff, &ox, &oy);
+      /* the text's box about its origin (a font size of slack for overhangs), rotated, in chart pixels */
+      const double pad = mm2pt(it.size_mm), ux[2] = { ox - pad, ox + it.tw + pad }, uy[2] = { oy - it.hgt - pad, oy + it.descent + pad };
+      double mnx = 1e300, mny = 1e300, mxx = -1e300, mxy = -1e300;
+      for (int k = 0; k < 4; k++)
+      {
+         const double X = (ca * ux[k & 1] - sa * uy[k >> 1]) * sc + cx[i], Y = (sa * ux[k & 1] + ca * uy[k >> 1]) * sc + cy[i];
+         mnx = fmin(mnx, X); mxx = fmax(mxx, X); mny = fmin(mny, Y); mxy = fmax(mxy, Y);
+      }
+      const int ix0 = (int) fmax(floor(mnx), 0.0), iy0 = (int) fmax(floor(mny), 0.0);
+      const int ix1 = (int) fmin(ceil(mxx), (double) W), iy1 = (int) fmin(ceil(mxy), (double) Hh);
+      if (ix1 <= ix0 || iy1 <= iy0) continue;
+      const int w = ix1 - ix0, h = iy1 - iy0;
+      /* recorded in pt on a recording surface and replayed at dpi/72, as the reference's chart is: libcairo rasterises the glyphs
+       * of a replayed recording differently from glyphs shown on an image directly (oracle/cairo_drive.c:cd_caption_direct
+       * against cd_caption_recorded: 60 % of the text pixels differ, against none) */
+      cr_rectangle_t ext = { 0, 0, P.proj.w * 72 / P.dpi, P.proj.h * 72 / P.dpi };
+      void *rec = CR.recording_surface_create(0x3000, &ext);
+      void *ctx = CR.create(rec);
+      CR.translate(ctx, cx[i] * 72 / P.dpi, cy[i] * 72 / P.dpi);
+      CR.rotate(ctx, a);
+      cap_font(ctx, cap->font);
+      CR.set_font_size(ctx, mm2pt(it.size_mm));
+      CR.set_source_rgba(ctx, (double) ((it.col >> 16) & 0xff) / 255.0, (double) ((it.col >> 8) & 0xff) / 255.0, (double) (it.col & 0xff) / 255.0,
+                         1.0 - (double) (((it.col & 0x7f000000u) >> 23) & 0xff) / 255.0);
+      CR.move_to(ctx, ox, oy);
+      CR.show_text(ctx, it.text.c_str());
+      CR.destroy(ctx);
+      void *sfc = CR.image_surface_create(0 /* ARGB32 */, w, h);
+      ctx = CR.create(sfc);
+      CR.translate(ctx, -ix0, -iy0);
+      CR.scale(ctx, sc, sc);
+      CR.set_source_surface(ctx, rec, 0, 0);
+      CR.paint(ctx);
+      CR.destroy(ctx);
+      CR.surface_destroy(rec);
+      CR.surface_flush(sfc);
+      const unsigned char *d = CR.image_surface_get_data(sfc);
+      const int stride = CR.image_surface_get_stride(sfc);
+      smr_blit_t b; b.x = ix0; b.y = iy0; b.w = w; b.h = h; b.offset = pixels.size();
+      pixels.resize(pixels.size() + (size_t) w * h);
+      for (int y = 0; y < h; y++) memcpy(&pixels[b.offset + (size_t) y * w], d + (size_t) y * stride, (size_t) w * 4);
+      CR.surface_destroy(sfc);
+      items.push_back(b);
+      if (pixels.size() > ((size_t) 16 << 20)) { const int rc = flush(); if (rc != SMR_OK) return rc; }
+   }
+   return flush();
 }
 
 static int cap_fini(smr_smrule_t *r)
@@ -1088,7 +1179,13 @@ static int cap_fini(smr_smrule_t *r)
          add_tag(it.o, cap->key, "autoangle", val);
          add_tag(it.o, cap->key, "autoalign", (final_pos[i] & SMR_POS_E) ? "east" : (final_pos[i] & SMR_POS_W) ? "west" : "center");
       }
-   plog(SMR_LOG_INFO, "cap: %zu captions scanned on the GPU in %d dependency level(s), %zu batch(es)", n_all, n_levels, n_groups);
+   if (ret == 0 && !cap->hide && n_all && cap_draw_glyphs(cap, cx, cy, angle, final_pos) != SMR_OK)
+   {
+      plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error());
+      ret = -1;
+   }
+   plog(SMR_LOG_INFO, "cap: %zu captions scanned on the GPU in %d dependency level(s), %zu batch(es)%s", n_all, n_levels, n_groups,
+        cap->hide ? "" : ", glyphs composited onto the device canvas");
    CR.destroy(cap->ctx);
    CR.surface_destroy(cap->sfc);
    delete cap;

@@ -3491,6 +3491,46 @@ extern "C" int smr_hip_canvas_extend(smr_canvas_t *c, smr_canvas_t **out)
    return SMR_OK;
 }
 
+/* one image OVER the band: lane = pixel of the image */
+__global__ void k_blit_over(uint32_t *__restrict__ canvas, int W, int band_y0, int band_h, const uint32_t *__restrict__ img,
+                            int x0, int y0, int w, int h)
+{
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= w * h) return;
+   const int px = x0 + i % w, py = y0 + i / w - band_y0;
+   if (px < 0 || px >= W || py < 0 || py >= band_h) return;
+   const uint32_t s = img[i];
+   if (s == 0u) return;
+   uint32_t *d = canvas + (size_t) py * W + px;
+   *d = smr_blend_over(s, *d);
+}
+
+extern "C" int smr_hip_canvas_blit(smr_canvas_t *c, const uint32_t *pixels, uint64_t n_pixels, const smr_blit_t *items, int n_items)
+{
+   SMR_NEED_INIT();
+   if (!c || n_items < 0 || (n_items && (!pixels || !items))) return smr_fail(SMR_E_INVAL, "canvas_blit: NULL argument");
+   for (int k = 0; k < n_items; k++)
+      if (items[k].w < 0 || items[k].h < 0 || (uint64_t) items[k].w * (uint64_t) items[k].h > n_pixels ||
+          items[k].offset > n_pixels - (uint64_t) items[k].w * (uint64_t) items[k].h)
+         return smr_fail(SMR_E_INVAL, "canvas_blit: item %d (%d x %d at offset %llu) lies outside the %llu pixels handed over", k,
+                         items[k].w, items[k].h, (unsigned long long) items[k].offset, (unsigned long long) n_pixels);
+   if (n_items == 0 || n_pixels == 0) return SMR_OK;
+   hipStream_t s = smr_g.stream;
+   uint32_t *d_img;
+   SMR_TRY(c->ensure(SMR_BUF_BLIT, (size_t) n_pixels * 4, (void **) &d_img));
+   SMR_HIP(hipMemcpyAsync(d_img, pixels, (size_t) n_pixels * 4, hipMemcpyHostToDevice, s));
+   for (int k = 0; k < n_items; k++)
+   {
+      const smr_blit_t &it = items[k];
+      const int n = it.w * it.h;
+      if (n == 0) continue;
+      k_blit_over<<<(n + 255) / 256, 256, 0, s>>>(c->pix, c->W, c->band_y0, c->band_h, d_img + it.offset, it.x, it.y, it.w, it.h);
+   }
+   SMR_HIP(hipGetLastError());
+   SMR_HIP(hipStreamSynchronize(s));      /* the caller's pixels may go */
+   return SMR_OK;
+}
+
 extern "C" int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *stride_px)
 {
    if (!c || !d_pix || !stride_px) return smr_fail(SMR_E_INVAL, "canvas_device: NULL argument");

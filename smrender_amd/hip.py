@@ -75,7 +75,7 @@ EXPORTS = [
     "smr_hip_init", "smr_hip_shutdown", "smr_hip_last_error", "smr_hip_device_name",
     "smr_hip_proj_from_window", "smr_hip_set_projection", "smr_hip_project", "smr_hip_unproject",
     "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_read", "smr_hip_canvas_device",
-    "smr_hip_canvas_set_halo", "smr_hip_canvas_set_halo_device", "smr_hip_canvas_extend", "smr_hip_canvas_clone",
+    "smr_hip_canvas_set_halo", "smr_hip_canvas_set_halo_device", "smr_hip_canvas_extend", "smr_hip_canvas_clone", "smr_hip_canvas_blit",
     "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
     "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
@@ -108,6 +108,7 @@ def lib():
         L.smr_hip_canvas_set_halo.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.smr_hip_canvas_set_halo_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.smr_hip_canvas_extend.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.smr_hip_canvas_blit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.smr_hip_canvas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.smr_hip_draw.argtypes = [C.c_void_p, C.POINTER(DrawStyle), C.POINTER(_DrawBatch)]
         L.smr_hip_debug_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -274,6 +275,16 @@ class Canvas:
         o.band_y0, o.band_h = self.band_y0 - self._n_above, self.band_h + self._n_above + self._n_below
         o._n_above = o._n_below = 0
         return o
+
+    def blit(self, images):
+        """images: [(x, y, premultiplied ARGB32 array [h, w])], painted OVER the canvas in this order (smr_hip_canvas_blit)"""
+        items = np.zeros(len(images), np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("offset", "<u8")]))
+        off = 0
+        for k, (x, y, im) in enumerate(images):
+            items[k] = (x, y, im.shape[1], im.shape[0], off)
+            off += im.size
+        pix = np.concatenate([np.ascontiguousarray(im, np.uint32).ravel() for _, _, im in images]) if images else np.zeros(0, np.uint32)
+        _chk(lib().smr_hip_canvas_blit(self.h, pix.ctypes.data, len(pix), items.ctypes.data, len(images)))
 
     def device_ptr(self):
         """(device address of the band's first pixel, row stride in pixels)"""

@@ -2,6 +2,7 @@
 driven through the reference's own libsmrender (oracle/_ref) by the miniature host, compared with
 the oracle restatement of act_draw / cap_coord + find_angle on the same objects."""
 import ctypes as C
+import os
 import numpy as np
 import pytest
 from oracle import pyoracle as po
@@ -277,7 +278,7 @@ def oracle_caption_tags(img, names, px, py, size_mm, col, weight):
         if np.pi / 2 < a < 3 * np.pi / 2:
             a -= np.pi
             pos_e = False
-        out.append(("%.1f" % np.degrees(a), "east" if pos_e else "west"))
+        out.append(("%.1f" % np.degrees(a), "east" if pos_e else "west", a))
         # the rectangle: translate(x, y) rotate(a) rectangle(ox, oy, tw + xoff, -ascent); colour of the rule's first object
         tw, asc, desc, th = met
         hgt = max(th, asc + desc)
@@ -463,3 +464,68 @@ def test_cap_on_closed_ways_uses_the_centroid(chart):
         assert hs.get_tag(hs.OSM_WAY, cap_ids[k], "name:autoalign") == want[k][1], k
     for k in (6, 7):
         assert hs.get_tag(hs.OSM_WAY, cap_ids[k], "name:autoangle") is None          # open ways get no caption
+
+
+def test_cap_glyphs_are_composited_onto_the_device_canvas(chart):
+    """SURVEY 8f rank 1 for captions: after the scan the plugin's cap draws the text itself (cap_coord :2363-2388): host
+    libcairo + FreeType rasterise every caption on the chart's pixel grid, smr_hip_canvas_blit paints the images OVER the
+    device canvas.  Compared with the real libcairo recording and replaying the same chart: draw rule, then one rule with
+    cairo_show_text per caption at the angle the scan chose.  hide=1 leaves the canvas as it was (only the tags)."""
+    sa, proj = chart
+    from smrender_amd import synth
+    from golden_io import within
+    cd = po.cairo()
+    if cd is None:
+        pytest.skip("libcairo not loadable")
+    arrs = po.synth_ways(70, W, H, seed=85)
+    wids, oways = load_ways(sa, proj, arrs)
+    assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", wids) == 0
+    before = plugin_canvas(sa)
+    rng = np.random.default_rng(31)
+    n = 10
+    cx, cy = rng.uniform(40, W - 90, n), rng.uniform(30, H - 30, n)
+    names = [f"Caption {k}" for k in range(n)]
+    lat, lon = synth.px_to_geo(proj, cx, cy)
+    size_mm, col = 2.5, 0x802010
+    for hide in (1, 0):
+        base = _next_id[0]; _next_id[0] += n + 1
+        nids = base + np.arange(n)
+        hs.add_nodes(nids, lat, lon, [f"name={t}" for t in names])
+        params = f"key=name;size={size_mm};angle=auto;color=#802010;halign=east;font=serif;weight=1.0;hide={hide}"
+        assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, params, nids) == 0, sa.lib().smr_hip_last_error()
+        got = plugin_canvas(sa)
+        if hide:
+            assert np.array_equal(got, before)
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    px, py, _, _, _ = po.project(op, lat, lon)
+    xoff = size_mm * 72 / 25.4 / 2
+
+    # the angles as find_angle returns them (the tags hold them rounded to 0.1 degree, which moves glyphs by whole pixels)
+    tags, _ = oracle_caption_tags(before, names, px, py, size_mm, col, 1.0)
+
+    def captions(L):
+        L.cd_rule_begin()
+        for k in range(n):
+            assert hs.get_tag(hs.OSM_NODE, nids[k], "name:autoangle") == tags[k][0]
+            a, east = tags[k][2], tags[k][1] == "east"
+            geo = np.zeros(3, np.int32)
+            L.cd_caption_geometry(b"serif", size_mm, names[k].encode(), xoff, xoff, 1, W * 72 / DPI, H * 72 / DPI, po.P(geo))
+            met = np.zeros(4); L.cd_last_metrics(po.P(met))
+            tw, asc, desc, th = met
+            hgt = max(th, asc + desc)
+            ox, oy = (xoff if east else -tw - xoff), hgt / 2          # pos_offset (:1478-1508): E/W aligned, vertically centred
+            assert L.cd_show_caption(b"serif", size_mm, names[k].encode(), px[k] * 72 / DPI, py[k] * 72 / DPI, a, ox, oy, col) == 0
+        L.cd_rule_end()
+
+    want = po.cairo_scene([(po.Style(1, 1, 0x4080c0, 0, 0, 0.1, 0), oways)], DPI, W, H, 0xfff8e0, before_render=captions)
+    plain = po.cairo_scene([(po.Style(1, 1, 0x4080c0, 0, 0, 0.1, 0), oways)], DPI, W, H, 0xfff8e0)
+    text = np.any(po.chan_diff(want, plain) > 0, axis=-1) if po.chan_diff(want, plain).ndim == 3 else po.chan_diff(want, plain) > 0
+    assert text.sum() > 2000                                   # the captions really are in the reference picture
+    if os.environ.get("SMR_TEST_DUMP"):
+        np.savez(os.path.join(os.environ["SMR_TEST_DUMP"], "glyphs_dump.npz"), got=got, want=want, plain=plain, px=px, py=py,
+                 ang=[hs.get_tag(hs.OSM_NODE, nids[k], "name:autoangle") for k in range(n)], al=[hs.get_tag(hs.OSM_NODE, nids[k], "name:autoalign") for k in range(n)])
+    assert within(got, want) >= 0.995                          # north star: +-2/255 on >= 99.5 % of the pixels
+    # and where the text is: the glyph pixels themselves agree (same FreeType masks, same positions)
+    d = po.chan_diff(got, want)
+    d = d.max(axis=-1) if d.ndim == 3 else d
+    assert (d[text] <= 2).mean() >= 0.97, float((d[text] <= 2).mean())
