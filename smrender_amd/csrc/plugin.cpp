@@ -754,6 +754,13 @@ static int cap_ini(smr_smrule_t *r)
       plog(SMR_LOG_ERR, "cap: host symbols match_attr/realloc_tags not found");
       return -1;
    }
+   if (P.band_y0 != 0 || P.band_h != P.H)
+   {
+      /* a caption's cut-out reaches into the neighbouring bands; the plugin is one process and exchanges no halo rows */
+      plog(SMR_LOG_ERR, "cap: the canvas is a row band (SMR_HIP_BAND_Y0/_H): the auto-rotation scan needs the neighbours' rows, which only a "
+                        "driver of the C-ABI exchanges (smr_hip_canvas_set_halo, smrender_amd/dist.py)");
+      return 1;
+   }
    if (cairo_load() != 0) return -1;
 
    cap_rule_t *cap = new cap_rule_t();
