@@ -529,3 +529,27 @@ def test_cap_glyphs_are_composited_onto_the_device_canvas(chart):
     d = po.chan_diff(got, want)
     d = d.max(axis=-1) if d.ndim == 3 else d
     assert (d[text] <= 2).mean() >= 0.97, float((d[text] <= 2).mean())
+
+
+def test_cap_on_a_banded_plugin_canvas_is_refused(chart, monkeypatch):
+    """the scan of a caption near a band boundary needs the neighbour's rows; the plugin has nobody to ask, so a
+    banded plugin canvas draws but refuses cap ('Two canvases'); dist.py is the banded caption path"""
+    sa, proj = chart
+    monkeypatch.setenv("SMR_HIP_BAND_Y0", "100")
+    monkeypatch.setenv("SMR_HIP_BAND_H", "100")
+    try:
+        wids, oways = load_ways(sa, proj, po.synth_ways(30, W, H, seed=3))
+        assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0", wids) == 0
+        want = po.oracle_scene([(po.Style(1, 0, 0x4080c0, 0, 0, 0, 0), oways)], DPI, W, H, 0xfff8e0)
+        got = np.empty((100, W), np.uint32)
+        assert sa.lib().smr_hip_canvas_read(sa.lib().smr_hip_plugin_canvas(), 0, 0, W, 100, got.ctypes.data) == 0      # band-local rows
+        assert np.array_equal(got, want[100:200])
+        from smrender_amd import synth
+        lat, lon = synth.px_to_geo(proj, np.array([150.0]), np.array([150.0]))
+        nid = _next_id[0]; _next_id[0] += 2
+        hs.add_nodes(np.array([nid]), lat, lon, ["name=Band"])
+        assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, "key=name;size=2;angle=auto;color=black", np.array([nid])) != 0
+        assert hs.get_tag(hs.OSM_NODE, nid, "name:autoangle") is None
+    finally:
+        monkeypatch.undo()
+        sa.lib().smr_hip_plugin_reset()
