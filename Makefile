@@ -17,7 +17,7 @@ build/%.cpp.o: $(CSRC)/%.cpp include/smr_hip.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 smrender_amd/libsmr_hip.so: $(OBJS)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -ldl
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) -o $@ $(OBJS) -ldl -lz -lpthread
 
 oracle:
 	$(MAKE) -C oracle all
@@ -32,4 +32,4 @@ clean:
 prof: tools/libsmr_hip_prof.so
 tools/libsmr_hip_prof.so: $(SRCS) $(CSRC)/smr_dev.h $(CSRC)/smr_host.h include/smr_hip.h
 	@mkdir -p build
-	$(HIPCC) $(HIPFLAGS) -DSMR_SECTION_PROFILE -x hip -shared -o $@ $(SRCS) -ldl
+	$(HIPCC) $(HIPFLAGS) -DSMR_SECTION_PROFILE -x hip -shared -o $@ $(SRCS) -ldl -lz -lpthread

@@ -100,6 +100,26 @@ int smr_hip_canvas_extend(smr_canvas_t *c, smr_canvas_t **out);
  * pixel (x, y); parts outside the band are clipped.  Items are composited one after the other (later over earlier). */
 typedef struct { int32_t x, y, w, h; uint64_t offset; } smr_blit_t;
 int smr_hip_canvas_blit(smr_canvas_t *c, const uint32_t *pixels, uint64_t n_pixels, const smr_blit_t *items, int n_items);
+/* PNG files straight from the device canvas.  canvas_write_png replaces the image branch of save_main_image
+ * (src/smrules_cairo.c:398-412: the chart as an ARGB32 image handed to cairo_surface_write_to_png_stream) for the unrotated page;
+ * canvas_write_tiles replaces the writer of create_tiles (src/smtile.c:186-222: clear_tile, cut_tile, save_image per tile,
+ * file <dir>/<x>/<y>.png below the zoom directory) for a canvas that was rendered ON the tile grid: nx x ny tiles of tile_px
+ * pixels whose first one has its corner at band pixel (x, y) and is named tx0/ty0.  (The reference re-rasterises its recording
+ * per tile at TILE_SIZE / tile width in pt; here the caller renders the zoom level as one canvas at that scale and this call
+ * cuts it.)  The decoded pixels are those of libcairo's PNG writer for the same ARGB32 data: all alpha 255 -> 8-bit RGB, else
+ * RGBA un-premultiplied as (c*255 + a/2)/a.  The un-premultiply, the choice among PNG's five row filters and the filtering run
+ * on the device; the filtered rows cross PCIe once; `threads` host workers (0: min(16, cores)) deflate them with zlib at `level`
+ * (-1: zlib's default, as libpng's).  Rows are band-local.  `st` may be NULL. */
+typedef struct
+{
+   uint64_t n_files, n_opaque;             /* files written; how many of them are RGB (no alpha channel needed) */
+   uint64_t bytes_filtered, bytes_written; /* deflate input (filter bytes + residuals) and file bytes */
+   float deflate_ms, total_ms;             /* wall time inside the host's deflate workers / of the whole call */
+   int32_t threads, pad_;
+} smr_png_stats_t;
+int smr_hip_canvas_write_png(smr_canvas_t *c, int x, int y, int w, int h, const char *path, int level, int threads, smr_png_stats_t *st);
+int smr_hip_canvas_write_tiles(smr_canvas_t *c, int x, int y, int nx, int ny, int tile_px, const char *dir, int tx0, int ty0,
+                               int level, int threads, smr_png_stats_t *st);
 /* device pointer + row stride (pixels) of the band, for zero-copy consumers */
 int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *stride_px);
 

@@ -231,6 +231,22 @@ int cd_save_png(double dpi, int W, int H, const char *path)
    return e;
 }
 
+/* libcairo's own PNG writer on given ARGB32 pixels (what save_main_image :409 and save_image :467 call on the rendered image):
+ * the pin of smr_hip_canvas_write_png / _write_tiles, whose files must DECODE to the same pixels */
+int cd_write_png_data(const uint32_t *argb, int W, int H, const char *path)
+{
+   cairo_surface_t *img = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, W, H);
+   if (p_cairo_surface_status(img)) return -1;
+   p_cairo_surface_flush(img);
+   unsigned char *d = p_cairo_image_surface_get_data(img);
+   int stride = p_cairo_image_surface_get_stride(img);
+   for (int y = 0; y < H; y++) memcpy(d + (size_t) y * stride, argb + (size_t) y * W, (size_t) W * 4);
+   p_cairo_surface_mark_dirty(img);
+   int e = p_cairo_surface_write_to_png(img, path);
+   p_cairo_surface_destroy(img);
+   return e;
+}
+
 /* cairo_smr_cut_out (src/smrules_cairo.c:1511-1533): the r x r pt window of the chart around (x, y) pt as find_angle takes it --
  * the recording replayed at dpi/72 with the translation (-x + r/2, -y + r/2) pt, i.e. at a sub-pixel offset whenever the
  * anchor is not on the pixel grid.  out holds n x n pixels, n = round(r * dpi / 72) (returned). */

@@ -138,6 +138,7 @@ def cairo():
         L.cd_fill.argtypes = [C.c_uint32]
         L.cd_render.argtypes = [C.c_double] + [C.c_int] * 4 + [C.c_void_p]
         L.cd_save_png.argtypes = [C.c_double, C.c_int, C.c_int, C.c_char_p]
+        L.cd_write_png_data.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
         L.cd_cut_out.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int]
         L.cd_direct_fill.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
         L.cd_rot_paint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]
@@ -390,4 +391,56 @@ def ways_from_arrays(x, y, way_off, ref):
         r = ref[way_off[w]:way_off[w + 1]]
         closed = len(r) >= 4 and r[0] == r[-1]
         out.append((x[r], y[r], closed))
+    return out
+
+
+# ---- PNG: what libcairo's writer makes of an ARGB32 image, and a decoder for the files ------------------------------------
+def png_pixels(argb):
+    """cairo 1.16 cairo-png.c write_png on a CAIRO_FORMAT_ARGB32 image (what save_main_image, src/smrules_cairo.c:409, and
+    save_image, :467, hand over), restated: every alpha 255 -> RGB samples [H, W, 3]; otherwise RGBA [H, W, 4], each colour
+    un-premultiplied as (c * 255 + a / 2) / a in integers, alpha 0 -> four zero bytes (unpremultiply_data)."""
+    p = np.asarray(argb, np.uint32)
+    a = (p >> 24).astype(np.uint32)
+    ch = [((p >> sh) & 0xff).astype(np.uint32) for sh in (16, 8, 0)]
+    if np.all(a == 255):
+        return np.stack(ch, -1).astype(np.uint8)
+    d = np.where(a == 0, 1, a)
+    out = [np.where(a == 0, 0, (c * 255 + a // 2) // d) & 0xff for c in ch] + [a]
+    return np.stack(out, -1).astype(np.uint8)
+
+
+def png_decode(path, with_info=False):
+    """decodes an 8-bit RGB / RGBA, non-interlaced PNG file into [H, W, 3 | 4] uint8; checks every chunk's CRC and the zlib
+    stream's Adler-32 (zlib.decompress does).  with_info: also {'filters': rows per filter type, 'idat_chunks', 'bytes'}"""
+    import struct
+    import zlib
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n", "not a PNG file"
+    pos, idat, ihdr, n_idat, ended = 8, [], None, 0, False
+    while pos < len(raw):
+        n, typ = struct.unpack(">I4s", raw[pos:pos + 8])
+        body = raw[pos + 8:pos + 8 + n]
+        crc, = struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])
+        assert zlib.crc32(typ + body) & 0xffffffff == crc, f"CRC of chunk {typ} wrong"
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat.append(body); n_idat += 1
+        elif typ == b"IEND":
+            ended = True
+        pos += 12 + n
+    assert ihdr and ended and pos == len(raw)
+    w, h, depth, ctype, comp, flt, lace = ihdr
+    assert depth == 8 and ctype in (2, 6) and comp == 0 and flt == 0 and lace == 0, ihdr
+    bpp = 3 if ctype == 2 else 4
+    data = zlib.decompress(b"".join(idat))
+    assert len(data) == h * (1 + w * bpp), (len(data), h, w, bpp)
+    src = np.frombuffer(data, np.uint8)
+    out = np.empty((h, w, bpp), np.uint8)
+    hist = np.zeros(5, np.int64)
+    L = orc()
+    L.orc_png_unfilter.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+    assert L.orc_png_unfilter(src.ctypes.data, w * bpp, h, bpp, out.ctypes.data, hist.ctypes.data) == 0
+    if with_info:
+        return out, {"filters": hist, "idat_chunks": n_idat, "bytes": len(raw)}
     return out

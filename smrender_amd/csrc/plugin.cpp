@@ -1203,91 +1203,6 @@ static int cap_fini(smr_smrule_t *r)
 /* ---------------------------------------------------------------------------------------- */
 /* hipsave: the device canvas -> PNG (stands in for save_main_image, src/smrules_cairo.c:388-412)   */
 /* ---------------------------------------------------------------------------------------- */
-static uint32_t crc_table[256];
-static void crc_init(void)
-{
-   for (uint32_t n = 0; n < 256; n++)
-   {
-      uint32_t c = n;
-      for (int k = 0; k < 8; k++) c = (c & 1) ? 0xedb88320u ^ (c >> 1) : c >> 1;
-      crc_table[n] = c;
-   }
-}
-static uint32_t crc_update(uint32_t c, const unsigned char *b, size_t n) { for (size_t i = 0; i < n; i++) c = crc_table[(c ^ b[i]) & 0xff] ^ (c >> 8); return c; }
-
-static void png_chunk(FILE *f, const char *type, const unsigned char *data, uint32_t len)
-{
-   unsigned char h[8] = { (unsigned char) (len >> 24), (unsigned char) (len >> 16), (unsigned char) (len >> 8), (unsigned char) len,
-                          (unsigned char) type[0], (unsigned char) type[1], (unsigned char) type[2], (unsigned char) type[3] };
-   fwrite(h, 1, 8, f);
-   if (len) fwrite(data, 1, len, f);
-   uint32_t c = crc_update(0xffffffffu, h + 4, 4);
-   c = crc_update(c, data, len) ^ 0xffffffffu;
-   unsigned char t[4] = { (unsigned char) (c >> 24), (unsigned char) (c >> 16), (unsigned char) (c >> 8), (unsigned char) c };
-   fwrite(t, 1, 4, f);
-}
-
-/* RGBA8 PNG with stored (uncompressed) deflate blocks, one IDAT per row block; pixels are
- * un-premultiplied the way cairo's PNG writer does */
-static int write_png(const char *path, int W, int Hh, int y0, int h)
-{
-   FILE *f = fopen(path, "wb");
-   if (!f) { plog(SMR_LOG_ERR, "hipsave: cannot open %s: %s", path, strerror(errno)); return -1; }
-   crc_init();
-   static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
-   fwrite(sig, 1, 8, f);
-   unsigned char ihdr[13] = { (unsigned char) (W >> 24), (unsigned char) (W >> 16), (unsigned char) (W >> 8), (unsigned char) W,
-                              (unsigned char) (h >> 24), (unsigned char) (h >> 16), (unsigned char) (h >> 8), (unsigned char) h, 8, 6, 0, 0, 0 };
-   png_chunk(f, "IHDR", ihdr, 13);
-   const size_t rowb = (size_t) W * 4 + 1;
-   std::vector<uint32_t> px((size_t) W);
-   std::vector<unsigned char> blk;
-   uint32_t s1 = 1, s2 = 0;
-   for (int y = 0; y < h; y++)
-   {
-      if (smr_hip_canvas_read(P.canvas, 0, y0 + y, W, 1, px.data()) != SMR_OK) { fclose(f); return -1; }
-      blk.clear();
-      if (y == 0) { blk.push_back(0x78); blk.push_back(0x01); }
-      /* stored blocks of at most 65535 bytes */
-      std::vector<unsigned char> row(rowb);
-      row[0] = 0;
-      for (int x = 0; x < W; x++)
-      {
-         uint32_t p = px[x], a = p >> 24;
-         unsigned char *o = &row[1 + 4 * (size_t) x];
-         if (a == 0) { o[0] = o[1] = o[2] = o[3] = 0; }
-         else
-         {
-            o[0] = (unsigned char) ((((p >> 16) & 0xff) * 255 + a / 2) / a);
-            o[1] = (unsigned char) ((((p >> 8) & 0xff) * 255 + a / 2) / a);
-            o[2] = (unsigned char) (((p & 0xff) * 255 + a / 2) / a);
-            o[3] = (unsigned char) a;
-         }
-      }
-      for (size_t i = 0; i < rowb; i++) { s1 = (s1 + row[i]) % 65521u; s2 = (s2 + s1) % 65521u; }
-      for (size_t off = 0; off < rowb;)
-      {
-         size_t n = std::min<size_t>(65535, rowb - off);
-         bool final = y == h - 1 && off + n == rowb;
-         blk.push_back(final ? 1 : 0);
-         blk.push_back((unsigned char) (n & 0xff)); blk.push_back((unsigned char) (n >> 8));
-         blk.push_back((unsigned char) (~n & 0xff)); blk.push_back((unsigned char) ((~n >> 8) & 0xff));
-         blk.insert(blk.end(), row.begin() + off, row.begin() + off + n);
-         off += n;
-      }
-      if (y == h - 1)
-      {
-         uint32_t ad = (s2 << 16) | s1;
-         blk.push_back((unsigned char) (ad >> 24)); blk.push_back((unsigned char) (ad >> 16));
-         blk.push_back((unsigned char) (ad >> 8)); blk.push_back((unsigned char) ad);
-      }
-      png_chunk(f, "IDAT", blk.data(), (uint32_t) blk.size());
-   }
-   png_chunk(f, "IEND", nullptr, 0);
-   fclose(f);
-   return 0;
-}
-
 static int hipsave_ini(smr_smrule_t *r)
 {
    int e;
@@ -1308,9 +1223,12 @@ static int hipsave_fini(smr_smrule_t *r)
    const char *file = H.get_param("file", nullptr, r->act);
    if (!file || !P.canvas) return -1;
    if (smr_hip_sync() != SMR_OK) return -1;
-   int e = write_png(file, P.W, P.band_h, 0, P.band_h);
-   if (e == 0) plog(SMR_LOG_NOTICE, "hipsave: %dx%d px (rows %d..%d of the chart) written to %s", P.W, P.band_h, P.band_y0,
-                    P.band_y0 + P.band_h - 1, file);
+   /* un-premultiply, filter choice and filtering on the device, one crossing of PCIe, deflate on the host's cores (png.hip) */
+   smr_png_stats_t st;
+   int e = smr_hip_canvas_write_png(P.canvas, 0, 0, P.W, P.band_h, file, env_int("SMR_HIP_PNG_LEVEL", -1), env_int("SMR_HIP_PNG_THREADS", 0), &st);
+   if (e != SMR_OK) { plog(SMR_LOG_ERR, "hipsave: %s", smr_hip_last_error()); return -1; }
+   plog(SMR_LOG_NOTICE, "hipsave: %dx%d px (rows %d..%d of the chart, %s) written to %s: %.1f MB in %.0f ms (%d deflate threads)", P.W, P.band_h,
+        P.band_y0, P.band_y0 + P.band_h - 1, st.n_opaque ? "RGB" : "RGBA", file, st.bytes_written / 1e6, st.total_ms, st.threads);
    return e;
 }
 

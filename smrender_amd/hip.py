@@ -70,12 +70,18 @@ class Timings(C.Structure):
                 ("cover_ms", C.c_float), ("n_cover_prims", C.c_uint32), ("n_cover_left", C.c_uint32), ("n_deltas", C.c_uint32)]
 
 
+class PngStats(C.Structure):
+    _fields_ = [("n_files", C.c_uint64), ("n_opaque", C.c_uint64), ("bytes_filtered", C.c_uint64), ("bytes_written", C.c_uint64),
+                ("deflate_ms", C.c_float), ("total_ms", C.c_float), ("threads", C.c_int32), ("pad_", C.c_int32)]
+
+
 # every symbol include/smr_hip.h declares (tests/test_abi.py checks the list against the header)
 EXPORTS = [
     "smr_hip_init", "smr_hip_shutdown", "smr_hip_last_error", "smr_hip_device_name",
     "smr_hip_proj_from_window", "smr_hip_set_projection", "smr_hip_project", "smr_hip_unproject",
     "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_read", "smr_hip_canvas_device",
     "smr_hip_canvas_set_halo", "smr_hip_canvas_set_halo_device", "smr_hip_canvas_extend", "smr_hip_canvas_clone", "smr_hip_canvas_blit",
+    "smr_hip_canvas_write_png", "smr_hip_canvas_write_tiles",
     "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
     "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
@@ -109,6 +115,9 @@ def lib():
         L.smr_hip_canvas_set_halo_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.smr_hip_canvas_extend.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.smr_hip_canvas_blit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.smr_hip_canvas_write_png.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
+        L.smr_hip_canvas_write_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
+                                                 C.c_int, C.c_int, C.c_void_p]
         L.smr_hip_canvas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.smr_hip_draw.argtypes = [C.c_void_p, C.POINTER(DrawStyle), C.POINTER(_DrawBatch)]
         L.smr_hip_debug_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -285,6 +294,20 @@ class Canvas:
             off += im.size
         pix = np.concatenate([np.ascontiguousarray(im, np.uint32).ravel() for _, _, im in images]) if images else np.zeros(0, np.uint32)
         _chk(lib().smr_hip_canvas_blit(self.h, pix.ctypes.data, len(pix), items.ctypes.data, len(images)))
+
+    def write_png(self, path, rect=None, level=-1, threads=0):
+        """the rectangle (x, y, w, h; band-local rows; default: the whole band) as a PNG file whose decoded pixels are those of
+        libcairo's writer for the same data (smr_hip_canvas_write_png); returns the call's PngStats"""
+        x, y, w, h = rect if rect else (0, 0, self.W, self.band_h)
+        st = PngStats()
+        _chk(lib().smr_hip_canvas_write_png(self.h, x, y, w, h, str(path).encode(), level, threads, C.byref(st)))
+        return st
+
+    def write_tiles(self, directory, x, y, nx, ny, tile_px=256, tx0=0, ty0=0, level=-1, threads=0):
+        """nx x ny tiles of tile_px pixels from band pixel (x, y) on, as <directory>/<tx0 + i>/<ty0 + j>.png (smr_hip_canvas_write_tiles)"""
+        st = PngStats()
+        _chk(lib().smr_hip_canvas_write_tiles(self.h, x, y, nx, ny, tile_px, str(directory).encode(), tx0, ty0, level, threads, C.byref(st)))
+        return st
 
     def device_ptr(self):
         """(device address of the band's first pixel, row stride in pixels)"""

@@ -553,3 +553,13 @@ def test_cap_on_a_banded_plugin_canvas_is_refused(chart, monkeypatch):
     finally:
         monkeypatch.undo()
         sa.lib().smr_hip_plugin_reset()
+
+
+def test_hipsave_writes_the_plugin_canvas(chart, tmp_path):
+    """hipsave@libsmr_hip.so:file=... -- the chart's PNG comes from the device canvas (smr_hip_canvas_write_png)"""
+    sa, proj = chart
+    wids, oways = load_ways(sa, proj, po.synth_ways(60, W, H, seed=77))
+    assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", wids) == 0
+    f = tmp_path / "chart.png"
+    assert hs.apply_rule(sa.lib(), "hipsave", hs.OSM_NODE, f"file={f}", np.zeros(0, np.int64)) == 0, sa.lib().smr_hip_last_error()
+    assert np.array_equal(po.png_decode(f), po.png_pixels(plugin_canvas(sa)))
