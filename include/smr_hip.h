@@ -249,7 +249,11 @@ int smr_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
  * header stays free of host types.
  *   draw    : act_draw_ini/_main/_fini   src/smrules_cairo.c:583, :1019, :1076
  *   cap     : act_cap_ini/_main/_fini    src/smrules_cairo.c:1243, :2447, :2487 (angle=auto scan:
- *             writes "<key>:autoangle" / "<key>:autoalign" tags, :2294-2349; glyphs stay on host Cairo)
+ *             writes "<key>:autoangle" / "<key>:autoalign" tags, :2294-2349; the text is rasterised by the host's
+ *             libcairo + FreeType and composited onto the device canvas, hide=1 leaves it out)
+ *   img     : act_img_ini/_main/_fini    src/smrules_cairo.c:2716, :2829, :2858 for NODES (img_place :2754-2826: PNG / SVG
+ *             symbol, scale, transparency, angle / anglekey / alignkey, angle=auto through the caption scan with the symbol as
+ *             the plane); decoded by the host's libcairo / librsvg, composited onto the device canvas
  *   hipsave : writes the device canvas to `file=` (replaces save_main_image :388-412 for the GPU canvas) */
 int act_draw_ini(void *rule);
 int act_draw_main(void *rule, void *obj);
@@ -257,6 +261,9 @@ int act_draw_fini(void *rule);
 int act_cap_ini(void *rule);
 int act_cap_main(void *rule, void *obj);
 int act_cap_fini(void *rule);
+int act_img_ini(void *rule);
+int act_img_main(void *rule, void *obj);
+int act_img_fini(void *rule);
 int act_hipsave_ini(void *rule);
 int act_hipsave_main(void *rule, void *obj);
 int act_hipsave_fini(void *rule);

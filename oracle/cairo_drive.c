@@ -487,3 +487,65 @@ int cd_plane(int w_pt, int h_pt, int x_pt, uint32_t col, int dpi, uint32_t *out)
    p_cairo_surface_destroy(img);
    return 0;
 }
+
+/* ---- act_img on nodes (src/smrules_cairo.c:2512-2871), the reference's call sequence on the real libcairo ---------------- */
+static cairo_surface_t *sym_;
+static double sym_w_, sym_h_;
+
+/* img_ini's PNG branch (:2627-2658): the file scaled into an ARGB32 image of (int) w x (int) h, transparency by DEST_OUT.
+ * Returns 0 and the image's size in wh[2] (pixels, as doubles: img->w, img->h) */
+int cd_img_load_png(const char *path, double scale, double trans, double *wh)
+{
+   static cairo_surface_t *(*from_png)(const char*);
+   static int (*get_w)(cairo_surface_t*), (*get_h)(cairo_surface_t*);
+   if (!from_png)
+   {
+      from_png = (cairo_surface_t *(*)(const char*)) dlsym(lib_, "cairo_image_surface_create_from_png");
+      get_w = (int (*)(cairo_surface_t*)) dlsym(lib_, "cairo_image_surface_get_width");
+      get_h = (int (*)(cairo_surface_t*)) dlsym(lib_, "cairo_image_surface_get_height");
+   }
+   if (!from_png || !get_w || !get_h) return -2;
+   if (sym_) { p_cairo_surface_destroy(sym_); sym_ = NULL; }
+   cairo_surface_t *sfc = from_png(path);
+   if (p_cairo_surface_status(sfc)) { p_cairo_surface_destroy(sfc); return -1; }
+   sym_w_ = get_w(sfc) * scale; sym_h_ = get_h(sfc) * scale;
+   sym_ = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, sym_w_, sym_h_);
+   cairo_t *ctx = p_cairo_create(sym_);
+   p_cairo_scale(ctx, scale, scale);
+   p_cairo_set_source_surface(ctx, sfc, 0, 0);
+   p_cairo_paint(ctx);
+   p_cairo_set_source_rgba(ctx, 0, 0, 0, trans);
+   p_cairo_set_operator(ctx, 9 /* CAIRO_OPERATOR_DEST_OUT */);
+   p_cairo_paint(ctx);
+   p_cairo_destroy(ctx);
+   p_cairo_surface_destroy(sfc);
+   wh[0] = sym_w_; wh[1] = sym_h_;
+   return 0;
+}
+
+/* the symbol's pixels ((int) w x (int) h premultiplied ARGB32): find_angle's plane for angle=auto (:2773-2790) */
+int cd_img_pixels(uint32_t *out)
+{
+   if (!sym_) return -1;
+   p_cairo_surface_flush(sym_);
+   unsigned char *d = p_cairo_image_surface_get_data(sym_);
+   int stride = p_cairo_image_surface_get_stride(sym_), W = (int) sym_w_, H = (int) sym_h_;
+   for (int y = 0; y < H; y++) memcpy(out + (size_t) y * W, d + (size_t) y * stride, (size_t) W * 4);
+   return 0;
+}
+
+/* img_place (:2754-2826) on the current rule's context, which img_ini (:2680-2683) scaled to pixels: save, translate to the
+ * node in px, rotate, the symbol as source centred on the node, paint, restore */
+int cd_img_place(double x_px, double y_px, double angle, double dpi)
+{
+   if (!rule_ || !sym_) return -1;
+   cairo_t *ctx = rule_;
+   p_cairo_save(ctx);
+   p_cairo_scale(ctx, 72 / dpi, 72 / dpi);
+   p_cairo_translate(ctx, x_px, y_px);
+   p_cairo_rotate(ctx, angle);
+   p_cairo_set_source_surface(ctx, sym_, sym_w_ / -2.0, sym_h_ / -2.0);
+   p_cairo_paint(ctx);
+   p_cairo_restore(ctx);
+   return p_cairo_status(ctx);
+}

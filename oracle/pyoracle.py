@@ -139,6 +139,9 @@ def cairo():
         L.cd_render.argtypes = [C.c_double] + [C.c_int] * 4 + [C.c_void_p]
         L.cd_save_png.argtypes = [C.c_double, C.c_int, C.c_int, C.c_char_p]
         L.cd_write_png_data.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
+        L.cd_img_load_png.argtypes = [C.c_char_p, C.c_double, C.c_double, C.c_void_p]
+        L.cd_img_pixels.argtypes = [C.c_void_p]
+        L.cd_img_place.argtypes = [C.c_double] * 4
         L.cd_cut_out.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int]
         L.cd_direct_fill.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
         L.cd_rot_paint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]

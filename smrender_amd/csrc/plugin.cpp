@@ -623,6 +623,11 @@ struct cairo_api_t
    void (*show_text)(void *, const char *);
    void (*set_source_surface)(void *, void *, double, double);
    void (*paint)(void *);
+   void (*set_operator)(void *, int);
+   void *(*image_surface_create_from_png)(const char *);
+   int (*surface_status)(void *);
+   int (*image_surface_get_width)(void *);
+   int (*image_surface_get_height)(void *);
    /* optional: fontconfig face like the reference's CAIRO_HAS_FC_FONT branch (:1345-1354) */
    void *(*ft_font_face_create_for_pattern)(void *);
    void (*set_font_face)(void *, void *);
@@ -656,6 +661,9 @@ static int cairo_load(void)
    CR_LOAD(fill, "cairo_fill");
    CR_LOAD(translate, "cairo_translate"); CR_LOAD(rotate, "cairo_rotate"); CR_LOAD(move_to, "cairo_move_to"); CR_LOAD(show_text, "cairo_show_text");
    CR_LOAD(set_source_surface, "cairo_set_source_surface"); CR_LOAD(paint, "cairo_paint");
+   CR_LOAD(set_operator, "cairo_set_operator"); CR_LOAD(image_surface_create_from_png, "cairo_image_surface_create_from_png");
+   CR_LOAD(surface_status, "cairo_surface_status"); CR_LOAD(image_surface_get_width, "cairo_image_surface_get_width");
+   CR_LOAD(image_surface_get_height, "cairo_image_surface_get_height");
    *(void **) (&CR.ft_font_face_create_for_pattern) = dlsym(CR.lib, "cairo_ft_font_face_create_for_pattern");
    *(void **) (&CR.set_font_face) = dlsym(CR.lib, "cairo_set_font_face");
    *(void **) (&CR.font_face_destroy) = dlsym(CR.lib, "cairo_font_face_destroy");
@@ -1201,6 +1209,348 @@ static int cap_fini(smr_smrule_t *r)
 }
 
 /* ---------------------------------------------------------------------------------------- */
+/* img: symbols on nodes (act_img_ini/_main/_fini, src/smrules_cairo.c:2512-2871)                    */
+/* ---------------------------------------------------------------------------------------- */
+/* The symbol itself is decoded / rendered by the host's libraries, as in the reference (PNG: libcairo; SVG: librsvg into a
+ * recording surface); every placement is recorded with the reference's call sequence (img_place :2754-2826), replayed at
+ * dpi/72 into an image on the chart's pixel grid and painted OVER the device canvas in object order (smr_hip_canvas_blit).
+ * angle=auto is find_angle with the symbol as the plane (:2767-2794): one smr_hip_caprot batch for all nodes of the rule
+ * (img has no auto_ctx: its symbols do not see each other, :2790 scans sfc_).  Not here: img on ways (a pattern fill,
+ * img_fill :2742-2751) and JPEG files (the reference's own decoder, src/cairo_jpg.c): refused, the rule stays built-in. */
+struct rsvg_api_t
+{
+   void *lib = nullptr, *gobj = nullptr;
+   void *(*handle_new_from_file)(const char *, void **) = nullptr;
+   void (*handle_set_dpi)(void *, double) = nullptr;
+   int (*handle_get_intrinsic_size_in_pixels)(void *, double *, double *) = nullptr;
+   void (*handle_get_dimensions)(void *, void *) = nullptr;
+   int (*handle_render_document)(void *, void *, const void *, void **) = nullptr;
+   int (*handle_render_cairo)(void *, void *) = nullptr;
+   void (*object_unref)(void *) = nullptr;
+};
+static rsvg_api_t RS;
+
+static int rsvg_load(void)
+{
+   if (RS.lib) return 0;
+   const char *cand[] = { getenv("SMR_HIP_LIBRSVG"), "librsvg-2.so.2", nullptr };
+   for (int i = 0; i < 3 && !RS.lib; i++)
+      if (cand[i] && *cand[i]) RS.lib = dlopen(cand[i], RTLD_NOW | RTLD_GLOBAL);
+   if (!RS.lib) { plog(SMR_LOG_WARN, "img: librsvg-2.so.2 cannot be loaded: %s", dlerror()); return -1; }
+   *(void **) (&RS.handle_new_from_file) = dlsym(RS.lib, "rsvg_handle_new_from_file");
+   *(void **) (&RS.handle_set_dpi) = dlsym(RS.lib, "rsvg_handle_set_dpi");
+   *(void **) (&RS.handle_get_intrinsic_size_in_pixels) = dlsym(RS.lib, "rsvg_handle_get_intrinsic_size_in_pixels");
+   *(void **) (&RS.handle_get_dimensions) = dlsym(RS.lib, "rsvg_handle_get_dimensions");
+   *(void **) (&RS.handle_render_document) = dlsym(RS.lib, "rsvg_handle_render_document");
+   *(void **) (&RS.handle_render_cairo) = dlsym(RS.lib, "rsvg_handle_render_cairo");
+   *(void **) (&RS.object_unref) = dlsym(RTLD_DEFAULT, "g_object_unref");
+   if (!RS.handle_new_from_file || !RS.handle_set_dpi || !RS.object_unref || (!RS.handle_render_document && !RS.handle_render_cairo) ||
+       (!RS.handle_get_intrinsic_size_in_pixels && !RS.handle_get_dimensions))
+   {
+      plog(SMR_LOG_WARN, "img: librsvg lacks the entry points the reference uses");
+      dlclose(RS.lib); RS.lib = nullptr;
+      return -1;
+   }
+   return 0;
+}
+
+struct img_item_t { double lat, lon, a; };
+
+struct img_rule_t
+{
+   void *img = nullptr;                /* the scaled symbol: an image surface (PNG) or a recording surface (SVG) */
+   bool vector = false;
+   double w = 0, h = 0, scale = 1, trans = 0, angle = 0, phase = 0, weight = 1;
+   bool autorot = false;
+   const char *akey = nullptr, *alignkey = nullptr;
+   std::vector<img_item_t> items;
+};
+
+static int img_ini(smr_smrule_t *r)
+{
+   int e;
+   host_resolve();
+   if ((e = plugin_setup()) != 0) return e;
+   if (r->oo->type != SMR_OSM_NODE)
+   {
+      plog(SMR_LOG_ERR, r->oo->type == SMR_OSM_WAY ? "img: on ways img is a pattern fill, which stays on the built-in path (no @libsmr_hip.so)"
+                                                    : "img() only applicable to nodes and ways");
+      return 1;
+   }
+   char *name;
+   if ((name = H.get_param("file", nullptr, r->act)) == nullptr)
+   {
+      plog(SMR_LOG_WARN, "parameter 'file' missing");
+      return -1;
+   }
+   if (cairo_load() != 0) return -1;
+   const size_t nl = strlen(name);
+   if (nl >= 4 && !strcasecmp(name + nl - 4, ".jpg"))
+   {
+      plog(SMR_LOG_ERR, "img: %s: JPEG symbols are decoded by the reference's own code; use the built-in img", name);
+      return 1;
+   }
+   img_rule_t *g = new img_rule_t();
+   if (H.get_param("scale", &g->scale, r->act) == nullptr) g->scale = 1;
+   g->scale *= H.rdata_get()->img_scale;
+   if (H.get_param("transparency", &g->trans, r->act) != nullptr) g->trans = fmin(fmax(g->trans, 0.0), 1.0);
+   void *ctx;
+   if (nl >= 4 && !strcasecmp(name + nl - 4, ".svg"))
+   {
+      if (rsvg_load() != 0) { delete g; return 1; }
+      void *rh = RS.handle_new_from_file(name, nullptr);
+      if (rh == nullptr) { plog(SMR_LOG_ERR, "error opening file %s", name); delete g; return -1; }
+      RS.handle_set_dpi(rh, (double) P.dpi);
+      double dw = 32, dh = 32;
+      if (RS.handle_get_intrinsic_size_in_pixels && RS.handle_render_document)
+      {
+         if (!RS.handle_get_intrinsic_size_in_pixels(rh, &dw, &dh))
+         {
+            plog(SMR_LOG_WARN, "rsvg_handle_get_intrinsic_size_in_pixels() failed");
+            dw = dh = 32;
+         }
+      }
+      else
+      {
+         struct { int width, height; double em, ex; } dd;
+         RS.handle_get_dimensions(rh, &dd);
+         dw = dd.width; dh = dd.height;
+      }
+      g->w = dw * g->scale; g->h = dh * g->scale;
+      cr_rectangle_t rect = { 0, 0, g->w, g->h };
+      g->img = CR.recording_surface_create(0x3000, &rect);
+      g->vector = true;
+      ctx = CR.create(g->img);
+      CR.scale(ctx, g->scale, g->scale);
+      int ok;
+      if (RS.handle_get_intrinsic_size_in_pixels && RS.handle_render_document)
+      {
+         const double vp[4] = { 0, 0, dw, dh };
+         ok = RS.handle_render_document(rh, ctx, vp, nullptr);
+      }
+      else ok = RS.handle_render_cairo(rh, ctx);
+      RS.object_unref(rh);
+      if (!ok)
+      {
+         plog(SMR_LOG_ERR, "rendering %s failed", name);
+         CR.destroy(ctx); CR.surface_destroy(g->img); delete g;
+         return -1;
+      }
+   }
+   else
+   {
+      void *sfc = CR.image_surface_create_from_png(name);
+      if (CR.surface_status(sfc) != 0)
+      {
+         plog(SMR_LOG_ERR, "cannot open file %s (cairo status %d)", name, CR.surface_status(sfc));
+         CR.surface_destroy(sfc); delete g;
+         return -1;
+      }
+      g->w = CR.image_surface_get_width(sfc) * g->scale; g->h = CR.image_surface_get_height(sfc) * g->scale;
+      g->img = CR.image_surface_create(0 /* ARGB32 */, (int) g->w, (int) g->h);
+      if (CR.surface_status(g->img) != 0)
+      {
+         plog(SMR_LOG_ERR, "cannot create the %g x %g image of %s", g->w, g->h, name);
+         CR.surface_destroy(sfc); CR.surface_destroy(g->img); delete g;
+         return -1;
+      }
+      ctx = CR.create(g->img);
+      CR.scale(ctx, g->scale, g->scale);
+      CR.set_source_surface(ctx, sfc, 0, 0);
+      CR.paint(ctx);
+      CR.surface_destroy(sfc);
+   }
+   /* add transparency (:2598-2601, :2653-2656) */
+   CR.set_source_rgba(ctx, 0, 0, 0, g->trans);
+   CR.set_operator(ctx, 9 /* CAIRO_OPERATOR_DEST_OUT */);
+   CR.paint(ctx);
+   CR.destroy(ctx);
+
+   /* parse_auto_rot (src/smrparse.c:1033-1074) */
+   char *val;
+   if ((val = H.get_param("angle", &g->angle, r->act)) != nullptr)
+   {
+      if (!strcasecmp("auto", val))
+      {
+         g->autorot = true;
+         if (H.get_param("weight", &g->weight, r->act) == nullptr) g->weight = 1.0;
+         g->weight = fmin(fmax(g->weight, -1.0), 1.0);
+         (void) H.get_param("phase", &g->phase, r->act);
+      }
+      else if (!strcasecmp("majoraxis", val))
+      {
+         plog(SMR_LOG_ERR, "img: angle=majoraxis is not implemented on the GPU path; use the built-in img");
+         CR.surface_destroy(g->img); delete g;
+         return 1;
+      }
+      else g->angle = fmod(g->angle, 360.0);
+   }
+   g->akey = H.get_param("anglekey", nullptr, r->act);
+   if (g->akey != nullptr && g->autorot)
+   {
+      plog(SMR_LOG_NOTICE, "ignoring angle=auto");
+      g->autorot = false; g->angle = 0;
+   }
+   g->alignkey = H.get_param("alignkey", nullptr, r->act);
+   if (g->autorot && (P.band_y0 != 0 || P.band_h != P.H))
+   {
+      plog(SMR_LOG_ERR, "img: angle=auto on a row band needs the neighbours' rows (see cap)");
+      CR.surface_destroy(g->img); delete g;
+      return 1;
+   }
+   if (!H.match_attr && (g->akey || g->alignkey))
+   {
+      plog(SMR_LOG_ERR, "img: host symbol match_attr not found");
+      CR.surface_destroy(g->img); delete g;
+      return -1;
+   }
+   r->data = g;
+   return 0;
+}
+
+static int img_main(smr_smrule_t *r, smr_osm_obj_t *o)
+{
+   img_rule_t *g = (img_rule_t *) r->data;
+   if (g == nullptr) { plog(SMR_LOG_WARN, "r->data == NULL"); return 1; }
+   if (o->type != SMR_OSM_NODE) return 1;
+   const smr_osm_node_t *n = (const smr_osm_node_t *) o;
+   img_item_t it; it.lat = n->lat; it.lon = n->lon; it.a = 0;
+   if (!g->autorot)
+   {
+      /* img_place :2796-2817 */
+      int m = -1;
+      if (g->akey != nullptr && (m = H.match_attr(o, g->akey, nullptr)) >= 0)
+         it.a = strtod(std::string(o->otag[m].v.buf, (size_t) o->otag[m].v.len).c_str(), nullptr) * M_PI / 180.0;
+      if (g->alignkey != nullptr && (m = H.match_attr(o, g->alignkey, nullptr)) >= 0)
+         if (alignment_str(std::string(o->otag[m].v.buf, (size_t) o->otag[m].v.len).c_str()) & SMR_POS_W) it.a += M_PI_2;
+      it.a += (360 - g->angle) * M_PI / 180.0;
+   }
+   g->items.push_back(it);
+   return 0;
+}
+
+/* anchors -> chart pixels through the device projection (geo2pxf) */
+static int project_anchors(const std::vector<double> &lat_in, const std::vector<double> &lon_in, std::vector<double> &hx, std::vector<double> &hy)
+{
+   const size_t n = lat_in.size(), np = (n + 1) & ~(size_t) 1;
+   std::vector<double> lat(lat_in), lon(lon_in);
+   lat.resize(np, n ? lat_in[n - 1] : 0.0); lon.resize(np, n ? lon_in[n - 1] : 0.0);
+   hx.assign(np, 0.0); hy.assign(np, 0.0);
+   if (n == 0) return 0;
+   dbuf_t dlat, dlon, dx, dy;
+   bool ok = dlat.put(lat.data(), np * 8) == 0 && dlon.put(lon.data(), np * 8) == 0 && dx.alloc(np * 8) == 0 && dy.alloc(np * 8) == 0;
+   if (ok) ok = smr_hip_project((const double *) dlat.p, (const double *) dlon.p, (int64_t) np, (double *) dx.p, (double *) dy.p,
+                                nullptr, nullptr, nullptr) == SMR_OK;
+   if (ok) ok = smr_hip_memcpy_d2h(hx.data(), dx.p, np * 8) == SMR_OK && smr_hip_memcpy_d2h(hy.data(), dy.p, np * 8) == SMR_OK;
+   return ok ? 0 : -1;
+}
+
+static int img_fini(smr_smrule_t *r)
+{
+   img_rule_t *g = (img_rule_t *) r->data;
+   if (g == nullptr) { plog(SMR_LOG_WARN, "r->data == NULL"); return 1; }
+   int ret = 0;
+   const size_t n = g->items.size();
+   std::vector<double> lat(n), lon(n), cx, cy;
+   for (size_t k = 0; k < n; k++) { lat[k] = g->items[k].lat; lon[k] = g->items[k].lon; }
+   if (n && project_anchors(lat, lon, cx, cy) != 0) { plog(SMR_LOG_ERR, "img: %s", smr_hip_last_error()); ret = -1; }
+   const int iw = (int) g->w, ih = (int) g->h;
+   if (ret == 0 && n && g->autorot && iw > 0 && ih > 0)
+   {
+      /* the plane of find_angle: the symbol as an ARGB32 image (:2773-2788) */
+      void *fg = CR.image_surface_create(0, iw, ih);
+      void *fx = CR.create(fg);
+      CR.set_source_surface(fx, g->img, 0, 0);
+      CR.paint(fx);
+      CR.destroy(fx);
+      CR.surface_flush(fg);
+      std::vector<uint32_t> plane((size_t) iw * ih);
+      const unsigned char *d = CR.image_surface_get_data(fg);
+      const int stride = CR.image_surface_get_stride(fg);
+      for (int y = 0; y < ih; y++) memcpy(&plane[(size_t) y * iw], d + (size_t) y * stride, (size_t) iw * 4);
+      CR.surface_destroy(fg);
+      dbuf_t dx, dy, dfg, dang;
+      std::vector<double> out(n);
+      bool ok = dx.put(cx.data(), n * 8) == 0 && dy.put(cy.data(), n * 8) == 0 && dfg.put(plane.data(), plane.size() * 4) == 0 && dang.alloc(n * 8) == 0;
+      if (ok)
+      {
+         smr_cap_batch_t b;
+         memset(&b, 0, sizeof(b));
+         b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) n;
+         b.fg_w = iw; b.fg_h = ih; b.phase_deg = g->phase; b.weight = g->weight; b.d_fg = (const uint32_t *) dfg.p;
+         ok = smr_hip_caprot(P.canvas, &b, (double *) dang.p, nullptr) == SMR_OK;
+      }
+      if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, n * 8) == SMR_OK;
+      if (!ok) { plog(SMR_LOG_ERR, "img: %s", smr_hip_last_error()); ret = -1; }
+      for (size_t k = 0; k < n && ok; k++) g->items[k].a = out[k];
+   }
+   if (ret == 0 && n)
+   {
+      std::vector<uint32_t> pixels;
+      std::vector<smr_blit_t> items;
+      const double sc = (double) P.dpi / 72.0;
+      const int W = (int) round(P.proj.w), Hh = (int) round(P.proj.h);
+      auto flush = [&]() -> int
+      {
+         if (items.empty()) return SMR_OK;
+         const int rc = smr_hip_canvas_blit(P.canvas, pixels.data(), pixels.size(), items.data(), (int) items.size());
+         pixels.clear(); items.clear();
+         return rc;
+      };
+      for (size_t i = 0; i < n && ret == 0; i++)
+      {
+         const double a = g->items[i].a, ca = cos(a), sa = sin(a);
+         double mnx = 1e300, mny = 1e300, mxx = -1e300, mxy = -1e300;
+         for (int k = 0; k < 4; k++)
+         {
+            const double ux = (k & 1 ? 0.5 : -0.5) * g->w, uy = (k >> 1 ? 0.5 : -0.5) * g->h;
+            const double X = ca * ux - sa * uy + cx[i], Y = sa * ux + ca * uy + cy[i];
+            mnx = fmin(mnx, X); mxx = fmax(mxx, X); mny = fmin(mny, Y); mxy = fmax(mxy, Y);
+         }
+         const int ix0 = (int) fmax(floor(mnx) - 2, 0.0), iy0 = (int) fmax(floor(mny) - 2, 0.0);
+         const int ix1 = (int) fmin(ceil(mxx) + 2, (double) W), iy1 = (int) fmin(ceil(mxy) + 2, (double) Hh);
+         if (ix1 <= ix0 || iy1 <= iy0) continue;
+         const int w = ix1 - ix0, h = iy1 - iy0;
+         /* img_ini :2680-2683 (the context on the chart, in px) + img_place :2763-2823, recorded in pt like the chart */
+         cr_rectangle_t ext = { 0, 0, P.proj.w * 72 / P.dpi, P.proj.h * 72 / P.dpi };
+         void *rec = CR.recording_surface_create(0x3000, &ext);
+         void *ctx = CR.create(rec);
+         CR.scale(ctx, 72.0 / P.dpi, 72.0 / P.dpi);
+         CR.translate(ctx, cx[i], cy[i]);
+         CR.rotate(ctx, a);
+         CR.set_source_surface(ctx, g->img, g->w / -2.0, g->h / -2.0);
+         CR.paint(ctx);
+         CR.destroy(ctx);
+         void *sfc = CR.image_surface_create(0, w, h);
+         ctx = CR.create(sfc);
+         CR.translate(ctx, -ix0, -iy0);
+         CR.scale(ctx, sc, sc);
+         CR.set_source_surface(ctx, rec, 0, 0);
+         CR.paint(ctx);
+         CR.destroy(ctx);
+         CR.surface_destroy(rec);
+         CR.surface_flush(sfc);
+         const unsigned char *d = CR.image_surface_get_data(sfc);
+         const int stride = CR.image_surface_get_stride(sfc);
+         smr_blit_t b; b.x = ix0; b.y = iy0; b.w = w; b.h = h; b.offset = pixels.size();
+         pixels.resize(pixels.size() + (size_t) w * h);
+         for (int y = 0; y < h; y++) memcpy(&pixels[b.offset + (size_t) y * w], d + (size_t) y * stride, (size_t) w * 4);
+         CR.surface_destroy(sfc);
+         items.push_back(b);
+         if (pixels.size() > ((size_t) 16 << 20) && flush() != SMR_OK) ret = -1;
+      }
+      if (ret == 0 && flush() != SMR_OK) ret = -1;
+      if (ret != 0) plog(SMR_LOG_ERR, "img: %s", smr_hip_last_error());
+   }
+   plog(SMR_LOG_INFO, "img: %zu symbols (%s, %.1f x %.1f px%s) composited onto the device canvas", n, g->vector ? "SVG" : "PNG", g->w, g->h,
+        g->autorot ? ", angle=auto scanned on the GPU" : "");
+   CR.surface_destroy(g->img);
+   delete g;
+   r->data = nullptr;
+   return ret;
+}
+
+/* ---------------------------------------------------------------------------------------- */
 /* hipsave: the device canvas -> PNG (stands in for save_main_image, src/smrules_cairo.c:388-412)   */
 /* ---------------------------------------------------------------------------------------- */
 static int hipsave_ini(smr_smrule_t *r)
@@ -1239,4 +1589,5 @@ static int hipsave_fini(smr_smrule_t *r)
    extern "C" int act_##name##_fini(void *r) { return name##_fini((smr_smrule_t *) r); }
 SMR_ACTION(draw)
 SMR_ACTION(cap)
+SMR_ACTION(img)
 SMR_ACTION(hipsave)

@@ -563,3 +563,125 @@ def test_hipsave_writes_the_plugin_canvas(chart, tmp_path):
     f = tmp_path / "chart.png"
     assert hs.apply_rule(sa.lib(), "hipsave", hs.OSM_NODE, f"file={f}", np.zeros(0, np.int64)) == 0, sa.lib().smr_hip_last_error()
     assert np.array_equal(po.png_decode(f), po.png_pixels(plugin_canvas(sa)))
+
+
+def symbol_png(path, w=37, h=23):
+    """an asymmetric, partly translucent symbol written by libcairo's own PNG writer"""
+    yy, xx = np.mgrid[0:h, 0:w]
+    a = np.where((xx + yy) % 7 < 4, 255, 120).astype(np.uint32)
+    a[(xx - w * 0.3) ** 2 + (yy - h * 0.5) ** 2 > (h * 0.62) ** 2] = 0
+    r, g, b = (200 * xx // w).astype(np.uint32), (60 + 150 * yy // h).astype(np.uint32), np.full((h, w), 40, np.uint32)
+    img = (a << 24 | (r * a // 255) << 16 | (g * a // 255) << 8 | (b * a // 255)).astype(np.uint32)
+    assert po.cairo().cd_write_png_data(po.P(img), w, h, str(path).encode()) == 0
+    return path
+
+
+def test_img_symbols_are_composited_onto_the_device_canvas(chart, tmp_path):
+    """SURVEY 8f rank 1 for symbols: img@libsmr_hip.so on nodes (act_img_*, src/smrules_cairo.c:2512-2871).  The symbol is
+    decoded and scaled by the host's libcairo as in img_ini, every placement recorded as in img_place, replayed onto the chart's
+    pixel grid and painted OVER the device canvas.  Compared with the real libcairo recording and replaying the same chart
+    (draw rule, then the img rule), for fixed angles (angle, anglekey, alignkey, scale, transparency) and for angle=auto, where
+    the angle is find_angle with the symbol as the plane (oracle/caprot.c on the canvas before the rule)."""
+    sa, proj = chart
+    from smrender_amd import synth
+    from golden_io import within
+    cd = po.cairo()
+    if cd is None:
+        pytest.skip("libcairo not loadable")
+    f = symbol_png(tmp_path / "sym.png")
+    arrs = po.synth_ways(70, W, H, seed=85)
+    rng = np.random.default_rng(77)
+    n = 9
+    cx, cy = rng.uniform(30, W - 30, n), rng.uniform(30, H - 30, n)
+    lat, lon = synth.px_to_geo(proj, cx, cy)
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    px, py, _, _, _ = po.project(op, lat, lon)
+    style = po.Style(1, 1, 0x4080c0, 0, 0, 0.1, 0)
+    for mode in ("fixed", "auto"):
+        sa.lib().smr_hip_plugin_reset()
+        wids, oways = load_ways(sa, proj, arrs)
+        assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", wids) == 0
+        before = plugin_canvas(sa)
+        base = _next_id[0]; _next_id[0] += n + 1
+        nids = base + np.arange(n)
+        scale, trans = (1.5, 0.25) if mode == "fixed" else (1.0, 0.0)
+        wh = np.zeros(2)
+        assert cd.cd_img_load_png(str(f).encode(), scale, trans, po.P(wh)) == 0
+        chk = np.zeros((int(wh[1]), int(wh[0])), np.uint32)
+        assert cd.cd_img_pixels(po.P(chk)) == 0
+        assert int((chk >> 24).max()) in ((191, 192) if mode == "fixed" else (255,))      # transparency=0.25 leaves 75 % (DEST_OUT)
+        if mode == "fixed":
+            tags = [("" if k % 3 == 0 else f"dir={17.5 * k}") + (";side=west" if k % 4 == 1 else ";side=east") for k in range(n)]
+            tags = [t.lstrip(";") for t in tags]
+            hs.add_nodes(nids, lat, lon, tags)
+            params = f"file={f};scale=1.5;transparency=0.25;angle=30;anglekey=dir;alignkey=side"
+            ang = [np.radians(17.5 * k if k % 3 else 0.0) + (np.pi / 2 if k % 4 == 1 else 0.0) + np.radians(360 - 30) for k in range(n)]
+        else:
+            hs.add_nodes(nids, lat, lon)
+            params = f"file={f};angle=auto;weight=0.8"
+            fw, fh = int(wh[0]), int(wh[1])
+            fg = np.zeros((fh, fw), np.uint32)
+            assert cd.cd_img_pixels(po.P(fg)) == 0
+            L = po.orc()
+            r = C.c_int()
+            steps = L.orc_num_steps(fw, fh, DPI, C.byref(r)); r = r.value
+            crnd = lambda v: int(np.sign(v) * np.floor(abs(v) + 0.5))
+            ang = []
+            for k in range(n):
+                ox, oy = crnd(px[k] - r / 2.0), crnd(py[k] - r / 2.0)
+                cut = np.zeros((r, r), np.uint32)
+                xs0, ys0, xs1, ys1 = max(ox, 0), max(oy, 0), min(ox + r, W), min(oy + r, H)
+                cut[ys0 - oy:ys1 - oy, xs0 - ox:xs1 - ox] = before[ys0:ys1, xs0:xs1]
+                ang.append(L.orc_find_angle(po.P(cut), r, po.P(fg), fw, fh, steps, 0.0, 0.8, None))
+            assert len(set(np.round(ang, 6))) >= 3             # the scan really chose different angles
+        assert hs.apply_rule(sa.lib(), "img", hs.OSM_NODE, params, nids) == 0, sa.lib().smr_hip_last_error()
+        got = plugin_canvas(sa)
+
+        def symbols(Lc):
+            Lc.cd_rule_begin()
+            for k in range(n):
+                assert Lc.cd_img_place(px[k], py[k], ang[k], float(DPI)) == 0
+            Lc.cd_rule_end()
+
+        want = po.cairo_scene([(style, oways)], DPI, W, H, 0xfff8e0, before_render=symbols)
+        plain = po.cairo_scene([(style, oways)], DPI, W, H, 0xfff8e0)
+        d = po.chan_diff(want, plain)
+        sym = (d.max(axis=-1) if d.ndim == 3 else d) > 0
+        assert sym.sum() > 1500, mode                           # the symbols really are in the reference picture
+        assert within(got, want) >= 0.995, (mode, within(got, want))
+        e = po.chan_diff(got, want)
+        e = e.max(axis=-1) if e.ndim == 3 else e
+        assert (e[sym] <= 2).mean() >= 0.99, (mode, float((e[sym] <= 2).mean()))
+
+
+def test_img_svg_symbol_and_refusals(chart, tmp_path):
+    sa, proj = chart
+    from smrender_amd import synth
+    if po.cairo() is None:
+        pytest.skip("libcairo not loadable")
+    f = symbol_png(tmp_path / "sym.png")
+    wids, _ = load_ways(sa, proj, po.synth_ways(5, W, H, seed=1))
+    # ways: a pattern fill, stays built-in; JPEG: the reference's own decoder; no file: refused like the reference
+    assert hs.apply_rule(sa.lib(), "img", hs.OSM_WAY, f"file={f}", wids) != 0
+    nid = _next_id[0]; _next_id[0] += 2
+    lat, lon = synth.px_to_geo(proj, np.array([100.0]), np.array([80.0]))
+    hs.add_nodes(np.array([nid]), lat, lon)
+    assert hs.apply_rule(sa.lib(), "img", hs.OSM_NODE, "file=symbol.jpg", np.array([nid])) != 0
+    assert hs.apply_rule(sa.lib(), "img", hs.OSM_NODE, "scale=2", np.array([nid])) != 0
+    assert hs.apply_rule(sa.lib(), "img", hs.OSM_NODE, f"file={tmp_path / 'missing.png'}", np.array([nid])) != 0
+    # an SVG symbol through librsvg: a 24 x 12 px red rectangle, centred on a node at a pixel corner
+    svg = tmp_path / "rect.svg"
+    svg.write_text('<svg xmlns="http://www.w3.org/2000/svg" width="24px" height="12px" viewBox="0 0 24 12">'
+                   '<rect x="0" y="0" width="24" height="12" fill="#ff0000"/></svg>')
+    before = plugin_canvas(sa)
+    rc = hs.apply_rule(sa.lib(), "img", hs.OSM_NODE, f"file={svg}", np.array([nid]))
+    if rc != 0:
+        pytest.skip("librsvg not loadable on this box: " + sa.lib().smr_hip_last_error().decode())
+    got = plugin_canvas(sa)
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    px, py, _, _, _ = po.project(op, lat, lon)
+    x0, y0 = int(round(px[0])) - 12, int(round(py[0])) - 6
+    assert np.all(got[y0 + 2:y0 + 10, x0 + 2:x0 + 22] == 0xffff0000)      # the interior is the symbol's red
+    changed = got != before
+    assert changed.sum() >= 24 * 12 - 40 and changed.sum() <= 26 * 14
+    assert not changed[:y0 - 2].any() and not changed[y0 + 15:].any()
