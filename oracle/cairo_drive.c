@@ -549,3 +549,24 @@ int cd_img_place(double x_px, double y_px, double angle, double dpi)
    p_cairo_restore(ctx);
    return p_cairo_status(ctx);
 }
+
+/* cap_coord's background box (fillcolor=, src/smrules_cairo.c:2367-2370 with cap_rect :2188-2199) on the current rule's context:
+ * translate to the anchor, rotate, then the box of the text (w x h pt at the aligned origin, h negative: upwards) scaled by
+ * `scale` about its middle */
+int cd_caption_box(double x_pt, double y_pt, double angle, double ox_pt, double oy_pt, double w, double h, double desc, double scale, uint32_t col)
+{
+   if (!rule_) return -1;
+   cairo_t *ctx = rule_;
+   double ws = w * scale, hs = h * scale;
+   p_cairo_save(ctx);
+   p_cairo_translate(ctx, x_pt, y_pt);
+   p_cairo_rotate(ctx, angle);
+   p_cairo_save(ctx);
+   p_cairo_translate(ctx, (w - ws) * .5, desc + (h - hs) * .5);
+   set_color(ctx, col);
+   p_cairo_rectangle(ctx, ox_pt, oy_pt, ws, hs);
+   p_cairo_fill(ctx);
+   p_cairo_restore(ctx);
+   p_cairo_restore(ctx);
+   return p_cairo_status(ctx);
+}

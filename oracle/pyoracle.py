@@ -142,6 +142,7 @@ def cairo():
         L.cd_img_load_png.argtypes = [C.c_char_p, C.c_double, C.c_double, C.c_void_p]
         L.cd_img_pixels.argtypes = [C.c_void_p]
         L.cd_img_place.argtypes = [C.c_double] * 4
+        L.cd_caption_box.argtypes = [C.c_double] * 9 + [C.c_uint32]
         L.cd_cut_out.argtypes = [C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_int]
         L.cd_direct_fill.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
         L.cd_rot_paint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]

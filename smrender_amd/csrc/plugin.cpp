@@ -623,6 +623,8 @@ struct cairo_api_t
    void (*show_text)(void *, const char *);
    void (*set_source_surface)(void *, void *, double, double);
    void (*paint)(void *);
+   void (*save)(void *);
+   void (*restore)(void *);
    void (*set_operator)(void *, int);
    void *(*image_surface_create_from_png)(const char *);
    int (*surface_status)(void *);
@@ -661,6 +663,7 @@ static int cairo_load(void)
    CR_LOAD(fill, "cairo_fill");
    CR_LOAD(translate, "cairo_translate"); CR_LOAD(rotate, "cairo_rotate"); CR_LOAD(move_to, "cairo_move_to"); CR_LOAD(show_text, "cairo_show_text");
    CR_LOAD(set_source_surface, "cairo_set_source_surface"); CR_LOAD(paint, "cairo_paint");
+   CR_LOAD(save, "cairo_save"); CR_LOAD(restore, "cairo_restore");
    CR_LOAD(set_operator, "cairo_set_operator"); CR_LOAD(image_surface_create_from_png, "cairo_image_surface_create_from_png");
    CR_LOAD(surface_status, "cairo_surface_status"); CR_LOAD(image_surface_get_width, "cairo_image_surface_get_width");
    CR_LOAD(image_surface_get_height, "cairo_image_surface_get_height");
@@ -684,6 +687,8 @@ struct cap_item_t
    short pos;
    double tw, hgt, ascent;    /* tx.width + tx.x_bearing, max(tx.height, ascent + descent), fe.ascent: the auto_ctx rectangle */
    double size_mm, descent;   /* for the glyphs */
+   double fixed_a;            /* fixed-angle rules: the angle of cap_coord :2353-2356 */
+   uint32_t fillcol;          /* fillcolor= box behind the text (cap_rect :2188-2199) */
    std::string text;
 };
 
@@ -697,6 +702,11 @@ struct cap_rule_t
    double min_auto_size = 0.5, max_auto_size = 12.0, min_area_size = 8.0, auto_scale = 0.2;   /* src/smrender_dev.h:107-110 */
    const char *halignkey = nullptr, *valignkey = nullptr;
    int hide = 0;
+   bool autorot = false;      /* angle=auto: the scan; otherwise angle= / anglekey= */
+   double angle = 0, bgbox_scale = 1.2;
+   const char *akey = nullptr;
+   bool fill_used = false;
+   col_spec_t fill_cs;
    void *sfc = nullptr, *ctx = nullptr;
    std::vector<cap_item_t> items;
 };
@@ -751,10 +761,27 @@ static int cap_ini(smr_smrule_t *r)
    host_resolve();
    if ((e = plugin_setup()) != 0) return e;
    char *s; double angle = 0;
-   /* parse_auto_rot, src/smrparse.c:1033-1074: only angle=auto runs on the GPU */
-   if ((s = H.get_param("angle", &angle, r->act)) == nullptr || strcasecmp(s, "auto") || H.get_param("anglekey", nullptr, r->act))
+   /* parse_auto_rot, src/smrparse.c:1033-1074; anglekey overrides angle=auto (act_cap_ini :1294-1299) */
+   bool autorot = false;
+   if ((s = H.get_param("angle", &angle, r->act)) != nullptr)
    {
-      plog(SMR_LOG_ERR, "cap: only angle=auto (the auto-rotation scan) runs on the GPU path; use the built-in cap for fixed angles");
+      if (!strcasecmp(s, "auto")) { autorot = true; angle = 0; }
+      else if (!strcasecmp(s, "majoraxis"))
+      {
+         plog(SMR_LOG_ERR, "cap: angle=majoraxis is not implemented on the GPU path; use the built-in cap");
+         return 1;
+      }
+      else angle = fmod(angle, 360.0);
+   }
+   const char *akey = H.get_param("anglekey", nullptr, r->act);
+   if (akey != nullptr && autorot)
+   {
+      plog(SMR_LOG_NOTICE, "anglekey=%s overrides angle=auto", akey);
+      autorot = false; angle = 0;
+   }
+   if (H.get_param_bool("fontbox", r->act))
+   {
+      plog(SMR_LOG_ERR, "cap: fontbox=1 adds objects to the host's data, which the GPU path does not; use the built-in cap");
       return 1;
    }
    if (!H.match_attr || !H.realloc_tags)
@@ -762,7 +789,7 @@ static int cap_ini(smr_smrule_t *r)
       plog(SMR_LOG_ERR, "cap: host symbols match_attr/realloc_tags not found");
       return -1;
    }
-   if (P.band_y0 != 0 || P.band_h != P.H)
+   if (autorot && (P.band_y0 != 0 || P.band_h != P.H))
    {
       /* a caption's cut-out reaches into the neighbouring bands; the plugin is one process and exchanges no halo rows */
       plog(SMR_LOG_ERR, "cap: the canvas is a row band (SMR_HIP_BAND_Y0/_H): the auto-rotation scan needs the neighbours' rows, which only a "
@@ -772,6 +799,9 @@ static int cap_ini(smr_smrule_t *r)
    if (cairo_load() != 0) return -1;
 
    cap_rule_t *cap = new cap_rule_t();
+   cap->autorot = autorot; cap->angle = angle; cap->akey = akey;
+   (void) H.get_param("bgbox_scale", &cap->bgbox_scale, r->act);
+   if ((s = H.get_param("fillcolor", nullptr, r->act)) != nullptr) { parse_col_spec(s, &cap->fill_cs); cap->fill_used = true; }
    if ((s = H.get_param("font", nullptr, r->act)) != nullptr) cap->font = s;
    else plog(SMR_LOG_NOTICE, "parameter 'font' missing, defaulting to \"%s\"", cap->font);
    if (H.get_param("size", &cap->size, r->act) == nullptr && r->oo->type == SMR_OSM_NODE)
@@ -850,7 +880,33 @@ static int cap_collect(cap_rule_t *cap, double size_mm, double lat, double lon, 
    double width = tx.width + tx.x_bearing + cap->xoff, height = fe.ascent;
    cap_item_t it;
    it.o = o; it.lat = lat; it.lon = lon;
-   it.pos = (cap->pos & 0xc) ? (short) ((cap->pos & 0xfff0) | SMR_POS_E) : cap->pos;
+   it.fixed_a = 0; it.fillcol = cap->fill_used ? color_by_cs(o, &cap->fill_cs) : 0;
+   if (cap->autorot) it.pos = (cap->pos & 0xc) ? (short) ((cap->pos & 0xfff0) | SMR_POS_E) : cap->pos;
+   else
+   {
+      /* alignment from the object's tags (:2233-2248, retr_align_key_pos :2088-2111), angle from anglekey (:2353-2356) */
+      auto key_pos = [&](const char *key) -> int
+      {
+         const int m = H.match_attr(o, key, nullptr);
+         if (m < 0 || o->otag[m].v.len > 9) return 0;
+         return alignment_str(std::string(o->otag[m].v.buf, (size_t) o->otag[m].v.len).c_str());
+      };
+      short pos = cap->pos;
+      if (cap->halignkey != nullptr || cap->valignkey != nullptr)
+      {
+         if (cap->halignkey == cap->valignkey) pos = (short) key_pos(cap->halignkey);
+         else
+         {
+            if (cap->halignkey != nullptr) pos = (short) ((pos & ~(SMR_POS_E | SMR_POS_W)) | (key_pos(cap->halignkey) & (SMR_POS_E | SMR_POS_W)));
+            if (cap->valignkey != nullptr) pos = (short) ((pos & ~(SMR_POS_N | SMR_POS_S)) | (key_pos(cap->valignkey) & (SMR_POS_N | SMR_POS_S)));
+         }
+      }
+      it.pos = pos;
+      int m;
+      if (cap->akey != nullptr && (m = H.match_attr(o, cap->akey, nullptr)) >= 0)
+         it.fixed_a = strtod(std::string(o->otag[m].v.buf, (size_t) o->otag[m].v.len).c_str(), nullptr) * M_PI / 180.0;
+      it.fixed_a += (360 - cap->angle) * M_PI / 180.0;
+   }
    it.col = color_by_cs(o, &cap->cs);
    it.tw = tx.width + tx.x_bearing; it.hgt = fmax(tx.height, fe.ascent + fe.descent); it.ascent = fe.ascent;
    it.size_mm = size_mm; it.descent = fe.descent; it.text = buf;
@@ -1007,7 +1063,8 @@ static int cap_draw_glyphs(const cap_rule_t *cap, const std::vector<double> &cx,
       double ox, oy;
       pos_offset(final_pos[i], it.tw, it.hgt, cap->xoff, cap->yoff, &ox, &oy);
       /* the text's box about its origin (a font size of slack for overhangs), rotated, in chart pixels */
-      const double pad = mm2pt(it.size_mm), ux[2] = { ox - pad, ox + it.tw + pad }, uy[2] = { oy - it.hgt - pad, oy + it.descent + pad };
+      const double pad = mm2pt(it.size_mm), bx = cap->fill_used ? fabs(cap->bgbox_scale - 1) * it.tw * .5 : 0, by = cap->fill_used ? fabs(cap->bgbox_scale - 1) * it.hgt * .5 : 0;
+      const double ux[2] = { ox - pad - bx, ox + it.tw + pad + bx }, uy[2] = { oy - it.hgt - pad - by, oy + it.descent + pad + by };
       double mnx = 1e300, mny = 1e300, mxx = -1e300, mxy = -1e300;
       for (int k = 0; k < 4; k++)
       {
@@ -1030,8 +1087,25 @@ static int cap_draw_glyphs(const cap_rule_t *cap, const std::vector<double> &cx,
       CR.set_font_size(ctx, mm2pt(it.size_mm));
       CR.set_source_rgba(ctx, (double) ((it.col >> 16) & 0xff) / 255.0, (double) ((it.col >> 8) & 0xff) / 255.0, (double) (it.col & 0xff) / 255.0,
                          1.0 - (double) (((it.col & 0x7f000000u) >> 23) & 0xff) / 255.0);
-      CR.move_to(ctx, ox, oy);
-      CR.show_text(ctx, it.text.c_str());
+      if (cap->fill_used)
+      {
+         /* cap_rect (:2188-2199): the box behind the text, scaled by bgbox_scale about the text's middle */
+         const double bw = it.tw, bh = -it.hgt, ws = bw * cap->bgbox_scale, hs = bh * cap->bgbox_scale;
+         CR.save(ctx);
+         CR.translate(ctx, (bw - ws) * .5, it.descent + (bh - hs) * .5);
+         CR.set_source_rgba(ctx, (double) ((it.fillcol >> 16) & 0xff) / 255.0, (double) ((it.fillcol >> 8) & 0xff) / 255.0, (double) (it.fillcol & 0xff) / 255.0,
+                            1.0 - (double) (((it.fillcol & 0x7f000000u) >> 23) & 0xff) / 255.0);
+         CR.rectangle(ctx, ox, oy, ws, hs);
+         CR.fill(ctx);
+         CR.restore(ctx);
+         CR.set_source_rgba(ctx, (double) ((it.col >> 16) & 0xff) / 255.0, (double) ((it.col >> 8) & 0xff) / 255.0, (double) (it.col & 0xff) / 255.0,
+                            1.0 - (double) (((it.col & 0x7f000000u) >> 23) & 0xff) / 255.0);
+      }
+      if (!cap->hide)
+      {
+         CR.move_to(ctx, ox, oy);
+         CR.show_text(ctx, it.text.c_str());
+      }
       CR.destroy(ctx);
       void *sfc = CR.image_surface_create(0 /* ARGB32 */, w, h);
       ctx = CR.create(sfc);
@@ -1091,8 +1165,10 @@ static int cap_fini(smr_smrule_t *r)
          /* what a caption can see (half the cut-out's diagonal) or paint (its rectangle): both within r_px */
          reach[k] = std::max(1.0, (double) rpx);
       }
-      if (ret == 0) cap_levels(cx, cy, reach, level, n_levels);
-      if (ret == 0 && smr_hip_canvas_clone(P.canvas, &autoc) != SMR_OK) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
+      if (!cap->autorot)
+         for (size_t k = 0; k < n_all; k++) { angle[k] = cap->items[k].fixed_a; final_pos[k] = cap->items[k].pos; }
+      if (ret == 0 && cap->autorot) cap_levels(cx, cy, reach, level, n_levels);
+      if (ret == 0 && cap->autorot && smr_hip_canvas_clone(P.canvas, &autoc) != SMR_OK) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
    }
    for (int lv = 0; lv < n_levels && ret == 0; lv++)
    {
@@ -1185,7 +1261,7 @@ static int cap_fini(smr_smrule_t *r)
       }
    }
    if (autoc) smr_hip_canvas_destroy(autoc);
-   if (ret == 0)
+   if (ret == 0 && cap->autorot)
       for (size_t i = 0; i < n_all; i++)
       {
          cap_item_t &it = cap->items[i];
@@ -1194,13 +1270,15 @@ static int cap_fini(smr_smrule_t *r)
          add_tag(it.o, cap->key, "autoangle", val);
          add_tag(it.o, cap->key, "autoalign", (final_pos[i] & SMR_POS_E) ? "east" : (final_pos[i] & SMR_POS_W) ? "west" : "center");
       }
-   if (ret == 0 && !cap->hide && n_all && cap_draw_glyphs(cap, cx, cy, angle, final_pos) != SMR_OK)
+   if (ret == 0 && (!cap->hide || cap->fill_used) && n_all && cap_draw_glyphs(cap, cx, cy, angle, final_pos) != SMR_OK)
    {
       plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error());
       ret = -1;
    }
-   plog(SMR_LOG_INFO, "cap: %zu captions scanned on the GPU in %d dependency level(s), %zu batch(es)%s", n_all, n_levels, n_groups,
-        cap->hide ? "" : ", glyphs composited onto the device canvas");
+   if (cap->autorot)
+      plog(SMR_LOG_INFO, "cap: %zu captions scanned on the GPU in %d dependency level(s), %zu batch(es)%s", n_all, n_levels, n_groups,
+           cap->hide ? "" : ", glyphs composited onto the device canvas");
+   else plog(SMR_LOG_INFO, "cap: %zu captions at their given angles%s", n_all, cap->hide ? "" : ", glyphs composited onto the device canvas");
    CR.destroy(cap->ctx);
    CR.surface_destroy(cap->sfc);
    delete cap;

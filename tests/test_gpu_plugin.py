@@ -521,9 +521,6 @@ def test_cap_glyphs_are_composited_onto_the_device_canvas(chart):
     plain = po.cairo_scene([(po.Style(1, 1, 0x4080c0, 0, 0, 0.1, 0), oways)], DPI, W, H, 0xfff8e0)
     text = np.any(po.chan_diff(want, plain) > 0, axis=-1) if po.chan_diff(want, plain).ndim == 3 else po.chan_diff(want, plain) > 0
     assert text.sum() > 2000                                   # the captions really are in the reference picture
-    if os.environ.get("SMR_TEST_DUMP"):
-        np.savez(os.path.join(os.environ["SMR_TEST_DUMP"], "glyphs_dump.npz"), got=got, want=want, plain=plain, px=px, py=py,
-                 ang=[hs.get_tag(hs.OSM_NODE, nids[k], "name:autoangle") for k in range(n)], al=[hs.get_tag(hs.OSM_NODE, nids[k], "name:autoalign") for k in range(n)])
     assert within(got, want) >= 0.995                          # north star: +-2/255 on >= 99.5 % of the pixels
     # and where the text is: the glyph pixels themselves agree (same FreeType masks, same positions)
     d = po.chan_diff(got, want)
@@ -685,3 +682,76 @@ def test_img_svg_symbol_and_refusals(chart, tmp_path):
     changed = got != before
     assert changed.sum() >= 24 * 12 - 40 and changed.sum() <= 26 * 14
     assert not changed[:y0 - 2].any() and not changed[y0 + 15:].any()
+
+
+def test_cap_with_given_angles_and_background_boxes(chart):
+    """cap with angle= / anglekey= / alignkey= / fillcolor= (cap_coord's else branch, src/smrules_cairo.c:2351-2388, cap_rect
+    :2188-2199): no scan, no tags; box and text of every caption go onto the device canvas.  Compared with libcairo recording
+    and replaying the same chart.  The reference's own chain works on the device canvas too: a hidden angle=auto rule writes the
+    tags, a second rule with anglekey=name:autoangle;alignkey=name:autoalign draws."""
+    sa, proj = chart
+    from smrender_amd import synth
+    from golden_io import within
+    cd = po.cairo()
+    if cd is None:
+        pytest.skip("libcairo not loadable")
+    arrs = po.synth_ways(70, W, H, seed=85)
+    wids, oways = load_ways(sa, proj, arrs)
+    assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", wids) == 0
+    rng = np.random.default_rng(41)
+    n = 8
+    cx, cy = rng.uniform(60, W - 60, n), rng.uniform(40, H - 40, n)
+    names = [f"Name {k}" for k in range(n)]
+    lat, lon = synth.px_to_geo(proj, cx, cy)
+    base = _next_id[0]; _next_id[0] += n + 1
+    nids = base + np.arange(n)
+    sides = ["east", "west", "center", "east", "northwest", "south", "west", "east"]
+    dirs = [None if k % 3 == 0 else 23.0 * k for k in range(n)]
+    hs.add_nodes(nids, lat, lon, [f"name={names[k]};side={sides[k]}" + (f";dir={dirs[k]}" if dirs[k] is not None else "") for k in range(n)])
+    size_mm, col, fillcol = 2.2, 0x102060, 0x40ffffff
+    params = f"key=name;size={size_mm};angle=15;anglekey=dir;alignkey=side;color=#102060;fillcolor=#40ffffff;font=serif"
+    assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, params, nids) == 0, sa.lib().smr_hip_last_error()
+    assert hs.get_tag(hs.OSM_NODE, nids[0], "name:autoangle") is None
+    got = plugin_canvas(sa)
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    px, py, _, _, _ = po.project(op, lat, lon)
+    xoff = size_mm * 72 / 25.4 / 2
+    POS = {"east": 4, "west": 8, "center": 0, "northwest": 8 | 1, "south": 2}
+
+    def captions(L):
+        L.cd_rule_begin()
+        for k in range(n):
+            a = np.radians(dirs[k] if dirs[k] is not None else 0.0) + np.radians(360 - 15)
+            geo = np.zeros(3, np.int32)
+            L.cd_caption_geometry(b"serif", size_mm, names[k].encode(), xoff, xoff, 1, W * 72 / DPI, H * 72 / DPI, po.P(geo))
+            met = np.zeros(4); L.cd_last_metrics(po.P(met))
+            tw, asc, desc, th = met
+            hgt = max(th, asc + desc)
+            pos = POS[sides[k]]
+            oy = -xoff if pos & 3 == 1 else hgt + xoff if pos & 3 == 2 else hgt / 2              # pos_offset (:1478-1508)
+            ox = xoff if pos & 12 == 4 else -tw - xoff if pos & 12 == 8 else -tw / 2
+            assert L.cd_caption_box(px[k] * 72 / DPI, py[k] * 72 / DPI, a, ox, oy, tw, -hgt, desc, 1.2, fillcol) == 0
+            assert L.cd_show_caption(b"serif", size_mm, names[k].encode(), px[k] * 72 / DPI, py[k] * 72 / DPI, a, ox, oy, col) == 0
+        L.cd_rule_end()
+
+    style = po.Style(1, 1, 0x4080c0, 0, 0, 0.1, 0)
+    want = po.cairo_scene([(style, oways)], DPI, W, H, 0xfff8e0, before_render=captions)
+    plain = po.cairo_scene([(style, oways)], DPI, W, H, 0xfff8e0)
+    d = po.chan_diff(want, plain)
+    ink = (d.max(axis=-1) if d.ndim == 3 else d) > 0
+    assert ink.sum() > 4000
+    assert within(got, want) >= 0.995, within(got, want)
+    e = po.chan_diff(got, want)
+    e = e.max(axis=-1) if e.ndim == 3 else e
+    assert (e[ink] <= 2).mean() >= 0.97, float((e[ink] <= 2).mean())
+
+    # the reference's chain, both rules on the device canvas
+    base = _next_id[0]; _next_id[0] += n + 1
+    nids2 = base + np.arange(n)
+    hs.add_nodes(nids2, lat, lon, [f"name={t}" for t in names])
+    assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, "key=name;size=2;angle=auto;halign=east;hide=1", nids2) == 0
+    mid = plugin_canvas(sa)
+    assert np.array_equal(mid, got)
+    assert hs.get_tag(hs.OSM_NODE, nids2[0], "name:autoangle") is not None
+    assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, "key=name;size=2;anglekey=name:autoangle;alignkey=name:autoalign;color=black", nids2) == 0
+    assert (plugin_canvas(sa) != mid).sum() > 1000
