@@ -212,6 +212,30 @@ int smr_hip_caprot_steps(int fg_w, int fg_h, int dpi, int *num_steps, int *r_px)
 #define SMR_CAPROT_NOALLOC_MAX_STEPS 1024
 int smr_hip_caprot_noalloc(smr_canvas_t *c, const smr_cap_batch_t *b, double *d_angle, double *d_dv);
 
+/* ---- the scan's cut-outs the reference's way: re-rasterised at a sub-pixel offset ---------------------------------------------
+ * cairo_smr_cut_out (src/smrules_cairo.c:1511-1533) does not crop the rendered chart: it replays the recording into an r x r
+ * image translated by (-x + r/2, -y + r/2) pt, so the cut-out's pixel grid carries the fraction of a pixel the caption's
+ * anchor has.  smr_hip_caprot on the chart's canvas crops at the rounded anchor instead (fast, and 11-13 % of the %.1f angle
+ * tags differ from the reference's: DESIGN.md 2).  These entry points render the reference's cut-outs: an ATLAS is a canvas
+ * holding one window of `size` px per caption, one below the other; smr_hip_windows_create makes it (transparent, then the
+ * chart's background rectangle), smr_hip_draw_windows draws a rule into every window it reaches -- the same style and batch
+ * smr_hip_draw took for the chart, in the same order, the caller keeps them -- and smr_hip_caprot scans the atlas at the anchors
+ * smr_hip_windows_anchors returns (the middle of each window), giving find_angle's angles for the real anchors.
+ * `size` is find_angle's r in px: smr_hip_caprot_steps' r_px for the caption's plane.  An atlas holds at most 65 536 rows
+ * (240 windows of 271 px): larger batches go in several atlases.  No counterpart in the reference beyond cairo_smr_cut_out
+ * itself: there the cut-out is made per caption, on the CPU, by replaying the whole chart. */
+typedef struct
+{
+   int64_t n;                      /* windows */
+   int32_t size, pad_;             /* width = height of every window, px: round(r_px) */
+   double r_px;                    /* find_angle's r before rounding, hypot(fg_w, fg_h) px (:1975): the windows are centred with IT
+                                      (cairo_smr_cut_out translates by r/2, :1526); 0 = size */
+   const double *cx, *cy;          /* [n] HOST: the captions' anchors in chart px (geo2pxf) */
+} smr_windows_t;
+int smr_hip_windows_create(int chart_w, int chart_h, int dpi, uint32_t bgcolor, const smr_windows_t *w, smr_canvas_t **atlas);
+int smr_hip_draw_windows(smr_canvas_t *atlas, const smr_draw_style_t *st, const smr_draw_batch_t *b);
+int smr_hip_windows_anchors(smr_canvas_t *atlas, double *cx, double *cy);      /* [n] HOST out */
+
 /* ---- stream / timing helpers --------------------------------------------------------- */
 int smr_hip_sync(void);
 void *smr_hip_stream(void);                    /* hipStream_t of the library */

@@ -667,6 +667,7 @@ struct orc_canvas
    int layer_clear;
    int img[4];           /* the image's rectangle on the chart, px (curve limits) */
    int cap_round;        /* line cap of the current rule's context (cairo_set_line_cap is never undone) */
+   int32_t shift_x, shift_y;   /* 24.8: the translation of a replay at an offset (cairo_smr_cut_out), added to every device vertex */
 };
 
 orc_canvas_t *orc_canvas_new(int x0, int y0, int W, int H, int dpi, uint32_t bgcolor)
@@ -680,6 +681,16 @@ orc_canvas_t *orc_canvas_new(int x0, int y0, int W, int H, int dpi, uint32_t bgc
    uint32_t bg = orc_color_pixel(bgcolor);       /* paint onto a clear image == SOURCE */
    for (size_t i = 0; i < (size_t) W * H; i++) c->pix[i] = bg;
    return c;
+}
+
+/* A replay of the recording translated by (tx, ty) pt under cairo_scale(dpi/72) (cairo_smr_cut_out, src/smrules_cairo.c:1524-1529):
+ * libcairo 1.16 transforms the recorded 24.8 path with the scale quantised to 24.8 and the matrix's translation x0 = tx * s
+ * quantised SEPARATELY (_cairo_path_fixed_offset_and_scale: p = fixed_mul(scale, p) + fixed(x0)), so the shifted replay is the
+ * unshifted device path plus one constant 24.8 vector; strokes are computed on the shifted path. */
+void orc_canvas_set_shift(orc_canvas_t *c, double tx_pt, double ty_pt)
+{
+   double s = (double) c->dpi / 72;
+   c->shift_x = orc_fixed_from_double(tx_pt * s); c->shift_y = orc_fixed_from_double(ty_pt * s);
 }
 
 void orc_canvas_set_image(orc_canvas_t *c, int x0, int y0, int x1, int y1) { c->img[0] = x0; c->img[1] = y0; c->img[2] = x1; c->img[3] = y1; }
@@ -896,6 +907,7 @@ void orc_draw_way(orc_canvas_t *c, const orc_draw_style_t *st, const double *x_p
    int32_t *dev = malloc(sizeof(int32_t) * 2 * n);
    tor_edge_t *e = malloc(sizeof(tor_edge_t) * 8 * n);
    orc_px_to_dev(x_px, y_px, n, c->dpi, dev);
+   for (int i = 0; i < n; i++) { dev[2 * i] += c->shift_x; dev[2 * i + 1] += c->shift_y; }
    if (st->border_used)
    {
       /* cairo_smr_border_width, :880-889 */

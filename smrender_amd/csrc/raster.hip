@@ -31,7 +31,8 @@ __device__ __forceinline__ int64_t smr_find_way(const int64_t *__restrict__ way_
 __global__ void k_dev_points(const double *__restrict__ x, const double *__restrict__ y,
                              const int32_t *__restrict__ ref, int64_t n_refs, int64_t n_nodes, int dpi, int32_t sfix,
                              const int64_t *__restrict__ way_off, int64_t n_ways,
-                             int2 *__restrict__ pts, int32_t *__restrict__ refway, uint32_t *__restrict__ status)
+                             int2 *__restrict__ pts, int32_t *__restrict__ refway, uint32_t *__restrict__ status,
+                             const int32_t *__restrict__ node_win, const int2 *__restrict__ win_shift)
 {
    int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    int64_t stride = (int64_t) gridDim.x * blockDim.x;
@@ -48,6 +49,9 @@ __global__ void k_dev_points(const double *__restrict__ x, const double *__restr
       int2 p;
       p.x = (int32_t) (((int64_t) fx * sfix) >> 8);
       p.y = (int32_t) (((int64_t) fy * sfix) >> 8);
+      /* a window of a replay at an offset (smr_hip_draw_windows): libcairo adds the replay matrix's translation, quantised to
+       * 24.8 by itself, to the scaled device point (_cairo_path_fixed_offset_and_scale); strokes are built on the shifted path */
+      if (node_win) { const int2 sh = win_shift[node_win[node]]; p.x += sh.x; p.y += sh.y; }
       pts[g] = p;
       refway[g] = (int32_t) smr_find_way(way_off, n_ways, g);
    }
@@ -942,6 +946,7 @@ struct smr_bigacc_t
 {
    int32_t minx, miny, maxx, maxy, bin_maxx;     /* atomicMin / atomicMax over the items */
    uint32_t item_flags, prim_id, valid;          /* SMR_PF_* of the items; the id the items carry (compound or own); set by k_big_finish */
+   int32_t clip0, clip1;                         /* the rows the primitive may touch (a window of an atlas), else 0 .. H */
 };
 
 struct setup_args_t
@@ -969,6 +974,7 @@ struct setup_args_t
    int band_y0, band_h;                                /* this canvas's rows (k_cover's arenas are sized for them) */
    uint32_t *biglist;                                  /* long primitives, left to the k_big_* kernels ([0] = their number, then (id, first item)) */
    struct smr_bigacc_t *bigacc;                        /* [biglist entry] what those kernels need of them */
+   const int2 *way_clip;                               /* [n_ways] rows [x, y) a way's primitives may touch: its window of an atlas (smr_hip_draw_windows); NULL: the chart */
 };
 
 struct setup_lds_t
@@ -1339,6 +1345,8 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    const int64_t item0 = A.K * base + kind * span;
    const bool on = role != 2 ? (wf & 2) != 0 : (wf & 12) != 0;
    const bool pieces = role != 2 || (wf & 8);
+   /* libcairo limits a polygon to the image it renders into; for a window of an atlas that image is the window's rows */
+   const int clip0 = A.way_clip ? A.way_clip[w].x : 0, clip1 = A.way_clip ? A.way_clip[w].y : A.H;
    smr_prim_t P;
    P.edge_off = 0; P.edge_cnt = 0; P.color = 0; P.minx = P.miny = INT32_MAX; P.maxx = P.maxy = INT32_MIN;
    P.flags = 0; P.mask_off = 0; P.row0 = 0; P.nrows = 0; P.drow_off = 0; P.pad_[0] = P.pad_[1] = P.pad_[2] = 0;
@@ -1375,6 +1383,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          smr_bigacc_t a;
          a.minx = a.miny = INT32_MAX; a.maxx = a.maxy = a.bin_maxx = INT32_MIN;
          a.item_flags = item_flags; a.prim_id = A.compound != 0xffffffffu ? A.compound : (uint32_t) p; a.valid = 0;
+         a.clip0 = clip0; a.clip1 = clip1;
          A.bigacc[b] = a;
          A.prims[p] = P;                 /* edge range and colour; not valid before k_big_finish */
       }
@@ -1413,8 +1422,18 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          it.cnt_flags = mnx <= mxx ? (cnt | (item_flags << 8)) : 0;
          it.color = P.color;
          it.minx = bmn; it.miny = mny; it.maxx = bmx; it.maxy = mxy;
+         if (A.way_clip)
+         {
+            it.miny = max(it.miny, clip0 * 256); it.maxy = min(it.maxy, clip1 * 256 - 1);
+            if (it.miny > it.maxy) it.cnt_flags = 0;
+         }
          A.items[item0 + k] = it;
       }
+   }
+   if (A.way_clip && P.minx <= P.maxx)
+   {
+      P.miny = max(P.miny, clip0 * 256); P.maxy = min(P.maxy, clip1 * 256 - 1);
+      if (P.miny > P.maxy) { P.minx = INT32_MAX; P.maxx = INT32_MIN; }
    }
    bool valid = P.minx <= P.maxx;
    if (valid)
@@ -1422,14 +1441,14 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
       int c0 = P.minx >> 8, c1 = P.maxx >> 8, r0 = P.miny >> 8, r1 = P.maxy >> 8;
       /* a member of a compound path (directional rule) left or right of the chart draws nothing, but its vertices still decide
        * which rows of the ONE polygon libcairo sub-samples: it keeps its row mask and its items (which no tile takes) */
-      const bool off_x = c1 < 0 || c0 >= A.W, off_y = r1 < 0 || r0 >= A.H;
+      const bool off_x = c1 < 0 || c0 >= A.W, off_y = r1 < clip0 || r0 >= clip1;
       if (off_y || (off_x && A.compound == 0xffffffffu)) valid = false;
    }
    /* a primitive off the chart needs no flag in its items: their boxes are off the chart too */
    if (!valid) { if (lane == 0) A.prims[p] = P; return; }
    P.flags = item_flags;
-   P.row0 = max(0, P.miny >> 8);
-   P.nrows = min(A.H - 1, P.maxy >> 8) - P.row0 + 1;
+   P.row0 = max(clip0, P.miny >> 8);
+   P.nrows = min(clip1 - 1, P.maxy >> 8) - P.row0 + 1;
    const uint32_t nwords = ((uint32_t) P.nrows + 31u) >> 5;
    /* fill chunks are binned up to the primitive's right edge: edges left of a tile carry winding into it */
    if (!pieces && nitems > 1)
@@ -1585,7 +1604,8 @@ __global__ __launch_bounds__(256) void k_big_items(const smr_prim_t *__restrict_
             it.prim = prim_id;
             it.cnt_flags = mnx <= mxx ? (min(64u, P.edge_cnt - k * 64u) | (item_flags << 8)) : 0;
             it.color = P.color;
-            it.minx = bmn; it.miny = mny; it.maxx = bmx; it.maxy = mxy;
+            it.minx = bmn; it.miny = max(mny, acc[b].clip0 * 256); it.maxx = bmx; it.maxy = min(mxy, acc[b].clip1 * 256 - 1);
+            if (it.miny > it.maxy) it.cnt_flags = 0;
             items[item0 + k] = it;
          }
          if (mnx <= mxx) { amnx = min(amnx, mnx); amny = min(amny, mny); amxx = max(amxx, mxx); amxy = max(amxy, mxy); abmx = max(abmx, bmx); }
@@ -1612,12 +1632,13 @@ __global__ void k_big_finish(smr_prim_t *prims, const uint32_t *__restrict__ big
    bool valid = P.minx <= P.maxx;
    if (valid)
    {
+      P.miny = max(P.miny, a.clip0 * 256); P.maxy = min(P.maxy, a.clip1 * 256 - 1);
       const int c0 = P.minx >> 8, c1 = P.maxx >> 8, r0 = P.miny >> 8, r1 = P.maxy >> 8;
-      if (c1 < 0 || r1 < 0 || c0 >= W || r0 >= H) valid = false;
+      if (c1 < 0 || P.miny > P.maxy || r1 < a.clip0 || c0 >= W || r0 >= a.clip1) valid = false;
    }
    if (!valid) { prims[p] = P; return; }
-   P.row0 = max(0, P.miny >> 8);
-   P.nrows = min(H - 1, P.maxy >> 8) - P.row0 + 1;
+   P.row0 = max(a.clip0, P.miny >> 8);
+   P.nrows = min(a.clip1 - 1, P.maxy >> 8) - P.row0 + 1;
    const uint32_t nwords = ((uint32_t) P.nrows + 31u) >> 5;
    const uint32_t moff = atomicAdd(&small[4], nwords);
    if ((uint64_t) moff + nwords > mask_cap) { atomicOr(&small[2], SMR_ST_MASK_ARENA); P.nrows = 0; prims[p] = P; return; }
@@ -3394,6 +3415,8 @@ extern "C" int smr_hip_canvas_destroy(smr_canvas_t *c)
    if (!c) return SMR_OK;
    hipStreamSynchronize(smr_g.stream);
    if (c->pix) hipFree(c->pix);
+   if (c->d_win_shift) hipFree(c->d_win_shift);
+   if (c->d_win_box) hipFree(c->d_win_box);
    if (c->halo_above) hipFree(c->halo_above);
    if (c->halo_below) hipFree(c->halo_below);
    for (auto &b : c->buf) if (b.p) hipFree(b.p);
@@ -3554,7 +3577,8 @@ extern "C" int smr_hip_debug_edges(smr_canvas_t *c, int32_t *host_xyxy, uint64_t
 
 static double mm2wu(double mm, int dpi) { return mm == 0.0 ? 1.0 * 72 / dpi : mm * 72 / 25.4; }
 
-static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, int mode);
+typedef smr_win_ctx_t win_ctx_t;
+static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, int mode, const win_ctx_t *wc = nullptr);
 
 __global__ void k_max_u32(const uint32_t *__restrict__ v, int64_t n, uint32_t *__restrict__ keep)
 {
@@ -3627,7 +3651,14 @@ static int host_pen(double hw_pt, int dpi, std::vector<int2> &out)
 
 extern "C" uint32_t smr_hip_draw_status(void) { return smr_g.draw_status; }
 
-extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b)
+int smr_scan_u32(uint32_t *buf, uint32_t n, uint32_t *sums, uint32_t *total_dev, uint32_t *total)
+{
+   return count_finish(buf, n, sums, total_dev, total, smr_g.stream);
+}
+
+extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b) { return smr_draw_instances(c, st, b, nullptr); }
+
+int smr_draw_instances(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, const smr_win_ctx_t *wc)
 {
    smr_g.draw_status = 0;
    SMR_NEED_INIT();
@@ -3645,10 +3676,10 @@ extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const s
        * (act_draw_fini :1084-1140) */
       smr_draw_style_t s2 = *st;
       s2.border_used = 0; s2.directional = 0;
-      SMR_TRY(draw_pass(c, &s2, b, SMR_PASS_OPEN));
-      return draw_pass(c, &s2, b, SMR_PASS_COMPOUND);
+      SMR_TRY(draw_pass(c, &s2, b, SMR_PASS_OPEN, wc));
+      return draw_pass(c, &s2, b, SMR_PASS_COMPOUND, wc);
    }
-   return draw_pass(c, st, b, SMR_PASS_NORMAL);      /* directional without a fill is not directional (:681-685) */
+   return draw_pass(c, st, b, SMR_PASS_NORMAL, wc);      /* directional without a fill is not directional (:681-685) */
 }
 
 /* most edge slots of one tile the second raster pass is given lists for; SMR_HIP_DEBUG_BIG_SLOTS lowers it so that a test can
@@ -3666,7 +3697,7 @@ static uint64_t big_slots_max()
    return e && *e ? strtoull(e, nullptr, 10) : (uint64_t) SMR_BIG_SLOTS_MAX;
 }
 
-static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, int mode)
+static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, int mode, const win_ctx_t *wc)
 {
    if (b->n_ways < 0 || b->n_refs < 0 || b->n_ways > 0x7ffffff0ll / 2 || b->n_refs > 0x7fffffffll)
       return smr_fail(SMR_E_INVAL, "draw: batch too large (n_ways %lld, n_refs %lld)", (long long) b->n_ways, (long long) b->n_refs);
@@ -3711,7 +3742,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    int32_t sfix = (int32_t) nearbyint((double) c->dpi / 72 * 256.0);
    {
       unsigned nb = blocks(n_refs, TB); if (nb > 65536u * 4) nb = 65536u * 4;
-      k_dev_points<<<nb, TB, 0, s>>>(b->d_x, b->d_y, b->d_ref, n_refs, b->n_nodes, c->dpi, sfix, b->d_way_off, n_ways, pts, refway, &small[2]);
+      k_dev_points<<<nb, TB, 0, s>>>(b->d_x, b->d_y, b->d_ref, n_refs, b->n_nodes, c->dpi, sfix, b->d_way_off, n_ways, pts, refway, &small[2],
+                                     wc ? wc->node_win : nullptr, wc ? wc->win_shift : nullptr);
    }
    k_way_info<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, b->d_ref, n_ways, n_refs, st->border_used, st->fill_used,
                                                 st->ignore_open, mode, wayflags, &small[0], &small[5], &small[2]);
@@ -3948,7 +3980,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SA.edges = edges; SA.way_off = way_off; SA.wayflags = wayflags; SA.n_ways = n_ways;
       SA.off_border = off_border; SA.off_fill = off_fill; SA.off_open = off_open;
       SA.border_pix = host_color_pixel(st->border_col); SA.fill_pix = host_color_pixel(st->fill_col);
-      SA.way_border_pix = wb_pix; SA.way_fill_pix = wf_pix; SA.W = c->W; SA.H = c->H;
+      SA.way_border_pix = wb_pix; SA.way_fill_pix = wf_pix; SA.W = c->W; SA.H = c->H; SA.way_clip = wc ? wc->way_clip : nullptr;
       SA.prims = prims; SA.items = items; SA.mask = maskbuf; SA.mask_cap = (uint32_t) std::min<size_t>(mask_cap, 0xffffffffu);
       SA.small = small; SA.compound = compound;
       SA.K = K; SA.off_dots = off_dots; SA.po_border = po_border; SA.po_dots = po_dots; SA.po_open = po_open; SA.id_off = id_off;

@@ -33,7 +33,9 @@ int smr_caprot_scratch_setup(int device);
 
 enum { SMR_BUF_PTS, SMR_BUF_WAYFLAGS, SMR_BUF_SMALL, SMR_BUF_PRIMS, SMR_BUF_EDGES, SMR_BUF_WAYPIX, SMR_BUF_COUNTS,
        SMR_BUF_TILEOFF, SMR_BUF_SUMS, SMR_BUF_ENTRIES, SMR_BUF_CAP0, SMR_BUF_CAP1, SMR_BUF_REFWAY, SMR_BUF_ITEMS, SMR_BUF_MASK, SMR_BUF_HDRS, SMR_BUF_COVERED, SMR_BUF_DASH, SMR_BUF_PEN,
-       SMR_BUF_CURVE_CNT, SMR_BUF_FPTS, SMR_BUF_FTIN, SMR_BUF_FTOUT, SMR_BUF_FREFWAY, SMR_BUF_FWAYOFF, SMR_BUF_FSKIP, SMR_BUF_BIGLIST, SMR_BUF_BIGACC, SMR_BUF_CURVEFIX, SMR_BUF_SNAPSHOT, SMR_BUF_OVFLIST, SMR_BUF_BIGBUCKET, SMR_BUF_DELTAS, SMR_BUF_DROWS, SMR_BUF_TILECNT, SMR_BUF_BLIT, SMR_BUF_MAX };
+       SMR_BUF_CURVE_CNT, SMR_BUF_FPTS, SMR_BUF_FTIN, SMR_BUF_FTOUT, SMR_BUF_FREFWAY, SMR_BUF_FWAYOFF, SMR_BUF_FSKIP, SMR_BUF_BIGLIST, SMR_BUF_BIGACC, SMR_BUF_CURVEFIX, SMR_BUF_SNAPSHOT, SMR_BUF_OVFLIST, SMR_BUF_BIGBUCKET, SMR_BUF_DELTAS, SMR_BUF_DROWS, SMR_BUF_TILECNT, SMR_BUF_BLIT,
+       SMR_BUF_WIN_WB, SMR_BUF_WIN_BOX, SMR_BUF_WIN_CNT, SMR_BUF_WIN_SUMS, SMR_BUF_WIN_TOT, SMR_BUF_WIN_IWAY, SMR_BUF_WIN_IWIN, SMR_BUF_WIN_IOFF, SMR_BUF_WIN_X, SMR_BUF_WIN_Y,
+       SMR_BUF_WIN_REF, SMR_BUF_WIN_NODEWIN, SMR_BUF_WIN_WAYOFF, SMR_BUF_WIN_CLIP, SMR_BUF_WIN_FCOL, SMR_BUF_WIN_BCOL, SMR_BUF_MAX };
 
 struct smr_devbuf_t { void *p = nullptr; size_t cap = 0; };
 
@@ -44,6 +46,10 @@ struct smr_canvas
    uint32_t *pix = nullptr;
    uint32_t *halo_above = nullptr, *halo_below = nullptr;     /* neighbour rows for the caption scan */
    int n_above = 0, n_below = 0;
+   /* an atlas of caption cut-outs (windows.hip): win_n windows of win_size px, one every win_pitch rows; per window the 24.8 shift of
+    * its replay (atlas placement included) and its box on the chart in px */
+   int win_n = 0, win_size = 0, win_pitch = 0, chart_w = 0, chart_h = 0;
+   int2 *d_win_shift = nullptr; void *d_win_box = nullptr;
    int own_y0 = -1, own_h = 0;         /* smr_hip_canvas_extend: the rows whose captions this canvas scans (-1: the band itself) */
    smr_devbuf_t buf[SMR_BUF_MAX];      /* grow-only work buffers, reused across draw calls */
    int strict_rows = 0;                /* draw_pass's second attempt: rows beyond SMR_ROWCAP spanning edges are sub-sampled (and reported) */
@@ -64,6 +70,14 @@ struct smr_canvas
       return SMR_OK;
    }
 };
+
+/* a batch whose ways are instances for the windows of an atlas (smr_hip_draw_windows): per node its window, per window the 24.8
+ * shift of its replay, per way the atlas rows of its window */
+struct smr_win_ctx_t { const int32_t *node_win; const int2 *win_shift; const int2 *way_clip; };
+/* raster.hip: smr_hip_draw with the window context; the in-place exclusive scan of the draw pass on the library's stream
+ * (buf[n] = total, which also comes back) */
+int smr_draw_instances(smr_canvas *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, const smr_win_ctx_t *wc);
+int smr_scan_u32(uint32_t *buf, uint32_t n, uint32_t *sums, uint32_t *total_dev, uint32_t *total);
 
 /* HIP-event stage timer on the library stream (only active when profiling is on) */
 struct smr_timer_t

@@ -1,0 +1,105 @@
+"""The caption scan's cut-outs the reference's way (smr_hip_windows_create / smr_hip_draw_windows, windows.hip): every caption's
+r x r window re-rasterised at the sub-pixel offset of its anchor, as cairo_smr_cut_out (src/smrules_cairo.c:1511-1533) replays
+the recording.  Pinned against libcairo's OWN cut-outs: tests/golden/cutout_subpixel.npz holds, for 2 x 2000 captions with
+non-integer anchors on a C2-like chart, find_angle on cd_cut_out's pixels (`ref`, made by tests/golden/make_cutout_vectors.py
+where libcairo 1.16 is).  The crop convention of smr_hip_caprot on the chart's canvas differs from `ref` in 11-13 % of the
+%.1f tags (tests/test_cutout_convention.py); the windows must not."""
+import ctypes as C
+import os
+import numpy as np
+import pytest
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "cutout_subpixel.npz"))
+W, H, DPI = int(G["W"]), int(G["H"]), int(G["dpi"])
+
+
+def tags(a):
+    return np.array(["%.1f" % (v * 180 / np.pi) for v in a])
+
+
+def scan_windows(sa, rules, cx, cy, fw, fh, fx, col=0, weight=1.0, bg=0xffffff, per_atlas=None):
+    """find_angle for every anchor through atlases of windows; rules = [(DrawStyle, device arrays x, y, off, ref, n_ways, n_refs)]"""
+    r = C.c_int(); L = po.orc()
+    L.orc_num_steps(fw, fh, DPI, C.byref(r)); r = r.value
+    pitch = (r + 3) & ~3
+    per_atlas = per_atlas or 65536 // pitch
+    out = np.zeros(len(cx))
+    for k0 in range(0, len(cx), per_atlas):
+        k1 = min(len(cx), k0 + per_atlas)
+        at = sa.Canvas.windows(W, H, DPI, bg, cx[k0:k1], cy[k0:k1], r, float(np.hypot(fw, fh)))
+        for st, x, y, off, ref, nw, nr in rules:
+            at.draw_windows(st, x, y, off, ref, nw, nr)
+        ax, ay = at.window_anchors()
+        d = sa.DeviceArray((k1 - k0,), np.float64)
+        at.caprot(sa.DeviceArray.from_numpy(ax), sa.DeviceArray.from_numpy(ay), k1 - k0, fw, fh, fx, col, 0.0, weight, d)
+        sa.sync()
+        out[k0:k1] = d.numpy()
+        at.close()
+    return out
+
+
+def test_windows_equal_libcairos_own_cutouts(hip):
+    """2 x 2000 captions: the angles are find_angle's on libcairo's sub-pixel cut-outs"""
+    sa = hip
+    x, y, off, ref = po.synth_ways(int(G["n_ways"]), W, H, seed=int(G["seed"]))
+    D = sa.DeviceArray.from_numpy
+    st = sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / DPI, 0, 0, 0, 0, 0, 0)
+    rules = [(st, D(x), D(y), D(off.astype(np.int64)), D(ref.astype(np.int32)), len(off) - 1, len(ref))]
+    for tag in ("c4", "small"):
+        fw, fh, fx = (int(v) for v in G[tag + "_plane"])
+        got = scan_windows(sa, rules, G[tag + "_cx"], G[tag + "_cy"], fw, fh, fx)
+        want = G[tag + "_ref"]
+        same = tags(got) == tags(want)
+        print(tag, "tags equal to libcairo's cut-outs:", int(same.sum()), "of", len(want), "| crop convention:",
+              int((tags(G[tag + "_gpu"]) == tags(want)).sum()))
+        assert same.mean() >= 0.999, (tag, int((~same).sum()))
+
+
+def test_window_pixels_equal_the_oracles_shifted_render(hip):
+    """a handful of windows pixel by pixel against the oracle rendering the same ways with the same 24.8 shift
+    (orc_canvas_set_shift: what libcairo's replay at an offset does to the recorded path)"""
+    sa = hip
+    L = po.orc()
+    L.orc_canvas_set_shift.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    x, y, off, ref = po.synth_ways(3000, 900, 700, seed=21)
+    ways = po.ways_from_arrays(x, y, off, ref)
+    sty = po.Style(1, 1, 0x304080c0, 0x50102030, 0, 0.2, 0)
+    rng = np.random.default_rng(3)
+    n, r = 7, 93
+    cx, cy = rng.uniform(-10, 910, n), rng.uniform(-10, 710, n)            # some windows hang over the chart's edge
+    D = sa.DeviceArray.from_numpy
+    at = sa.Canvas.windows(900, 700, DPI, 0xfff8e0, cx, cy, r)
+    from golden_io import draw_style
+    at.draw_windows(draw_style(sa, sty), D(x), D(y), D(off.astype(np.int64)), D(ref.astype(np.int32)), len(off) - 1, len(ref))
+    img = at.read()
+    at.close()
+    r_pt = r * 72 / DPI
+    for k in range(n):
+        c = L.orc_canvas_new(0, 0, r, r, DPI, 0xfff8e0)
+        tx, ty = -cx[k] * 72 / DPI + r_pt / 2, -cy[k] * 72 / DPI + r_pt / 2
+        L.orc_canvas_set_shift(c, tx, ty)
+        L.orc_rule_begin(c)
+        for wx, wy, closed in ways:
+            wx = np.ascontiguousarray(wx, np.float64); wy = np.ascontiguousarray(wy, np.float64)
+            if wx.max() < cx[k] - r or wx.min() > cx[k] + r or wy.max() < cy[k] - r or wy.min() > cy[k] + r:
+                continue
+            L.orc_draw_way(c, C.byref(sty), po.P(wx), po.P(wy), len(wx), int(closed), 0, 0, 0, 0)
+        L.orc_rule_end(c)
+        want = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (r, r)).copy()
+        L.orc_canvas_free(c)
+        got = img[k * at.window_pitch:k * at.window_pitch + r]
+        # outside the chart the window is transparent; inside, the oracle's canvas started as background
+        inside = np.zeros((r, r), bool)
+        x0, y0 = -tx * DPI / 72, -ty * DPI / 72                                  # the window's corner on the chart, px
+        xs, ys = np.arange(r) + x0, np.arange(r) + y0
+        inside[np.ix_((ys >= 1) & (ys + 1 <= 699), (xs >= 1) & (xs + 1 <= 899))] = True
+        assert np.array_equal(got[inside], want[inside]), (k, int((got[inside] != want[inside]).sum()))
+        if (~inside).any():
+            far = np.zeros((r, r), bool)
+            far[np.ix_((ys + 1 < 0) | (ys > 700), np.ones(r, bool))] = True
+            far[np.ix_(np.ones(r, bool), (xs + 1 < 0) | (xs > 900))] = True
+            assert np.all(got[far] == 0), k
+    assert np.all(img[r:at.window_pitch] == 0)                                  # the gutter rows below a window stay clear
