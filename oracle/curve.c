@@ -182,17 +182,23 @@ static void curve_to(sink_t *s, pt_t a, pt_t b, pt_t c, pt_t d, const int32_t *l
  * orc_pt_to_dev) and decomposed: pts[2m], tin[2m] (direction of the face the stroker puts on the segment
  * ARRIVING at the point), tout[2m] (... LEAVING it).  lim = { x0, y0, x1, y1 } in 24.8: the image (fill) or the
  * image grown by the stroke's reach (stroke); NULL: no limit.  Returns m, or -1 when cap is too small. */
+/* the 24.8 translation of a replay at an offset (orc_canvas_set_shift), added to every knot before the decomposition */
+static int32_t flatten_shift_[2];
+void orc_curve_set_shift(int32_t sx, int32_t sy) { flatten_shift_[0] = sx; flatten_shift_[1] = sy; }
+
 int orc_curve_flatten(const double *start_pt, const double *curves_pt, int ncurves, int dpi, const int32_t *lim,
                       int32_t *pts, int32_t *tin, int32_t *tout, int cap)
 {
    sink_t s; s.pts = pts; s.tin = tin; s.tout = tout; s.m = 0; s.cap = cap; s.overflow = 0;
    int32_t dv[6];
    orc_pt_to_dev(start_pt, 1, dpi, dv);
+   dv[0] += flatten_shift_[0]; dv[1] += flatten_shift_[1];
    pt_t cur = { dv[0], dv[1] };
    sink_point(&s, cur, 0, 0);
    for (int k = 0; k < ncurves; k++)
    {
       orc_pt_to_dev(curves_pt + 6 * k, 3, dpi, dv);
+      for (int t = 0; t < 6; t++) dv[t] += flatten_shift_[t & 1];
       pt_t b = { dv[0], dv[1] }, c = { dv[2], dv[3] }, d = { dv[4], dv[5] };
       curve_to(&s, cur, b, c, d, lim);
       cur = d;

@@ -691,6 +691,7 @@ void orc_canvas_set_shift(orc_canvas_t *c, double tx_pt, double ty_pt)
 {
    double s = (double) c->dpi / 72;
    c->shift_x = orc_fixed_from_double(tx_pt * s); c->shift_y = orc_fixed_from_double(ty_pt * s);
+   orc_curve_set_shift(c->shift_x, c->shift_y);      /* curve.c keeps it for orc_curve_flatten (one shifted canvas at a time) */
 }
 
 void orc_canvas_set_image(orc_canvas_t *c, int x0, int y0, int x1, int y1) { c->img[0] = x0; c->img[1] = y0; c->img[2] = x1; c->img[3] = y1; }
@@ -704,7 +705,7 @@ double orc_stroke_reach_px(double width_pt, int dpi)
    return e * hypot((double) dpi / 72, 0.0);
 }
 
-void orc_canvas_free(orc_canvas_t *c) { free(c->pix); free(c->layer); free(c->cov); free(c); }
+void orc_canvas_free(orc_canvas_t *c) { if (c->shift_x || c->shift_y) orc_curve_set_shift(0, 0); free(c->pix); free(c->layer); free(c->cov); free(c); }
 const uint32_t *orc_canvas_pixels(const orc_canvas_t *c) { return c->pix; }
 
 /* cairo_push_group (src/smrules_cairo.c:660): drawing goes to a clear ARGB32 layer */

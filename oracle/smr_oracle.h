@@ -50,6 +50,7 @@ int orc_pen(double hw_pt, int dpi, int32_t *vx, int32_t *vy, int cap);
  * of the decomposed curve (faces along the tangents).  out of the stroker: room for 8 * m edges. */
 void orc_control_points(const double *g, const double *l, double f, double *p1, double *p2);
 int orc_curve_path(const double *x_pt, const double *y_pt, int n, int closed, double f, double *start, double *curves);
+void orc_curve_set_shift(int32_t sx, int32_t sy);
 int orc_curve_flatten(const double *start_pt, const double *curves_pt, int ncurves, int dpi, const int32_t *lim,
                       int32_t *pts, int32_t *tin, int32_t *tout, int cap);
 /* reach of a stroke beyond its path, px: _cairo_stroke_style_max_distance_from_path (miter joins, limit 10) */

@@ -152,6 +152,8 @@ struct curve_args_t
    /* ill-conditioned control points (see smr_control_points): recorded by the first count pass (fix_n counts them, fix their
     * slot and inputs), computed on the host with its libm, and looked up by slot (sorted) in the passes that follow */
    uint32_t *fix_n; struct smr_curvefix_t *fix; uint32_t fix_cnt;
+   /* windows of an atlas (smr_hip_draw_windows): the shift of a node's window, the rows that are a way's image */
+   const int32_t *node_win; const int2 *win_shift; const int2 *way_clip;
 };
 
 #define SMR_CURVEFIX_CAP 8192u
@@ -307,15 +309,17 @@ __global__ void k_curve(curve_args_t A)
                if (i == npt - 1) { c2x = lax; c2y = lay; }
             }
             auto dev = [&](double v) { return (int32_t) (((int64_t) (int32_t) rint(v * 256.0) * A.sfix) >> 8); };
+            const int2 sh = A.node_win ? A.win_shift[A.node_win[n1]] : make_int2(0, 0);      /* as k_dev_points shifts the nodes */
             K.a = A.pts[a0 + i1]; K.d = A.pts[a0 + i2];
-            K.b = make_int2(dev(c1x), dev(c1y)); K.c = make_int2(dev(c2x), dev(c2y));
+            K.b = make_int2(dev(c1x) + sh.x, dev(c1y) + sh.y); K.c = make_int2(dev(c2x) + sh.x, dev(c2y) + sh.y);
          }
          last = K.a;
          bool line = K.a.x == K.b.x && K.a.y == K.b.y && K.c.x == K.d.x && K.c.y == K.d.y;
          /* _cairo_spline_intersects against the image (grown by the stroke's reach): a curve that cannot reach it is a line_to */
          {
             const int32_t r = A.border_used ? A.reach[!A.fill_used ? 0 : closed ? 2 : 1] : closed ? 0 : A.reach[3];
-            const int32_t lx0 = -r, ly0 = -r, lx1 = A.W256 + r, ly1 = A.H256 + r;
+            const int32_t iy0 = A.way_clip ? A.way_clip[w].x * 256 : 0, iy1 = A.way_clip ? A.way_clip[w].y * 256 : A.H256;      /* the image's rows */
+            const int32_t lx0 = -r, ly0 = iy0 - r, lx1 = A.W256 + r, ly1 = iy1 + r;
             const int2 kk[4] = { K.a, K.b, K.c, K.d };
             bool inside = false;
             int32_t x0 = K.a.x, x1 = K.a.x, y0 = K.a.y, y1 = K.a.y;
@@ -334,8 +338,8 @@ __global__ void k_curve(curve_args_t A)
                const int32_t r2 = closed ? 0 : A.reach[3];       /* open ways: the fill is a stroke of the fill width */
                bool in0 = false;
 #pragma unroll
-               for (int t = 0; t < 4; t++) if (-r2 <= kk[t].x && kk[t].x <= A.W256 + r2 && -r2 <= kk[t].y && kk[t].y <= A.H256 + r2) in0 = true;
-               fill_line = !in0 && (x1 <= -r2 || x0 >= A.W256 + r2 || y1 <= -r2 || y0 >= A.H256 + r2);
+               for (int t = 0; t < 4; t++) if (-r2 <= kk[t].x && kk[t].x <= A.W256 + r2 && iy0 - r2 <= kk[t].y && kk[t].y <= iy1 + r2) in0 = true;
+               fill_line = !in0 && (x1 <= -r2 || x0 >= A.W256 + r2 || y1 <= iy0 - r2 || y0 >= iy1 + r2);
             }
          }
          int2 is = make_int2(0, 0), fs = make_int2(0, 0);
@@ -3779,6 +3783,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       curve_args_t CA;
       CA.x = b->d_x; CA.y = b->d_y; CA.ref = b->d_ref; CA.pts = pts; CA.way_off = way_off; CA.refway = refway; CA.wayflags = wayflags;
       CA.n_refs = n_refs; CA.n_ways = n_ways; CA.dpi = c->dpi; CA.sfix = sfix; CA.f = st->curve_factor; CA.knots = st->curve == 2;
+      CA.node_win = wc ? wc->node_win : nullptr; CA.win_shift = wc ? wc->win_shift : nullptr; CA.way_clip = wc ? wc->way_clip : nullptr;
       CA.border_used = st->border_used; CA.fill_used = st->fill_used;
       CA.W256 = c->W * 256; CA.H256 = c->H * 256;
       /* _cairo_stroke_style_max_distance_from_path: miter joins, limit 10 -> sqrt(2) * 10 line widths, in device px */

@@ -58,25 +58,62 @@ def test_windows_equal_libcairos_own_cutouts(hip):
         assert same.mean() >= 0.999, (tag, int((~same).sum()))
 
 
-def test_window_pixels_equal_the_oracles_shifted_render(hip):
+STYLES = {
+    "translucent": po.Style(1, 1, 0x304080c0, 0x50102030, 0, 0.2, 0),
+    "curve": None,          # made below: curve=1 fill + border
+    "dashed": None,
+    "open+closed wide": po.Style(1, 1, 0x4080c0, 0x000000, 0.5, 0.3, 0),
+}
+
+
+def _style(name):
+    if name == "curve":
+        return po.Style(1, 1, 0x4080c0, 0x203040, 0, 0.25, 0).with_curve(0.2)
+    if name == "dashed":
+        return po.Style(0, 1, 0, 0x204060, 0, 0.3, 0).with_dash(border_style=1)
+    return STYLES[name]
+
+
+@pytest.mark.parametrize("name", list(STYLES))
+def test_window_pixels_equal_the_oracles_shifted_render(hip, name):
     """a handful of windows pixel by pixel against the oracle rendering the same ways with the same 24.8 shift
-    (orc_canvas_set_shift: what libcairo's replay at an offset does to the recorded path)"""
+    (orc_canvas_set_shift: what libcairo's replay at an offset does to the recorded path), closed and open ways"""
     sa = hip
     L = po.orc()
     L.orc_canvas_set_shift.argtypes = [C.c_void_p, C.c_double, C.c_double]
-    x, y, off, ref = po.synth_ways(3000, 900, 700, seed=21)
-    ways = po.ways_from_arrays(x, y, off, ref)
-    sty = po.Style(1, 1, 0x304080c0, 0x50102030, 0, 0.2, 0)
+    x, y, off, ref = po.synth_ways(1500, 900, 700, seed=21)
+    x2, y2, off2, ref2 = po.synth_ways(600, 900, 700, seed=22)
+    keep = np.ones(len(ref2), bool); keep[off2[1:] - 1] = False               # without their closing refs: open ways
+    ref2, off2 = ref2[keep], off2 - np.arange(len(off2))
+    ways = po.ways_from_arrays(x, y, off, ref) + po.ways_from_arrays(x2, y2, off2, ref2)
+    X, Y = np.concatenate([x, x2]), np.concatenate([y, y2])
+    OFF = np.concatenate([off, off2[1:] + off[-1]]).astype(np.int64)
+    REF = np.concatenate([ref, ref2 + len(x)]).astype(np.int32)
+    sty = _style(name)
     rng = np.random.default_rng(3)
     n, r = 7, 93
     cx, cy = rng.uniform(-10, 910, n), rng.uniform(-10, 710, n)            # some windows hang over the chart's edge
     D = sa.DeviceArray.from_numpy
     at = sa.Canvas.windows(900, 700, DPI, 0xfff8e0, cx, cy, r)
     from golden_io import draw_style
-    at.draw_windows(draw_style(sa, sty), D(x), D(y), D(off.astype(np.int64)), D(ref.astype(np.int32)), len(off) - 1, len(ref))
+    at.draw_windows(draw_style(sa, sty), D(X), D(Y), D(OFF), D(REF), len(OFF) - 1, len(REF))
     img = at.read()
     at.close()
     r_pt = r * 72 / DPI
+    reach = 40 if name != "curve" else 120
+    # libcairo's own cut-outs of the same chart (the recording stays in the driver after cairo_scene)
+    cd = po.cairo()
+    if cd is not None:
+        from golden_io import within
+        po.cairo_scene([(sty, ways)], DPI, 900, 700, 0xfff8e0)
+        sub = np.zeros((r + 2) * (r + 2), np.uint32)
+        fr = []
+        for k in range(n):
+            assert cd.cd_cut_out(cx[k] * 72 / DPI, cy[k] * 72 / DPI, r_pt, float(DPI), po.P(sub), len(sub)) == r
+            ref_cut = sub[:r * r].reshape(r, r)
+            got = img[k * at.window_pitch:k * at.window_pitch + r]
+            fr.append(within(got, ref_cut))
+        assert np.mean(fr) >= 0.995 and min(fr) >= 0.99, (name, fr)       # the north star's bar over all windows (each is 93 x 93 px only)
     for k in range(n):
         c = L.orc_canvas_new(0, 0, r, r, DPI, 0xfff8e0)
         tx, ty = -cx[k] * 72 / DPI + r_pt / 2, -cy[k] * 72 / DPI + r_pt / 2
@@ -84,7 +121,7 @@ def test_window_pixels_equal_the_oracles_shifted_render(hip):
         L.orc_rule_begin(c)
         for wx, wy, closed in ways:
             wx = np.ascontiguousarray(wx, np.float64); wy = np.ascontiguousarray(wy, np.float64)
-            if wx.max() < cx[k] - r or wx.min() > cx[k] + r or wy.max() < cy[k] - r or wy.min() > cy[k] + r:
+            if wx.max() < cx[k] - r / 2 - reach or wx.min() > cx[k] + r / 2 + reach or wy.max() < cy[k] - r / 2 - reach or wy.min() > cy[k] + r / 2 + reach:
                 continue
             L.orc_draw_way(c, C.byref(sty), po.P(wx), po.P(wy), len(wx), int(closed), 0, 0, 0, 0)
         L.orc_rule_end(c)
@@ -96,10 +133,51 @@ def test_window_pixels_equal_the_oracles_shifted_render(hip):
         x0, y0 = -tx * DPI / 72, -ty * DPI / 72                                  # the window's corner on the chart, px
         xs, ys = np.arange(r) + x0, np.arange(r) + y0
         inside[np.ix_((ys >= 1) & (ys + 1 <= 699), (xs >= 1) & (xs + 1 <= 899))] = True
+        if os.environ.get("SMR_TEST_DUMP") and not np.array_equal(got[inside], want[inside]):
+            np.savez(os.path.join(os.environ["SMR_TEST_DUMP"], f"win_{name.split()[0]}_{k}.npz"), got=got, want=want, inside=inside, cx=cx[k], cy=cy[k])
+        assert len(np.unique(got[inside])) > 3
+        if name == "curve":
+            # measured: 0 to 3 pixels of a window one level off at the window's edge rows (the limits of a decomposed curve)
+            d = po.chan_diff(got, want); d = d.max(axis=-1) if d.ndim == 3 else d
+            assert (d[inside] > 0).sum() <= 4 and d[inside].max() <= 1, (k, int((d[inside] > 0).sum()), int(d[inside].max()))
+            continue
         assert np.array_equal(got[inside], want[inside]), (k, int((got[inside] != want[inside]).sum()))
-        if (~inside).any():
-            far = np.zeros((r, r), bool)
-            far[np.ix_((ys + 1 < 0) | (ys > 700), np.ones(r, bool))] = True
-            far[np.ix_(np.ones(r, bool), (xs + 1 < 0) | (xs > 900))] = True
-            assert np.all(got[far] == 0), k
     assert np.all(img[r:at.window_pitch] == 0)                                  # the gutter rows below a window stay clear
+
+
+def test_windows_at_whole_pixel_offsets_are_crops_of_the_chart(hip):
+    """size-independent property, for a directional rule (one compound fill per window) after a bordered one with per-way
+    colours: when anchor and r/2 are whole pixels the replay's shift is a whole number of pixels and a window inside the chart
+    is the chart's own pixels -- up to the anti-aliasing of the rows where libcairo, limiting the polygons to the window instead
+    of the chart, finds a vertex more or less"""
+    sa = hip
+    from golden_io import draw_style
+    Wc, Hc = 1000, 800
+    D = sa.DeviceArray.from_numpy
+    x, y, off, ref = po.synth_ways(900, Wc, Hc, seed=5)
+    rng = np.random.default_rng(8)
+    fcol = rng.integers(0, 1 << 24, len(off) - 1).astype(np.uint32)
+    bcol = rng.integers(0, 1 << 24, len(off) - 1).astype(np.uint32)
+    rules = [(draw_style(sa, po.Style(1, 0, 0x90c0e0, 0, 0, 0, 0), directional=1), po.synth_ways(60, Wc, Hc, seed=6), None, None),
+             (draw_style(sa, po.Style(1, 1, 0x4080c0, 0, 0, 0.15, 0)), (x, y, off, ref), fcol, bcol)]
+    cv = sa.Canvas(Wc, Hc, DPI, 0xfff8e0)
+    n, r = 12, 120
+    cx, cy = rng.integers(r, Wc - r, n).astype(float), rng.integers(r, Hc - r, n).astype(float)
+    at = sa.Canvas.windows(Wc, Hc, DPI, 0xfff8e0, cx, cy, r)
+    for st, (ax, ay, ao, ar), fc, bc in rules:
+        args = (st, D(ax), D(ay), D(ao.astype(np.int64)), D(ar.astype(np.int32)), len(ao) - 1, len(ar), D(fc) if fc is not None else None,
+                D(bc) if bc is not None else None)
+        cv.draw(*args)
+        at.draw_windows(*args)
+    chart, img = cv.read(), at.read()
+    cv.close(); at.close()
+    same = tot = 0
+    for k in range(n):
+        got = img[k * at.window_pitch:k * at.window_pitch + r]
+        want = chart[int(cy[k]) - r // 2:int(cy[k]) + r // 2, int(cx[k]) - r // 2:int(cx[k]) + r // 2]
+        assert len(np.unique(want)) > 3
+        d = po.chan_diff(got, want)
+        d = d.max(axis=-1) if d.ndim == 3 else d
+        assert d.max() <= 6, (k, int(d.max()))
+        same += int((d == 0).sum()); tot += d.size
+    assert same / tot >= 0.995, same / tot
