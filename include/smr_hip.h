@@ -221,20 +221,28 @@ int smr_hip_caprot_noalloc(smr_canvas_t *c, const smr_cap_batch_t *b, double *d_
  * chart's background rectangle), smr_hip_draw_windows draws a rule into every window it reaches -- the same style and batch
  * smr_hip_draw took for the chart, in the same order, the caller keeps them -- and smr_hip_caprot scans the atlas at the anchors
  * smr_hip_windows_anchors returns (the middle of each window), giving find_angle's angles for the real anchors.
- * `size` is find_angle's r in px: smr_hip_caprot_steps' r_px for the caption's plane.  An atlas holds at most 65 536 rows
- * (240 windows of 271 px): larger batches go in several atlases.  No counterpart in the reference beyond cairo_smr_cut_out
+ * The atlas is as wide as its largest window and gives every window that many rows (rounded up to 4): windows of different
+ * sizes may share an atlas; a smaller one is limited to its own rows exactly and to the ATLAS's columns (so a polygon crossing
+ * its right edge is limited a little further right than libcairo limits it: the anti-aliasing of that polygon's row at the
+ * crossing can differ by a level; group windows of similar size).  An atlas holds at most 65 536 rows (240 windows of 271 px):
+ * larger batches go in several atlases.  No counterpart in the reference beyond cairo_smr_cut_out
  * itself: there the cut-out is made per caption, on the CPU, by replaying the whole chart. */
 typedef struct
 {
    int64_t n;                      /* windows */
-   int32_t size, pad_;             /* width = height of every window, px: round(r_px) */
-   double r_px;                    /* find_angle's r before rounding, hypot(fg_w, fg_h) px (:1975): the windows are centred with IT
-                                      (cairo_smr_cut_out translates by r/2, :1526); 0 = size */
+   const int32_t *size;            /* [n] HOST: width = height of each window in px, find_angle's round(r) (smr_hip_caprot_steps' r_px) */
+   const double *r_px;             /* [n] HOST: find_angle's r before rounding, hypot(fg_w, fg_h) px (:1975): a window is centred with
+                                      IT (cairo_smr_cut_out translates by r/2, :1526); NULL = size */
    const double *cx, *cy;          /* [n] HOST: the captions' anchors in chart px (geo2pxf) */
 } smr_windows_t;
 int smr_hip_windows_create(int chart_w, int chart_h, int dpi, uint32_t bgcolor, const smr_windows_t *w, smr_canvas_t **atlas);
 int smr_hip_draw_windows(smr_canvas_t *atlas, const smr_draw_style_t *st, const smr_draw_batch_t *b);
+/* call after the last draw into the atlas: it also clears what the rules left beyond the chart's rectangle (the reference's
+ * recording has the chart's extents), then returns the anchors to scan at */
 int smr_hip_windows_anchors(smr_canvas_t *atlas, double *cx, double *cy);      /* [n] HOST out */
+/* smr_hip_canvas_blit for an atlas: what was composited onto the chart (caption text, symbols) lands in every window it meets,
+ * at the window's offset ROUNDED to whole pixels: the images were rasterised on the chart's pixel grid */
+int smr_hip_blit_windows(smr_canvas_t *atlas, const uint32_t *pixels, uint64_t n_pixels, const smr_blit_t *items, int n_items);
 
 /* ---- stream / timing helpers --------------------------------------------------------- */
 int smr_hip_sync(void);

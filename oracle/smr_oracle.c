@@ -799,6 +799,7 @@ void orc_direct_fill_pt(orc_canvas_t *c, const double *xy_pt, int n, uint32_t sm
    int32_t *dev = malloc(sizeof(int32_t) * 2 * n);
    tor_edge_t *e = malloc(sizeof(tor_edge_t) * n);
    orc_pt_to_dev(xy_pt, n, c->dpi, dev);
+   for (int i = 0; i < n; i++) { dev[2 * i] += c->shift_x; dev[2 * i + 1] += c->shift_y; }
    orc_direct_edges(c, e, orc_fill_edges(dev, n, e), 1, smr_col);
    free(dev); free(e);
 }

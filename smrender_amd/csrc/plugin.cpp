@@ -93,8 +93,46 @@ struct plugin_t
    smr_canvas_t *canvas = nullptr;
    smr_proj_t proj;
    int W = 0, H = 0, dpi = 0, band_y0 = 0, band_h = 0;
+   uint32_t bg = 0xffffff;
 };
 static plugin_t P;
+
+/* What has been drawn so far, in order: the caption scan cuts its windows out of the chart the reference's way, by rendering the
+ * rules again at each caption's sub-pixel offset (smr_hip_draw_windows, windows.hip), so every draw rule's style and device
+ * arrays and every composited image stay until the chart is reset.  SMR_HIP_CUTOUT=crop keeps nothing and scans crops of the
+ * canvas at the rounded anchors instead (faster; 11-13 % of the %.1f angle tags then differ from the reference's). */
+struct kept_rule_t
+{
+   bool is_blit = false;
+   smr_draw_style_t st;
+   smr_draw_batch_t b;                                   /* device arrays, owned */
+   std::vector<uint32_t> pixels; std::vector<smr_blit_t> items;
+};
+static std::vector<kept_rule_t> kept_;
+
+static bool cutout_replay(void)
+{
+   const char *e = getenv("SMR_HIP_CUTOUT");
+   return !(e && !strcasecmp(e, "crop"));
+}
+
+static void kept_release(void)
+{
+   for (kept_rule_t &k : kept_)
+      if (!k.is_blit)
+      {
+         void *p[6] = { (void *) k.b.d_x, (void *) k.b.d_y, (void *) k.b.d_way_off, (void *) k.b.d_ref, (void *) k.b.d_way_fill_col, (void *) k.b.d_way_border_col };
+         for (void *q : p) if (q) smr_hip_free(q);
+      }
+   kept_.clear();
+}
+
+static void kept_blit(const std::vector<uint32_t> &pixels, const std::vector<smr_blit_t> &items)
+{
+   if (!cutout_replay() || items.empty()) return;
+   kept_.emplace_back();
+   kept_.back().is_blit = true; kept_.back().pixels = pixels; kept_.back().items = items;
+}
 
 extern "C" smr_canvas_t *smr_hip_plugin_canvas(void) { return P.canvas; }
 
@@ -103,6 +141,7 @@ static void pool_release(void);
 extern "C" int smr_hip_plugin_reset(void)
 {
    if (P.canvas) smr_hip_canvas_destroy(P.canvas);
+   kept_release();
    pool_release();
    P = plugin_t();
    return SMR_OK;
@@ -152,6 +191,7 @@ static int plugin_setup(void)
    P.band_h = env_int("SMR_HIP_BAND_H", P.H - P.band_y0);
    uint32_t bg = 0xffffff;
    if (H.parse_color) bg = (uint32_t) H.parse_color("bgcolor");     /* src/smrules_cairo.c:324 */
+   P.bg = bg;
    if (smr_hip_canvas_create(P.W, P.H, P.dpi, bg, P.band_y0, P.band_h, &P.canvas) != SMR_OK)
    {
       plog(SMR_LOG_ERR, "%s", smr_hip_last_error());
@@ -558,12 +598,22 @@ static int draw_fini(smr_smrule_t *r)
    {
       size_t n = d->lat.size();
       if (n & 1) { d->lat.push_back(d->lat.back()); d->lon.push_back(d->lon.back()); n++; }
-      void *lat = pool_put(0, d->lat.data(), n * 8), *lon = pool_put(1, d->lon.data(), n * 8), *x = pool_get(2, n * 8), *y = pool_get(3, n * 8);
-      void *off = pool_put(4, d->way_off.data(), d->way_off.size() * 8), *ref = pool_put(5, d->ref.data(), d->ref.size() * 4);
+      /* a rule that is kept for the caption scan's windows owns its arrays; otherwise they come from the grow-only pool */
+      const bool keep = cutout_replay() && P.band_y0 == 0 && P.band_h == P.H;
+      auto own_put = [&](int i, const void *h, size_t bytes) -> void *
+      {
+         if (!keep) return h ? pool_put(i, h, bytes) : pool_get(i, bytes);
+         void *q = nullptr;
+         if (smr_hip_malloc(&q, bytes ? bytes : 16) != SMR_OK) return nullptr;
+         if (h && bytes && smr_hip_memcpy_h2d(q, h, bytes) != SMR_OK) { smr_hip_free(q); return nullptr; }
+         return q;
+      };
+      void *lat = pool_put(0, d->lat.data(), n * 8), *lon = pool_put(1, d->lon.data(), n * 8), *x = own_put(2, nullptr, n * 8), *y = own_put(3, nullptr, n * 8);
+      void *off = own_put(4, d->way_off.data(), d->way_off.size() * 8), *ref = own_put(5, d->ref.data(), d->ref.size() * 4);
       void *fc = nullptr, *bc = nullptr;
       bool ok = lat && lon && x && y && off && ref;
-      if (ok && d->fill_cs.key) ok = (fc = pool_put(6, d->fill_col.data(), d->fill_col.size() * 4)) != nullptr;
-      if (ok && d->border_cs.key) ok = (bc = pool_put(7, d->border_col.data(), d->border_col.size() * 4)) != nullptr;
+      if (ok && d->fill_cs.key) ok = (fc = own_put(6, d->fill_col.data(), d->fill_col.size() * 4)) != nullptr;
+      if (ok && d->border_cs.key) ok = (bc = own_put(7, d->border_col.data(), d->border_col.size() * 4)) != nullptr;
       if (ok) ok = smr_hip_project((const double *) lat, (const double *) lon, (int64_t) n, (double *) x, (double *) y,
                                    nullptr, nullptr, nullptr) == SMR_OK;
       if (ok)
@@ -575,7 +625,13 @@ static int draw_fini(smr_smrule_t *r)
          b.d_way_fill_col = (const uint32_t *) fc;
          b.d_way_border_col = (const uint32_t *) bc;
          ok = smr_hip_draw(P.canvas, &d->st, &b) == SMR_OK;
+         if (keep)
+         {
+            kept_.emplace_back();
+            kept_.back().st = d->st; kept_.back().b = b;        /* freed by kept_release, drawn or not */
+         }
       }
+      else if (keep) { void *q[6] = { x, y, off, ref, fc, bc }; for (void *v : q) if (v) smr_hip_free(v); }
       if (ok) ok = smr_hip_sync() == SMR_OK;
       if (!ok) { plog(SMR_LOG_ERR, "draw: %s", smr_hip_last_error()); ret = -1; }
       else if (smr_hip_draw_status() & SMR_DRAW_DEGRADED_ROWS)
@@ -1038,6 +1094,109 @@ static void cap_levels(const std::vector<double> &cx, const std::vector<double> 
    }
 }
 
+/* ---------------------------------------------------------------------------------------- */
+/* find_angle over the reference's own cut-outs: atlases of windows (windows.hip)             */
+/* ---------------------------------------------------------------------------------------- */
+struct scan_item_t
+{
+   size_t id;                          /* the caller's index: angle[id] is the result */
+   double cx, cy;                      /* anchor, chart px */
+   int fw, fh;                         /* plane, px */
+   std::vector<int64_t> key;           /* captions with equal keys share plane pixels (one caprot batch) */
+   int rpx = 0; double r = 0;          /* find_angle's r: rounded (the window) and as hypot(fw, fh) */
+};
+
+/* the rectangles the rule's earlier captions left on auto_ctx (:2376-2382), as a batch in chart px */
+struct rect_batch_t { std::vector<double> x, y; std::vector<int64_t> off = std::vector<int64_t>(1, 0); std::vector<int32_t> ref; uint32_t col = 0; };
+
+template <typename PlaneFn>
+static int scan_windows(std::vector<scan_item_t> items, PlaneFn plane_of, double phase, double weight, const rect_batch_t *rects, std::vector<double> &angle,
+                        size_t *n_atlases)
+{
+   for (scan_item_t &it : items)
+   {
+      int steps = 0;
+      smr_hip_caprot_steps(it.fw, it.fh, P.dpi, &steps, &it.rpx);
+      it.r = hypot((double) it.fw, (double) it.fh);
+   }
+   std::stable_sort(items.begin(), items.end(), [](const scan_item_t &a, const scan_item_t &b) { return a.rpx > b.rpx; });
+   /* the rectangles go up once */
+   dbuf_t rdx, rdy, rdoff, rdref;
+   smr_draw_batch_t rb;
+   memset(&rb, 0, sizeof(rb));
+   if (rects && !rects->ref.empty())
+   {
+      std::vector<double> rx(rects->x), ry(rects->y);
+      if (rx.size() & 1) { rx.push_back(0); ry.push_back(0); }
+      if (rdx.put(rx.data(), rx.size() * 8) || rdy.put(ry.data(), ry.size() * 8) || rdoff.put(rects->off.data(), rects->off.size() * 8) ||
+          rdref.put(rects->ref.data(), rects->ref.size() * 4))
+         return -1;
+      rb.d_x = (const double *) rdx.p; rb.d_y = (const double *) rdy.p; rb.n_nodes = (int64_t) rx.size();
+      rb.d_way_off = (const int64_t *) rdoff.p; rb.d_ref = (const int32_t *) rdref.p;
+      rb.n_ways = (int64_t) rects->off.size() - 1; rb.n_refs = (int64_t) rects->ref.size();
+   }
+   for (size_t i0 = 0; i0 < items.size();)
+   {
+      if (items[i0].rpx <= 0 || items[i0].fw <= 0 || items[i0].fh <= 0) { i0++; continue; }      /* an empty plane: angle 0 */
+      /* one atlas: windows of similar size (a smaller window is limited to the atlas's columns, include/smr_hip.h) */
+      const int maxsize = items[i0].rpx, pitch = (maxsize + 3) & ~3;
+      size_t i1 = i0;
+      while (i1 < items.size() && (int) (i1 - i0 + 1) * pitch <= 65536 && items[i1].rpx * 4 >= maxsize * 3 && items[i1].rpx > 0) i1++;
+      const size_t n = i1 - i0;
+      std::vector<int32_t> size(n); std::vector<double> rp(n), cx(n), cy(n), ax(n), ay(n);
+      for (size_t k = 0; k < n; k++) { const scan_item_t &it = items[i0 + k]; size[k] = it.rpx; rp[k] = it.r; cx[k] = it.cx; cy[k] = it.cy; }
+      smr_windows_t w;
+      w.n = (int64_t) n; w.size = size.data(); w.r_px = rp.data(); w.cx = cx.data(); w.cy = cy.data();
+      smr_canvas_t *atlas = nullptr;
+      if (smr_hip_windows_create(P.W, P.H, P.dpi, P.bg, &w, &atlas) != SMR_OK) return -1;
+      if (n_atlases) ++*n_atlases;
+      int rc = SMR_OK;
+      for (const kept_rule_t &k : kept_)
+      {
+         rc = k.is_blit ? smr_hip_blit_windows(atlas, k.pixels.data(), k.pixels.size(), k.items.data(), (int) k.items.size())
+                        : smr_hip_draw_windows(atlas, &k.st, &k.b);
+         if (rc != SMR_OK) break;
+      }
+      if (rc == SMR_OK && rb.n_ways)
+      {
+         smr_draw_style_t st;
+         memset(&st, 0, sizeof(st));
+         st.fill_used = 1; st.fill_col = rects->col; st.direct = 1;
+         rc = smr_hip_draw_windows(atlas, &st, &rb);
+      }
+      if (rc == SMR_OK) rc = smr_hip_windows_anchors(atlas, ax.data(), ay.data());
+      std::map<std::vector<int64_t>, std::vector<size_t>> groups;
+      for (size_t k = 0; k < n; k++) groups[items[i0 + k].key].push_back(k);
+      for (auto &g : groups)
+      {
+         if (rc != SMR_OK) break;
+         const std::vector<size_t> &idx = g.second;
+         std::vector<uint32_t> plane; int w_px = 0, h_px = 0;
+         if (plane_of(items[i0 + idx[0]].id, plane, &w_px, &h_px) != 0) continue;
+         const size_t m = idx.size();
+         std::vector<double> gx(m), gy(m), out(m);
+         for (size_t k = 0; k < m; k++) { gx[k] = ax[idx[k]]; gy[k] = ay[idx[k]]; }
+         dbuf_t dx, dy, dfg, dang;
+         bool ok = dx.put(gx.data(), m * 8) == 0 && dy.put(gy.data(), m * 8) == 0 && dfg.put(plane.data(), plane.size() * 4) == 0 && dang.alloc(m * 8) == 0;
+         if (ok)
+         {
+            smr_cap_batch_t b;
+            memset(&b, 0, sizeof(b));
+            b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) m;
+            b.fg_w = w_px; b.fg_h = h_px; b.fg_x = 0; b.phase_deg = phase; b.weight = weight; b.d_fg = (const uint32_t *) dfg.p;
+            ok = smr_hip_caprot(atlas, &b, (double *) dang.p, nullptr) == SMR_OK;
+         }
+         if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, m * 8) == SMR_OK;
+         if (!ok) { rc = -1; break; }
+         for (size_t k = 0; k < m; k++) angle[items[i0 + idx[k]].id] = out[k];
+      }
+      smr_hip_canvas_destroy(atlas);
+      if (rc != SMR_OK) return -1;
+      i0 = i1;
+   }
+   return 0;
+}
+
 /* cairo_show_text of every caption (cap_coord :2363-2388: translate to the anchor, rotate, move_to the aligned origin, show_text),
  * rasterised by the host's libcairo + FreeType into a small image per caption on the chart's own pixel grid and painted OVER
  * the device canvas in object order (smr_hip_canvas_blit): glyph outlines stay on the host, the pixels land on the device */
@@ -1052,6 +1211,7 @@ static int cap_draw_glyphs(const cap_rule_t *cap, const std::vector<double> &cx,
    {
       if (items.empty()) return SMR_OK;
       const int rc = smr_hip_canvas_blit(P.canvas, pixels.data(), pixels.size(), items.data(), (int) items.size());
+      if (rc == SMR_OK) kept_blit(pixels, items);
       pixels.clear(); items.clear();
       return rc;
    };
@@ -1139,8 +1299,11 @@ static int cap_fini(smr_smrule_t *r)
    std::vector<short> final_pos(n_all);
    int n_levels = 0;
    smr_canvas_t *autoc = nullptr;
-   size_t n_groups = 0;
+   size_t n_groups = 0, n_atlases = 0;
    const double sc = (double) P.dpi / 72.0;
+   /* the reference's cut-outs (windows of the chart rendered again at each anchor's sub-pixel offset) unless told to crop */
+   const bool replay = cutout_replay();
+   rect_batch_t rects;
    if (n_all)
    {
       /* all anchors -> px in one projection call */
@@ -1168,43 +1331,69 @@ static int cap_fini(smr_smrule_t *r)
       if (!cap->autorot)
          for (size_t k = 0; k < n_all; k++) { angle[k] = cap->items[k].fixed_a; final_pos[k] = cap->items[k].pos; }
       if (ret == 0 && cap->autorot) cap_levels(cx, cy, reach, level, n_levels);
-      if (ret == 0 && cap->autorot && smr_hip_canvas_clone(P.canvas, &autoc) != SMR_OK) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
+      if (ret == 0 && cap->autorot && !replay && smr_hip_canvas_clone(P.canvas, &autoc) != SMR_OK) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
    }
    for (int lv = 0; lv < n_levels && ret == 0; lv++)
    {
-      /* one GPU batch per distinct caption plane of this level */
-      std::map<std::vector<int64_t>, std::vector<size_t>> groups;
-      for (size_t i = 0; i < n_all; i++)
+      if (replay)
       {
-         if (level[i] != lv) continue;
-         const cap_item_t &it = cap->items[i];
-         groups[{ it.pw, it.ph, it.px, (int64_t) it.col }].push_back(i);
-      }
-      n_groups += groups.size();
-      for (auto &g : groups)
-      {
-         const std::vector<size_t> &idx = g.second;
-         const cap_item_t &first = cap->items[idx[0]];
-         std::vector<uint32_t> plane; int w_px, h_px;
-         if (make_plane(first.pw, first.ph, first.px, first.col, P.dpi, plane, &w_px, &h_px) != 0) continue;   /* empty plane: angle 0 */
-         const size_t n = idx.size();
-         std::vector<double> gx(n), gy(n), out(n);
-         for (size_t k = 0; k < n; k++) { gx[k] = cx[idx[k]]; gy[k] = cy[idx[k]]; }
-         dbuf_t dx, dy, dfg, dang;
-         bool ok = dx.put(gx.data(), n * 8) == 0 && dy.put(gy.data(), n * 8) == 0 && dfg.put(plane.data(), plane.size() * 4) == 0 &&
-                   dang.alloc(n * 8) == 0;
-         if (ok)
+         std::vector<scan_item_t> todo;
+         for (size_t i = 0; i < n_all; i++)
          {
-            smr_cap_batch_t b;
-            memset(&b, 0, sizeof(b));
-            b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) n;
-            b.fg_w = w_px; b.fg_h = h_px; b.fg_x = 0; b.col = first.col; b.phase_deg = cap->phase; b.weight = cap->weight;
-            b.d_fg = (const uint32_t *) dfg.p;
-            ok = smr_hip_caprot(autoc, &b, (double *) dang.p, nullptr) == SMR_OK;
+            if (level[i] != lv) continue;
+            const cap_item_t &it = cap->items[i];
+            scan_item_t q;
+            q.id = i; q.cx = cx[i]; q.cy = cy[i]; q.fw = fw[i]; q.fh = fh[i]; q.key = { it.pw, it.ph, it.px, (int64_t) it.col };
+            todo.push_back(q);
          }
-         if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, n * 8) == SMR_OK;
-         if (!ok) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; break; }
-         for (size_t k = 0; k < n; k++) angle[idx[k]] = out[k];
+         auto plane_of = [&](size_t id, std::vector<uint32_t> &plane, int *w_px, int *h_px)
+         {
+            const cap_item_t &it = cap->items[id];
+            return make_plane(it.pw, it.ph, it.px, it.col, P.dpi, plane, w_px, h_px);
+         };
+         n_groups += todo.size();
+         if (scan_windows(todo, plane_of, cap->phase, cap->weight, &rects, angle, &n_atlases) != 0)
+         {
+            plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error());
+            ret = -1;
+         }
+      }
+      else
+      {
+         /* one GPU batch per distinct caption plane of this level */
+         std::map<std::vector<int64_t>, std::vector<size_t>> groups;
+         for (size_t i = 0; i < n_all; i++)
+         {
+            if (level[i] != lv) continue;
+            const cap_item_t &it = cap->items[i];
+            groups[{ it.pw, it.ph, it.px, (int64_t) it.col }].push_back(i);
+         }
+         n_groups += groups.size();
+         for (auto &g : groups)
+         {
+            const std::vector<size_t> &idx = g.second;
+            const cap_item_t &first = cap->items[idx[0]];
+            std::vector<uint32_t> plane; int w_px, h_px;
+            if (make_plane(first.pw, first.ph, first.px, first.col, P.dpi, plane, &w_px, &h_px) != 0) continue;   /* empty plane: angle 0 */
+            const size_t n = idx.size();
+            std::vector<double> gx(n), gy(n), out(n);
+            for (size_t k = 0; k < n; k++) { gx[k] = cx[idx[k]]; gy[k] = cy[idx[k]]; }
+            dbuf_t dx, dy, dfg, dang;
+            bool ok = dx.put(gx.data(), n * 8) == 0 && dy.put(gy.data(), n * 8) == 0 && dfg.put(plane.data(), plane.size() * 4) == 0 &&
+                      dang.alloc(n * 8) == 0;
+            if (ok)
+            {
+               smr_cap_batch_t b;
+               memset(&b, 0, sizeof(b));
+               b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) n;
+               b.fg_w = w_px; b.fg_h = h_px; b.fg_x = 0; b.col = first.col; b.phase_deg = cap->phase; b.weight = cap->weight;
+               b.d_fg = (const uint32_t *) dfg.p;
+               ok = smr_hip_caprot(autoc, &b, (double *) dang.p, nullptr) == SMR_OK;
+            }
+            if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, n * 8) == SMR_OK;
+            if (!ok) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; break; }
+            for (size_t k = 0; k < n; k++) angle[idx[k]] = out[k];
+         }
       }
       if (ret != 0) break;
       /* flip (:2284-2292), then this level's rectangles onto the private background (:2376-2382) */
@@ -1239,7 +1428,16 @@ static int cap_fini(smr_smrule_t *r)
          rref.push_back(base);
          roff.push_back((int64_t) rref.size());
       }
-      if (!rref.empty())
+      if (!rref.empty() && replay)
+      {
+         /* the later levels' windows get every earlier level's rectangles, after the chart's rules */
+         const int32_t nb = (int32_t) rects.x.size(), rb0 = (int32_t) rects.ref.size();
+         rects.x.insert(rects.x.end(), rx.begin(), rx.end()); rects.y.insert(rects.y.end(), ry.begin(), ry.end());
+         for (int32_t v : rref) rects.ref.push_back(v + nb);
+         for (size_t k = 1; k < roff.size(); k++) rects.off.push_back(roff[k] + rb0);
+         rects.col = cap->items[0].col;                        /* auto_ctx's source: the first object's colour (:2459) */
+      }
+      else if (!rref.empty())
       {
          if (rx.size() & 1) { rx.push_back(0); ry.push_back(0); }
          dbuf_t dx, dy, doff, dref;
@@ -1275,8 +1473,11 @@ static int cap_fini(smr_smrule_t *r)
       plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error());
       ret = -1;
    }
-   if (cap->autorot)
-      plog(SMR_LOG_INFO, "cap: %zu captions scanned on the GPU in %d dependency level(s), %zu batch(es)%s", n_all, n_levels, n_groups,
+   if (cap->autorot && replay)
+      plog(SMR_LOG_INFO, "cap: %zu captions scanned on the GPU in %d dependency level(s): %zu atlas(es) of cut-outs, each with the %zu rule(s) drawn so far%s",
+           n_all, n_levels, n_atlases, kept_.size(), cap->hide ? "" : "; glyphs composited onto the device canvas");
+   else if (cap->autorot)
+      plog(SMR_LOG_INFO, "cap: %zu captions scanned on the GPU in %d dependency level(s), %zu batch(es), crops of the canvas%s", n_all, n_levels, n_groups,
            cap->hide ? "" : ", glyphs composited onto the device canvas");
    else plog(SMR_LOG_INFO, "cap: %zu captions at their given angles%s", n_all, cap->hide ? "" : ", glyphs composited onto the device canvas");
    CR.destroy(cap->ctx);
@@ -1547,20 +1748,32 @@ static int img_fini(smr_smrule_t *r)
       const int stride = CR.image_surface_get_stride(fg);
       for (int y = 0; y < ih; y++) memcpy(&plane[(size_t) y * iw], d + (size_t) y * stride, (size_t) iw * 4);
       CR.surface_destroy(fg);
-      dbuf_t dx, dy, dfg, dang;
-      std::vector<double> out(n);
-      bool ok = dx.put(cx.data(), n * 8) == 0 && dy.put(cy.data(), n * 8) == 0 && dfg.put(plane.data(), plane.size() * 4) == 0 && dang.alloc(n * 8) == 0;
-      if (ok)
+      if (cutout_replay())
       {
-         smr_cap_batch_t b;
-         memset(&b, 0, sizeof(b));
-         b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) n;
-         b.fg_w = iw; b.fg_h = ih; b.phase_deg = g->phase; b.weight = g->weight; b.d_fg = (const uint32_t *) dfg.p;
-         ok = smr_hip_caprot(P.canvas, &b, (double *) dang.p, nullptr) == SMR_OK;
+         std::vector<scan_item_t> todo(n);
+         for (size_t k = 0; k < n; k++) { todo[k].id = k; todo[k].cx = cx[k]; todo[k].cy = cy[k]; todo[k].fw = iw; todo[k].fh = ih; todo[k].key = { 0 }; }
+         auto plane_of = [&](size_t, std::vector<uint32_t> &pl, int *w_px, int *h_px) { pl = plane; *w_px = iw; *h_px = ih; return 0; };
+         std::vector<double> out(n, 0.0);
+         if (scan_windows(todo, plane_of, g->phase, g->weight, nullptr, out, nullptr) != 0) { plog(SMR_LOG_ERR, "img: %s", smr_hip_last_error()); ret = -1; }
+         else for (size_t k = 0; k < n; k++) g->items[k].a = out[k];
       }
-      if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, n * 8) == SMR_OK;
-      if (!ok) { plog(SMR_LOG_ERR, "img: %s", smr_hip_last_error()); ret = -1; }
-      for (size_t k = 0; k < n && ok; k++) g->items[k].a = out[k];
+      else
+      {
+         dbuf_t dx, dy, dfg, dang;
+         std::vector<double> out(n);
+         bool ok = dx.put(cx.data(), n * 8) == 0 && dy.put(cy.data(), n * 8) == 0 && dfg.put(plane.data(), plane.size() * 4) == 0 && dang.alloc(n * 8) == 0;
+         if (ok)
+         {
+            smr_cap_batch_t b;
+            memset(&b, 0, sizeof(b));
+            b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) n;
+            b.fg_w = iw; b.fg_h = ih; b.phase_deg = g->phase; b.weight = g->weight; b.d_fg = (const uint32_t *) dfg.p;
+            ok = smr_hip_caprot(P.canvas, &b, (double *) dang.p, nullptr) == SMR_OK;
+         }
+         if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, n * 8) == SMR_OK;
+         if (!ok) { plog(SMR_LOG_ERR, "img: %s", smr_hip_last_error()); ret = -1; }
+         for (size_t k = 0; k < n && ok; k++) g->items[k].a = out[k];
+      }
    }
    if (ret == 0 && n)
    {
@@ -1572,6 +1785,7 @@ static int img_fini(smr_smrule_t *r)
       {
          if (items.empty()) return SMR_OK;
          const int rc = smr_hip_canvas_blit(P.canvas, pixels.data(), pixels.size(), items.data(), (int) items.size());
+         if (rc == SMR_OK) kept_blit(pixels, items);
          pixels.clear(); items.clear();
          return rc;
       };

@@ -3421,6 +3421,7 @@ extern "C" int smr_hip_canvas_destroy(smr_canvas_t *c)
    if (c->pix) hipFree(c->pix);
    if (c->d_win_shift) hipFree(c->d_win_shift);
    if (c->d_win_box) hipFree(c->d_win_box);
+   if (c->d_win_clip) hipFree(c->d_win_clip);
    if (c->halo_above) hipFree(c->halo_above);
    if (c->halo_below) hipFree(c->halo_below);
    for (auto &b : c->buf) if (b.p) hipFree(b.p);
@@ -3555,6 +3556,45 @@ extern "C" int smr_hip_canvas_blit(smr_canvas_t *c, const uint32_t *pixels, uint
    }
    SMR_HIP(hipGetLastError());
    SMR_HIP(hipStreamSynchronize(s));      /* the caller's pixels may go */
+   return SMR_OK;
+}
+
+/* smr_hip_canvas_blit for the windows of an atlas: every image lands in every window it meets, at the window's offset rounded to
+ * whole pixels (the images are rasterised on the chart's pixel grid: their sub-pixel shift is not redone) */
+extern "C" int smr_hip_blit_windows(smr_canvas_t *c, const uint32_t *pixels, uint64_t n_pixels, const smr_blit_t *items, int n_items)
+{
+   SMR_NEED_INIT();
+   if (!c || c->win_n <= 0) return smr_fail(SMR_E_INVAL, "blit_windows: the canvas is not an atlas of windows");
+   if (n_items < 0 || (n_items && (!pixels || !items))) return smr_fail(SMR_E_INVAL, "blit_windows: NULL argument");
+   for (int k = 0; k < n_items; k++)
+      if (items[k].w < 0 || items[k].h < 0 || (uint64_t) items[k].w * (uint64_t) items[k].h > n_pixels ||
+          items[k].offset > n_pixels - (uint64_t) items[k].w * (uint64_t) items[k].h)
+         return smr_fail(SMR_E_INVAL, "blit_windows: item %d lies outside the %llu pixels handed over", k, (unsigned long long) n_pixels);
+   if (n_items == 0 || n_pixels == 0) return SMR_OK;
+   hipStream_t s = smr_g.stream;
+   uint32_t *d_img = nullptr;
+   bool up = false;
+   for (int k = 0; k < n_items; k++)
+   {
+      const smr_blit_t &it = items[k];
+      if (it.w == 0 || it.h == 0) continue;
+      for (int q = 0; q < c->win_n; q++)
+      {
+         const int sz = c->win_sizes[(size_t) q];
+         const int ox = (int) lrint(c->win_ox[(size_t) q]), oy = (int) lrint(c->win_oy[(size_t) q]);
+         if (it.x + it.w <= ox || it.x >= ox + sz || it.y + it.h <= oy || it.y >= oy + sz) continue;
+         if (!up)
+         {
+            SMR_TRY(c->ensure(SMR_BUF_BLIT, (size_t) n_pixels * 4, (void **) &d_img));
+            SMR_HIP(hipMemcpyAsync(d_img, pixels, (size_t) n_pixels * 4, hipMemcpyHostToDevice, s));
+            up = true;
+         }
+         const int n = it.w * it.h;
+         k_blit_over<<<(n + 255) / 256, 256, 0, s>>>(c->pix + (size_t) q * c->win_pitch * c->W, c->W, 0, sz, d_img + it.offset, it.x - ox, it.y - oy, it.w, it.h);
+      }
+   }
+   SMR_HIP(hipGetLastError());
+   SMR_HIP(hipStreamSynchronize(s));
    return SMR_OK;
 }
 

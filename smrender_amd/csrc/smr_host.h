@@ -6,6 +6,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <math.h>
+#include <vector>
 #include "../../include/smr_hip.h"
 
 struct smr_global_t
@@ -49,7 +50,9 @@ struct smr_canvas
    /* an atlas of caption cut-outs (windows.hip): win_n windows of win_size px, one every win_pitch rows; per window the 24.8 shift of
     * its replay (atlas placement included) and its box on the chart in px */
    int win_n = 0, win_size = 0, win_pitch = 0, chart_w = 0, chart_h = 0;
-   int2 *d_win_shift = nullptr; void *d_win_box = nullptr;
+   int2 *d_win_shift = nullptr, *d_win_clip = nullptr; void *d_win_box = nullptr;
+   std::vector<int> win_sizes;
+   std::vector<double> win_ox, win_oy;      /* each window's corner on the chart, px */
    int own_y0 = -1, own_h = 0;         /* smr_hip_canvas_extend: the rows whose captions this canvas scans (-1: the band itself) */
    smr_devbuf_t buf[SMR_BUF_MAX];      /* grow-only work buffers, reused across draw calls */
    int strict_rows = 0;                /* draw_pass's second attempt: rows beyond SMR_ROWCAP spanning edges are sub-sampled (and reported) */

@@ -94,7 +94,7 @@ struct win_fill_args_t
    const uint32_t *way_fill_col, *way_border_col;
    const uint32_t *inst_way, *inst_win, *inst_off;      /* inst_off[n_inst] = all refs */
    uint32_t n_inst, n_out;
-   int pitch, size;
+   const int2 *win_clip;
    double *ox, *oy; int32_t *oref, *onode_win; int64_t *oway_off; int2 *oway_clip; uint32_t *ofill_col, *oborder_col;
 };
 
@@ -107,8 +107,7 @@ __global__ void k_win_fill(win_fill_args_t A)
       A.oway_off[g] = (int64_t) A.inst_off[g];
       if (g < A.n_inst)
       {
-         const int k = (int) A.inst_win[g];
-         A.oway_clip[g] = make_int2(k * A.pitch, k * A.pitch + A.size);
+         A.oway_clip[g] = A.win_clip[A.inst_win[g]];
          if (A.ofill_col) A.ofill_col[g] = A.way_fill_col[A.inst_way[g]];
          if (A.oborder_col) A.oborder_col[g] = A.way_border_col[A.inst_way[g]];
       }
@@ -147,35 +146,46 @@ static double style_reach_px(const smr_draw_style_t *st, int dpi)
 extern "C" int smr_hip_windows_create(int chart_w, int chart_h, int dpi, uint32_t bgcolor, const smr_windows_t *w, smr_canvas_t **out)
 {
    SMR_NEED_INIT();
-   if (!w || !out || w->n <= 0 || w->size <= 0 || !w->cx || !w->cy) return smr_fail(SMR_E_INVAL, "windows_create: no windows");
+   if (!w || !out || w->n <= 0 || !w->size || !w->cx || !w->cy) return smr_fail(SMR_E_INVAL, "windows_create: no windows");
+   int maxsize = 0;
+   for (int64_t k = 0; k < w->n; k++)
+   {
+      if (w->size[k] <= 0 || w->size[k] > 65536) return smr_fail(SMR_E_INVAL, "windows_create: window %lld of %d px", (long long) k, w->size[k]);
+      maxsize = std::max(maxsize, w->size[k]);
+   }
    if (chart_w <= 0 || chart_h <= 0 || dpi <= 0) return smr_fail(SMR_E_INVAL, "windows_create: bad chart %d x %d @ %d dpi", chart_w, chart_h, dpi);
-   const int pitch = (w->size + SMR_TH - 1) & ~(SMR_TH - 1);
-   if (w->size > 65536 || (int64_t) w->n * pitch > 65536)
+   const int pitch = (maxsize + SMR_TH - 1) & ~(SMR_TH - 1);
+   if ((int64_t) w->n * pitch > 65536)
       return smr_fail(SMR_E_CAPACITY, "windows_create: %lld windows of %d px do not fit one atlas (65 536 rows): at most %d per call",
-                      (long long) w->n, w->size, 65536 / pitch);
+                      (long long) w->n, maxsize, 65536 / pitch);
    smr_canvas_t *c = nullptr;
-   SMR_TRY(smr_hip_canvas_create(w->size, (int) w->n * pitch, dpi, 0, 0, (int) w->n * pitch, &c));
-   SMR_HIP(hipMemsetAsync(c->pix, 0, (size_t) w->size * (size_t) ((int) w->n * pitch) * 4, smr_g.stream));      /* a clear image: transparent */
-   c->win_n = (int) w->n; c->win_size = w->size; c->win_pitch = pitch; c->chart_w = chart_w; c->chart_h = chart_h;
+   SMR_TRY(smr_hip_canvas_create(maxsize, (int) w->n * pitch, dpi, 0, 0, (int) w->n * pitch, &c));
+   SMR_HIP(hipMemsetAsync(c->pix, 0, (size_t) maxsize * (size_t) ((int) w->n * pitch) * 4, smr_g.stream));      /* a clear image: transparent */
+   c->win_n = (int) w->n; c->win_size = maxsize; c->win_pitch = pitch; c->chart_w = chart_w; c->chart_h = chart_h;
+   c->win_sizes.assign(w->size, w->size + w->n);
    std::vector<int2> shift((size_t) w->n);
    std::vector<win_box_t> box((size_t) w->n);
    const double s = (double) dpi / 72;
    /* find_angle :1974-1975, cairo_smr_cut_out :1516-1528 with r = the window's size in pt */
-   const double r_pt = (w->r_px > 0 ? w->r_px : (double) w->size) * 72 / dpi;
+   std::vector<int2> clip((size_t) w->n);
    for (int64_t k = 0; k < w->n; k++)
    {
+      const double r_pt = (w->r_px && w->r_px[k] > 0 ? w->r_px[k] : (double) w->size[k]) * 72 / dpi;
+      clip[(size_t) k] = make_int2((int) k * pitch, (int) k * pitch + w->size[k]);
       const double x_pt = w->cx[k] * 72 / dpi, y_pt = w->cy[k] * 72 / dpi;
       const double tx = -x_pt + r_pt / 2, ty = -y_pt + r_pt / 2;
       shift[(size_t) k] = make_int2((int32_t) nearbyint(tx * s * 256.0), (int32_t) nearbyint(ty * s * 256.0) + (int32_t) k * pitch * 256);
       /* the window on the chart, in chart px (what lies further than a rule's reach from it cannot touch it) */
-      box[(size_t) k] = { -tx * s, -ty * s, -tx * s + w->size, -ty * s + w->size };
+      box[(size_t) k] = { -tx * s, -ty * s, -tx * s + maxsize, -ty * s + w->size[k] };
+      c->win_ox.push_back(-tx * s); c->win_oy.push_back(-ty * s);
    }
-   if (hipMalloc((void **) &c->d_win_shift, (size_t) w->n * sizeof(int2)) != hipSuccess || hipMalloc((void **) &c->d_win_box, (size_t) w->n * sizeof(win_box_t)) != hipSuccess)
+   if (hipMalloc((void **) &c->d_win_shift, (size_t) w->n * sizeof(int2)) != hipSuccess || hipMalloc((void **) &c->d_win_clip, (size_t) w->n * sizeof(int2)) != hipSuccess || hipMalloc((void **) &c->d_win_box, (size_t) w->n * sizeof(win_box_t)) != hipSuccess)
    {
       smr_hip_canvas_destroy(c);
       return smr_fail(SMR_E_NOMEM, "windows_create: window tables");
    }
    SMR_HIP(hipMemcpyAsync(c->d_win_shift, shift.data(), (size_t) w->n * sizeof(int2), hipMemcpyHostToDevice, smr_g.stream));
+   SMR_HIP(hipMemcpyAsync(c->d_win_clip, clip.data(), (size_t) w->n * sizeof(int2), hipMemcpyHostToDevice, smr_g.stream));
    SMR_HIP(hipMemcpyAsync(c->d_win_box, box.data(), (size_t) w->n * sizeof(win_box_t), hipMemcpyHostToDevice, smr_g.stream));
    SMR_HIP(hipStreamSynchronize(smr_g.stream));
    *out = c;
@@ -207,11 +217,32 @@ extern "C" int smr_hip_windows_create(int chart_w, int chart_h, int dpi, uint32_
    return rc;
 }
 
+/* the recording the reference replays has the chart's extents: nothing is drawn beyond them.  Pixels of a window whose centres lie
+ * outside the chart's rectangle are cleared (whole pixels: the background rectangle's own edge is anti-aliased) */
+__global__ void k_win_outside(uint32_t *__restrict__ pix, int W, int pitch, int n_win, const win_box_t *__restrict__ box, const int2 *__restrict__ clip,
+                              int chart_w, int chart_h)
+{
+   const int k = blockIdx.y;
+   const win_box_t b = box[k];
+   const int rows = clip[k].y - clip[k].x;
+   /* only windows that hang over an edge have anything to clear */
+   if (b.x0 >= 0 && b.y0 >= 0 && b.x0 + W <= chart_w && b.y0 + rows <= chart_h) return;
+   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * W; i += gridDim.x * blockDim.x)
+   {
+      const int x = i % W, y = i / W;
+      const double px = b.x0 + x + 0.5, py = b.y0 + y + 0.5;
+      if (px < 0 || py < 0 || px > chart_w || py > chart_h) pix[(size_t) (k * pitch + y) * W + x] = 0u;
+   }
+}
+
 extern "C" int smr_hip_windows_anchors(smr_canvas_t *atlas, double *cx, double *cy)
 {
    if (!atlas || atlas->win_n <= 0 || !cx || !cy) return smr_fail(SMR_E_INVAL, "windows_anchors: not an atlas");
+   k_win_outside<<<dim3(16, (unsigned) atlas->win_n), 256, 0, smr_g.stream>>>(atlas->pix, atlas->W, atlas->win_pitch, atlas->win_n,
+                                                                              (const win_box_t *) atlas->d_win_box, atlas->d_win_clip, atlas->chart_w, atlas->chart_h);
+   SMR_HIP(hipGetLastError());
    /* smr_hip_caprot crops at the anchor minus r/2, rounded: r/2 itself puts the crop on the window */
-   for (int k = 0; k < atlas->win_n; k++) { cx[k] = atlas->win_size / 2.0; cy[k] = (double) k * atlas->win_pitch + atlas->win_size / 2.0; }
+   for (int k = 0; k < atlas->win_n; k++) { cx[k] = atlas->win_sizes[(size_t) k] / 2.0; cy[k] = (double) k * atlas->win_pitch + atlas->win_sizes[(size_t) k] / 2.0; }
    return SMR_OK;
 }
 
@@ -274,7 +305,7 @@ static int draw_windows_range(smr_canvas_t *c, const smr_draw_style_t *st, const
    F.x = b->d_x; F.y = b->d_y; F.way_off = b->d_way_off; F.ref = b->d_ref; F.n_nodes = b->n_nodes;
    F.way_fill_col = b->d_way_fill_col; F.way_border_col = b->d_way_border_col;
    F.inst_way = inst_way; F.inst_win = inst_win; F.inst_off = inst_off; F.n_inst = n_inst; F.n_out = n_out;
-   F.pitch = c->win_pitch; F.size = c->win_size;
+   F.win_clip = c->d_win_clip;
    F.ox = ox; F.oy = oy; F.oref = oref; F.onode_win = onw; F.oway_off = owo; F.oway_clip = oclip; F.ofill_col = ofc; F.oborder_col = obc;
    k_win_fill<<<(std::max(n_out, n_inst + 1) + 255) / 256, 256, 0, s>>>(F);
    SMR_HIP(hipGetLastError());

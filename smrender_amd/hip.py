@@ -76,7 +76,7 @@ class PngStats(C.Structure):
 
 
 class _Windows(C.Structure):
-    _fields_ = [("n", C.c_int64), ("size", C.c_int32), ("pad_", C.c_int32), ("r_px", C.c_double), ("cx", C.c_void_p), ("cy", C.c_void_p)]
+    _fields_ = [("n", C.c_int64), ("size", C.c_void_p), ("r_px", C.c_void_p), ("cx", C.c_void_p), ("cy", C.c_void_p)]
 
 
 # every symbol include/smr_hip.h declares (tests/test_abi.py checks the list against the header)
@@ -86,7 +86,7 @@ EXPORTS = [
     "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_read", "smr_hip_canvas_device",
     "smr_hip_canvas_set_halo", "smr_hip_canvas_set_halo_device", "smr_hip_canvas_extend", "smr_hip_canvas_clone", "smr_hip_canvas_blit",
     "smr_hip_canvas_write_png", "smr_hip_canvas_write_tiles",
-    "smr_hip_windows_create", "smr_hip_draw_windows", "smr_hip_windows_anchors",
+    "smr_hip_windows_create", "smr_hip_draw_windows", "smr_hip_windows_anchors", "smr_hip_blit_windows",
     "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
     "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
@@ -123,6 +123,7 @@ def lib():
         L.smr_hip_windows_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         L.smr_hip_draw_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.smr_hip_windows_anchors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.smr_hip_blit_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.smr_hip_canvas_write_png.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         L.smr_hip_canvas_write_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, C.c_void_p]
@@ -253,18 +254,21 @@ class Canvas:
         _chk(lib().smr_hip_draw(self.h, C.byref(style), C.byref(b)))
 
     @classmethod
-    def windows(cls, chart_w, chart_h, dpi, bgcolor, cx, cy, size, r_px=0.0):
-        """an ATLAS of caption cut-outs the reference's way (smr_hip_windows_create): one window of `size` px per anchor (chart px,
-        host arrays; r_px: find_angle's r before rounding, hypot of the caption plane), transparent but for the chart's background; draw_windows() then renders rules into it"""
+    def windows(cls, chart_w, chart_h, dpi, bgcolor, cx, cy, size, r_px=None):
+        """an ATLAS of caption cut-outs the reference's way (smr_hip_windows_create): one window per anchor (chart px, host
+        arrays) of `size` px (one int or one per window; r_px: find_angle's r before rounding, hypot of the caption plane),
+        transparent but for the chart's background; draw_windows() then renders rules into it"""
         cx, cy = np.ascontiguousarray(cx, np.float64), np.ascontiguousarray(cy, np.float64)
-        w = _Windows(len(cx), size, 0, r_px, cx.ctypes.data, cy.ctypes.data)
+        sizes = np.ascontiguousarray(np.broadcast_to(np.asarray(size, np.int32), cx.shape))
+        rp = None if r_px is None else np.ascontiguousarray(np.broadcast_to(np.asarray(r_px, np.float64), cx.shape))
+        w = _Windows(len(cx), sizes.ctypes.data, None if rp is None else rp.ctypes.data, cx.ctypes.data, cy.ctypes.data)
         h = C.c_void_p()
         _chk(lib().smr_hip_windows_create(chart_w, chart_h, dpi, bgcolor, C.byref(w), C.byref(h)))
         o = cls.__new__(cls)
-        pitch = (size + 3) & ~3
-        o.W, o.H, o.dpi, o.band_y0, o.band_h, o.h = size, len(cx) * pitch, dpi, 0, len(cx) * pitch, h.value
+        pitch = (int(sizes.max()) + 3) & ~3
+        o.W, o.H, o.dpi, o.band_y0, o.band_h, o.h = int(sizes.max()), len(cx) * pitch, dpi, 0, len(cx) * pitch, h.value
         o._n_above = o._n_below = 0
-        o.n_windows, o.window_size, o.window_pitch = len(cx), size, pitch
+        o.n_windows, o.window_sizes, o.window_pitch = len(cx), sizes, pitch
         return o
 
     def draw_windows(self, style, d_x, d_y, d_way_off, d_ref, n_ways, n_refs, d_fill_col=None, d_border_col=None):
