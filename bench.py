@@ -323,7 +323,33 @@ def main():
                "caprot_ms": round(cap_ms, 3), "captions_per_s": round(args.captions * world / (cap_ms * 1e-3), 1),
                "roofline": {"kernel": "k_caprot", "bound": "hbm", "achieved": round(cap_bytes / (cap_ms * 1e-3) / 1e9, 2),
                             "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(cap_bytes / (cap_ms * 1e-3) / HBM_PEAK, 5)},
-               "distinct_angles": int(len(np.unique(ang))), "halo_exchange": halo_path}
+               "distinct_angles": int(len(np.unique(ang))), "halo_exchange": halo_path,
+               "cutout": "crop of the canvas at the rounded anchor (smr_hip_caprot on the chart)"}
+        if world == 1 and not args.strong:
+            # the same captions the reference's way: every cut-out re-rasterised at its anchor's sub-pixel offset (atlases of
+            # windows, smr_hip_draw_windows), wall time of everything: instancing, drawing, scan
+            sa.set_profiling(False)
+            per = 65536 // ((r_px + 3) & ~3)
+            sa.sync()
+            t0 = time.perf_counter()
+            ang2 = np.zeros(args.captions)
+            for k0 in range(0, args.captions, per):
+                k1 = min(args.captions, k0 + per)
+                at = sa.Canvas.windows(W, chart_h, args.dpi, 0xffffff, cx[k0:k1], cy[k0:k1], r_px, float(np.hypot(fg_w, fg_h)))
+                at.draw_windows(style, d_x, d_y, d_off, d_ref, n_ways, n_refs)
+                ax, ay = at.window_anchors()
+                d2 = sa.DeviceArray((k1 - k0,), np.float64)
+                at.caprot(sa.DeviceArray.from_numpy(ax), sa.DeviceArray.from_numpy(ay), k1 - k0, fg_w, fg_h, fg_x, 0x000000, 0.0, 1.0, d2)
+                sa.sync()
+                ang2[k0:k1] = d2.numpy()
+                at.close()
+            t_rep = time.perf_counter() - t0
+            sa.set_profiling(True)
+            tag = lambda v: np.array(["%.1f" % (q * 180 / np.pi) for q in v])
+            cap["replay"] = {"cutout": "re-rasterised at the anchor's sub-pixel offset, as cairo_smr_cut_out replays the recording (smr_hip_draw_windows)",
+                             "captions": args.captions, "atlases": (args.captions + per - 1) // per, "seconds": round(t_rep, 3),
+                             "captions_per_s": round(args.captions / t_rep, 1),
+                             "tags_differing_from_the_crop_scan": int((tag(ang) != tag(ang2)).sum())}
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
