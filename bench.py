@@ -215,6 +215,7 @@ def main():
     ap.add_argument("--size", type=int, default=16384)
     ap.add_argument("--dpi", type=int, default=300)
     ap.add_argument("--captions", type=int, default=20000, help="C4 captions scanned after the timed region (0 = skip)")
+    ap.add_argument("--no-replay", action="store_true", help="skip the caption scan through re-rasterised cut-outs (profiling runs: keeps the chart's own kernels apart)")
     ap.add_argument("--cpu-window", type=int, default=3072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-charts", action="store_true", help="skip the 32k target and the C3-like chart (reported outside the timed region)")
@@ -325,7 +326,7 @@ def main():
                             "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(cap_bytes / (cap_ms * 1e-3) / HBM_PEAK, 5)},
                "distinct_angles": int(len(np.unique(ang))), "halo_exchange": halo_path,
                "cutout": "crop of the canvas at the rounded anchor (smr_hip_caprot on the chart)"}
-        if world == 1 and not args.strong:
+        if world == 1 and not args.strong and not args.no_replay:
             # the same captions the reference's way: every cut-out re-rasterised at its anchor's sub-pixel offset (atlases of
             # windows, smr_hip_draw_windows), wall time of everything: instancing, drawing, scan
             sa.set_profiling(False)

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-other-charts"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-other-charts --no-replay"
 timeout -s KILL 280 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace --output-format csv -- python3 $R/bench.py $ARGS > $OUT/${TAG}_trace.log 2>&1 || exit 1
 echo "trace done"
 timeout -s KILL 170 rocprofv3 --pmc FETCH_SIZE -d $OUT/${TAG}_fetch --output-format csv -- python3 $R/bench.py $ARGS > $OUT/${TAG}_fetch.log 2>&1 || exit 1
