@@ -78,6 +78,9 @@ int smr_hip_canvas_destroy(smr_canvas_t *c);
 int smr_hip_canvas_clone(smr_canvas_t *c, smr_canvas_t **out);
 /* repaint the background (what cairo_smr_init_main_image does once per chart, :320-326) */
 int smr_hip_canvas_clear(smr_canvas_t *c);
+/* gives back the canvas's grow-only work buffers (edge arenas, bins: several times the size of a small canvas after a large rule);
+ * the pixels stay, the next draw allocates again.  For canvases that wait: the atlases of a caption rule between its levels */
+int smr_hip_canvas_trim(smr_canvas_t *c);
 /* copy a rectangle (band-local rows) of premultiplied ARGB32 to host memory */
 int smr_hip_canvas_read(smr_canvas_t *c, int x, int y, int w, int h, uint32_t *host_dst);
 /* Multi-GPU caption scan: rows of the neighbouring bands the scan may read (cut-outs of

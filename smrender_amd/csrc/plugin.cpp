@@ -1109,93 +1109,116 @@ struct scan_item_t
 /* the rectangles the rule's earlier captions left on auto_ctx (:2376-2382), as a batch in chart px */
 struct rect_batch_t { std::vector<double> x, y; std::vector<int64_t> off = std::vector<int64_t>(1, 0); std::vector<int32_t> ref; uint32_t col = 0; };
 
-template <typename PlaneFn>
-static int scan_windows(std::vector<scan_item_t> items, PlaneFn plane_of, double phase, double weight, const rect_batch_t *rects, std::vector<double> &angle,
-                        size_t *n_atlases)
+/* The atlases of one rule's captions.  The chart's rules are rendered ONCE into every window (build); the rule's dependency
+ * levels then take turns on the same atlases: scan(level) runs find_angle for the level's captions, add_rects() draws the
+ * rectangles they left (auto_ctx, :2376-2382) into every window they reach, where the later levels' scans see them. */
+struct atlas_set_t
 {
-   for (scan_item_t &it : items)
+   struct atlas_t { smr_canvas_t *c = nullptr; size_t i0 = 0, i1 = 0; std::vector<double> ax, ay; };
+   std::vector<scan_item_t> items;          /* sorted by window size, largest first */
+   std::vector<int> level;                  /* per item */
+   std::vector<atlas_t> atlases;
+
+   ~atlas_set_t() { for (atlas_t &a : atlases) if (a.c) smr_hip_canvas_destroy(a.c); }
+
+   int build(std::vector<scan_item_t> in, const std::vector<int> &lev)
    {
-      int steps = 0;
-      smr_hip_caprot_steps(it.fw, it.fh, P.dpi, &steps, &it.rpx);
-      it.r = hypot((double) it.fw, (double) it.fh);
-   }
-   std::stable_sort(items.begin(), items.end(), [](const scan_item_t &a, const scan_item_t &b) { return a.rpx > b.rpx; });
-   /* the rectangles go up once */
-   dbuf_t rdx, rdy, rdoff, rdref;
-   smr_draw_batch_t rb;
-   memset(&rb, 0, sizeof(rb));
-   if (rects && !rects->ref.empty())
-   {
-      std::vector<double> rx(rects->x), ry(rects->y);
-      if (rx.size() & 1) { rx.push_back(0); ry.push_back(0); }
-      if (rdx.put(rx.data(), rx.size() * 8) || rdy.put(ry.data(), ry.size() * 8) || rdoff.put(rects->off.data(), rects->off.size() * 8) ||
-          rdref.put(rects->ref.data(), rects->ref.size() * 4))
-         return -1;
-      rb.d_x = (const double *) rdx.p; rb.d_y = (const double *) rdy.p; rb.n_nodes = (int64_t) rx.size();
-      rb.d_way_off = (const int64_t *) rdoff.p; rb.d_ref = (const int32_t *) rdref.p;
-      rb.n_ways = (int64_t) rects->off.size() - 1; rb.n_refs = (int64_t) rects->ref.size();
-   }
-   for (size_t i0 = 0; i0 < items.size();)
-   {
-      if (items[i0].rpx <= 0 || items[i0].fw <= 0 || items[i0].fh <= 0) { i0++; continue; }      /* an empty plane: angle 0 */
-      /* one atlas: windows of similar size (a smaller window is limited to the atlas's columns, include/smr_hip.h) */
-      const int maxsize = items[i0].rpx, pitch = (maxsize + 3) & ~3;
-      size_t i1 = i0;
-      while (i1 < items.size() && (int) (i1 - i0 + 1) * pitch <= 65536 && items[i1].rpx * 4 >= maxsize * 3 && items[i1].rpx > 0) i1++;
-      const size_t n = i1 - i0;
-      std::vector<int32_t> size(n); std::vector<double> rp(n), cx(n), cy(n), ax(n), ay(n);
-      for (size_t k = 0; k < n; k++) { const scan_item_t &it = items[i0 + k]; size[k] = it.rpx; rp[k] = it.r; cx[k] = it.cx; cy[k] = it.cy; }
-      smr_windows_t w;
-      w.n = (int64_t) n; w.size = size.data(); w.r_px = rp.data(); w.cx = cx.data(); w.cy = cy.data();
-      smr_canvas_t *atlas = nullptr;
-      if (smr_hip_windows_create(P.W, P.H, P.dpi, P.bg, &w, &atlas) != SMR_OK) return -1;
-      if (n_atlases) ++*n_atlases;
-      int rc = SMR_OK;
-      for (const kept_rule_t &k : kept_)
+      std::vector<size_t> order(in.size());
+      for (size_t k = 0; k < in.size(); k++)
       {
-         rc = k.is_blit ? smr_hip_blit_windows(atlas, k.pixels.data(), k.pixels.size(), k.items.data(), (int) k.items.size())
-                        : smr_hip_draw_windows(atlas, &k.st, &k.b);
-         if (rc != SMR_OK) break;
+         order[k] = k;
+         int steps = 0;
+         in[k].rpx = 0;
+         if (in[k].fw > 0 && in[k].fh > 0) smr_hip_caprot_steps(in[k].fw, in[k].fh, P.dpi, &steps, &in[k].rpx);
+         in[k].r = hypot((double) in[k].fw, (double) in[k].fh);
       }
-      if (rc == SMR_OK && rb.n_ways)
+      std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return in[a].rpx > in[b].rpx; });
+      for (size_t k : order) if (in[k].rpx > 0) { items.push_back(in[k]); level.push_back(lev.empty() ? 0 : lev[k]); }      /* an empty plane: angle 0 */
+      for (size_t i0 = 0; i0 < items.size();)
       {
-         smr_draw_style_t st;
-         memset(&st, 0, sizeof(st));
-         st.fill_used = 1; st.fill_col = rects->col; st.direct = 1;
-         rc = smr_hip_draw_windows(atlas, &st, &rb);
-      }
-      if (rc == SMR_OK) rc = smr_hip_windows_anchors(atlas, ax.data(), ay.data());
-      std::map<std::vector<int64_t>, std::vector<size_t>> groups;
-      for (size_t k = 0; k < n; k++) groups[items[i0 + k].key].push_back(k);
-      for (auto &g : groups)
-      {
-         if (rc != SMR_OK) break;
-         const std::vector<size_t> &idx = g.second;
-         std::vector<uint32_t> plane; int w_px = 0, h_px = 0;
-         if (plane_of(items[i0 + idx[0]].id, plane, &w_px, &h_px) != 0) continue;
-         const size_t m = idx.size();
-         std::vector<double> gx(m), gy(m), out(m);
-         for (size_t k = 0; k < m; k++) { gx[k] = ax[idx[k]]; gy[k] = ay[idx[k]]; }
-         dbuf_t dx, dy, dfg, dang;
-         bool ok = dx.put(gx.data(), m * 8) == 0 && dy.put(gy.data(), m * 8) == 0 && dfg.put(plane.data(), plane.size() * 4) == 0 && dang.alloc(m * 8) == 0;
-         if (ok)
+         /* one atlas: windows of similar size (a smaller window is limited to the atlas's columns, include/smr_hip.h) */
+         const int maxsize = items[i0].rpx, pitch = (maxsize + 3) & ~3;
+         size_t i1 = i0;
+         while (i1 < items.size() && (int) (i1 - i0 + 1) * pitch <= 65536 && items[i1].rpx * 4 >= maxsize * 3) i1++;
+         const size_t n = i1 - i0;
+         std::vector<int32_t> size(n); std::vector<double> rp(n), cx(n), cy(n);
+         for (size_t k = 0; k < n; k++) { const scan_item_t &it = items[i0 + k]; size[k] = it.rpx; rp[k] = it.r; cx[k] = it.cx; cy[k] = it.cy; }
+         smr_windows_t w;
+         w.n = (int64_t) n; w.size = size.data(); w.r_px = rp.data(); w.cx = cx.data(); w.cy = cy.data();
+         atlases.emplace_back();
+         atlas_t &a = atlases.back();
+         a.i0 = i0; a.i1 = i1; a.ax.resize(n); a.ay.resize(n);
+         if (smr_hip_windows_create(P.W, P.H, P.dpi, P.bg, &w, &a.c) != SMR_OK) return -1;
+         for (const kept_rule_t &k : kept_)
          {
-            smr_cap_batch_t b;
-            memset(&b, 0, sizeof(b));
-            b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) m;
-            b.fg_w = w_px; b.fg_h = h_px; b.fg_x = 0; b.phase_deg = phase; b.weight = weight; b.d_fg = (const uint32_t *) dfg.p;
-            ok = smr_hip_caprot(atlas, &b, (double *) dang.p, nullptr) == SMR_OK;
+            const int rc = k.is_blit ? smr_hip_blit_windows(a.c, k.pixels.data(), k.pixels.size(), k.items.data(), (int) k.items.size())
+                                     : smr_hip_draw_windows(a.c, &k.st, &k.b);
+            if (rc != SMR_OK) return -1;
          }
-         if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, m * 8) == SMR_OK;
-         if (!ok) { rc = -1; break; }
-         for (size_t k = 0; k < m; k++) angle[items[i0 + idx[k]].id] = out[k];
+         /* the work buffers of the replay (edge arenas, bins) are not needed while the atlas waits for its levels */
+         if (smr_hip_canvas_trim(a.c) != SMR_OK) return -1;
+         i0 = i1;
       }
-      smr_hip_canvas_destroy(atlas);
-      if (rc != SMR_OK) return -1;
-      i0 = i1;
+      return 0;
    }
-   return 0;
-}
+
+   template <typename PlaneFn>
+   int scan(int lv, PlaneFn plane_of, double phase, double weight, std::vector<double> &angle)
+   {
+      for (atlas_t &a : atlases)
+      {
+         std::map<std::vector<int64_t>, std::vector<size_t>> groups;
+         for (size_t k = a.i0; k < a.i1; k++) if (level[k] == lv) groups[items[k].key].push_back(k);
+         if (groups.empty()) continue;
+         /* clears what lies beyond the chart's extents, too (rectangles of earlier levels included) */
+         if (smr_hip_windows_anchors(a.c, a.ax.data(), a.ay.data()) != SMR_OK) return -1;
+         for (auto &g : groups)
+         {
+            const std::vector<size_t> &idx = g.second;
+            std::vector<uint32_t> plane; int w_px = 0, h_px = 0;
+            if (plane_of(items[idx[0]].id, plane, &w_px, &h_px) != 0) continue;
+            const size_t m = idx.size();
+            std::vector<double> gx(m), gy(m), out(m);
+            for (size_t k = 0; k < m; k++) { gx[k] = a.ax[idx[k] - a.i0]; gy[k] = a.ay[idx[k] - a.i0]; }
+            dbuf_t dx, dy, dfg, dang;
+            bool ok = dx.put(gx.data(), m * 8) == 0 && dy.put(gy.data(), m * 8) == 0 && dfg.put(plane.data(), plane.size() * 4) == 0 && dang.alloc(m * 8) == 0;
+            if (ok)
+            {
+               smr_cap_batch_t b;
+               memset(&b, 0, sizeof(b));
+               b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) m;
+               b.fg_w = w_px; b.fg_h = h_px; b.fg_x = 0; b.phase_deg = phase; b.weight = weight; b.d_fg = (const uint32_t *) dfg.p;
+               ok = smr_hip_caprot(a.c, &b, (double *) dang.p, nullptr) == SMR_OK;
+            }
+            if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, m * 8) == SMR_OK;
+            if (!ok) return -1;
+            for (size_t k = 0; k < m; k++) angle[items[idx[k]].id] = out[k];
+         }
+      }
+      return 0;
+   }
+
+   int add_rects(const rect_batch_t &r)
+   {
+      if (r.ref.empty()) return 0;
+      std::vector<double> rx(r.x), ry(r.y);
+      if (rx.size() & 1) { rx.push_back(0); ry.push_back(0); }
+      dbuf_t dx, dy, doff, dref;
+      if (dx.put(rx.data(), rx.size() * 8) || dy.put(ry.data(), ry.size() * 8) || doff.put(r.off.data(), r.off.size() * 8) || dref.put(r.ref.data(), r.ref.size() * 4))
+         return -1;
+      smr_draw_style_t st;
+      memset(&st, 0, sizeof(st));
+      st.fill_used = 1; st.fill_col = r.col; st.direct = 1;
+      smr_draw_batch_t b;
+      memset(&b, 0, sizeof(b));
+      b.d_x = (const double *) dx.p; b.d_y = (const double *) dy.p; b.n_nodes = (int64_t) rx.size();
+      b.d_way_off = (const int64_t *) doff.p; b.d_ref = (const int32_t *) dref.p;
+      b.n_ways = (int64_t) r.off.size() - 1; b.n_refs = (int64_t) r.ref.size();
+      for (atlas_t &a : atlases)
+         if (smr_hip_draw_windows(a.c, &st, &b) != SMR_OK || smr_hip_sync() != SMR_OK) return -1;
+      return 0;
+   }
+};
 
 /* cairo_show_text of every caption (cap_coord :2363-2388: translate to the anchor, rotate, move_to the aligned origin, show_text),
  * rasterised by the host's libcairo + FreeType into a small image per caption on the chart's own pixel grid and painted OVER
@@ -1303,7 +1326,7 @@ static int cap_fini(smr_smrule_t *r)
    const double sc = (double) P.dpi / 72.0;
    /* the reference's cut-outs (windows of the chart rendered again at each anchor's sub-pixel offset) unless told to crop */
    const bool replay = cutout_replay();
-   rect_batch_t rects;
+   atlas_set_t atl;
    if (n_all)
    {
       /* all anchors -> px in one projection call */
@@ -1337,26 +1360,24 @@ static int cap_fini(smr_smrule_t *r)
    {
       if (replay)
       {
-         std::vector<scan_item_t> todo;
-         for (size_t i = 0; i < n_all; i++)
-         {
-            if (level[i] != lv) continue;
-            const cap_item_t &it = cap->items[i];
-            scan_item_t q;
-            q.id = i; q.cx = cx[i]; q.cy = cy[i]; q.fw = fw[i]; q.fh = fh[i]; q.key = { it.pw, it.ph, it.px, (int64_t) it.col };
-            todo.push_back(q);
-         }
          auto plane_of = [&](size_t id, std::vector<uint32_t> &plane, int *w_px, int *h_px)
          {
             const cap_item_t &it = cap->items[id];
             return make_plane(it.pw, it.ph, it.px, it.col, P.dpi, plane, w_px, h_px);
          };
-         n_groups += todo.size();
-         if (scan_windows(todo, plane_of, cap->phase, cap->weight, &rects, angle, &n_atlases) != 0)
+         if (lv == 0)
          {
-            plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error());
-            ret = -1;
+            std::vector<scan_item_t> todo(n_all);
+            for (size_t i = 0; i < n_all; i++)
+            {
+               const cap_item_t &it = cap->items[i];
+               scan_item_t &q = todo[i];
+               q.id = i; q.cx = cx[i]; q.cy = cy[i]; q.fw = fw[i]; q.fh = fh[i]; q.key = { it.pw, it.ph, it.px, (int64_t) it.col };
+            }
+            if (atl.build(todo, level) != 0) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
+            n_atlases = atl.atlases.size();
          }
+         if (ret == 0 && atl.scan(lv, plane_of, cap->phase, cap->weight, angle) != 0) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
       }
       else
       {
@@ -1430,12 +1451,11 @@ static int cap_fini(smr_smrule_t *r)
       }
       if (!rref.empty() && replay)
       {
-         /* the later levels' windows get every earlier level's rectangles, after the chart's rules */
-         const int32_t nb = (int32_t) rects.x.size(), rb0 = (int32_t) rects.ref.size();
-         rects.x.insert(rects.x.end(), rx.begin(), rx.end()); rects.y.insert(rects.y.end(), ry.begin(), ry.end());
-         for (int32_t v : rref) rects.ref.push_back(v + nb);
-         for (size_t k = 1; k < roff.size(); k++) rects.off.push_back(roff[k] + rb0);
-         rects.col = cap->items[0].col;                        /* auto_ctx's source: the first object's colour (:2459) */
+         /* this level's rectangles into every window they reach: the later levels' scans see them */
+         rect_batch_t rb;
+         rb.x = rx; rb.y = ry; rb.off = roff; rb.ref = rref;
+         rb.col = cap->items[0].col;                           /* auto_ctx's source: the first object's colour (:2459) */
+         if (atl.add_rects(rb) != 0) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
       }
       else if (!rref.empty())
       {
@@ -1754,7 +1774,8 @@ static int img_fini(smr_smrule_t *r)
          for (size_t k = 0; k < n; k++) { todo[k].id = k; todo[k].cx = cx[k]; todo[k].cy = cy[k]; todo[k].fw = iw; todo[k].fh = ih; todo[k].key = { 0 }; }
          auto plane_of = [&](size_t, std::vector<uint32_t> &pl, int *w_px, int *h_px) { pl = plane; *w_px = iw; *h_px = ih; return 0; };
          std::vector<double> out(n, 0.0);
-         if (scan_windows(todo, plane_of, g->phase, g->weight, nullptr, out, nullptr) != 0) { plog(SMR_LOG_ERR, "img: %s", smr_hip_last_error()); ret = -1; }
+         atlas_set_t atl;
+         if (atl.build(todo, std::vector<int>()) != 0 || atl.scan(0, plane_of, g->phase, g->weight, out) != 0) { plog(SMR_LOG_ERR, "img: %s", smr_hip_last_error()); ret = -1; }
          else for (size_t k = 0; k < n; k++) g->items[k].a = out[k];
       }
       else

@@ -3429,6 +3429,15 @@ extern "C" int smr_hip_canvas_destroy(smr_canvas_t *c)
    return SMR_OK;
 }
 
+extern "C" int smr_hip_canvas_trim(smr_canvas_t *c)
+{
+   SMR_NEED_INIT();
+   if (!c) return smr_fail(SMR_E_INVAL, "canvas_trim: NULL");
+   SMR_HIP(hipStreamSynchronize(smr_g.stream));
+   for (auto &b : c->buf) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+   return SMR_OK;
+}
+
 extern "C" int smr_hip_canvas_read(smr_canvas_t *c, int x, int y, int w, int h, uint32_t *host_dst)
 {
    SMR_NEED_INIT();

@@ -83,7 +83,7 @@ class _Windows(C.Structure):
 EXPORTS = [
     "smr_hip_init", "smr_hip_shutdown", "smr_hip_last_error", "smr_hip_device_name",
     "smr_hip_proj_from_window", "smr_hip_set_projection", "smr_hip_project", "smr_hip_unproject",
-    "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_read", "smr_hip_canvas_device",
+    "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_trim", "smr_hip_canvas_read", "smr_hip_canvas_device",
     "smr_hip_canvas_set_halo", "smr_hip_canvas_set_halo_device", "smr_hip_canvas_extend", "smr_hip_canvas_clone", "smr_hip_canvas_blit",
     "smr_hip_canvas_write_png", "smr_hip_canvas_write_tiles",
     "smr_hip_windows_create", "smr_hip_draw_windows", "smr_hip_windows_anchors", "smr_hip_blit_windows",
