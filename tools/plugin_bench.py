@@ -53,3 +53,21 @@ for rep in range(2):
 refs = sum(len(a[3]) for _, a in rules)
 print(f"{n_rules} rules x {n_ways} ways ({refs} refs) on {W}x{H}: plugin path {t_plugin * 1e3:.1f} ms ({t_plugin / n_rules * 1e3:.2f} ms per rule, "
       f"{refs / t_plugin / 1e6:.2f} M refs/s), C-ABI from resident arrays {t_abi * 1e3:.1f} ms ({t_abi / n_rules * 1e3:.2f} ms per rule)")
+# ---- a caption rule on that chart: 2 000 captions, angle=auto, the reference's cut-outs (default) and crops of the canvas ----
+if po.cairo() is not None:
+    n_cap = int(sys.argv[3]) if len(sys.argv) > 3 else 2000
+    rng = np.random.default_rng(7)
+    cx, cy = rng.uniform(100, W - 100, n_cap), rng.uniform(100, H - 100, n_cap)
+    lat, lon = synth.px_to_geo(proj, cx, cy)
+    for mode in ("replay", "crop"):
+        os.environ["SMR_HIP_CUTOUT"] = mode
+        sa.lib().smr_hip_plugin_reset()
+        for r, (wids, _) in enumerate(rules):
+            assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, f"color={col(r)};bcolor=black;bwidth=0.1", wids) == 0
+        sa.sync()
+        nids = nid + np.arange(n_cap); nid += n_cap + 1
+        hs.add_nodes(nids, lat, lon, [f"name=Name {k % 37}" for k in range(n_cap)])
+        t0 = time.perf_counter()
+        assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, "key=name;size=2;angle=auto;color=black;halign=east;hide=1", nids) == 0
+        dt = time.perf_counter() - t0
+        print(f"cap rule, {n_cap} captions after {n_rules} draw rules, SMR_HIP_CUTOUT={mode}: {dt:.3f} s ({n_cap / dt:.0f} captions/s)")
