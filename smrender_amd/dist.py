@@ -53,6 +53,13 @@ def stroke_margin_px(fill_width_mm, border_width_mm, dpi, curve_factor=0.0, long
     return max(w, 1.0) / 2 * 10 + 1 + curve_factor * longest_segment_px + wavy_length_px
 
 
+def window_margin_px(r_px, stroke_margin):
+    """The caption scan on the reference's own cut-outs (smr_hip_draw_windows) needs NO pixel halo: a rank renders
+    the windows of the captions whose anchors lie in its band from geometry.  What it needs instead are the ways within a
+    window's reach of its band: half a window (the anchor is its middle) plus the rule's own stroke margin."""
+    return r_px / 2.0 + 1.0 + stroke_margin
+
+
 def longest_segment_px(x_px, y_px, way_off, ref):
     """longest segment of any way in px (for stroke_margin_px's curve term)"""
     xs, ys = x_px[ref], y_px[ref]

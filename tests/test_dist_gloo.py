@@ -131,6 +131,83 @@ print("rank", g.rank, "ok")
 '''
 
 
+WIN_WORKER = r'''
+import os, sys, ctypes as C, numpy as np
+sys.path.insert(0, os.environ["SMR_ROOT"])
+from smrender_amd import dist, synth
+from oracle import pyoracle as po
+g = dist.Group("gloo")
+L = po.orc()
+L.orc_canvas_set_shift.argtypes = [C.c_void_p, C.c_double, C.c_double]
+W, H, dpi = 256, int(os.environ["SMR_TEST_H"]), 300
+x, y, off, ref = synth.synth_ways(140, W, H, seed=11)
+st = po.Style(1, 1, 0x4080c0, 0x000000, 0.0, 0.3, 0)
+bands = dist.bands(H, g.world)
+y0, h = bands[g.rank]
+rng = np.random.default_rng(3)
+cx, cy = [rng.uniform(30, W - 30, 10)], [rng.uniform(30, H - 30, 10)]
+for by, bh in bands[1:]:
+    if bh > 0 and 40 < by < H - 40:
+        cx.append(rng.uniform(60, 120, 6)); cy.append(rng.uniform(by - 9, by + 9, 6))
+cx, cy = np.concatenate(cx), np.concatenate(cy)
+n = len(cx)
+fw, fh, fx, col = 40, 8, 20, 0x102030
+r = C.c_int(); steps = L.orc_num_steps(fw, fh, dpi, C.byref(r)); r = r.value
+r_pt = np.hypot(fw, fh) * 72 / dpi
+fg = np.zeros((fh, fw), np.uint32); L.orc_make_plane(po.P(fg), fw, fh, fx, col)
+
+def rect_pt(k, a):
+    if np.pi / 2 < a < 3 * np.pi / 2:
+        a -= np.pi
+    ca, sa = np.cos(a), np.sin(a)
+    pts = []
+    for ux, uy in ((0, 0), (fx, 0), (fx, -fh), (0, -fh)):
+        pts += [(cx[k] + ca * ux - sa * uy) * 72 / dpi, (cy[k] + sa * ux + ca * uy) * 72 / dpi]
+    return np.array(pts)
+
+def find(ways, rects, k):
+    """find_angle on the reference's cut-out of caption k: the ways and the rectangles so far rendered again with the 24.8 shift
+    of a replay translated by (-x + r/2, -y + r/2) pt (cairo_smr_cut_out; oracle: orc_canvas_set_shift)"""
+    c = L.orc_canvas_new(0, 0, r, r, dpi, 0xffffff)
+    L.orc_canvas_set_shift(c, -cx[k] * 72 / dpi + r_pt / 2, -cy[k] * 72 / dpi + r_pt / 2)
+    L.orc_rule_begin(c)
+    for wx, wy, closed in ways:
+        wx = np.ascontiguousarray(wx, np.float64); wy = np.ascontiguousarray(wy, np.float64)
+        L.orc_draw_way(c, C.byref(st), po.P(wx), po.P(wy), len(wx), int(closed), 0, 0, 0, 0)
+    L.orc_rule_end(c)
+    for pts in rects:
+        L.orc_direct_fill_pt(c, po.P(pts), 4, col)
+    cut = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (r, r)).copy()
+    L.orc_canvas_free(c)
+    return L.orc_find_angle(po.P(cut), r, po.P(fg), fw, fh, steps, 0.0, 1.0, None)
+
+# the reference's way: one caption after the other, every way of the chart
+all_ways = po.ways_from_arrays(x, y, off, ref)
+want, rects = np.zeros(n), []
+for k in range(n):
+    want[k] = find(all_ways, rects, k)
+    rects.append(rect_pt(k, want[k]))
+
+# banded: a rank holds only the ways within a window's reach of its band, and scans the captions anchored in its band
+margin = dist.window_margin_px(r, dist.stroke_margin_px(0.0, 0.3, dpi))
+keep = dist.ways_for_band(y, off, ref, y0, h, margin) if h > 0 else np.zeros(len(off) - 1, bool)
+mine = po.ways_from_arrays(*synth.select_ways(x, y, off, ref, keep))
+level, n_levels = dist.caption_levels(cx, cy, np.full(n, float(r)))
+seen = []
+scan = lambda idx: np.array([find(mine, seen, int(k)) for k in idx])
+def paint(idx, ang):
+    for k, a in zip(idx, ang):
+        seen.append(rect_pt(int(k), float(a)))
+got = dist.scan_captions_banded(g, cy, bands, level, n_levels, scan, paint)
+assert n_levels >= 3, n_levels
+assert np.array_equal(got, want), (np.nonzero(got != want)[0].tolist(), g.rank)
+if g.world > 1 and h > 0:
+    assert keep.sum() < len(keep)                      # the rank really holds a part of the chart only
+g.barrier(); g.close()
+print("rank", g.rank, "ok")
+'''
+
+
 def _run(tmp_path, text, world, port, extra_env=None):
     script = tmp_path / "worker.py"
     script.write_text(text)
@@ -152,6 +229,14 @@ def test_same_rule_captions_across_band_boundaries_2_ranks(tmp_path):
 def test_same_rule_captions_8_ranks_ragged_height(tmp_path):
     """8 ranks on a chart whose height is no multiple of 32: short last band, halo strips of unequal length"""
     _run(tmp_path, CAP_WORKER, 8, 29521, {"SMR_TEST_H": "203"})
+
+
+def test_captions_on_re_rasterised_cutouts_need_no_halo(tmp_path):
+    """the scan on the reference's own cut-outs (windows rendered again at each anchor's sub-pixel offset) over row
+    bands: no pixel exchange at all -- a rank holds the ways within dist.window_margin_px of its band, scans the captions
+    anchored in its band, and the levels' angles are summed over the ranks as before; 3 ranks give the angles of the
+    one-after-the-other scan with every way of the chart"""
+    _run(tmp_path, WIN_WORKER, 3, 29523, {"SMR_TEST_H": "300"})
 
 
 def test_two_gloo_ranks(tmp_path):
