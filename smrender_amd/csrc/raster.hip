@@ -1966,6 +1966,7 @@ struct sort_args_t
    int TX, band_y0, band_h;
    const uint2 *drows;        /* k_cover's strip table (primitives with SMR_PF_DELTA) */
    uint32_t *tile_cnt;        /* [n_tiles] entries of the tile's work stream (entries that bring nothing are left out) */
+   int vec;                   /* a sparse rule: every wavefront looks at 64 tiles at once and sorts the few that hold anything */
 };
 
 /* SORT_WAVES independent wavefronts per workgroup, one tile each (a chart of 4 M tiles is 4 M one-wave workgroups otherwise,
@@ -1978,11 +1979,24 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
    extern __shared__ uint32_t sall[];              /* [SORT_WAVES][A.lds_cap]: sized for the fullest tile of the launch */
    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    uint32_t *s = sall + (size_t) wv * A.lds_cap;
-   const uint32_t tile = smr_xcd_remap(blockIdx.x, gridDim.x) * SORT_WAVES + wv;      /* an XCD's workgroups sort neighbouring tiles */
-   if (tile >= A.n_tiles) return;
-   const uint32_t beg = A.tile_off[tile], n = A.tile_off[tile + 1] - beg;
+   const uint32_t wid = smr_xcd_remap(blockIdx.x, gridDim.x) * SORT_WAVES + wv;       /* an XCD's workgroups sort neighbouring tiles */
    const uint32_t lane = threadIdx.x & 63u;
-   if (n == 0) { if (lane == 0) A.tile_cnt[tile] = 0; return; }
+   const uint32_t t0 = A.vec ? wid * 64u : wid;
+   if (t0 >= A.n_tiles) return;
+   unsigned long long todo = 1ull;
+   if (A.vec)
+   {
+      const uint32_t tl = t0 + lane;
+      const uint32_t nl = tl < A.n_tiles ? A.tile_off[tl + 1] - A.tile_off[tl] : 0u;
+      if (tl < A.n_tiles && nl == 0u) A.tile_cnt[tl] = 0u;
+      todo = __ballot(nl != 0u);
+   }
+   while (todo)
+   {
+   const uint32_t tile = t0 + (uint32_t) __ffsll((long long) todo) - 1u;
+   todo &= todo - 1ull;
+   const uint32_t beg = A.tile_off[tile], n = A.tile_off[tile + 1] - beg;
+   if (n == 0) { if (lane == 0) A.tile_cnt[tile] = 0; continue; }
    uint32_t N = 2;
    while (N < n) N <<= 1;
    const bool in_lds = N <= A.lds_cap;
@@ -2093,6 +2107,8 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
       if (valid && in_lds && n >= 2) A.entries[beg + i] = idx;
    }
    if (lane == 0) A.tile_cnt[tile] = kept;
+   SMR_WAVE_SYNC();            /* the next tile of this wavefront reuses the LDS block */
+   }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -2302,8 +2318,19 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
    k0 = __builtin_amdgcn_readfirstlane(k0);
    if (k0 >= (BIG ? A.ovf_n : ktotal)) break;
    const uint32_t k1 = BIG ? k0 + 1u : min(k0 + A.chunk, ktotal);
-   for (uint32_t kg = k0; kg < k1; kg++)
+   /* a sparse rule leaves most tiles empty: the lanes look at 64 tiles of the chunk at once, and only those with entries are visited */
+   for (uint32_t kb = k0; kb < k1; kb += 64u)
    {
+   unsigned long long todo = 1ull;
+   if (!BIG)
+   {
+      const uint32_t kl = kb + (uint32_t) lane;
+      todo = __ballot(kl < k1 && A.tile_cnt[(uint32_t) (kl % TYt) * A.TX + (xcd + 8u * (kl / TYt))] != 0u);
+   }
+   while (todo)
+   {
+      const uint32_t kg = kb + (uint32_t) __ffsll((long long) todo) - 1u;
+      todo &= todo - 1ull;
       /* the overflowed tiles come from the list (one queue: they are few), the others from the XCD's columns */
       const uint32_t tile = BIG ? A.ovf_list[kg] : (uint32_t) (kg % TYt) * A.TX + (xcd + 8u * (kg / TYt));
       const int tx = (int) (tile % (uint32_t) A.TX), ty = (int) (tile / (uint32_t) A.TX);
@@ -2835,6 +2862,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
       TICK(8);            /* layer OVER canvas */
    }
    }
+   }
 #ifdef SMR_SECTION_PROFILE
    if (lane == 0) for (int i = 0; i < 12; i++) atomicAdd((unsigned long long *) (A.status + 14) + i, prof[i]);
 #endif
@@ -2868,6 +2896,7 @@ struct cover_args_t
    uint32_t drow_cap;
    uint32_t *ctr;             /* [0] next primitive [1] alpha words taken [2] strips taken [3] primitives done [4] primitives left to k_raster */
    int band_y0, band_h;
+   uint32_t chunk;            /* primitives a wavefront takes from the queue with one atomic: SMR_CV_CHUNK on a full chart, fewer when the rule is small */
 };
 
 struct cover_lds_t
@@ -2916,10 +2945,10 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
    for (;;)
    {
    uint32_t p0 = 0;
-   if (lane == 0) p0 = atomicAdd(&A.ctr[0], SMR_CV_CHUNK);
+   if (lane == 0) p0 = atomicAdd(&A.ctr[0], A.chunk);
    p0 = __builtin_amdgcn_readfirstlane(p0);
    if (p0 >= A.n_prims) break;
-   const uint32_t p1 = min(p0 + SMR_CV_CHUNK, A.n_prims);
+   const uint32_t p1 = min(p0 + A.chunk, A.n_prims);
    for (uint32_t p = p0; p < p1; p++)
    {
       const smr_prim_t P = A.prims[p];
@@ -4115,7 +4144,10 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       /* k_prim_setup has added up what the eligible primitives need at most (h_small[11] strips, h_small[12..13] alpha words);
        * on top of it the blocks the wavefronts take and do not use up.  An arena that runs out (beyond 2^32 words) leaves the
        * remaining primitives to k_raster's own path */
-      const unsigned nwg = (unsigned) std::min<int64_t>((n_prims + SMR_CV_CHUNK * SMR_CV_WAVES - 1) / (SMR_CV_CHUNK * SMR_CV_WAVES), 256 * 20 / SMR_CV_WAVES);
+      /* a small rule is spread over as many wavefronts as it has primitives (a wavefront needs ~30 us per primitive) */
+      const unsigned max_wg = 256 * 20 / SMR_CV_WAVES;
+      const uint32_t cv_chunk = (uint32_t) std::max<int64_t>(1, std::min<int64_t>(SMR_CV_CHUNK, n_prims / ((int64_t) max_wg * SMR_CV_WAVES)));
+      const unsigned nwg = (unsigned) std::min<int64_t>((n_prims + cv_chunk * SMR_CV_WAVES - 1) / (cv_chunk * SMR_CV_WAVES), max_wg);
       uint64_t need_a = (uint64_t) h_small[12] | ((uint64_t) h_small[13] << 32);
       uint64_t acap = need_a + (uint64_t) nwg * SMR_CV_WAVES * SMR_CV_DBLOCK + 65536;
       uint64_t rcap = (uint64_t) h_small[11] + (uint64_t) nwg * SMR_CV_WAVES * SMR_CV_RBLOCK + 65536;
@@ -4126,7 +4158,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       cover_args_t CV;
       CV.prims = prims; CV.n_prims = (uint32_t) n_prims; CV.edges = edges; CV.mask = maskbuf;
       CV.alpha = alpha; CV.alpha_cap = (uint32_t) acap; CV.drows = drows; CV.drow_cap = (uint32_t) rcap;
-      CV.ctr = cvctr; CV.band_y0 = c->band_y0; CV.band_h = c->band_h;
+      CV.ctr = cvctr; CV.band_y0 = c->band_y0; CV.band_h = c->band_h; CV.chunk = cv_chunk;
       k_cover<<<nwg, 64 * SMR_CV_WAVES, 0, s>>>(CV);
       SMR_HIP(hipGetLastError());
    }
@@ -4168,7 +4200,9 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       uint32_t cap = 64;
       while (cap < h_small[7] && cap < SORT_LDS) cap <<= 1;       /* h_small[7]: entries of the fullest tile (k_scan_block) */
       SO.lds_cap = cap;
-      k_tile_sort<<<(n_tiles + SORT_WAVES - 1) / SORT_WAVES, 64 * SORT_WAVES, (size_t) SORT_WAVES * cap * 4, s>>>(SO);
+      SO.vec = (uint64_t) n_entries * 16ull < n_tiles ? 1 : 0;
+      const uint32_t nwork = SO.vec ? (n_tiles + 63u) / 64u : n_tiles;
+      k_tile_sort<<<(nwork + SORT_WAVES - 1) / SORT_WAVES, 64 * SORT_WAVES, (size_t) SORT_WAVES * cap * 4, s>>>(SO);
    }
    SMR_HIP(hipGetLastError());
    T.mark(s);                                                   /* 4: binned + sorted */
@@ -4185,7 +4219,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    A.tile_ctr = &small[64];       /* zero since the memset at the top of the pass */
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
-   A.chunk = n_entries >= 8ull * n_tiles ? SMR_TILE_CHUNK : n_entries >= 2ull * n_tiles ? 2 * SMR_TILE_CHUNK : 4 * SMR_TILE_CHUNK;
+   A.chunk = n_entries >= 8ull * n_tiles ? SMR_TILE_CHUNK : n_entries >= 2ull * n_tiles ? 2 * SMR_TILE_CHUNK : n_entries * 16ull >= n_tiles ? 4 * SMR_TILE_CHUNK : 64;
    A.direct = st->direct != 0;
    A.ovf_list = ovf_list; A.ovf_cnt = &small[8]; A.ovf_n = 0; A.big_bucket = nullptr; A.big_cap = 0; A.alpha = alpha;
    {
