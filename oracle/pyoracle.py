@@ -219,11 +219,14 @@ def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0, image=None):
     if image is not None:
         L.orc_canvas_set_image(c, *image)
     L.orc_rule_begin(c)
-    for x, y, closed in ways:
+    for way in ways:
+        x, y, closed = way[:3]
+        fcol = way[3] if len(way) > 3 else None                  # optional per-way colour (color=%key): open ways keep their own
         if not closed:
             x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
-            L.orc_draw_way(c, C.byref(s1), P(x), P(y), len(x), 0, 0, 0, 0, 0)
+            L.orc_draw_way(c, C.byref(s1), P(x), P(y), len(x), 0, fcol is not None, fcol or 0, 0, 0)
     L.orc_rule_end(c)
+    ways = [w[:3] for w in ways]
     edges = []
     img = image if image is not None else (x0, y0, x0 + W, y0 + H)
     lim = np.array([v * 256 for v in img], np.int32)

@@ -286,6 +286,7 @@ struct draw_rule_t
    std::vector<uint32_t> fill_col, border_col;
    /* directional=1: the closed way with the largest |area| decides about the page rectangle (:1091-1109) */
    double max_area = -1; bool max_cw = false; uint32_t max_col = 0;
+   double min_area = 1e300; uint32_t min_col = 0;      /* the smallest closed way: the LAST after act_draw_fini's qsort by area (:1099) */
    double wavy_deg = 0;                   /* wavy=1: wavy_length in degrees (:632-642) */
 };
 
@@ -497,6 +498,11 @@ static int draw_way_wavy(draw_rule_t *d, const smr_osm_way_t *w)
       d->max_area = fabs(ar); d->max_cw = ar < 0;
       d->max_col = d->fill_cs.key ? d->fill_col.back() : d->fill_cs.col;
    }
+   if (closed && d->st.directional && fabs(ar) <= d->min_area)
+   {
+      d->min_area = fabs(ar);
+      d->min_col = d->fill_cs.key ? d->fill_col.back() : d->fill_cs.col;
+   }
    return 0;
 }
 
@@ -550,6 +556,11 @@ static int draw_way(draw_rule_t *d, const smr_osm_way_t *w)
       d->max_area = fabs(ar); d->max_cw = ar < 0;
       d->max_col = d->fill_cs.key ? d->fill_col.back() : d->fill_cs.col;
    }
+   if (closed && d->st.directional && fabs(ar) <= d->min_area)
+   {
+      d->min_area = fabs(ar);
+      d->min_col = d->fill_cs.key ? d->fill_col.back() : d->fill_cs.col;
+   }
    return 0;
 }
 
@@ -584,6 +595,8 @@ static int draw_fini(smr_smrule_t *r)
    {
       /* the largest polygon is clockwise: a page-sized polygon goes first, so that it becomes a hole
        * (:1103-1109); the fill colour is the one of that first way unless it is the hole (:1116-1129) */
+      const bool cw = d->max_cw;                        /* of the chart's own ways: the page rectangle below goes through draw_way too */
+      const uint32_t max_col = d->max_col, min_col = d->min_col;
       if (d->max_cw)
       {
          const smr_osm_way_t *pw = H.page_way ? H.page_way() : nullptr;
@@ -591,7 +604,16 @@ static int draw_fini(smr_smrule_t *r)
          else { const char *k1 = d->fill_cs.key, *k2 = d->border_cs.key; d->fill_cs.key = d->border_cs.key = nullptr;
                 draw_way(d, pw); d->fill_cs.key = k1; d->border_cs.key = k2; if (k1) d->fill_col.push_back(0); }
       }
-      d->st.fill_col = d->max_cw ? (d->fill_cs.key ? 0u : d->fill_cs.col) : d->max_col;
+      /* key colouring with a clockwise largest way: act_draw_fini sets no colour (:1117-1125), the fill takes the source that
+       * render_poly_line (:1002) left for the last way of the sorted list, the smallest one */
+      d->st.fill_col = cw ? (d->fill_cs.key ? min_col : d->fill_cs.col) : max_col;
+      /* with key colouring every way carries its own colour; the closed ways are ONE fill in the colour decided above */
+      if (d->fill_cs.key)
+         for (size_t w = 0; w + 1 < d->way_off.size() && w < d->fill_col.size(); w++)
+         {
+            const int64_t a = d->way_off[w], b = d->way_off[w + 1];
+            if (b - a >= 4 && d->ref[(size_t) a] == d->ref[(size_t) b - 1]) d->fill_col[w] = d->st.fill_col;
+         }
    }
    const int64_t n_ways = (int64_t) d->way_off.size() - 1, n_refs = (int64_t) d->ref.size();
    if (n_ways > 0 && n_refs > 0)
@@ -763,6 +785,7 @@ struct cap_rule_t
    const char *akey = nullptr;
    bool fill_used = false;
    col_spec_t fill_cs;
+   bool have_auto_col = false; uint32_t auto_col = 0;      /* auto_ctx's source: the colour of the FIRST object act_cap_main sees, matched or not (:2455-2459) */
    void *sfc = nullptr, *ctx = nullptr;
    std::vector<cap_item_t> items;
 };
@@ -977,6 +1000,7 @@ static int cap_main(smr_smrule_t *r, smr_osm_obj_t *o)
 {
    cap_rule_t *cap = (cap_rule_t *) r->data;
    if (cap == nullptr) return -1;
+   if (!cap->have_auto_col) { cap->auto_col = color_by_cs(o, &cap->cs); cap->have_auto_col = true; }
    int n = -1;
    for (size_t i = 0; i < cap->klist.size(); i++)
       if ((n = H.match_attr(o, cap->klist[i].c_str(), nullptr)) >= 0) break;
@@ -1454,7 +1478,7 @@ static int cap_fini(smr_smrule_t *r)
          /* this level's rectangles into every window they reach: the later levels' scans see them */
          rect_batch_t rb;
          rb.x = rx; rb.y = ry; rb.off = roff; rb.ref = rref;
-         rb.col = cap->items[0].col;                           /* auto_ctx's source: the first object's colour (:2459) */
+         rb.col = cap->auto_col;                               /* auto_ctx's source: the first object's colour (:2459) */
          if (atl.add_rects(rb) != 0) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
       }
       else if (!rref.empty())
@@ -1467,7 +1491,7 @@ static int cap_fini(smr_smrule_t *r)
          {
             smr_draw_style_t st;
             memset(&st, 0, sizeof(st));
-            st.fill_used = 1; st.fill_col = cap->items[0].col; st.direct = 1;     /* auto_ctx's source: the first object's colour (:2459) */
+            st.fill_used = 1; st.fill_col = cap->auto_col; st.direct = 1;       /* auto_ctx's source: the first object's colour (:2459) */
             smr_draw_batch_t b;
             memset(&b, 0, sizeof(b));
             b.d_x = (const double *) dx.p; b.d_y = (const double *) dy.p; b.n_nodes = (int64_t) rx.size();

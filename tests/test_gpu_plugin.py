@@ -184,7 +184,7 @@ def test_wavy_rule_through_the_action_api(chart, params, width_mm, length_mm):
 
 
 @pytest.mark.parametrize("sea_first", [True, False])
-def test_directional_rule_with_page_rectangle(chart, sea_first):
+def test_directional_rule_with_page_rectangle(chart, sea_first, keycol=False):
     """directional=1 through the action API (act_draw_ini :673-686, _main :1039-1052, _fini :1084-1140): the way
     with the largest area decides; if it runs clockwise the page rectangle of page_way() becomes the outer ring"""
     from test_oracle_cairo import _nested_scene
@@ -199,8 +199,19 @@ def test_directional_rule_with_page_rectangle(chart, sea_first):
         # make the largest way clockwise (page rectangle expected) / counterclockwise (none) as the case wants
         ways = [(x[::-1].copy(), y[::-1].copy(), c) if c else (x, y, c) for x, y, c in ways]
     arrs = _ways_to_arrays(ways)
-    wids, oways = load_ways(sa, proj, arrs)
-    rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.2;width=0.3;directional=1", wids)
+    fill = 0x4080c0
+    if keycol:
+        # color=%col: the fill takes the colour of the largest way, or, when that one runs clockwise, no colour is set and the
+        # source of the last way of the list sorted by area stays: the smallest closed way's (act_draw_fini :1099, :1117-1125)
+        cols = [((37 * k + 16) % 256) << 16 | ((91 * k + 32) % 256) << 8 | ((53 * k + 48) % 256) for k in range(len(ways))]
+        wids, oways = load_ways(sa, proj, arrs, [f"col=#{c:06x}" for c in cols])
+        closed = [k for k, w in enumerate(ways) if w[2]]
+        by_area = sorted(closed, key=lambda k: abs(area_on_chart(ways[k][0], ways[k][1])))
+        fill = cols[by_area[0]] if sea_first else cols[by_area[-1]]
+        rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=%col;width=0.3;directional=1", wids)
+    else:
+        wids, oways = load_ways(sa, proj, arrs)
+        rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.2;width=0.3;directional=1", wids)
     assert rc == 0, sa.lib().smr_hip_last_error()
     if sea_first:
         op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
@@ -208,11 +219,19 @@ def test_directional_rule_with_page_rectangle(chart, sea_first):
         plon = np.array([proj.lon0, proj.lon0, proj.lon_ru, proj.lon_ru, proj.lon0])
         px, py, _, _, _ = po.project(op, plat, plon)
         oways = oways + [(px, py, True)]
-    want = po.oracle_directional(po.Style(1, 0, 0x4080c0, 0, 0.3, 0, 0), oways, DPI, W, H, 0xfff8e0)
+    if keycol:
+        # open ways are stroked in their own colours; the oracle helper takes per-way colours as (x, y, closed, fill, border)
+        oways = [(w[0], w[1], w[2], (cols[k] if k < len(cols) else None), None) if not w[2] else w for k, w in enumerate(oways)]
+    want = po.oracle_directional(po.Style(1, 0, fill, 0, 0.3, 0, 0), oways, DPI, W, H, 0xfff8e0)
     got = plugin_canvas(sa)
-    assert np.array_equal(got, want)
+    assert np.array_equal(got, want), (int((got != want).sum()), [hex(v) for v in np.unique(got[got != want])[:6]], [hex(v) for v in np.unique(want[got != want])[:6]])
     # with the page rectangle the chart's corner is painted; without, it is outside every ring
     assert ((got[0, 0] & 0xffffff) != 0xfff8e0) == sea_first
+
+
+@pytest.mark.parametrize("sea_first", [True, False])
+def test_directional_rule_with_key_colours(chart, sea_first):
+    test_directional_rule_with_page_rectangle(chart, sea_first, keycol=True)
 
 
 def test_directional_wavy_rule_with_page_rectangle(chart):
