@@ -126,6 +126,18 @@ int smr_hip_canvas_write_tiles(smr_canvas_t *c, int x, int y, int nx, int ny, in
 /* device pointer + row stride (pixels) of the band, for zero-copy consumers */
 int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *stride_px);
 
+/* ---- poly_area: replaces poly_area() per way --------------------------------------------
+ * src/smfunc.c:377-432: signed area in square nautical miles (> 0: counterclockwise, < 0: clockwise) and centroid of every
+ * CLOSED way of a batch given in degrees, sums in the reference's order.  It is what act_draw_fini sorts the ways of a
+ * directional rule by (src/smrules_cairo.c:1087-1099), cap_way places a caption with (:2395-2444) and the coastline closing
+ * orients its polygons with.  d_ref NULL = identity; an open way gets area 0 and a NaN centroid (the
+ * reference returns -1 for it); d_clat / d_clon may be NULL.  The formula cancels about nine digits for chart-sized ways, so the
+ * last bit of cos() shows as ~1e-10 square miles of area whatever the way's size (and in the centroid divided by the area: metres
+ * for a 100 m islet): the device's values agree with the host's that far (sign and order of the areas are what act_draw_fini uses);
+ * the plugin keeps the host's poly_area for caption anchors. */
+int smr_hip_poly_area(const double *d_lat, const double *d_lon, int64_t n_nodes, const int64_t *d_way_off, const int32_t *d_ref,
+                      int64_t n_ways, double *d_area, double *d_clat, double *d_clon);
+
 /* ---- draw: replaces act_draw_ini/_main/_fini for one rule --------------------------------
  * src/smrules_cairo.c:583-694 (style), :845-863 (path), :880-895 (widths), :953-1016
  * (render_poly_line: border stroke then fill / open stroke), :1019-1073, :1076-1148

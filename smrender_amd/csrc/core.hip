@@ -204,3 +204,50 @@ extern "C" int smr_hip_unproject(const double *d_x, const double *d_y, int64_t n
    SMR_HIP(hipGetLastError());
    return SMR_OK;
 }
+
+/* ---- poly_area (src/smfunc.c:377-432): signed area in square nautical miles (> 0: counterclockwise) and centroid of every closed
+ * way, the sums taken in the reference's order (one lane walks one way from its first node on).  What act_draw_fini sorts the
+ * ways of a directional rule by (:1087-1099) and cap_way places a caption with (:2395-2444).  An open way (is_closed_poly,
+ * src/smcoast.c:115-125: at least 4 refs, first == last) gets area 0 and a NaN centroid, where the reference returns -1. ---- */
+__global__ void k_poly_area(const double *__restrict__ lat, const double *__restrict__ lon, int64_t n_nodes, const int64_t *__restrict__ way_off,
+                            const int32_t *__restrict__ ref, int64_t n_ways, double *__restrict__ area, double *__restrict__ clat, double *__restrict__ clon)
+{
+   const int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (w >= n_ways) return;
+   const int64_t a = way_off[w], b = way_off[w + 1];
+   auto node = [&](int64_t g) { int64_t v = ref ? (int64_t) ref[g] : g; return v < 0 || v >= n_nodes ? (int64_t) -1 : v; };
+   double ar = 0, cla = 0, clo = 0;
+   bool ok = b - a >= 4 && node(a) >= 0 && node(a) == node(b - 1);
+   if (ok)
+   {
+      int64_t n1 = node(a);
+      for (int64_t g = a; g + 1 < b; g++)
+      {
+         const int64_t n0 = n1;
+         n1 = node(g + 1);
+         if (n1 < 0) { ok = false; break; }
+         const double x0 = lon[n0] * cos(lat[n0] * M_PI / 180.0), x1 = lon[n1] * cos(lat[n1] * M_PI / 180.0);
+         const double f = x0 * lat[n1] - x1 * lat[n0];
+         clo += (x0 + x1) * f;
+         cla += (lat[n0] + lat[n1]) * f;
+         ar += f;
+      }
+   }
+   if (!ok) { area[w] = 0; if (clat) clat[w] = NAN; if (clon) clon[w] = NAN; return; }
+   cla /= 3.0 * ar;
+   clo /= 3.0 * ar * cos(cla * M_PI / 180.0);
+   area[w] = ar * 1800.0;
+   if (clat) clat[w] = cla;
+   if (clon) clon[w] = clo;
+}
+
+extern "C" int smr_hip_poly_area(const double *d_lat, const double *d_lon, int64_t n_nodes, const int64_t *d_way_off, const int32_t *d_ref,
+                                 int64_t n_ways, double *d_area, double *d_clat, double *d_clon)
+{
+   SMR_NEED_INIT();
+   if (!d_lat || !d_lon || !d_way_off || !d_area || n_ways < 0 || n_nodes < 0) return smr_fail(SMR_E_INVAL, "poly_area: NULL argument");
+   if (n_ways == 0) return SMR_OK;
+   k_poly_area<<<(unsigned) ((n_ways + 127) / 128), 128, 0, smr_g.stream>>>(d_lat, d_lon, n_nodes, d_way_off, d_ref, n_ways, d_area, d_clat, d_clon);
+   SMR_HIP(hipGetLastError());
+   return SMR_OK;
+}

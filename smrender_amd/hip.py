@@ -87,7 +87,7 @@ EXPORTS = [
     "smr_hip_canvas_set_halo", "smr_hip_canvas_set_halo_device", "smr_hip_canvas_extend", "smr_hip_canvas_clone", "smr_hip_canvas_blit",
     "smr_hip_canvas_write_png", "smr_hip_canvas_write_tiles",
     "smr_hip_windows_create", "smr_hip_draw_windows", "smr_hip_windows_anchors", "smr_hip_blit_windows",
-    "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
+    "smr_hip_poly_area", "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
     "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
     "act_draw_ini", "act_draw_main", "act_draw_fini", "act_cap_ini", "act_cap_main", "act_cap_fini",
@@ -120,6 +120,7 @@ def lib():
         L.smr_hip_canvas_set_halo_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         L.smr_hip_canvas_extend.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.smr_hip_canvas_blit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.smr_hip_poly_area.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.smr_hip_windows_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         L.smr_hip_draw_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.smr_hip_windows_anchors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -223,6 +224,12 @@ def project(d_lat, d_lon, d_x, d_y, d_ix=None, d_iy=None, d_on=None):
     n = int(np.prod(d_lat.shape))
     _chk(lib().smr_hip_project(d_lat.ptr, d_lon.ptr, n, d_x.ptr, d_y.ptr,
                                d_ix.ptr if d_ix else None, d_iy.ptr if d_iy else None, d_on.ptr if d_on else None))
+
+
+def poly_area(d_lat, d_lon, d_way_off, d_ref, n_ways, d_area, d_clat=None, d_clon=None):
+    """poly_area (src/smfunc.c:377-432) of every closed way: signed square nautical miles, centroid in degrees (smr_hip_poly_area)"""
+    _chk(lib().smr_hip_poly_area(d_lat.ptr, d_lon.ptr, int(np.prod(d_lat.shape)), d_way_off.ptr, d_ref.ptr if d_ref else None, n_ways,
+                                 d_area.ptr, d_clat.ptr if d_clat else None, d_clon.ptr if d_clon else None))
 
 
 def unproject(d_x, d_y, d_lon, d_lat):

@@ -88,3 +88,52 @@ def test_project_rejects_misaligned_arrays(hip):
     d = sa.DeviceArray((8,), np.float64)
     rc = sa.lib().smr_hip_project(d.ptr + 8, d.ptr, 2, d.ptr, d.ptr, None, None, None)
     assert rc == -2 and b"aligned" in sa.lib().smr_hip_last_error()
+
+
+@pytest.mark.gpu
+def test_poly_area_matches_the_hosts(hip):
+    """smr_hip_poly_area against poly_area as the miniature host runs it (oracle/hostsim.c: the reference's loop, src/smfunc.c:
+    377-432, over the reference's own libsmrender objects; pinned there by an independent shoelace): area and centroid of
+    closed ways as far as the formula defines them (see below), orientation sign exact, open ways area 0 / NaN centroid"""
+    import hostsim as hs
+    if not hs.available():
+        pytest.skip("oracle/_ref not built")
+    sa = hip
+    from smrender_amd import synth
+    proj = sa.Projection.from_window(45.0, 15.0, 25000.0, 400.0, 300.0, 300)
+    hs.set_chart(proj, 0xffffff)
+    x, y, off, ref = synth.synth_ways(60, 400, 300, seed=17)
+    # every third way reversed (clockwise / counterclockwise mix), every fifth opened (its closing ref dropped)
+    lat, lon = synth.px_to_geo(proj, x, y)
+    refs, offs, wids = [], [0], []
+    base = 5_000_000
+    hs.add_nodes(base + np.arange(len(x)), lat, lon)
+    for w in range(len(off) - 1):
+        r = ref[off[w]:off[w + 1]].copy()
+        if w % 3 == 0:
+            r = r[::-1].copy()
+        if w % 5 == 4:
+            r = r[:-1]
+        refs.append(r); offs.append(offs[-1] + len(r))
+        hs.add_way(base + len(x) + w, base + r.astype(np.int64))
+        wids.append(base + len(x) + w)
+    D = sa.DeviceArray.from_numpy
+    n = len(wids)
+    d_area, d_clat, d_clon = (sa.DeviceArray((n,), np.float64) for _ in range(3))
+    sa.poly_area(D(lat), D(lon), D(np.array(offs, np.int64)), D(np.concatenate(refs).astype(np.int32)), n, d_area, d_clat, d_clon)
+    sa.sync()
+    area, clat, clon = d_area.numpy(), d_clat.numpy(), d_clon.numpy()
+    seen_cw = seen_ccw = 0
+    for w in range(n):
+        if w % 5 == 4:
+            assert area[w] == 0 and np.isnan(clat[w]) and np.isnan(clon[w])
+            continue
+        hlat, hlon, har = hs.poly_area(wids[w])
+        assert np.sign(area[w]) == np.sign(har)
+        # the reference's formula cancels about nine digits (terms of ~500 deg^2 sum to ~1e-6 deg^2 for a way of this size), so
+        # a last-bit difference between the device's cos and glibc's shows at 1e-7 relative: the reference's own value is only
+        # that well defined
+        # (an ABSOLUTE error of ~1e-10 square miles whatever the way's size; the centroid divides by the area)
+        assert abs(area[w] - har) <= 1e-9 and abs(clat[w] - hlat) <= 4e-9 / abs(har) and abs(clon[w] - hlon) <= 4e-9 / abs(har), w
+        seen_cw += har < 0; seen_ccw += har > 0
+    assert seen_cw > 5 and seen_ccw > 5
