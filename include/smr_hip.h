@@ -138,6 +138,46 @@ int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *stride_px);
 int smr_hip_poly_area(const double *d_lat, const double *d_lon, int64_t n_nodes, const int64_t *d_way_off, const int32_t *d_ref,
                       int64_t n_ways, double *d_area, double *d_clat, double *d_clon);
 
+/* ---- objects: the host's object tree as structure-of-arrays, and the rule executor's filter on the device -------------------
+ * SURVEY 8f rank 3.  Replaces, for many rules at once, what apply_smrules does per rule and object (src/smcore.c:424-491:
+ * traverse -> apply_rule :248-312 -> bs_match_attr, libsmrender/smutil.c:330-356 -> `_main`): one export of the objects
+ * (smr_hip_objects_create: `nodes` / `ways` are the host's own osm_node_t* / osm_way_t*, e.g. gathered by one traverse() of the
+ * bxtree, in the order the executor visits them), then per batch of rules one bitmap row per rule with a bit for every object
+ * apply_rule would have called `_main` for, then per rule the selected ways as a smr_draw_batch_t's arrays or the selected
+ * nodes as indices.  Tags are dictionary encoded (one id per distinct byte string); way refs become node indices on the
+ * device (a ref whose node is not among `nodes` becomes -1, and selections pass over it as poly_line does,
+ * src/smrules_cairo.c:853-857).  `nodes` must hold every node the ways refer to. */
+typedef struct smr_objects smr_objects_t;
+typedef struct
+{
+   int64_t n_nodes, n_ways, n_refs, n_node_tags, n_way_tags, n_strings, pool_bytes, missing_refs;
+   const int64_t *d_node_id; const double *d_lat, *d_lon;                    /* [n_nodes] device: input of smr_hip_project */
+   const int64_t *d_way_id; const int64_t *d_way_off; const int32_t *d_ref;  /* [n_ways], [n_ways+1], [n_refs] device */
+   double extract_ms, upload_ms, index_ms;                                   /* host walk + dictionary, copies, ref look-up */
+} smr_objects_info_t;
+int smr_hip_objects_create(const void *const *nodes, int64_t n_nodes, const void *const *ways, int64_t n_ways, int threads, smr_objects_t **out);
+int smr_hip_objects_destroy(smr_objects_t *o);
+int smr_hip_objects_info(const smr_objects_t *o, smr_objects_info_t *info);
+/* rules[r] = the host's smrule_t* after init_rules (match tags parsed by parse_matchtag, src/smrparse.c:150-159: patterns in
+ * oo->otag[], kinds in act->stag[]).  Row r of d_bitmap (words_per_rule 64-bit words, >= (max(n_nodes, n_ways) + 63) / 64;
+ * bit i of word j = object 64 j + i of the rule's type) gets a 1 where apply_rule reaches the call of `_main`: the node is on
+ * the page (d_node_on_page = smr_hip_project's onpage output, NULL = render_all_nodes), an ACTION_CLOSED_WAY / ACTION_OPEN_WAY
+ * rule meets a closed / open way, every match tag finds its tag (direct, /regex/, ]greater[, [less], !inverted!, ~not~), the
+ * object is visible.  counts[r] (HOST) = the number of 1s; -1 for a relation rule (not handled: its row is all 0).
+ * Regular expressions run on the host, once per distinct string, through regexec() on the rule's own regex_t. */
+int smr_hip_objects_match(smr_objects_t *o, const void *const *rules, int n_rules, const uint8_t *d_node_on_page,
+                          uint64_t *d_bitmap, int64_t words_per_rule, int64_t *counts);
+/* the ways / nodes of one bitmap row, in object order.  The arrays belong to `o` and hold until its next selection */
+typedef struct
+{
+   int64_t n_ways, n_refs;
+   const int64_t *d_way_off;        /* [n_ways+1] device */
+   const int32_t *d_ref;            /* [n_refs] device: node indices, missing nodes dropped */
+   const int32_t *d_way_index;      /* [n_ways] device: which way of the export each one is */
+} smr_way_selection_t;
+int smr_hip_objects_select_ways(smr_objects_t *o, const uint64_t *d_bitmap_row, smr_way_selection_t *sel);
+int smr_hip_objects_select_nodes(smr_objects_t *o, const uint64_t *d_bitmap_row, const int32_t **d_index, int64_t *n);
+
 /* ---- draw: replaces act_draw_ini/_main/_fini for one rule --------------------------------
  * src/smrules_cairo.c:583-694 (style), :845-863 (path), :880-895 (widths), :953-1016
  * (render_poly_line: border stroke then fill / open stroke), :1019-1073, :1076-1148

@@ -44,6 +44,11 @@ SAME(smr_smrule_t, smrule_t); SAMEF(smr_smrule_t, smrule_t, data); SAMEF(smr_smr
 _Static_assert(sizeof(smr_action_t) == offsetof(action_t, stag), "action_t head");
 SAMEF(smr_action_t, action_t, fp); SAMEF(smr_action_t, action_t, flags); SAMEF(smr_action_t, action_t, tag_cnt);
 SAMEF(smr_action_t, action_t, libhandle); SAMEF(smr_action_t, action_t, parm);
+SAME(struct smr_special_tag, struct specialTag); SAMEF(struct smr_special_tag, struct specialTag, val); SAMEF(struct smr_special_tag, struct specialTag, re);
+SAME(struct smr_stag, struct stag); SAMEF(struct smr_stag, struct stag, stv);
+_Static_assert(SMR_SPECIAL_REGEX == SPECIAL_REGEX && SMR_SPECIAL_GT == SPECIAL_GT && SMR_SPECIAL_LT == SPECIAL_LT && SMR_SPECIAL_MASK == SPECIAL_MASK
+               && SMR_SPECIAL_NOT == SPECIAL_NOT && SMR_SPECIAL_INVERT == SPECIAL_INVERT && SMR_SPECIAL_DIRECT == SPECIAL_DIRECT, "match kinds");
+_Static_assert(SMR_ACTION_OPEN_WAY == ACTION_OPEN_WAY && SMR_ACTION_CLOSED_WAY == ACTION_CLOSED_WAY, "way flags");
 SAME(struct smr_rdata, struct rdata); SAMEF(struct smr_rdata, struct rdata, bb); SAMEF(struct smr_rdata, struct rdata, polygon_window);
 SAMEF(struct smr_rdata, struct rdata, wc); SAMEF(struct smr_rdata, struct rdata, lath); SAMEF(struct smr_rdata, struct rdata, lath_len);
 SAMEF(struct smr_rdata, struct rdata, w); SAMEF(struct smr_rdata, struct rdata, h); SAMEF(struct smr_rdata, struct rdata, dpi);
@@ -298,4 +303,98 @@ const char *hs_get_tag(int type, int64_t id, const char *key)
    memcpy(buf, o->otag[n].v.buf, l);
    buf[l] = '\0';
    return buf;
+}
+
+/* ---- match tags and the executor's filter (for smr_hip_objects_match) ----
+ * A rule as init_rule leaves it (src/smrparse.c:365-467): oo->otag[] = the patterns with their markers stripped, act->stag[] =
+ * their kinds, act->flags = ACTION_OPEN_WAY / ACTION_CLOSED_WAY from the rule way's own refs (check_way_type :340-351).
+ * match_kind restates parse_matchtype (:65-139): "!..!" inverts, "~..~" negates, then "/../" is a regular expression
+ * (regcomp, extended, no sub-matches), "]..[" greater than, "[..]" less than (strtod); anything else compares bytes. */
+static int match_kind(bstring_t *b, struct specialTag *t)
+{
+   t->type = 0;
+   if (b->len > 2 && b->buf[0] == b->buf[b->len - 1] && (b->buf[0] == '!' || b->buf[0] == '~'))
+   {
+      t->type |= b->buf[0] == '!' ? SPECIAL_INVERT : SPECIAL_NOT;
+      b->buf[b->len - 1] = '\0'; b->buf++; b->len -= 2;
+   }
+   if (b->len <= 2) return 0;
+   const char c0 = b->buf[0], c1 = b->buf[b->len - 1];
+   if (!((c0 == '/' && c1 == '/') || (c0 == ']' && c1 == '[') || (c0 == '[' && c1 == ']'))) return 0;
+   b->buf[b->len - 1] = '\0'; b->buf++; b->len -= 2;
+   if (c0 == '/')
+   {
+      if (regcomp(&t->re, b->buf, REG_EXTENDED | REG_NOSUB)) return -1;
+      t->type |= SPECIAL_REGEX;
+      return 0;
+   }
+   errno = 0;
+   t->val = strtod(b->buf, NULL);
+   if (errno) return -2;
+   t->type |= c0 == ']' ? SPECIAL_GT : SPECIAL_LT;
+   return 0;
+}
+
+/* way_kind: 0 = the rule way has no refs, 1 = open (ACTION_OPEN_WAY), 2 = closed (ACTION_CLOSED_WAY) */
+smrule_t *hs_match_rule(int type, const char *const *keys, const char *const *vals, int n, int way_kind)
+{
+   smrule_t *r = calloc(1, sizeof(*r));
+   action_t *a = calloc(1, sizeof(*a) + sizeof(struct stag) * (n > 0 ? n : 1));
+   osm_node_t *oo = calloc(1, sizeof(osm_storage_t));
+   oo->obj.type = (int8_t) type;
+   oo->obj.id = 0x7f000002;
+   oo->obj.otag = calloc(n > 0 ? n : 1, sizeof(struct otag));
+   oo->obj.tag_cnt = (short) n;
+   r->oo = &oo->obj; r->act = a;
+   a->tag_cnt = (short) n;
+   if (type == OSM_WAY && way_kind) a->flags |= way_kind == 2 ? ACTION_CLOSED_WAY : ACTION_OPEN_WAY;
+   for (int i = 0; i < n; i++)
+   {
+      struct otag *ot = &oo->obj.otag[i];
+      ot->k.buf = strdup(keys[i]); ot->k.len = (int) strlen(keys[i]);
+      ot->v.buf = strdup(vals[i]); ot->v.len = (int) strlen(vals[i]);
+      if (match_kind(&ot->k, &a->stag[i].stk) < 0 || match_kind(&ot->v, &a->stag[i].stv) < 0) break;      /* init_rule :385-386 */
+   }
+   return r;
+}
+
+/* apply_rule (src/smcore.c:248-291) up to the call of `_main`, with the REAL bs_match_attr of libsmrender: out[i] = 1 where the
+ * action would be called.  on_page: the is_on_page verdict per node (NULL = render_all_nodes_) */
+int hs_filter(const smrule_t *r, int type, const int64_t *ids, int n, const uint8_t *on_page, uint8_t *out)
+{
+   for (int k = 0; k < n; k++)
+   {
+      const osm_obj_t *o = get_object(type, ids[k]);
+      out[k] = 0;
+      if (o == NULL) return -1;
+      if (o->type == OSM_NODE && on_page != NULL && !on_page[k]) continue;
+      if (r->oo->type == OSM_WAY)
+      {
+         const osm_way_t *w = (const osm_way_t *) o;
+         if (sm_is_flag_set(r, ACTION_CLOSED_WAY)) { if (w->ref_cnt && w->ref[0] != w->ref[w->ref_cnt - 1]) continue; }
+         else if (sm_is_flag_set(r, ACTION_OPEN_WAY)) { if (w->ref_cnt && w->ref[0] == w->ref[w->ref_cnt - 1]) continue; }
+      }
+      int i;
+      for (i = 0; i < r->oo->tag_cnt; i++)
+         if (bs_match_attr(o, &r->oo->otag[i], &r->act->stag[i]) == -1) break;
+      if (i < r->oo->tag_cnt) continue;
+      if (!o->vis) continue;
+      out[k] = 1;
+   }
+   return 0;
+}
+
+int hs_object_ptrs(int type, const int64_t *ids, int n, void **out)
+{
+   for (int k = 0; k < n; k++)
+      if ((out[k] = get_object(type, ids[k])) == NULL) return -1;
+   return 0;
+}
+
+int hs_set_visible(int type, int64_t id, int vis)
+{
+   osm_obj_t *o = get_object(type, id);
+   if (o == NULL) return -1;
+   o->vis = (int8_t) vis;
+   return 0;
 }

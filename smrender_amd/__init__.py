@@ -7,9 +7,9 @@ The compute lives in ``libsmr_hip.so`` (hand-written HIP for gfx950, C-ABI in
 works anywhere, but every compute call raises if the library or a GPU is missing.
 """
 from .hip import (SmrHipError, lib, init, shutdown, DeviceArray, Projection, DrawStyle, Canvas,
-                  project, unproject, poly_area, set_projection, timings, set_profiling, sync, device_name,
+                  project, unproject, poly_area, Objects, set_projection, timings, set_profiling, sync, device_name,
                   caprot_steps)
 
 __all__ = ["SmrHipError", "lib", "init", "shutdown", "DeviceArray", "Projection", "DrawStyle", "Canvas",
-           "project", "unproject", "poly_area", "set_projection", "timings", "set_profiling", "sync", "device_name",
+           "project", "unproject", "poly_area", "Objects", "set_projection", "timings", "set_profiling", "sync", "device_name",
            "caprot_steps"]

@@ -5,12 +5,14 @@
  *   bstring_t, otag     libsmrender/bstring.h:31-35, libsmrender/osm_inplace.h:49-52
  *   osm_obj_t (2024 layout), osm_node_t, osm_way_t, osm_rel_t, rmember   osm_inplace.h:71-118
  *   struct rdata        src/rdata.h:99-158 (with bbox_t :76-79, dstats :81-92, MAX_ITER 64)
+ *   struct specialTag, struct stag   libsmrender/smaction.h:75-89 (the array behind action_t: objects.hip reads it)
  * and lists the host symbols the plugin calls.
  */
 #ifndef SMR_ABI_H
 #define SMR_ABI_H
 #include <stdint.h>
 #include <time.h>
+#include <regex.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -51,6 +53,13 @@ typedef struct smr_action
 } smr_action_t;
 
 typedef struct { smr_osm_obj_t *oo; void *data; smr_action_t *act; } smr_smrule_t;
+
+/* how a rule's match tag compares (parse_matchtype, src/smrparse.c:65-139, fills it): libsmrender/smaction.h:33-39, :52-54 */
+enum { SMR_SPECIAL_DIRECT = 0, SMR_SPECIAL_REGEX = 1, SMR_SPECIAL_GT = 2, SMR_SPECIAL_LT = 3, SMR_SPECIAL_MASK = 0xff,
+       SMR_SPECIAL_NOT = 0x4000, SMR_SPECIAL_INVERT = 0x8000 };
+enum { SMR_ACTION_OPEN_WAY = 1 << 5, SMR_ACTION_CLOSED_WAY = 1 << 6 };
+struct smr_special_tag { short type; union { regex_t re; double val; }; };
+struct smr_stag { struct smr_special_tag stk, stv; };
 
 struct smr_coord { double lat, lon; };
 typedef struct { struct smr_coord ll, ru; } smr_bbox_t;

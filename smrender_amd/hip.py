@@ -75,6 +75,16 @@ class PngStats(C.Structure):
                 ("deflate_ms", C.c_float), ("total_ms", C.c_float), ("threads", C.c_int32), ("pad_", C.c_int32)]
 
 
+class ObjectsInfo(C.Structure):
+    _fields_ = [(k, C.c_int64) for k in ("n_nodes", "n_ways", "n_refs", "n_node_tags", "n_way_tags", "n_strings", "pool_bytes", "missing_refs")] + \
+               [(k, C.c_void_p) for k in ("d_node_id", "d_lat", "d_lon", "d_way_id", "d_way_off", "d_ref")] + \
+               [(k, C.c_double) for k in ("extract_ms", "upload_ms", "index_ms")]
+
+
+class WaySelection(C.Structure):
+    _fields_ = [("n_ways", C.c_int64), ("n_refs", C.c_int64), ("d_way_off", C.c_void_p), ("d_ref", C.c_void_p), ("d_way_index", C.c_void_p)]
+
+
 class _Windows(C.Structure):
     _fields_ = [("n", C.c_int64), ("size", C.c_void_p), ("r_px", C.c_void_p), ("cx", C.c_void_p), ("cy", C.c_void_p)]
 
@@ -87,6 +97,8 @@ EXPORTS = [
     "smr_hip_canvas_set_halo", "smr_hip_canvas_set_halo_device", "smr_hip_canvas_extend", "smr_hip_canvas_clone", "smr_hip_canvas_blit",
     "smr_hip_canvas_write_png", "smr_hip_canvas_write_tiles",
     "smr_hip_windows_create", "smr_hip_draw_windows", "smr_hip_windows_anchors", "smr_hip_blit_windows",
+    "smr_hip_objects_create", "smr_hip_objects_destroy", "smr_hip_objects_info", "smr_hip_objects_match",
+    "smr_hip_objects_select_ways", "smr_hip_objects_select_nodes",
     "smr_hip_poly_area", "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
     "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
@@ -121,6 +133,12 @@ def lib():
         L.smr_hip_canvas_extend.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         L.smr_hip_canvas_blit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.smr_hip_poly_area.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.smr_hip_objects_create.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_void_p)]
+        L.smr_hip_objects_destroy.argtypes = [C.c_void_p]
+        L.smr_hip_objects_info.argtypes = [C.c_void_p, C.POINTER(ObjectsInfo)]
+        L.smr_hip_objects_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.smr_hip_objects_select_ways.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(WaySelection)]
+        L.smr_hip_objects_select_nodes.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
         L.smr_hip_windows_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         L.smr_hip_draw_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.smr_hip_windows_anchors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -230,6 +248,69 @@ def poly_area(d_lat, d_lon, d_way_off, d_ref, n_ways, d_area, d_clat=None, d_clo
     """poly_area (src/smfunc.c:377-432) of every closed way: signed square nautical miles, centroid in degrees (smr_hip_poly_area)"""
     _chk(lib().smr_hip_poly_area(d_lat.ptr, d_lon.ptr, int(np.prod(d_lat.shape)), d_way_off.ptr, d_ref.ptr if d_ref else None, n_ways,
                                  d_area.ptr, d_clat.ptr if d_clat else None, d_clon.ptr if d_clon else None))
+
+
+class _View:
+    """a typed view of device memory that something else owns"""
+
+    def __init__(self, ptr, shape, dtype):
+        self.ptr, self.shape, self.dtype = ptr, tuple(np.atleast_1d(shape).tolist()), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            _chk(lib().smr_hip_memcpy_d2h(out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+
+class Objects:
+    """The host's nodes and ways as structure-of-arrays on the device (smr_hip_objects_*): node_ptrs / way_ptrs are arrays of
+    the host's own osm_node_t* / osm_way_t* (uint64)."""
+
+    def __init__(self, node_ptrs, way_ptrs, threads=0):
+        node_ptrs = np.ascontiguousarray(node_ptrs, np.uint64)
+        way_ptrs = np.ascontiguousarray(way_ptrs, np.uint64)
+        h = C.c_void_p()
+        _chk(lib().smr_hip_objects_create(node_ptrs.ctypes.data, len(node_ptrs), way_ptrs.ctypes.data, len(way_ptrs), int(threads), C.byref(h)))
+        self.h = h
+        self.info = ObjectsInfo()
+        _chk(lib().smr_hip_objects_info(self.h, C.byref(self.info)))
+        i = self.info
+        self.words = (max(i.n_nodes, i.n_ways) + 63) // 64
+        self.lat, self.lon = _View(i.d_lat, (i.n_nodes,), np.float64), _View(i.d_lon, (i.n_nodes,), np.float64)
+        self.node_id, self.way_id = _View(i.d_node_id, (i.n_nodes,), np.int64), _View(i.d_way_id, (i.n_ways,), np.int64)
+        self.way_off, self.ref = _View(i.d_way_off, (i.n_ways + 1,), np.int64), _View(i.d_ref, (i.n_refs,), np.int32)
+
+    def match(self, rules, d_on_page=None):
+        """rules: the host's smrule_t* (ints).  Returns (bitmap DeviceArray [n_rules, words] of uint64, counts)."""
+        R = np.ascontiguousarray(rules, np.uint64)
+        bm = DeviceArray((len(R), max(self.words, 1)), np.uint64)
+        counts = np.zeros(len(R), np.int64)
+        _chk(lib().smr_hip_objects_match(self.h, R.ctypes.data, len(R), d_on_page.ptr if d_on_page else None, bm.ptr, max(self.words, 1), counts.ctypes.data))
+        return bm, counts
+
+    def select_ways(self, bitmap, row):
+        sel = WaySelection()
+        _chk(lib().smr_hip_objects_select_ways(self.h, bitmap.ptr + row * bitmap.shape[1] * 8, C.byref(sel)))
+        return (_View(sel.d_way_off, (sel.n_ways + 1,), np.int64), _View(sel.d_ref, (sel.n_refs,), np.int32),
+                _View(sel.d_way_index, (sel.n_ways,), np.int32), int(sel.n_ways), int(sel.n_refs))
+
+    def select_nodes(self, bitmap, row):
+        p, n = C.c_void_p(), C.c_int64()
+        _chk(lib().smr_hip_objects_select_nodes(self.h, bitmap.ptr + row * bitmap.shape[1] * 8, C.byref(p), C.byref(n)))
+        return _View(p.value, (n.value,), np.int32)
+
+    def close(self):
+        if self.h:
+            lib().smr_hip_objects_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def unproject(d_x, d_y, d_lon, d_lat):

@@ -31,6 +31,11 @@ def host():
         L.hs_get_tag.restype = C.c_char_p
         L.hs_get_tag.argtypes = [C.c_int, C.c_int64, C.c_char_p]
         L.hs_poly_area.argtypes = [C.c_longlong, C.c_void_p]
+        L.hs_match_rule.restype = C.c_void_p
+        L.hs_match_rule.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.hs_filter.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.hs_object_ptrs.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.hs_set_visible.argtypes = [C.c_int, C.c_int64, C.c_int]
         L.rdata_square_mm.restype = C.c_double
         L.rdata_square_nm.restype = C.c_double
         _hs = L
@@ -80,3 +85,33 @@ def poly_area(wid):
     out = np.zeros(3)
     assert host().hs_poly_area(int(wid), out.ctypes.data) == 0
     return tuple(out)
+
+
+def match_rule(obj_type, tags, way_kind=0):
+    """a rule as init_rule leaves it (match tags parsed into otag[] / stag[]); tags = [(key pattern, value pattern), ...];
+    way_kind 1 / 2: the rule way itself is open / closed (ACTION_OPEN_WAY / ACTION_CLOSED_WAY)"""
+    n = len(tags)
+    K = (C.c_char_p * max(n, 1))(*[k.encode() for k, _ in tags])
+    V = (C.c_char_p * max(n, 1))(*[v.encode() for _, v in tags])
+    return host().hs_match_rule(obj_type, K, V, n, way_kind)
+
+
+def filter_objects(rule, obj_type, ids, on_page=None):
+    """apply_rule's verdict per object (1 = `_main` would be called) through the reference's own bs_match_attr"""
+    ids = np.ascontiguousarray(ids, np.int64)
+    out = np.zeros(len(ids), np.uint8)
+    op = None if on_page is None else np.ascontiguousarray(on_page, np.uint8)
+    assert host().hs_filter(rule, obj_type, ids.ctypes.data, len(ids), None if op is None else op.ctypes.data, out.ctypes.data) == 0
+    return out
+
+
+def object_ptrs(obj_type, ids):
+    """the host's own osm_node_t* / osm_way_t* of the given objects, as an array of pointers"""
+    ids = np.ascontiguousarray(ids, np.int64)
+    out = np.zeros(len(ids), np.uint64)
+    assert host().hs_object_ptrs(obj_type, ids.ctypes.data, len(ids), out.ctypes.data) == 0
+    return out
+
+
+def set_visible(obj_type, oid, vis):
+    assert host().hs_set_visible(obj_type, int(oid), int(vis)) == 0
