@@ -154,6 +154,7 @@ typedef struct
    const int64_t *d_node_id; const double *d_lat, *d_lon;                    /* [n_nodes] device: input of smr_hip_project */
    const int64_t *d_way_id; const int64_t *d_way_off; const int32_t *d_ref;  /* [n_ways], [n_ways+1], [n_refs] device */
    double extract_ms, upload_ms, index_ms;                                   /* host walk + dictionary, copies, ref look-up */
+   double match_host_ms, match_device_ms;                                    /* the last smr_hip_objects_match: patterns + regexec on the host; copies, kernels, counts */
 } smr_objects_info_t;
 int smr_hip_objects_create(const void *const *nodes, int64_t n_nodes, const void *const *ways, int64_t n_ways, int threads, smr_objects_t **out);
 int smr_hip_objects_destroy(smr_objects_t *o);

@@ -360,11 +360,11 @@ smrule_t *hs_match_rule(int type, const char *const *keys, const char *const *va
 
 /* apply_rule (src/smcore.c:248-291) up to the call of `_main`, with the REAL bs_match_attr of libsmrender: out[i] = 1 where the
  * action would be called.  on_page: the is_on_page verdict per node (NULL = render_all_nodes_) */
-int hs_filter(const smrule_t *r, int type, const int64_t *ids, int n, const uint8_t *on_page, uint8_t *out)
+int hs_filter_ptrs(const smrule_t *r, const void *const *objs, int64_t n, const uint8_t *on_page, uint8_t *out)
 {
-   for (int k = 0; k < n; k++)
+   for (int64_t k = 0; k < n; k++)
    {
-      const osm_obj_t *o = get_object(type, ids[k]);
+      const osm_obj_t *o = objs[k];
       out[k] = 0;
       if (o == NULL) return -1;
       if (o->type == OSM_NODE && on_page != NULL && !on_page[k]) continue;
@@ -384,6 +384,15 @@ int hs_filter(const smrule_t *r, int type, const int64_t *ids, int n, const uint
    return 0;
 }
 
+int hs_filter(const smrule_t *r, int type, const int64_t *ids, int n, const uint8_t *on_page, uint8_t *out)
+{
+   const void **p = malloc(sizeof(*p) * (n > 0 ? n : 1));
+   for (int k = 0; k < n; k++) p[k] = get_object(type, ids[k]);
+   int e = hs_filter_ptrs(r, p, n, on_page, out);
+   free(p);
+   return e;
+}
+
 int hs_object_ptrs(int type, const int64_t *ids, int n, void **out)
 {
    for (int k = 0; k < n; k++)
@@ -396,5 +405,51 @@ int hs_set_visible(int type, int64_t id, int vis)
    osm_obj_t *o = get_object(type, id);
    if (o == NULL) return -1;
    o->vis = (int8_t) vis;
+   return 0;
+}
+
+/* a large synthetic world for tools/objects_bench.py, allocated with the real malloc_node / malloc_way but kept OUT of the
+ * bxtree (the export takes pointers): n_ways closed ways of refs_per_way nodes of their own, every way with tags_per_way tags
+ * drawn from the given pairs plus a name of its own; one node in node_tag_every carries one tag */
+static unsigned long long rng_(unsigned long long *s) { *s ^= *s << 13; *s ^= *s >> 7; *s ^= *s << 17; return *s; }
+
+int hs_synth_world(int64_t n_ways, int refs_per_way, const char *const *keys, const char *const *vals, int n_pairs, int tags_per_way,
+                   int node_tag_every, unsigned seed, void **nodes_out, void **ways_out)
+{
+   unsigned long long st = 0x9e3779b97f4a7c15ull ^ seed;
+   const int64_t per = refs_per_way - 1;
+   char *names = malloc((size_t) n_ways * 12);
+   for (int64_t w = 0; w < n_ways; w++)
+   {
+      for (int64_t k = 0; k < per; k++)
+      {
+         const int64_t i = w * per + k;
+         const int tagged = node_tag_every > 0 && rng_(&st) % node_tag_every == 0;
+         osm_node_t *n = malloc_node((short) tagged);
+         n->obj.type = OSM_NODE; n->obj.vis = 1; n->obj.id = i + 1;
+         n->lat = 44.0 + (double) (rng_(&st) % 2000000) * 1e-6; n->lon = 14.0 + (double) (rng_(&st) % 2000000) * 1e-6;
+         if (tagged)
+         {
+            const int p = (int) (rng_(&st) % n_pairs);
+            n->obj.otag[0].k.buf = (char *) keys[p]; n->obj.otag[0].k.len = (int) strlen(keys[p]);
+            n->obj.otag[0].v.buf = (char *) vals[p]; n->obj.otag[0].v.len = (int) strlen(vals[p]);
+         }
+         nodes_out[i] = n;
+      }
+      osm_way_t *wy = malloc_way((short) (tags_per_way + 1), refs_per_way);
+      wy->obj.type = OSM_WAY; wy->obj.vis = 1; wy->obj.id = w + 1;
+      for (int64_t k = 0; k < per; k++) wy->ref[k] = w * per + k + 1;
+      wy->ref[per] = wy->ref[0];
+      for (int t = 0; t < tags_per_way; t++)
+      {
+         const int p = (int) (rng_(&st) % n_pairs);
+         wy->obj.otag[t].k.buf = (char *) keys[p]; wy->obj.otag[t].k.len = (int) strlen(keys[p]);
+         wy->obj.otag[t].v.buf = (char *) vals[p]; wy->obj.otag[t].v.len = (int) strlen(vals[p]);
+      }
+      char *nm = names + w * 12;
+      wy->obj.otag[tags_per_way].k.buf = "name"; wy->obj.otag[tags_per_way].k.len = 4;
+      wy->obj.otag[tags_per_way].v.buf = nm; wy->obj.otag[tags_per_way].v.len = snprintf(nm, 12, "w%lld", (long long) w);
+      ways_out[w] = wy;
+   }
    return 0;
 }

@@ -14,6 +14,7 @@
 #include "smr_host.h"
 #include "smr_abi.h"
 #include <string.h>
+#include <string>
 #include <chrono>
 #include <thread>
 #include <algorithm>
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256) void k_iota(int32_t *v, int64_t n)
 /* one side (key or value) of a rule's match tag: struct specialTag (libsmrender/smaction.h:75-83) with the pattern resolved */
 struct rside_t { int32_t has, type, pat, pad_; double val; };
 struct rtag_t { rside_t k, v; };
-struct rdesc_t { int32_t tag0, ntags, wayflag, pad_; int64_t row; };
+struct rdesc_t { int32_t tag0, ntags, wayflag, empty_ok; int64_t row; };      /* empty_ok: an object without tags passes (every match tag is a ~not~) */
 enum { SP_DIRECT = SMR_SPECIAL_DIRECT, SP_REGEX = SMR_SPECIAL_REGEX, SP_GT = SMR_SPECIAL_GT, SP_LT = SMR_SPECIAL_LT, SP_MASK = SMR_SPECIAL_MASK,
        SP_NOT = SMR_SPECIAL_NOT, SP_INVERT = SMR_SPECIAL_INVERT };
 
@@ -172,7 +173,7 @@ struct match_args_t
    int64_t n_obj;
    const rdesc_t *rules; const rtag_t *rtags; int n_rules, is_way;
    const double *tod; const uint32_t *rbits; int64_t rwords;
-   uint64_t *bitmap; unsigned long long *counts;
+   uint64_t *bitmap; unsigned long long *counts;      /* counts: k_row_count's */
 };
 
 /* bs_match (libsmrender/smutil.c:282-318) on the id of the object's string */
@@ -189,58 +190,127 @@ __device__ __forceinline__ int side_match(const rside_t &s, int32_t id, const ma
    return (s.type & SP_INVERT) ? r != 0 : r == 0;
 }
 
-#define MATCH_RULES_PER_BLOCK 16
+#define MATCH_RULES_PER_BLOCK 64
+#define MATCH_LDS_TAGS 256
+#define MATCH_OBJ_ITERS 4          /* a block takes 4 x 256 objects, one after the other */
 
-/* apply_rule's filter (src/smcore.c:248-291) for one object per lane and MATCH_RULES_PER_BLOCK rules per block: page test for
- * nodes, open/closed for ways, every match tag through bs_match_attr (libsmrender/smutil.c:330-356), visibility.  The rule
- * records are the same for all lanes (scalar loads); a wavefront's 64 verdicts are one word of the rule's bitmap row */
+/* apply_rule's filter (src/smcore.c:248-291) for 1024 objects and MATCH_RULES_PER_BLOCK rules per block: page test for nodes,
+ * open/closed for ways, every match tag through bs_match_attr (libsmrender/smutil.c:330-356), visibility.
+ * Most nodes carry no tag, and what a rule says to a tagless object does not depend on the object (rdesc_t.empty_ok): their
+ * verdicts are a few bitwise operations on 64-object words.  The objects that do have tags are gathered into a list and take
+ * the lanes densely, one object per lane; the rule records wait in LDS (all lanes read the same one).  A rule's 16 words of
+ * the block leave as one 128-byte piece of its bitmap row */
 __global__ __launch_bounds__(256) void k_match(match_args_t a)
 {
-   const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
-   const bool live = i < a.n_obj;
-   int64_t t0 = 0, t1 = 0;
-   int vis = 0, extra = 0;
-   if (live)
+   constexpr int WPB = MATCH_OBJ_ITERS * 4;
+   __shared__ rdesc_t s_rule[MATCH_RULES_PER_BLOCK];
+   __shared__ rtag_t s_tag[MATCH_LDS_TAGS];
+   __shared__ unsigned long long s_word[MATCH_RULES_PER_BLOCK][WPB];
+   __shared__ uint64_t s_base[WPB], s_tagged[WPB], s_open[WPB], s_closed[WPB];
+   __shared__ uint16_t s_list[256 * MATCH_OBJ_ITERS];
+   __shared__ int s_n;
+   const int rb = blockIdx.y * MATCH_RULES_PER_BLOCK, nr = min(a.n_rules - rb, MATCH_RULES_PER_BLOCK);
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   if ((int) threadIdx.x < nr) s_rule[threadIdx.x] = a.rules[rb + threadIdx.x];
+   if (threadIdx.x == 0) s_n = 0;
+   __syncthreads();
+   const int tag_base = s_rule[0].tag0, n_tags = s_rule[nr - 1].tag0 + s_rule[nr - 1].ntags - tag_base;
+   const bool in_lds = n_tags <= MATCH_LDS_TAGS;
+   if (in_lds) for (int t = threadIdx.x; t < n_tags; t += 256) s_tag[t] = a.rtags[tag_base + t];
+
+   /* what does not depend on the rule, 64 objects per word, and the list of the objects with tags */
+   const int64_t obj0 = (int64_t) blockIdx.x * (256 * MATCH_OBJ_ITERS);
+   for (int it = 0; it < MATCH_OBJ_ITERS; it++)
    {
-      t0 = a.tag_off[i]; t1 = a.tag_off[i + 1];
-      vis = a.vis[i];
-      extra = a.extra ? a.extra[i] : 1;
-   }
-   const int r1 = min(a.n_rules, (int) (blockIdx.y + 1) * MATCH_RULES_PER_BLOCK);
-   for (int r = blockIdx.y * MATCH_RULES_PER_BLOCK; r < r1; r++)
-   {
-      const rdesc_t R = a.rules[r];
-      bool ok = live && vis;
-      if (a.is_way)
+      const int64_t i = obj0 + it * 256 + threadIdx.x;
+      bool base = false, tagged = false;
+      int kind = 0;
+      if (i < a.n_obj)
       {
-         if (R.wayflag == 2 && extra == 1) ok = false;            /* ACTION_CLOSED_WAY and the way is open */
-         else if (R.wayflag == 1 && extra == 2) ok = false;       /* ACTION_OPEN_WAY and the way is closed */
+         const int extra = a.extra ? a.extra[i] : 1;
+         base = a.vis[i] != 0 && (a.is_way || extra != 0);          /* invisible, or a node outside the page (ERULE_OUTOFBBOX) */
+         tagged = base && a.tag_off[i + 1] > a.tag_off[i];
+         kind = a.is_way ? extra : 0;
       }
-      else if (!extra) ok = false;                                /* ERULE_OUTOFBBOX */
-      for (int t = 0; t < R.ntags && __any(ok); t++)
+      const uint64_t wb = __ballot(base), wt = __ballot(tagged), wo = __ballot(kind == 1), wc = __ballot(kind == 2);
+      int at = 0;
+      if (lane == 0)
       {
-         const rtag_t T = a.rtags[R.tag0 + t];
-         if (!ok) continue;
-         int res = -1;
-         bool done = false;
-         for (int64_t j = t0; j < t1; j++)
+         s_base[it * 4 + wave] = wb; s_tagged[it * 4 + wave] = wt; s_open[it * 4 + wave] = wo; s_closed[it * 4 + wave] = wc;
+         if (wt) at = atomicAdd(&s_n, __popcll(wt));
+      }
+      at = __shfl(at, 0);
+      if (tagged) s_list[at + __popcll(wt & ((1ull << lane) - 1))] = (uint16_t) (it * 256 + threadIdx.x);
+   }
+   __syncthreads();
+   const int n_list = s_n;
+   for (int k = threadIdx.x; k < nr * WPB; k += 256)
+   {
+      const rdesc_t R = s_rule[k / WPB];
+      const int w = k % WPB;
+      const uint64_t excl = R.wayflag == 2 ? s_open[w] : R.wayflag == 1 ? s_closed[w] : 0;       /* ACTION_CLOSED_WAY meets an open way, ACTION_OPEN_WAY a closed one */
+      s_word[k / WPB][w] = R.empty_ok ? (s_base[w] & ~s_tagged[w] & ~excl) : 0;
+   }
+   __syncthreads();
+
+   for (int k0 = 0; k0 < n_list; k0 += 256)
+   {
+      const int k = k0 + threadIdx.x;
+      const bool live = k < n_list;
+      const int o = live ? s_list[k] : 0;
+      int64_t t0 = 0, t1 = 0;
+      int kind = 0;
+      if (live)
+      {
+         t0 = a.tag_off[obj0 + o]; t1 = a.tag_off[obj0 + o + 1];
+         kind = a.is_way ? a.extra[obj0 + o] : 0;
+      }
+      if (!__any(live)) continue;
+      for (int r = 0; r < nr; r++)
+      {
+         const rdesc_t R = s_rule[r];
+         bool ok = live && !(R.wayflag == 2 && kind == 1) && !(R.wayflag == 1 && kind == 2);
+         for (int t = 0; t < R.ntags && __any(ok); t++)
          {
-            const int km = T.k.has ? side_match(T.k, a.kid[j], a) : 1;
-            const int vm = T.v.has ? side_match(T.v, a.vid[j], a) : 1;
-            if (km && (T.k.type & SP_NOT)) { res = -1; done = true; break; }
-            if (vm && (T.v.type & SP_NOT)) { res = -1; done = true; break; }
-            if (km && vm) { res = (int) (j - t0); done = true; break; }
+            const rtag_t T = in_lds ? s_tag[R.tag0 - tag_base + t] : a.rtags[R.tag0 + t];
+            if (!ok) continue;
+            int res = -1;
+            bool done = false;
+            for (int64_t j = t0; j < t1; j++)
+            {
+               const int km = T.k.has ? side_match(T.k, a.kid[j], a) : 1;
+               const int vm = T.v.has ? side_match(T.v, a.vid[j], a) : 1;
+               if (km && (T.k.type & SP_NOT)) { res = -1; done = true; break; }
+               if (vm && (T.v.type & SP_NOT)) { res = -1; done = true; break; }
+               if (km && vm) { res = (int) (j - t0); done = true; break; }
+            }
+            if (!done && ((T.k.type & SP_NOT) || (T.v.type & SP_NOT))) res = 0x7fffffff;
+            if (res == -1) ok = false;
          }
-         if (!done && ((T.k.type & SP_NOT) || (T.v.type & SP_NOT))) res = 0x7fffffff;
-         if (res == -1) ok = false;
-      }
-      const uint64_t word = __ballot(ok);
-      if ((threadIdx.x & 63) == 0 && live)
-      {
-         a.bitmap[R.row + (i >> 6)] = word;
-         if (word) atomicAdd(&a.counts[r], (unsigned long long) __popcll(word));
+         if (ok) atomicOr(&s_word[r][o >> 6], 1ull << (o & 63));
       }
    }
+   __syncthreads();
+   const int64_t n_words = (a.n_obj + 63) / 64;
+   for (int k = threadIdx.x; k < nr * WPB; k += 256)
+   {
+      const int64_t w = (int64_t) blockIdx.x * WPB + k % WPB;
+      if (w < n_words) a.bitmap[s_rule[k / WPB].row + w] = s_word[k / WPB][k % WPB];
+   }
+}
+
+/* the 1s of every rule's row (counted from the finished rows: a rule that most objects pass would otherwise send one atomic
+ * per wavefront to one address) */
+__global__ __launch_bounds__(256) void k_row_count(const uint64_t *__restrict__ bitmap, const rdesc_t *__restrict__ rules, int64_t n_words, unsigned long long *__restrict__ counts)
+{
+   __shared__ uint32_t part[4];
+   const uint64_t *row = bitmap + rules[blockIdx.y].row;
+   uint32_t c = 0;
+   for (int64_t i = (int64_t) blockIdx.x * 4096 + threadIdx.x, e = min(n_words, ((int64_t) blockIdx.x + 1) * 4096); i < e; i += 256) c += (uint32_t) __popcll(row[i]);
+   for (int d = 32; d; d >>= 1) c += __shfl_xor(c, d);
+   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+   __syncthreads();
+   if (threadIdx.x == 0 && part[0] + part[1] + part[2] + part[3]) atomicAdd(&counts[blockIdx.y], (unsigned long long) part[0] + part[1] + part[2] + part[3]);
 }
 
 /* ------------------------------------------------------------------------------------------------------------ selection */
@@ -328,7 +398,7 @@ struct smr_objects
    dbuf_t pool, str_off, tod, sorted_id, sorted_idx, sort_tmp, misc;
    dbuf_t rules, rtags, rbits, counts;                   /* per match call */
    dbuf_t pop, sums, sel_index, sel_cnt, sel_off, sel_ref;        /* per selection */
-   double extract_ms = 0, upload_ms = 0, index_ms = 0;
+   double extract_ms = 0, upload_ms = 0, index_ms = 0, match_host_ms = 0, match_device_ms = 0;
    bool nodes_ascending = true;
 
    void release()
@@ -501,6 +571,7 @@ extern "C" int smr_hip_objects_info(const smr_objects_t *o, smr_objects_info_t *
    info->d_node_id = o->node_id.as<int64_t>(); info->d_lat = o->lat.as<double>(); info->d_lon = o->lon.as<double>();
    info->d_way_id = o->way_id.as<int64_t>(); info->d_way_off = o->way_off.as<int64_t>(); info->d_ref = o->ref.as<int32_t>();
    info->extract_ms = o->extract_ms; info->upload_ms = o->upload_ms; info->index_ms = o->index_ms;
+   info->match_host_ms = o->match_host_ms; info->match_device_ms = o->match_device_ms;
    return SMR_OK;
 }
 
@@ -537,13 +608,14 @@ extern "C" int smr_hip_objects_match(smr_objects_t *o, const void *const *rules,
    if (words_per_rule < need_words) return smr_fail(SMR_E_INVAL, "objects_match: %lld words per rule, %lld objects need %lld", (long long) words_per_rule,
                                                     (long long) std::max(o->n_nodes, o->n_ways), (long long) need_words);
    hipStream_t s = smr_g.stream;
+   const double t_begin = now_ms();
    const int64_t n_str = (int64_t) o->dict.size(), rwords = (n_str + 31) / 32;
    /* rules in two groups, node rules and way rules, each keeping the caller's numbering through `row` and `slot` */
    std::vector<rdesc_t> desc[2];
    std::vector<int> slot[2];
    std::vector<rtag_t> rtags;
    std::vector<uint32_t> rbits;
-   struct regex_job_t { const regex_t *re; int row; uint8_t role; };
+   struct regex_job_t { const regex_t *re; int row; uint8_t role; std::string pat; };
    std::vector<regex_job_t> jobs;
    int n_regex = 0;
    for (int r = 0; r < n_rules; r++)
@@ -555,7 +627,7 @@ extern "C" int smr_hip_objects_match(smr_objects_t *o, const void *const *rules,
       const int g = R->oo->type == SMR_OSM_WAY;
       const smr_stag *st = (const smr_stag *) ((const char *) R->act + sizeof(smr_action_t));
       rdesc_t d;
-      d.tag0 = (int32_t) rtags.size(); d.ntags = R->oo->tag_cnt > 0 ? R->oo->tag_cnt : 0; d.pad_ = 0;
+      d.tag0 = (int32_t) rtags.size(); d.ntags = R->oo->tag_cnt > 0 ? R->oo->tag_cnt : 0; d.empty_ok = 1;
       d.wayflag = (R->act->flags & SMR_ACTION_CLOSED_WAY) ? 2 : (R->act->flags & SMR_ACTION_OPEN_WAY) ? 1 : 0;
       d.row = (int64_t) r * words_per_rule;
       for (int t = 0; t < d.ntags; t++)
@@ -563,11 +635,12 @@ extern "C" int smr_hip_objects_match(smr_objects_t *o, const void *const *rules,
          rtag_t T;
          const int before = n_regex;
          SMR_TRY(resolve_side(o, R->oo->otag[t].k, st[t].stk, &T.k, rbits, rwords, &n_regex));
-         if (n_regex > before) jobs.push_back({ &st[t].stk.re, T.k.pat, 1 });
+         if (n_regex > before) jobs.push_back({ &st[t].stk.re, T.k.pat, 1, std::string(R->oo->otag[t].k.buf, R->oo->otag[t].k.len) });
          const int mid = n_regex;
          SMR_TRY(resolve_side(o, R->oo->otag[t].v, st[t].stv, &T.v, rbits, rwords, &n_regex));
-         if (n_regex > mid) jobs.push_back({ &st[t].stv.re, T.v.pat, 2 });
+         if (n_regex > mid) jobs.push_back({ &st[t].stv.re, T.v.pat, 2, std::string(R->oo->otag[t].v.buf, R->oo->otag[t].v.len) });
          rtags.push_back(T);
+         if (!((T.k.type | T.v.type) & SP_NOT)) d.empty_ok = 0;
       }
       desc[g].push_back(d); slot[g].push_back(r);
    }
@@ -575,18 +648,27 @@ extern "C" int smr_hip_objects_match(smr_objects_t *o, const void *const *rules,
     * lock per compiled expression, so the jobs, not the strings, are what threads share) */
    if (!jobs.empty())
    {
-      const int nth = (int) std::min<size_t>(jobs.size(), 16);
+      /* glibc's regexec takes a lock per compiled expression, so threads that share the strings each need expressions of their
+       * own: compiled from the rule's pattern text with the flags parse_matchtype uses (thread 0, and any thread whose copy
+       * does not compile, runs the rule's own regex_t).  A thread's strings start at a multiple of 32: no two share a word */
+      const int nth = (int64_t) jobs.size() * n_str > 100000 ? 16 : 1;
       std::vector<std::thread> th;
       for (int t = 0; t < nth; t++) th.emplace_back([&, t]() {
-         for (size_t j = t; j < jobs.size(); j += nth)
+         const int64_t lo = rwords * t / nth * 32, hi = std::min<int64_t>(n_str, rwords * (t + 1) / nth * 32);
+         for (size_t j = 0; j < jobs.size(); j++)
          {
+            regex_t own;
+            const bool have = t > 0 && regcomp(&own, jobs[j].pat.c_str(), REG_EXTENDED | REG_NOSUB) == 0;
+            const regex_t *re = have ? &own : jobs[j].re;
             uint32_t *bits = rbits.data() + (size_t) jobs[j].row * rwords;
-            for (int64_t id = 0; id < n_str; id++)
-               if ((o->dict.role[id] & jobs[j].role) && regexec(jobs[j].re, o->dict.str((uint32_t) id), 0, nullptr, 0) == 0) bits[id >> 5] |= 1u << (id & 31);
+            for (int64_t id = lo; id < hi; id++)
+               if ((o->dict.role[id] & jobs[j].role) && regexec(re, o->dict.str((uint32_t) id), 0, nullptr, 0) == 0) bits[id >> 5] |= 1u << (id & 31);
+            if (have) regfree(&own);
          }
       });
       for (auto &t : th) t.join();
    }
+   const double t_host = now_ms();
    std::vector<rdesc_t> all(desc[0]);
    all.insert(all.end(), desc[1].begin(), desc[1].end());
    SMR_TRY(upload(o->rules, all)); SMR_TRY(upload(o->rtags, rtags)); SMR_TRY(upload(o->rbits, rbits));
@@ -607,13 +689,16 @@ extern "C" int smr_hip_objects_match(smr_objects_t *o, const void *const *rules,
       a.rules = o->rules.as<rdesc_t>() + first; a.rtags = o->rtags.as<rtag_t>(); a.n_rules = (int) desc[g].size();
       a.tod = o->tod.as<double>(); a.rbits = o->rbits.as<uint32_t>(); a.rwords = rwords;
       a.bitmap = d_bitmap; a.counts = o->counts.as<unsigned long long>() + first;
-      dim3 grid(blocks(a.n_obj), (unsigned) ((desc[g].size() + MATCH_RULES_PER_BLOCK - 1) / MATCH_RULES_PER_BLOCK));
+      dim3 grid(blocks(a.n_obj, 256 * MATCH_OBJ_ITERS), (unsigned) ((desc[g].size() + MATCH_RULES_PER_BLOCK - 1) / MATCH_RULES_PER_BLOCK));
       k_match<<<grid, 256, 0, s>>>(a);
+      const int64_t n_words = (a.n_obj + 63) / 64;
+      k_row_count<<<dim3(blocks(n_words, 4096), (unsigned) desc[g].size()), 256, 0, s>>>(d_bitmap, a.rules, n_words, a.counts);
    }
    SMR_HIP(hipGetLastError());
    std::vector<unsigned long long> got(std::max<size_t>(1, all.size()));
    SMR_HIP(hipMemcpyAsync(got.data(), o->counts.p, all.size() * 8, hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
+   o->match_host_ms = t_host - t_begin; o->match_device_ms = now_ms() - t_host;
    for (size_t i = 0; i < slot[0].size(); i++) counts[slot[0][i]] = (int64_t) got[i];
    for (size_t i = 0; i < slot[1].size(); i++) counts[slot[1][i]] = (int64_t) got[slot[0].size() + i];
    return SMR_OK;

@@ -78,7 +78,7 @@ class PngStats(C.Structure):
 class ObjectsInfo(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("n_nodes", "n_ways", "n_refs", "n_node_tags", "n_way_tags", "n_strings", "pool_bytes", "missing_refs")] + \
                [(k, C.c_void_p) for k in ("d_node_id", "d_lat", "d_lon", "d_way_id", "d_way_off", "d_ref")] + \
-               [(k, C.c_double) for k in ("extract_ms", "upload_ms", "index_ms")]
+               [(k, C.c_double) for k in ("extract_ms", "upload_ms", "index_ms", "match_host_ms", "match_device_ms")]
 
 
 class WaySelection(C.Structure):
@@ -288,6 +288,7 @@ class Objects:
         bm = DeviceArray((len(R), max(self.words, 1)), np.uint64)
         counts = np.zeros(len(R), np.int64)
         _chk(lib().smr_hip_objects_match(self.h, R.ctypes.data, len(R), d_on_page.ptr if d_on_page else None, bm.ptr, max(self.words, 1), counts.ctypes.data))
+        _chk(lib().smr_hip_objects_info(self.h, C.byref(self.info)))
         return bm, counts
 
     def select_ways(self, bitmap, row):

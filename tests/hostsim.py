@@ -34,6 +34,8 @@ def host():
         L.hs_match_rule.restype = C.c_void_p
         L.hs_match_rule.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.hs_filter.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.hs_filter_ptrs.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.hs_synth_world.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_void_p]
         L.hs_object_ptrs.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.hs_set_visible.argtypes = [C.c_int, C.c_int64, C.c_int]
         L.rdata_square_mm.restype = C.c_double
@@ -115,3 +117,21 @@ def object_ptrs(obj_type, ids):
 
 def set_visible(obj_type, oid, vis):
     assert host().hs_set_visible(obj_type, int(oid), int(vis)) == 0
+
+
+def filter_ptrs(rule, ptrs, on_page=None):
+    ptrs = np.ascontiguousarray(ptrs, np.uint64)
+    out = np.zeros(len(ptrs), np.uint8)
+    op = None if on_page is None else np.ascontiguousarray(on_page, np.uint8)
+    assert host().hs_filter_ptrs(rule, ptrs.ctypes.data, len(ptrs), None if op is None else op.ctypes.data, out.ctypes.data) == 0
+    return out
+
+
+def synth_world(n_ways, refs_per_way, pairs, tags_per_way=3, node_tag_every=50, seed=1):
+    """(node pointers, way pointers) of a synthetic world kept outside the object tree; `pairs` must stay alive with it"""
+    K = (C.c_char_p * len(pairs))(*[k.encode() for k, _ in pairs])
+    V = (C.c_char_p * len(pairs))(*[v.encode() for _, v in pairs])
+    nodes = np.zeros(n_ways * (refs_per_way - 1), np.uint64)
+    ways = np.zeros(n_ways, np.uint64)
+    assert host().hs_synth_world(n_ways, refs_per_way, K, V, len(pairs), tags_per_way, node_tag_every, seed, nodes.ctypes.data, ways.ctypes.data) == 0
+    return nodes, ways, (K, V)
