@@ -124,6 +124,20 @@ int smr_hip_canvas_write_png(smr_canvas_t *c, int x, int y, int w, int h, const 
 int smr_hip_canvas_write_tiles(smr_canvas_t *c, int x, int y, int nx, int ny, int tile_px, const char *dir, int tx0, int ty0,
                                int level, int threads, smr_png_stats_t *st);
 /* device pointer + row stride (pixels) of the band, for zero-copy consumers */
+/* ---- KAP (BSB raster chart) from the device canvas: replaces save_kap from "OST/1" on -----------------------
+ * src/smkap.c:196-245 with cairo_smr_image_surface_color_reduce (src/median_cut.c:293-350: median cut to at most 127 colours,
+ * nearest colour per pixel) and bsb_compress_row (src/smkap.c:70-114).  `header` = the text gen_kap_header (:143-167) writes
+ * (the caller's: title, scale, REF/PLY corners; may be NULL), then this call writes the palette lines, the rows and the
+ * offset table.  The bytes equal the reference's for a libc whose qsort is stable (glibc <= 2.36: the cut depends on the
+ * order of equal points).  Whole canvases only, at most 65535 x 65535 px. */
+typedef struct
+{
+   int32_t n_colors, depth;
+   uint32_t palette[127];          /* 0xffRRGGBB, in palette order (RGB/1 first) */
+   int64_t row_bytes, file_bytes, sorted_points;
+   double reduce_ms, index_ms, rows_ms, write_ms;
+} smr_kap_stats_t;
+int smr_hip_canvas_write_kap(smr_canvas_t *c, const char *header, const char *path, smr_kap_stats_t *st);
 int smr_hip_canvas_device(smr_canvas_t *c, uint32_t **d_pix, int *stride_px);
 
 /* ---- poly_area: replaces poly_area() per way --------------------------------------------

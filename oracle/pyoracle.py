@@ -451,3 +451,74 @@ def png_decode(path, with_info=False):
     if with_info:
         return out, {"filters": hist, "idat_chunks": n_idat, "bytes": len(raw)}
     return out
+
+
+# ---- KAP: colour reduction and BSB rows (oracle/kap.c) ---------------------------------------------------------------------
+def _kap():
+    L = orc()
+    if not hasattr(L, "_kap_bound"):
+        L.orc_median_cut.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]
+        L.orc_nearest.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_bsb_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_bsb_decode_row.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_void_p]
+        L.orc_kap_body.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_kap_body.restype = C.c_long
+        L._kap_bound = True
+    return L
+
+
+def argb_points(argb):
+    """[n, 3] bytes (blue, green, red) as mc_cairo_color_to_point (src/median_cut.c:277-283) reads a pixel"""
+    p = np.ascontiguousarray(argb, np.uint32).reshape(-1)
+    return np.stack([p & 0xff, (p >> 8) & 0xff, (p >> 16) & 0xff], -1).astype(np.uint8)
+
+
+def median_cut(points, desired=127, ref=None):
+    """(avg [n, 3], len [n], the points as the cut leaves them) -- oracle/kap.c, or with ref = a loaded oracle/_ref/libref_median.so
+    the reference's own src/median_cut.c"""
+    pts = np.ascontiguousarray(points, np.uint8).copy()
+    avg = np.zeros((desired, 3), np.uint8)
+    ln = np.zeros(desired, np.int32)
+    if ref is None:
+        n = _kap().orc_median_cut(P(pts), len(pts), desired, P(avg), P(ln))
+    else:
+        ref.ref_median_cut.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]
+        n = ref.ref_median_cut(P(pts), len(pts), desired, P(avg), P(ln))
+    return avg[:n], ln[:n], pts
+
+
+def ref_median():
+    """the reference's own median_cut.c compiled here (None where oracle/_ref was not built).  Its log_msg comes from the
+    reference's libsmrender, loaded first"""
+    d = os.path.join(_HERE, "_ref")
+    if not os.path.exists(os.path.join(d, "libref_median.so")):
+        return None
+    C.CDLL(os.path.join(d, "libsmrender_ref.so"), mode=C.RTLD_GLOBAL)
+    return C.CDLL(os.path.join(d, "libref_median.so"))
+
+
+def bsb_row(idx, depth, line):
+    idx = np.ascontiguousarray(idx, np.uint8)
+    out = np.zeros(2 * len(idx) + 16, np.uint8)
+    n = _kap().orc_bsb_row(P(idx), len(idx), depth, line, P(out))
+    return out[:n].copy()
+
+
+def bsb_decode_row(data, w, depth):
+    """(bytes consumed, line number, indices) of one row; consumed = 0 for a malformed row"""
+    data = np.ascontiguousarray(data, np.uint8)
+    out = np.zeros(w, np.uint8)
+    line = C.c_int()
+    n = _kap().orc_bsb_decode_row(P(data), len(data), w, depth, C.byref(line), P(out))
+    return n, line.value, out
+
+
+def kap_body(argb, header_len):
+    """save_kap (src/smkap.c:196-245) from "OST/1" on for an ARGB32 image: (bytes, palette [n] 0xffRRGGBB)"""
+    img = np.ascontiguousarray(argb, np.uint32)
+    h, w = img.shape
+    out = np.zeros(64 + 127 * 24 + h * (2 * w + 8) + 4 * (h + 1), np.uint8)
+    pal = np.zeros(127, np.uint32)
+    nc = C.c_int()
+    n = _kap().orc_kap_body(P(img), w, h, header_len, P(out), P(pal), C.byref(nc))
+    return out[:n].copy(), pal[:nc.value].copy()

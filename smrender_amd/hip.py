@@ -75,6 +75,11 @@ class PngStats(C.Structure):
                 ("deflate_ms", C.c_float), ("total_ms", C.c_float), ("threads", C.c_int32), ("pad_", C.c_int32)]
 
 
+class KapStats(C.Structure):
+    _fields_ = [("n_colors", C.c_int32), ("depth", C.c_int32), ("palette", C.c_uint32 * 127), ("row_bytes", C.c_int64), ("file_bytes", C.c_int64),
+                ("sorted_points", C.c_int64), ("reduce_ms", C.c_double), ("index_ms", C.c_double), ("rows_ms", C.c_double), ("write_ms", C.c_double)]
+
+
 class ObjectsInfo(C.Structure):
     _fields_ = [(k, C.c_int64) for k in ("n_nodes", "n_ways", "n_refs", "n_node_tags", "n_way_tags", "n_strings", "pool_bytes", "missing_refs")] + \
                [(k, C.c_void_p) for k in ("d_node_id", "d_lat", "d_lon", "d_way_id", "d_way_off", "d_ref")] + \
@@ -95,7 +100,7 @@ EXPORTS = [
     "smr_hip_proj_from_window", "smr_hip_set_projection", "smr_hip_project", "smr_hip_unproject",
     "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_trim", "smr_hip_canvas_read", "smr_hip_canvas_device",
     "smr_hip_canvas_set_halo", "smr_hip_canvas_set_halo_device", "smr_hip_canvas_extend", "smr_hip_canvas_clone", "smr_hip_canvas_blit",
-    "smr_hip_canvas_write_png", "smr_hip_canvas_write_tiles",
+    "smr_hip_canvas_write_png", "smr_hip_canvas_write_tiles", "smr_hip_canvas_write_kap",
     "smr_hip_windows_create", "smr_hip_draw_windows", "smr_hip_windows_anchors", "smr_hip_blit_windows",
     "smr_hip_objects_create", "smr_hip_objects_destroy", "smr_hip_objects_info", "smr_hip_objects_match",
     "smr_hip_objects_select_ways", "smr_hip_objects_select_nodes",
@@ -146,6 +151,7 @@ def lib():
         L.smr_hip_canvas_write_png.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         L.smr_hip_canvas_write_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
                                                  C.c_int, C.c_int, C.c_void_p]
+        L.smr_hip_canvas_write_kap.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p]
         L.smr_hip_canvas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.smr_hip_draw.argtypes = [C.c_void_p, C.POINTER(DrawStyle), C.POINTER(_DrawBatch)]
         L.smr_hip_debug_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -429,6 +435,12 @@ class Canvas:
         x, y, w, h = rect if rect else (0, 0, self.W, self.band_h)
         st = PngStats()
         _chk(lib().smr_hip_canvas_write_png(self.h, x, y, w, h, str(path).encode(), level, threads, C.byref(st)))
+        return st
+
+    def write_kap(self, path, header=""):
+        """the KAP body (palette, run-length rows, offset table) behind `header` (smr_hip_canvas_write_kap); returns KapStats"""
+        st = KapStats()
+        _chk(lib().smr_hip_canvas_write_kap(self.h, header.encode() if header else None, str(path).encode(), C.byref(st)))
         return st
 
     def write_tiles(self, directory, x, y, nx, ny, tile_px=256, tx0=0, ty0=0, level=-1, threads=0):
