@@ -1905,11 +1905,60 @@ static int hipsave_ini(smr_smrule_t *r)
 
 static int hipsave_main(smr_smrule_t *, smr_osm_obj_t *) { return 0; }
 
+/* the text gen_kap_header (src/smkap.c:143-167) puts before "OST/1": chart name and scale, size, the corners' coordinates
+ * (pxf2geo through smr_hip_unproject).  The first line names this library where the reference prints its PACKAGE_STRING */
+static int kap_header(std::string &out)
+{
+   const struct smr_rdata *rd = H.rdata_get();
+   const double px[7] = { 0, rd->w, 0, 0, rd->w, rd->w, 0 }, py[7] = { 0, rd->h, rd->h, 0, 0, rd->h, rd->h };
+   double lon[7], lat[7];
+   void *d = nullptr;
+   if (smr_hip_malloc(&d, 4 * 7 * sizeof(double)) != SMR_OK) return -1;
+   double *dd = (double *) d;
+   int e = smr_hip_memcpy_h2d(dd, px, sizeof(px));
+   if (e == SMR_OK) e = smr_hip_memcpy_h2d(dd + 7, py, sizeof(py));
+   if (e == SMR_OK) e = smr_hip_unproject(dd, dd + 7, 7, dd + 14, dd + 21);
+   if (e == SMR_OK) e = smr_hip_memcpy_d2h(lon, dd + 14, sizeof(lon));
+   if (e == SMR_OK) e = smr_hip_memcpy_d2h(lat, dd + 21, sizeof(lat));
+   smr_hip_free(d);
+   if (e != SMR_OK) return -1;
+   std::string title = rd->title ? rd->title : "";
+   for (char &ch : title) if (ch == ',') ch = ' ';
+   const double mppx = rd->mean_lat_len / rd->w * 1852.0 * 60.0;
+   char buf[512];
+   out = "! generated by smrender (libsmr_hip)\r\n";
+   snprintf(buf, sizeof(buf), "VER/2.0\r\nBSB/NA=%s %d\r\n    NU=,RA=%d,%d,DU=%d\r\n", title.c_str(), (int) round(rd->scale), (int) round(rd->w), (int) round(rd->h), rd->dpi);
+   out += buf;
+   snprintf(buf, sizeof(buf), "KNP/SC=%d,GD=WGS84,PR=MERCATOR\r\n    PP=%f,PI=UNKNOWN,SP=UNKNOWN,SK=0.0,TA=90.0\r\n", (int) round(rd->scale), rd->mean_lat);
+   out += buf;
+   snprintf(buf, sizeof(buf), "    UN=METRES,SD=MLWS,DX=%.2f,DY=%.2f\r\n", mppx, mppx);
+   out += buf;
+   for (int k = 0; k < 3; k++) { snprintf(buf, sizeof(buf), "REF/%d,%.0f,%.0f,%.8f,%.8f\r\n", k + 1, px[k], py[k], lat[k], lon[k]); out += buf; }
+   for (int k = 0; k < 4; k++) { snprintf(buf, sizeof(buf), "PLY/%d,%.8f,%.8f\r\n", k + 1, lat[3 + k], lon[3 + k]); out += buf; }
+   out += "DTM/0.0,0.0\r\nCPH/0.0\r\n";
+   return 0;
+}
+
 static int hipsave_fini(smr_smrule_t *r)
 {
    const char *file = H.get_param("file", nullptr, r->act);
    if (!file || !P.canvas) return -1;
    if (smr_hip_sync() != SMR_OK) return -1;
+   const size_t fl = strlen(file);
+   if (fl > 4 && strcasecmp(file + fl - 4, ".kap") == 0)
+   {
+      /* a KAP chart (what `smrender -k` writes through save_kap, src/smkap.c:196-245): colour reduction, indices and rows on the device (kap.hip) */
+      std::string header;
+      smr_kap_stats_t ks;
+      if (kap_header(header) != 0 || smr_hip_canvas_write_kap(P.canvas, header.c_str(), file, &ks) != SMR_OK)
+      {
+         plog(SMR_LOG_ERR, "hipsave: %s", smr_hip_last_error());
+         return -1;
+      }
+      plog(SMR_LOG_NOTICE, "hipsave: KAP chart of %dx%d px, %d colours, written to %s: %.1f MB in %.0f ms", P.W, P.H, ks.n_colors, file, ks.file_bytes / 1e6,
+           ks.reduce_ms + ks.index_ms + ks.rows_ms + ks.write_ms);
+      return 0;
+   }
    /* un-premultiply, filter choice and filtering on the device, one crossing of PCIe, deflate on the host's cores (png.hip) */
    smr_png_stats_t st;
    int e = smr_hip_canvas_write_png(P.canvas, 0, 0, P.W, P.band_h, file, env_int("SMR_HIP_PNG_LEVEL", -1), env_int("SMR_HIP_PNG_THREADS", 0), &st);

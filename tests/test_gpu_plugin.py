@@ -596,6 +596,36 @@ def test_hipsave_writes_the_plugin_canvas(chart, tmp_path):
     assert np.array_equal(po.png_decode(f), po.png_pixels(plugin_canvas(sa)))
 
 
+def test_hipsave_writes_a_kap_chart(chart, tmp_path):
+    """hipsave@libsmr_hip.so:file=chart.kap -- what `smrender -k` writes (save_kap, src/smkap.c:196-245): the header of
+    gen_kap_header (:143-167) with the corners un-projected, then palette, rows and offset table from the device canvas"""
+    import ctypes as C
+    sa, proj = chart
+    wids, oways = load_ways(sa, proj, po.synth_ways(60, W, H, seed=79))
+    assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=#203040;bwidth=0.3", wids) == 0
+    f = tmp_path / "chart.kap"
+    assert hs.apply_rule(sa.lib(), "hipsave", hs.OSM_NODE, f"file={f}", np.zeros(0, np.int64)) == 0, sa.lib().smr_hip_last_error()
+    data = f.read_bytes()
+    cut = data.index(b"OST/1\r\n")
+    header = data[:cut].decode()
+    lines = header.split("\r\n")
+    assert lines[1] == "VER/2.0" and f"RA={W},{H},DU={DPI}" in lines[3] and "PR=MERCATOR" in lines[4] and lines[-2] == "CPH/0.0" and lines[-1] == ""
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    corners = {"REF/1": (0, 0), "REF/2": (W, H), "REF/3": (0, H), "PLY/1": (0, 0), "PLY/2": (W, 0), "PLY/3": (W, H), "PLY/4": (0, H)}
+    seen = 0
+    for ln in lines:
+        key = ln.split(",")[0]
+        if key in corners:
+            lon, lat = C.c_double(), C.c_double()
+            po.orc().orc_pxf2geo(C.byref(op), float(corners[key][0]), float(corners[key][1]), C.byref(lon), C.byref(lat))
+            got_lat, got_lon = [float(v) for v in ln.split(",")[-2:]]
+            assert abs(got_lat - lat.value) < 2e-8 and abs(got_lon - lon.value) < 2e-8, ln
+            seen += 1
+    assert seen == 7
+    body, pal = po.kap_body(plugin_canvas(sa), cut)
+    assert data[cut:] == body.tobytes()
+
+
 def symbol_png(path, w=37, h=23):
     """an asymmetric, partly translucent symbol written by libcairo's own PNG writer"""
     yy, xx = np.mgrid[0:h, 0:w]
