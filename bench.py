@@ -61,7 +61,7 @@ def measured_traffic(kernel, args):
     best = None
     # the latest set: names sort by their numbers (r01_s5 < r01_s11 < r02_...), not as strings
     for f in sorted(os.listdir(os.path.join(ROOT, "profiles")), key=lambda n: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", n)]):
-        if f.endswith("_hbm_traffic.json"):
+        if f.endswith("_hbm_traffic.json") and json.load(open(os.path.join(ROOT, "profiles", f))).get("workload", "").startswith("C2 "):
             best = os.path.join(ROOT, "profiles", f)
     if best is None:
         return None
@@ -400,6 +400,22 @@ def main():
         if cap is not None:
             res["caption_scan"] = cap
         if world == 1 and not args.no_other_charts:
+            # the chart's files from the device canvas, outside the timed region: PNG and KAP (rank 4)
+            import shutil, tempfile
+            tmp = tempfile.mkdtemp(prefix="smr_bench_", dir="/tmp")
+            try:
+                t0 = time.perf_counter()
+                ps = cv.write_png(os.path.join(tmp, "chart.png"))
+                t_png = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                ks = cv.write_kap(os.path.join(tmp, "chart.kap"), "VER/2.0\r\n")
+                t_kap = time.perf_counter() - t0
+                res["output_files"] = {
+                    "png": {"seconds": round(t_png, 3), "Mpx_per_s": round(mpx / t_png, 1), "MB": round(ps.bytes_written / 1e6, 2), "deflate_threads": ps.threads},
+                    "kap": {"seconds": round(t_kap, 3), "Mpx_per_s": round(mpx / t_kap, 1), "MB": round(ks.file_bytes / 1e6, 2), "colors": ks.n_colors,
+                            "reduce_ms": round(ks.reduce_ms, 1), "index_ms": round(ks.index_ms, 1), "rows_ms": round(ks.rows_ms, 1)}}
+            finally:
+                shutil.rmtree(tmp, ignore_errors=True)
             cv.close()
             res["other_charts"] = other_charts(args)
         if cpu_res is not None:
