@@ -115,6 +115,7 @@ int orc_fill_edges(const int32_t *p, int n, tor_edge_t *out)
  * what we emit (same orientation for every piece). ---- */
 
 typedef struct { int32_t x, y; } pt_t;
+static int64_t turn2(pt_t a, pt_t b, pt_t c) { return (int64_t) (b.x - a.x) * (c.y - b.y) - (int64_t) (b.y - a.y) * (c.x - b.x); }
 
 static int emit_poly(const pt_t *p, int n, tor_edge_t *out)
 {
@@ -274,6 +275,111 @@ int orc_stroke_edges(const int32_t *xy, int n, double hw_pt, int dpi, tor_edge_t
    }
    free(p);
    return cnt;
+}
+
+/* The same stroker's polygon ITSELF, edge by edge: the contour on the cw side forward (face corner or miter point to face
+ * corner or miter point; at a bevel the two outer corners; at an inner join the incoming corner, the vertex, the outgoing
+ * corner), the butt cap, the contour on the ccw side backward, the other cap.  Filled non-zero it IS what libcairo fills;
+ * the pieces above are its union-of-convex-parts form, which differs where a negatively wound loop cancels coverage: an
+ * inner join whose corner pokes out of the neighbouring segment's body (segments shorter than the stroke is wide, hairpins). */
+int orc_stroke_outline_edges(const int32_t *xy, int n, double hw_pt, int dpi, tor_edge_t *out)
+{
+   double s = (double) dpi / 72;
+   int cnt = 0;
+   pt_t *p = malloc(sizeof(pt_t) * (n > 0 ? n : 1));
+   int m = 0;
+   for (int i = 0; i < n; i++)
+   {
+      pt_t q = { xy[2 * i], xy[2 * i + 1] };
+      if (m == 0 || p[m - 1].x != q.x || p[m - 1].y != q.y) p[m++] = q;
+   }
+   #define EDGE(a, b) do { out[cnt].x1 = (a).x; out[cnt].y1 = (a).y; out[cnt].x2 = (b).x; out[cnt].y2 = (b).y; cnt++; } while (0)
+   face_t prev_end;
+   for (int i = 0; i + 1 < m; i++)
+   {
+      int32_t ddx = p[i + 1].x - p[i].x, ddy = p[i + 1].y - p[i].y;
+      face_t start, end;
+      compute_face(p[i], ddx, ddy, hw_pt, s, &start);
+      end = start;
+      end.point = p[i + 1];
+      end.ccw.x += ddx; end.ccw.y += ddy; end.cw.x += ddx; end.cw.y += ddy;
+      pt_t a_cw = start.cw, a_ccw = start.ccw, b_cw = end.cw, b_ccw = end.ccw;
+      if (i > 0)
+      {
+         join_t j = stroke_join(&prev_end, &start);
+         if (j.kind != 0)
+         {
+            if (j.clockwise)
+            {
+               /* cw is the outer side */
+               if (j.kind == 1) a_cw = j.m; else EDGE(prev_end.cw, start.cw);
+               EDGE(start.ccw, p[i]); EDGE(p[i], prev_end.ccw);
+            }
+            else
+            {
+               if (j.kind == 1) a_ccw = j.m; else EDGE(start.ccw, prev_end.ccw);
+               EDGE(prev_end.cw, p[i]); EDGE(p[i], start.cw);
+            }
+         }
+      }
+      else EDGE(start.ccw, start.cw);
+      if (i + 2 < m)
+      {
+         face_t nstart;
+         compute_face(p[i + 1], p[i + 2].x - p[i + 1].x, p[i + 2].y - p[i + 1].y, hw_pt, s, &nstart);
+         join_t j = stroke_join(&end, &nstart);
+         if (j.kind == 1) { if (j.clockwise) b_cw = j.m; else b_ccw = j.m; }
+      }
+      else EDGE(end.cw, end.ccw);
+      EDGE(a_cw, b_cw);
+      EDGE(b_ccw, a_ccw);
+      prev_end = end;
+   }
+   #undef EDGE
+   free(p);
+   return cnt;
+}
+
+/* Does the union of the pieces equal the polygon?  It does while at every join the inner corner of each face lies within
+ * the body of the OTHER segment (then the triangle vertex / incoming corner / outgoing corner is inside both bodies and the
+ * loop the inner contour makes there is wound like the rest).  A corner that pokes out of a neighbour shorter than the
+ * stroke is wide makes a loop wound the other way, which cancels coverage: such a way is "risky" and takes the polygon. */
+static int inside4(pt_t a, pt_t b, pt_t c, pt_t d, pt_t q)
+{
+   int64_t t0 = turn2(a, b, q), t1 = turn2(b, c, q), t2 = turn2(c, d, q), t3 = turn2(d, a, q);
+   return (t0 >= 0 && t1 >= 0 && t2 >= 0 && t3 >= 0) || (t0 <= 0 && t1 <= 0 && t2 <= 0 && t3 <= 0);
+}
+
+int orc_stroke_risky(const int32_t *xy, int n, double hw_pt, int dpi)
+{
+   double s = (double) dpi / 72;
+   pt_t *p = malloc(sizeof(pt_t) * (n > 0 ? n : 1));
+   int m = 0, risky = 0;
+   for (int i = 0; i < n; i++)
+   {
+      pt_t q = { xy[2 * i], xy[2 * i + 1] };
+      if (m == 0 || p[m - 1].x != q.x || p[m - 1].y != q.y) p[m++] = q;
+   }
+   /* a corner reaches hw * sin(turn) <= hw along the other segment: only a segment shorter than the half width (and the few
+    * 1/256 px of the corners' rounding) can be poked through.  The integer test comes first and is part of the rule: joins of
+    * longer segments are never looked at (their corners may sit a rounding step outside a neighbour that is nearly in line) */
+   const int64_t thr = (int64_t) ceil(hw_pt * s * 256.0) + 4, thr2 = thr * thr;
+   for (int i = 1; i + 1 < m && !risky; i++)
+   {
+      face_t a0, a1, b0, b1;
+      int32_t adx = p[i].x - p[i - 1].x, ady = p[i].y - p[i - 1].y, bdx = p[i + 1].x - p[i].x, bdy = p[i + 1].y - p[i].y;
+      if ((int64_t) adx * adx + (int64_t) ady * ady >= thr2 && (int64_t) bdx * bdx + (int64_t) bdy * bdy >= thr2) continue;
+      compute_face(p[i - 1], adx, ady, hw_pt, s, &a0);
+      a1 = a0; a1.point = p[i]; a1.ccw.x += adx; a1.ccw.y += ady; a1.cw.x += adx; a1.cw.y += ady;
+      compute_face(p[i], bdx, bdy, hw_pt, s, &b0);
+      b1 = b0; b1.ccw.x += bdx; b1.ccw.y += bdy; b1.cw.x += bdx; b1.cw.y += bdy;
+      join_t j = stroke_join(&a1, &b0);
+      if (j.kind == 0) continue;
+      pt_t in_inner = j.clockwise ? a1.ccw : a1.cw, out_inner = j.clockwise ? b0.ccw : b0.cw;
+      if (!inside4(b0.ccw, b1.ccw, b1.cw, b0.cw, in_inner) || !inside4(a0.ccw, a1.ccw, a1.cw, a0.cw, out_inner)) risky = 1;
+   }
+   free(p);
+   return risky;
 }
 
 /* Where a curve bends within less than half the line width, the inner corners of two consecutive faces change
@@ -826,7 +932,11 @@ static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double wid
    {
       /* a solid stroke with round caps would take libcairo's other stroker: not restated */
       e = malloc(sizeof(tor_edge_t) * 8 * n);
-      ne = orc_stroke_edges(dev, n, width_pt / 2, c->dpi, e);
+      /* the polygon itself for a way with a poked-through join, its pieces otherwise (ORC_STROKE_OUTLINE=0 / 1: always the
+       * pieces / always the polygon, for measurements) */
+      const char *mode = getenv("ORC_STROKE_OUTLINE");
+      int outline = mode && mode[0] == '1' ? 1 : mode && mode[0] == '0' ? 0 : orc_stroke_risky(dev, n, width_pt / 2, c->dpi);
+      ne = outline ? orc_stroke_outline_edges(dev, n, width_pt / 2, c->dpi, e) : orc_stroke_edges(dev, n, width_pt / 2, c->dpi, e);
    }
    else
    {

@@ -12,6 +12,7 @@
 #include "smr_host.h"
 #include <algorithm>
 #include <cmath>
+#include <string.h>
 #include <vector>
 
 /* ------------------------------------------------------------------------------------ */
@@ -529,6 +530,63 @@ __device__ __forceinline__ smr_join_t smr_join(const smr_face_t &in, const smr_f
  *               bevel -> quad (vertex, incoming outer, outgoing outer, incoming inner corner)                  */
 /* TAN: the way is a decomposed curve; the face at a point looks along tin (arriving segment) / tout (leaving
  * segment) instead of along the chords, and consecutive points are taken as they come (oracle: orc_stroke_edges_tan) */
+/* Is the union of a way's pieces its stroke polygon?  Not where the inner corner of a face pokes through a neighbouring
+ * segment shorter than the stroke's half width: the loop the inner contour makes there is wound against the rest and cancels
+ * coverage (oracle/smr_oracle.c: orc_stroke_risky, the same rule step by step).  The lane of a segment SHORTER than the half
+ * width (plus the corners' rounding: an integer test that is part of the rule) looks at the joins at its two ends; a way with
+ * a poked-through join gets bit 16 (border) / 32 (fill stroke of an open way) and is then stroked as the polygon itself */
+__device__ __forceinline__ bool smr_inside4(int2 a, int2 b, int2 c, int2 d, int2 q)
+{
+   const int64_t t0 = smr_turn(a, b, q), t1 = smr_turn(b, c, q), t2 = smr_turn(c, d, q), t3 = smr_turn(d, a, q);
+   return (t0 >= 0 && t1 >= 0 && t2 >= 0 && t3 >= 0) || (t0 <= 0 && t1 <= 0 && t2 <= 0 && t3 <= 0);
+}
+
+__device__ __forceinline__ bool smr_join_poked(int2 q0, int2 p1, int2 p2, double hw, double s)
+{
+   const int32_t adx = p1.x - q0.x, ady = p1.y - q0.y, bdx = p2.x - p1.x, bdy = p2.y - p1.y;
+   const smr_face_t a1 = smr_face(p1, adx, ady, hw, s), b0 = smr_face(p1, bdx, bdy, hw, s);
+   const smr_join_t j = smr_join(a1, b0, p1);
+   if (j.kind == 0) return false;
+   const int2 in_inner = j.clockwise ? a1.ccw : a1.cw, out_inner = j.clockwise ? b0.ccw : b0.cw;
+   const int2 a0c = make_int2(a1.ccw.x - adx, a1.ccw.y - ady), a0w = make_int2(a1.cw.x - adx, a1.cw.y - ady);
+   const int2 b1c = make_int2(b0.ccw.x + bdx, b0.ccw.y + bdy), b1w = make_int2(b0.cw.x + bdx, b0.cw.y + bdy);
+   return !smr_inside4(b0.ccw, b1c, b1w, b0.cw, in_inner) || !smr_inside4(a0c, a1.ccw, a1.cw, a0w, out_inner);
+}
+
+__global__ void k_stroke_risk(const int2 *__restrict__ pts, const int64_t *__restrict__ way_off, const int32_t *__restrict__ refway, int64_t n_refs,
+                              uint8_t *wayflags, int mode, int dpi, double hw_nofill_pt, double hw_open_pt, double hw_closed_pt, double hw_fill_pt,
+                              int fill_used, int force)
+{
+   const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+   if (g >= n_refs) return;
+   const int64_t w = refway[g];
+   const uint8_t wf = wayflags[w];
+   if (!(mode == 0 ? (wf & 2) : (wf & 8))) return;
+   const int64_t a = way_off[w], b = way_off[w + 1];
+   if (force) { if (g == a) atomicOr(reinterpret_cast<uint32_t *>(wayflags) + (w >> 2), (mode == 0 ? 16u : 32u) << (8 * (w & 3))); return; }
+   if (g + 1 >= b) return;
+   const int2 p1 = pts[g], p2 = pts[g + 1];
+   const int32_t ddx = p2.x - p1.x, ddy = p2.y - p1.y;
+   if (ddx == 0 && ddy == 0) return;
+   const double hw = mode == 1 ? hw_fill_pt : (!fill_used ? hw_nofill_pt : ((wf & 1) ? hw_closed_pt : hw_open_pt));
+   const double s = (double) dpi / 72;
+   const int64_t thr = (int64_t) ceil(hw * s * 256.0) + 4;
+   if ((int64_t) ddx * ddx + (int64_t) ddy * ddy >= thr * thr) return;
+   bool poked = false;
+   for (int64_t k = g - 1; k >= a; k--)
+   {
+      const int2 q = pts[k];
+      if (q.x != p1.x || q.y != p1.y) { poked = smr_join_poked(q, p1, p2, hw, s); break; }
+   }
+   for (int64_t k = g + 2; k < b && !poked; k++)
+   {
+      const int2 q = pts[k];
+      if (q.x != p2.x || q.y != p2.y) { poked = smr_join_poked(p1, p2, q, hw, s); break; }
+   }
+   /* the way's flag byte, set through its aligned word (other bytes: other ways, OR-ing 0 into them) */
+   if (poked) atomicOr(reinterpret_cast<uint32_t *>(wayflags) + (w >> 2), (mode == 0 ? 16u : 32u) << (8 * (w & 3)));
+}
+
 template <bool TAN>
 __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__restrict__ way_off,
                                const int32_t *__restrict__ refway, int64_t n_refs,
@@ -583,6 +641,14 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
             k--;
          }
          if (TAN) have = g > a;
+         /* a way with a poked-through join (k_stroke_risk): the stroker's polygon itself, edge by edge, filled non-zero --
+          * the contour forward on the cw side, backward on the ccw side, an inner join through the vertex, a butt cap at
+          * either end of the way (oracle: orc_stroke_outline_edges) */
+         const bool outline = !TAN && (wf & (mode == 0 ? 16 : 32)) != 0;
+         int no = 0;
+         /* (straight to memory: a register array indexed by a running count would live in scratch) */
+         smr_edge_t *const oline = edges + (size_t) SMR_SLOTS * g;
+         auto edge = [&](int2 u, int2 v) { smr_edge_t ed; ed.x1 = u.x; ed.y1 = u.y; ed.x2 = v.x; ed.y2 = v.y; oline[no++] = ed; };
          if (have)
          {
             int32_t pdx = p1.x - q0.x, pdy = p1.y - q0.y;
@@ -591,9 +657,25 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
             smr_join_t j = smr_join(cur, start, p1);
             int2 in_inner = j.clockwise ? cur.ccw : cur.cw, out_inner = j.clockwise ? start.ccw : start.cw;
             int2 in_outer = j.clockwise ? cur.cw : cur.ccw, out_outer = j.clockwise ? start.cw : start.ccw;
-            if (j.kind == 1)
+            if (j.kind == 1) { if (j.clockwise) c_cw0 = j.m; else c_ccw0 = j.m; }
+            if (outline)
             {
-               if (j.clockwise) c_cw0 = j.m; else c_ccw0 = j.m;
+               if (j.kind != 0)
+               {
+                  if (j.clockwise)
+                  {
+                     if (j.kind == 2) edge(cur.cw, start.cw);
+                     edge(start.ccw, p1); edge(p1, cur.ccw);
+                  }
+                  else
+                  {
+                     if (j.kind == 2) edge(start.ccw, cur.ccw);
+                     edge(cur.cw, p1); edge(p1, start.cw);
+                  }
+               }
+            }
+            else if (j.kind == 1)
+            {
                int2 q[3] = { p1, in_inner, out_inner };
                smr_emit_poly(q, 3, loc);
             }
@@ -603,6 +685,7 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
                smr_emit_poly(q, 4, loc);
             }
          }
+         else if (outline) edge(start.ccw, start.cw);
          /* next non-degenerate segment of the same way starts at p2 */
          k = g + 2;
          have = false;
@@ -623,8 +706,15 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
             smr_join_t j = smr_join(end, nstart, p2);
             if (j.kind == 1) { if (j.clockwise) c_cw1 = j.m; else c_ccw1 = j.m; }
          }
+         else if (outline) edge(c_cw1, c_ccw1);
          int2 q[4] = { c_ccw0, c_ccw1, c_cw1, c_cw0 };
-         if (TAN)
+         if (outline)
+         {
+            edge(c_cw0, c_cw1); edge(c_ccw1, c_ccw0);
+            for (; no < SMR_SLOTS; no++) oline[no] = z;
+            return;
+         }
+         else if (TAN)
          {
             /* a curve that bends within half the line width makes this quad cross itself: the piece has to be convex
              * (one interval per sub-row), so the hull of the four corners stands in (oracle: hull4) */
@@ -1348,7 +1438,10 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    const int64_t base = (ua >> 3) + w, span = (ub >> 3) + (w + 1) - base;
    const int64_t item0 = A.K * base + kind * span;
    const bool on = role != 2 ? (wf & 2) != 0 : (wf & 12) != 0;
-   const bool pieces = role != 2 || (wf & 8);
+   /* strokes keep 8 slots per ref (or 4 per dash piece), empty ones zeroed; a solid stroke of a way with a poked-through join
+    * (k_stroke_risk) holds the stroker's polygon in them and is filled non-zero like a fill polygon */
+   const bool sparse = role != 2 || (wf & 8);
+   const bool pieces = sparse && !(role == 0 ? (wf & 16) != 0 && !A.po_border : role == 2 ? (wf & 32) != 0 && !A.po_open : false);
    /* libcairo limits a polygon to the image it renders into; for a window of an atlas that image is the window's rows */
    const int clip0 = A.way_clip ? A.way_clip[w].x : 0, clip1 = A.way_clip ? A.way_clip[w].y : A.H;
    smr_prim_t P;
@@ -1403,9 +1496,9 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
       smr_edge_t e; e.x1 = e.y1 = e.x2 = e.y2 = 0;
       if (idx < P.edge_cnt) e = E[idx];
       if (k == 0) e0 = e;
-      bool has = idx < P.edge_cnt && (e.x1 != e.x2 || e.y1 != e.y2 || !pieces);
-      /* fill polygons: every vertex counts (one per slot); pieces: empty slots are all zero */
-      if (pieces && e.x1 == 0 && e.y1 == 0 && e.x2 == 0 && e.y2 == 0) has = false;
+      bool has = idx < P.edge_cnt && (e.x1 != e.x2 || e.y1 != e.y2 || !sparse);
+      /* fill polygons: every vertex counts (one per slot); strokes: empty slots are all zero */
+      if (sparse && e.x1 == 0 && e.y1 == 0 && e.x2 == 0 && e.y2 == 0) has = false;
       int mnx = has ? min(e.x1, e.x2) : INT32_MAX, mxx = has ? max(e.x1, e.x2) : INT32_MIN;
       int mny = has ? min(e.y1, e.y2) : INT32_MAX, mxy = has ? max(e.y1, e.y2) : INT32_MIN;
       /* the exact full-row path evaluates an edge at the row boundaries, up to half a sub-row beyond
@@ -3731,6 +3824,13 @@ static int host_pen(double hw_pt, int dpi, std::vector<int2> &out)
    return SMR_OK;
 }
 
+/* SMR_HIP_STROKE=polygon: every solid stroke as the stroker's polygon (measurements; the oracle's ORC_STROKE_OUTLINE=1) */
+static int stroke_polygon_always(void)
+{
+   const char *e = getenv("SMR_HIP_STROKE");
+   return e && strcmp(e, "polygon") == 0;
+}
+
 extern "C" uint32_t smr_hip_draw_status(void) { return smr_g.draw_status; }
 
 int smr_scan_u32(uint32_t *buf, uint32_t n, uint32_t *sums, uint32_t *total_dev, uint32_t *total)
@@ -3809,7 +3909,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    int2 *pts; int32_t *refway; uint8_t *wayflags; uint32_t *small; smr_prim_t *prims; smr_item_t *items; uint32_t *way_pix = nullptr;
    SMR_TRY(c->ensure(SMR_BUF_PTS, (size_t) n_refs * sizeof(int2), (void **) &pts));
    SMR_TRY(c->ensure(SMR_BUF_REFWAY, (size_t) n_refs * 4, (void **) &refway));
-   SMR_TRY(c->ensure(SMR_BUF_WAYFLAGS, (size_t) n_ways, (void **) &wayflags));
+   SMR_TRY(c->ensure(SMR_BUF_WAYFLAGS, (size_t) n_ways + 4, (void **) &wayflags));      /* k_stroke_risk sets a byte through its aligned word */
    SMR_TRY(c->ensure(SMR_BUF_SMALL, 1024, (void **) &small));     /* [0] any_open_fill [1] first_prim [2] status [3] entries [4] mask words */
    SMR_TRY(c->ensure(SMR_BUF_PRIMS, ((size_t) n_prims + 1) * sizeof(smr_prim_t), (void **) &prims));
    const uint32_t compound = mode == SMR_PASS_COMPOUND ? (uint32_t) n_prims : 0xffffffffu;
@@ -4024,8 +4124,12 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    {
       if (tin) k_stroke_edges<true><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill,
                                                                       hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border, tin, tout, fskip);
-      else k_stroke_edges<false><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill,
-                                                                   hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border, nullptr, nullptr, nullptr);
+      else
+      {
+         k_stroke_risk<<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill, hw_open, hw_closed, hw_fill, st->fill_used, stroke_polygon_always());
+         k_stroke_edges<false><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill,
+                                                                 hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border, nullptr, nullptr, nullptr);
+      }
    }
    if (st->fill_used)
       k_fill_edges<<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, edges + off_fill, fskip);
@@ -4034,8 +4138,12 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    {
       if (tin) k_stroke_edges<true><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill,
                                                                       hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open, tin, tout, fskip);
-      else k_stroke_edges<false><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill,
-                                                                   hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open, nullptr, nullptr, nullptr);
+      else
+      {
+         k_stroke_risk<<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill, hw_open, hw_closed, hw_fill, st->fill_used, stroke_polygon_always());
+         k_stroke_edges<false><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill,
+                                                                 hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open, nullptr, nullptr, nullptr);
+      }
    }
    uint32_t *wb_pix = nullptr, *wf_pix = nullptr;
    if (b->d_way_border_col || b->d_way_fill_col)

@@ -7,6 +7,7 @@ cites the smrender lines it restates).  The reference's own tests hold no expect
 reference delegates to, reached through its own call sites -- are what pins the oracle.
 
     python tests/golden/make_golden.py        # rewrites tests/golden/*.npz (needs libcairo)
+    python tests/golden/make_golden.py hairpins_300      # only the named scenes
 """
 import os
 import sys
@@ -32,6 +33,25 @@ def open_ways(n_ways, W, H, seed):
     return np.concatenate(xs), np.concatenate(ys), np.array(off, np.int64), np.array(ref, np.int32)
 
 
+def hairpin_ways(n_ways, W, H, seg_px, margin, seed):
+    """sharp turns and segments shorter than the stroke is wide, kept `margin` px inside the window"""
+    rng = np.random.default_rng(seed)
+    xs, ys, off, ref = [], [], [0], []
+    while len(off) - 1 < n_ways:
+        n = int(rng.integers(3, 9))
+        x = [rng.uniform(margin, W - margin)]; y = [rng.uniform(margin, H - margin)]
+        ang = rng.uniform(0, 2 * np.pi)
+        for _ in range(n - 1):
+            ang += rng.choice([rng.uniform(2.6, 3.6), rng.uniform(-0.5, 0.5), rng.uniform(1.5, 2.5)])
+            L = rng.uniform(0.3, 3.0) * seg_px
+            x.append(x[-1] + L * np.cos(ang)); y.append(y[-1] + L * np.sin(ang))
+        x, y = np.array(x), np.array(y)
+        if x.min() < margin or y.min() < margin or x.max() > W - margin or y.max() > H - margin:
+            continue
+        xs.append(x); ys.append(y); ref.extend(range(off[-1], off[-1] + n)); off.append(off[-1] + n)
+    return np.concatenate(xs), np.concatenate(ys), np.array(off, np.int64), np.array(ref, np.int32)
+
+
 def style_tuple(st):
     return np.array([st.fill_used, st.border_used, st.fill_col, st.border_col, st.ignore_open,
                      st.border_style, st.fill_style, st.border_ndash, st.fill_ndash, st.curve], np.int64), \
@@ -46,7 +66,7 @@ def main():
 
     # 1. scan-converter KATs: single polygons filled black on white straight onto an image
     polys, alphas = [], []
-    for t in range(48):
+    for t in range(48 if not sys.argv[1:] else 0):
         W = int(rng.integers(12, 48))
         n = 3 + t % 9
         ang = np.sort(rng.uniform(0, 2 * np.pi, n))
@@ -58,7 +78,8 @@ def main():
         cd.cd_direct_fill(po.P(np.ascontiguousarray(xy)), n, 0x000000, 0xffffff, W, W, po.P(out))
         polys.append(xy)
         alphas.append((255 - (out & 0xff)).astype(np.uint8))
-    np.savez_compressed(os.path.join(HERE, "tor_kat.npz"), n=len(polys),
+    if not sys.argv[1:]:
+      np.savez_compressed(os.path.join(HERE, "tor_kat.npz"), n=len(polys),
                         **{f"xy{i}": p for i, p in enumerate(polys)}, **{f"a{i}": a for i, a in enumerate(alphas)})
 
     # 2. whole scenes through the reference call sequence (recording surface in pt, group per rule, replay)
@@ -97,7 +118,16 @@ def main():
         (S(1, 1, 0x4080c0, 0x000000, 0, 0.2, 0).with_curve(), synth.synth_ways(14, 256, 200, seed=87, rmin=10.0, rmax=60.0)),
         (S(0, 1, 0, 0x204060, 0, 0.3, 0).with_curve(), open_ways(10, 256, 200, seed=88)),
         (S(1, 1, 0x30c0d8f0, 0x000000, 0.4, 0.15, 0).with_curve(0.35), open_ways(8, 256, 200, seed=89))])
+    # hairpins: joins whose inner corner pokes through a neighbouring segment shorter than the stroke is wide (the stroker's
+    # polygon winds against itself there); a wide border, a narrow one, the fill stroke of open ways
+    scenes["hairpins_300"] = dict(dpi=300, W=400, H=300, bg=0xffffff, rules=[
+        (S(0, 1, 0, 0x203040, 0, 1.2, 0), hairpin_ways(14, 400, 300, 8, 75, seed=90)),
+        (S(0, 1, 0, 0x802010, 0, 0.3, 0), hairpin_ways(20, 400, 300, 3, 20, seed=91)),
+        (S(1, 0, 0x6030a060, 0, 0.8, 0, 0), hairpin_ways(14, 400, 300, 6, 50, seed=92))])
+    only = sys.argv[1:]
     for name, sc in scenes.items():
+        if only and name not in only:
+            continue
         rules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in sc["rules"]]
         img = po.cairo_scene(rules, sc["dpi"], sc["W"], sc["H"], sc["bg"], sc.get("x0", 0), sc.get("y0", 0),
                              sc.get("full_w"), sc.get("full_h"))
@@ -110,6 +140,8 @@ def main():
         print(name, img.shape)
 
     # 3. rotated bilinear OVER paint (cairo_smr_diff, src/smrules_cairo.c:1746-1759)
+    if sys.argv[1:]:
+        return
     d = {}
     for t in range(12):
         dw, dh = int(rng.integers(8, 60)), int(rng.integers(4, 24))

@@ -4,7 +4,7 @@ import numpy as np
 from oracle import pyoracle as po
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SCENES = ["c2_fill_border_300", "open_border_300", "layers_translucent_600", "far_window_300", "dashes_300", "curves_300"]
+SCENES = ["c2_fill_border_300", "open_border_300", "layers_translucent_600", "far_window_300", "dashes_300", "curves_300", "hairpins_300"]
 
 
 def load_scene(name):
@@ -29,8 +29,8 @@ def load_scene(name):
 # Solid fills, dashes and ordinary strokes are bit-identical; what is left are joins that libcairo's contour
 # stroker resolves by winding cancellation (turns sharper than ~150 degrees between segments shorter than the
 # line width: the random walks of open_border / layers_translucent are full of them), see DESIGN.md deviations.
-BARS = {"c2_fill_border_300": (0.9999, 0.9999), "open_border_300": (0.999, 0.998), "layers_translucent_600": (0.997, 0.99),
-        "far_window_300": (1.0, 0.999), "dashes_300": (0.9998, 0.9995), "curves_300": (0.9995, 0.998)}
+BARS = {"c2_fill_border_300": (0.9999, 0.9999), "open_border_300": (0.999, 0.998), "layers_translucent_600": (0.9993, 0.996),
+        "far_window_300": (1.0, 0.999), "dashes_300": (0.9998, 0.9995), "curves_300": (0.9995, 0.998), "hairpins_300": (0.9998, 0.9994)}
 
 
 def draw_style(sa, st, **kw):

@@ -34,6 +34,24 @@ def test_golden_scene(hip, name):
     assert np.array_equal(got, o)
 
 
+@pytest.mark.parametrize("name", ["hairpins_300", "open_border_300", "layers_translucent_600"])
+def test_golden_scene_with_every_stroke_as_the_strokers_polygon(hip, name, monkeypatch):
+    """SMR_HIP_STROKE=polygon (the oracle's ORC_STROKE_OUTLINE=1): every solid stroke is filled as libcairo's stroke polygon
+    itself instead of the union of its convex pieces (the default takes the polygon only for ways with a poked-through join).
+    Costs 10 % of a C2 step; the hairpin scene is then libcairo's image pixel for pixel."""
+    monkeypatch.setenv("SMR_HIP_STROKE", "polygon")
+    monkeypatch.setenv("ORC_STROKE_OUTLINE", "1")
+    meta, rules, want = load_scene(name)
+    got = gpu_render(hip, meta, rules)
+    orules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in rules]
+    o = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"])
+    assert np.array_equal(got, o)
+    if name == "hairpins_300":
+        assert np.array_equal(got, want)
+    else:
+        assert within(got, want, 0) >= {"open_border_300": 0.999, "layers_translucent_600": 0.9975}[name]
+
+
 def test_full_size_c2_windows_vs_oracle(hip):
     """BASELINE config 2 at full size (1 M ways, 16384^2): windows of the device canvas must equal the
     oracle's render of the ways that reach the window (drawing order preserved)."""

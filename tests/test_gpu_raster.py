@@ -654,3 +654,63 @@ def test_bad_batches_are_refused_before_anything_is_drawn(hip):
     got = cv.read(); cv.close()
     want = oracle_of([(STYLES["fill+border"], (x, y, off, ref))], 300, W, H, 0xffffff)
     assert np.array_equal(got, want), report(got, want)
+
+
+def _hairpin_ways(n_ways, W, H, seg_px, seed, closed_share=0.0):
+    """ways of sharp turns and short segments: joins whose inner corner pokes through the neighbouring segment"""
+    rng = np.random.default_rng(seed)
+    xs, ys, off, ref = [], [], [0], []
+    for w in range(n_ways):
+        n = int(rng.integers(3, 10))
+        x = [rng.uniform(0, W)]; y = [rng.uniform(0, H)]
+        ang = rng.uniform(0, 2 * np.pi)
+        for k in range(n - 1):
+            ang += rng.choice([rng.uniform(2.6, 3.6), rng.uniform(-0.5, 0.5), rng.uniform(1.5, 2.5)])
+            L = rng.uniform(0.3, 3.0) * seg_px
+            if rng.random() < 0.1:
+                L = 0.0                               # a repeated point
+            x.append(x[-1] + L * np.cos(ang)); y.append(y[-1] + L * np.sin(ang))
+        r = list(range(off[-1], off[-1] + n))
+        if rng.random() < closed_share and n >= 4:
+            r[-1] = r[0]                              # a closed way: its last ref is its first node (the node of its own stays unused)
+        xs.append(np.array(x)); ys.append(np.array(y)); ref.extend(r); off.append(off[-1] + n)
+    return np.concatenate(xs), np.concatenate(ys), np.array(off, np.int64), np.array(ref, np.int32)
+
+
+@pytest.mark.parametrize("case", ["border_wide", "border_narrow", "open_fill_stroke", "fill+border_mixed", "translucent_600dpi"])
+def test_hairpin_ways_take_the_strokers_polygon(hip, case):
+    """Where a face's inner corner pokes through a neighbouring segment shorter than the stroke's half width, the union of the
+    stroke's convex pieces is not libcairo's polygon (a loop wound the other way cancels coverage there): such ways are
+    stroked as the polygon itself (k_stroke_risk).  GPU == oracle bit for bit; and against the real libcairo the
+    gross differences of the pieces (up to 200 levels) are gone."""
+    W, H, dpi = 400, 300, 300
+    st, seg, closed = {
+        "border_wide": (po.Style(0, 1, 0, 0x203040, 0, 1.2, 0), 8, 0.0),
+        "border_narrow": (po.Style(0, 1, 0, 0x203040, 0, 0.3, 0), 3, 0.0),
+        "open_fill_stroke": (po.Style(1, 0, 0xc04020, 0, 0.8, 0, 0), 6, 0.0),
+        "fill+border_mixed": (po.Style(1, 1, 0xe0c000, 0x000000, 0.6, 0.3, 0), 6, 0.4),
+        "translucent_600dpi": (po.Style(0, 1, 0, 0x60102030, 0, 0.8, 0), 10, 0.0),
+    }[case]
+    if case == "translucent_600dpi":
+        dpi = 600
+    arrs = _hairpin_ways(40, W, H, seg, seed=len(case), closed_share=closed)
+    rules = [(st, arrs)]
+    g = gpu_scene(hip, rules, dpi, W, H, 0xffffff)
+    o = oracle_of(rules, dpi, W, H, 0xffffff)
+    assert np.array_equal(g, o), report(g, o)
+    # the rule really met poked-through joins
+    L = po.orc()
+    L.orc_stroke_risky.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_int]
+    x, y, off, ref = arrs
+    width_mm = st.border_width_mm if st.border_used and not st.fill_used else (st.fill_width_mm if not st.border_used else 2 * st.border_width_mm + st.fill_width_mm)
+    risky = 0
+    for w in range(len(off) - 1):
+        r = ref[off[w]:off[w + 1]]
+        dev = np.zeros(2 * len(r), np.int32)
+        L.orc_px_to_dev(po.P(np.ascontiguousarray(x[r])), po.P(np.ascontiguousarray(y[r])), len(r), dpi, po.P(dev))
+        risky += L.orc_stroke_risky(po.P(dev), len(r), width_mm * 72 / 25.4 / 2, dpi)
+    assert risky >= 5, risky
+    if po.cairo() is not None and case != "fill+border_mixed":
+        c = po.cairo_scene([(st, po.ways_from_arrays(*arrs))], dpi, W, H, 0xffffff)
+        d = po.chan_diff(g, c)[2:-2, 2:-2]        # (the image's last row and column: the translucent layer's own edge)
+        assert (d > 0).mean() < 0.004 and (d > 64).sum() <= 4, ((d > 0).sum(), d.max(), (d > 64).sum())
