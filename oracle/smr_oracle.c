@@ -111,8 +111,9 @@ int orc_fill_edges(const int32_t *p, int n, tor_edge_t *out)
 /* ---- stroker: cairo-path-stroke-polygon.c semantics for an open poly-line, butt caps,
  * miter joins with Cairo's default limit 10 (the reference never sets join/limit).  The
  * stroke polygon's non-zero region equals the union of one quad per segment and one
- * wedge (miter quad or bevel triangle) on the outer side of every join; that union is
- * what we emit (same orientation for every piece). ---- */
+ * wedge (miter quad or bevel triangle) on the outer side of every join -- unless a join's
+ * inner corner pokes through a short neighbouring segment (orc_stroke_risky below): then
+ * the polygon itself is emitted (orc_stroke_outline_edges). ---- */
 
 typedef struct { int32_t x, y; } pt_t;
 static int64_t turn2(pt_t a, pt_t b, pt_t c) { return (int64_t) (b.x - a.x) * (c.y - b.y) - (int64_t) (b.y - a.y) * (c.x - b.x); }
