@@ -775,6 +775,7 @@ struct orc_canvas
    int img[4];           /* the image's rectangle on the chart, px (curve limits) */
    int cap_round;        /* line cap of the current rule's context (cairo_set_line_cap is never undone) */
    int32_t shift_x, shift_y;   /* 24.8: the translation of a replay at an offset (cairo_smr_cut_out), added to every device vertex */
+   int no_cuts;          /* the edges of the next orc_layer_edges are a stroke's PIECES: their inner edges are not the polygon's, no cuts at the image's sides */
 };
 
 orc_canvas_t *orc_canvas_new(int x0, int y0, int W, int H, int dpi, uint32_t bgcolor)
@@ -853,7 +854,16 @@ void orc_layer_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, u
    if (by1 > c->H) by1 = c->H;
    if (bx0 >= bx1 || by0 >= by1) return;      /* nothing drawn: the layer stays "clear" for libcairo too */
    int bw = bx1 - bx0, bh = by1 - by0;
+   {
+      /* the clip of the replay is the recording surface's rectangle: whole pt (floor / ceil of the page in pt), through the
+       * replay's 24.8 scale -- at 300 dpi a little MORE than the page, at 600 dpi a little less */
+      const int32_t sc = orc_fixed_from_double((double) c->dpi / 72);
+      const int32_t xl = fixed_mul((int32_t) floor((double) c->img[0] * 72 / c->dpi) * 256, sc), xr = fixed_mul((int32_t) ceil((double) c->img[2] * 72 / c->dpi) * 256, sc);
+      /* (a replay at an offset, cairo_smr_cut_out: the page's sides are somewhere else, rarely inside the cut-out; left out) */
+      tor_set_limits(getenv("ORC_NO_LIMITS") == NULL && !c->no_cuts && !c->shift_x && !c->shift_y, xl, xr);
+   }
    tor_coverage(e, n, nonzero, c->x0 + bx0, c->y0 + by0, bw, bh, c->cov);
+   tor_set_limits(0, 0, 0);
    for (int y = 0; y < bh; y++)
       for (int x = 0; x < bw; x++)
       {
@@ -889,7 +899,7 @@ void orc_direct_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, 
    if (by1 > c->H) by1 = c->H;
    if (bx0 >= bx1 || by0 >= by1) return;
    int bw = bx1 - bx0, bh = by1 - by0;
-   tor_coverage(e, n, nonzero, c->x0 + bx0, c->y0 + by0, bw, bh, c->cov);
+   tor_coverage(e, n, nonzero, c->x0 + bx0, c->y0 + by0, bw, bh, c->cov);      /* (straight onto an image: no clip, no limits) */
    for (int y = 0; y < bh; y++)
       for (int x = 0; x < bw; x++)
       {
@@ -928,7 +938,7 @@ static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double wid
    if (style == 5) c->cap_round = 1;
    if (style == 4) { c->cap_round = 1; dash[0] = 0; dash[1] = l; nd = 2; }
    tor_edge_t *e;
-   int ne;
+   int ne, outline_used = 0;
    if (nd == 0)
    {
       /* a solid stroke with round caps would take libcairo's other stroker: not restated */
@@ -937,6 +947,7 @@ static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double wid
        * pieces / always the polygon, for measurements) */
       const char *mode = getenv("ORC_STROKE_OUTLINE");
       int outline = mode && mode[0] == '1' ? 1 : mode && mode[0] == '0' ? 0 : orc_stroke_risky(dev, n, width_pt / 2, c->dpi);
+      outline_used = outline;
       ne = outline ? orc_stroke_outline_edges(dev, n, width_pt / 2, c->dpi, e) : orc_stroke_edges(dev, n, width_pt / 2, c->dpi, e);
    }
    else
@@ -945,7 +956,9 @@ static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double wid
       e = malloc(sizeof(tor_edge_t) * (ne > 0 ? ne : 1));
       if (ne > 0) orc_dash_edges(dev, n, width_pt / 2, c->dpi, dash, nd, c->cap_round, e);
    }
+   c->no_cuts = !(nd == 0 && outline_used);
    if (ne > 0) orc_layer_edges(c, e, ne, 1, col);
+   c->no_cuts = 0;
    free(e);
 }
 
@@ -996,7 +1009,9 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
       else bw = mm2wu(2 * st->border_width_mm, c->dpi);
       FLATTEN(orc_stroke_reach_px(bw, c->dpi));
       int ne = m >= 2 ? orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e) : 0;
+      c->no_cuts = 1;
       if (ne > 0) orc_layer_edges(c, e, ne, 1, has_border_col ? border_col : st->border_col);
+      c->no_cuts = 0;
    }
    if (st->fill_used)
    {
@@ -1004,7 +1019,9 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
       double fw = mm2wu(st->fill_width_mm, c->dpi);
       FLATTEN(closed ? 0.0 : orc_stroke_reach_px(fw, c->dpi));
       int ne = m < 2 ? 0 : closed ? orc_fill_edges(pts, m, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e);
+      c->no_cuts = !closed;
       if (ne > 0) orc_layer_edges(c, e, ne, 1, col);
+      c->no_cuts = 0;
    }
    #undef FLATTEN
    free(e); free(pts); free(curves); free(xp);

@@ -21,9 +21,66 @@ typedef struct
    quorem_t dxdy, dxdy_full;
    /* per-row scratch */
    quorem_t x; int64_t cell; quorem_t xn; int64_t celln;
+   int ncut, cut[2];
 } edge_t;
 
 static int to_grid_y(int64_t y) { return (int) ((GRID_Y * y + 128) >> 8); }
+
+static int lim_on_;
+static int64_t lim_x0_, lim_x1_;
+void tor_set_limits(int on, int32_t x_left, int32_t x_right) { lim_on_ = on; lim_x0_ = x_left; lim_x1_ = x_right; }
+
+static int64_t floor_div(int64_t a, int64_t b)
+{
+   int64_t q = a / b;
+   if ((a % b != 0) && ((a < 0) != (b < 0))) q--;
+   return q;
+}
+static int64_t y_for_x(int64_t p1x, int64_t p1y, int64_t p2x, int64_t p2y, int64_t x)
+{
+   if (x == p1x) return p1y;
+   if (x == p2x) return p2y;
+   int64_t dx = p2x - p1x;
+   return dx ? p1y + floor_div((x - p1x) * (p2y - p1y), dx) : p1y;
+}
+static int64_t x_for_y(int64_t p1x, int64_t p1y, int64_t p2x, int64_t p2y, int64_t y)
+{
+   if (y == p1y) return p1x;
+   if (y == p2y) return p2x;
+   int64_t dy = p2y - p1y;
+   return dy ? p1x + floor_div((y - p1y) * (p2x - p1x), dy) : p1x;
+}
+static int limit_cuts(int64_t p1x, int64_t p1y, int64_t p2x, int64_t p2y, int64_t *cut)
+{
+   int n = 0;
+   if (!lim_on_) return 0;
+   const int64_t L = lim_x0_, R = lim_x1_, pleft = p1x < p2x ? p1x : p2x, pright = p1x < p2x ? p2x : p1x;
+   if ((L <= pleft && pright <= R) || pright <= L || R <= pleft) return 0;
+   int64_t top_y = p1y, bot_y = p2y, left_y, right_y;
+   if (p1x <= p2x)
+   {
+      if (pleft >= L) left_y = top_y;
+      else { left_y = y_for_x(p1x, p1y, p2x, p2y, L); if (x_for_y(p1x, p1y, p2x, p2y, left_y) < L) left_y++; }
+      if (left_y > bot_y) left_y = bot_y;
+      if (top_y < left_y) { cut[n++] = left_y; top_y = left_y; }
+      if (pright <= R) right_y = bot_y;
+      else { right_y = y_for_x(p1x, p1y, p2x, p2y, R); if (x_for_y(p1x, p1y, p2x, p2y, right_y) > R) right_y--; }
+      if (right_y < top_y) right_y = top_y;
+      if (bot_y > right_y) cut[n++] = right_y;
+   }
+   else
+   {
+      if (pright <= R) right_y = top_y;
+      else { right_y = y_for_x(p1x, p1y, p2x, p2y, R); if (x_for_y(p1x, p1y, p2x, p2y, right_y) > R) right_y++; }
+      if (right_y > bot_y) right_y = bot_y;
+      if (top_y < right_y) { cut[n++] = right_y; top_y = right_y; }
+      if (pleft >= L) left_y = bot_y;
+      else { left_y = y_for_x(p1x, p1y, p2x, p2y, L); if (x_for_y(p1x, p1y, p2x, p2y, left_y) < L) left_y--; }
+      if (left_y < top_y) left_y = top_y;
+      if (bot_y > left_y) cut[n++] = left_y;
+   }
+   return n;
+}
 
 /* x at the centre of sub-row ys, exact: quo + rem/Ey, 0 <= rem < Ey */
 static quorem_t edge_x(const edge_t *e, int ys)
@@ -159,6 +216,11 @@ void tor_coverage(const tor_edge_t *in, int n, int nonzero, int x0, int y0, int 
       if (e->ybot > H * GRID_Y) e->ybot = H * GRID_Y;
       if (e->ybot <= e->ytop) continue;
       e->dir = dir; e->p1x = ax; e->p1y = ay;
+      {
+         int64_t cy[2];
+         e->ncut = limit_cuts((int64_t) ax + (int64_t) x0 * 256, (int64_t) ay + (int64_t) y0 * 256, (int64_t) bx + (int64_t) x0 * 256, (int64_t) by + (int64_t) y0 * 256, cy);
+         for (int k = 0; k < e->ncut; k++) e->cut[k] = to_grid_y(cy[k] - (int64_t) y0 * 256);
+      }
       if (ax == bx)
       {
          e->vertical = 1; e->Ex = 0; e->Ey = 0;
@@ -185,6 +247,7 @@ void tor_coverage(const tor_edge_t *in, int n, int nonzero, int x0, int y0, int 
          if (e->ytop >= ys1 || e->ybot <= ys0) continue;
          act[na++] = e;
          if (e->ytop > ys0 || e->ybot < ys1) partial = 1;       /* starts below the row's first sub-row, or ends inside the row */
+         for (int k = 0; k < e->ncut; k++) if (e->cut[k] > ys0 && e->cut[k] < ys1) partial = 1;
       }
       if (!na) continue;
       cells_t c = { W, 0, cover, uarea };

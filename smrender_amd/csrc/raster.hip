@@ -1041,6 +1041,7 @@ struct smr_bigacc_t
    int32_t minx, miny, maxx, maxy, bin_maxx;     /* atomicMin / atomicMax over the items */
    uint32_t item_flags, prim_id, valid;          /* SMR_PF_* of the items; the id the items carry (compound or own); set by k_big_finish */
    int32_t clip0, clip1;                         /* the rows the primitive may touch (a window of an atlas), else 0 .. H */
+   int32_t lim_l, lim_r, lim_on;                 /* smr_setup_cuts, for k_big_vrows */
 };
 
 struct setup_args_t
@@ -1069,6 +1070,7 @@ struct setup_args_t
    uint32_t *biglist;                                  /* long primitives, left to the k_big_* kernels ([0] = their number, then (id, first item)) */
    struct smr_bigacc_t *bigacc;                        /* [biglist entry] what those kernels need of them */
    const int2 *way_clip;                               /* [n_ways] rows [x, y) a way's primitives may touch: its window of an atlas (smr_hip_draw_windows); NULL: the chart */
+   int32_t lim_l, lim_r; int lim_on;                   /* the replay's clip box, left and right side, 24.8 (smr_setup_cuts) */
 };
 
 struct setup_lds_t
@@ -1099,6 +1101,72 @@ __device__ __forceinline__ int smr_wave_max(int v)
    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xa, 0xf, false));
    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xc, 0xf, false));
    return __builtin_amdgcn_readlane(v, 63);
+}
+
+/* libcairo replays the chart under the recording surface's rectangle as clip, and a polygon built under a clip is LIMITED to
+ * the clip's box (_cairo_polygon_init_with_clip): an edge that crosses the box's left or right side is cut there
+ * (_add_clipped_edge, cairo-polygon.c), the part outside going straight down the side.  The coverage is the same, but the cut
+ * is a vertex, and the pixel row of a vertex is sub-sampled.  Restated in oracle/tor.c (limit_cuts), step by step the same
+ * integers.  Only for primitives whose edges ARE the polygon's (fills, strokes as polygons): the inner edges of a stroke's
+ * pieces are not libcairo's. */
+__device__ __forceinline__ int64_t smr_floor_div(int64_t a, int64_t b)
+{
+   int64_t q = a / b;
+   if ((a % b != 0) && ((a < 0) != (b < 0))) q--;
+   return q;
+}
+__device__ __forceinline__ int64_t smr_y_for_x(int64_t p1x, int64_t p1y, int64_t p2x, int64_t p2y, int64_t x)
+{
+   if (x == p1x) return p1y;
+   if (x == p2x) return p2y;
+   const int64_t dx = p2x - p1x;
+   return dx ? p1y + smr_floor_div((x - p1x) * (p2y - p1y), dx) : p1y;
+}
+__device__ __forceinline__ int64_t smr_x_for_y(int64_t p1x, int64_t p1y, int64_t p2x, int64_t p2y, int64_t y)
+{
+   if (y == p1y) return p1x;
+   if (y == p2y) return p2x;
+   const int64_t dy = p2y - p1y;
+   return dy ? p1x + smr_floor_div((y - p1y) * (p2x - p1x), dy) : p1x;
+}
+__device__ __forceinline__ void smr_setup_cuts(const smr_edge_t &e, int32_t lim_l, int32_t lim_r, int row0, int nrows, uint32_t *mask)
+{
+   if (e.y1 == e.y2) return;
+   const bool up = e.y1 > e.y2;
+   const int64_t p1x = up ? e.x2 : e.x1, p1y = up ? e.y2 : e.y1, p2x = up ? e.x1 : e.x2, p2y = up ? e.y1 : e.y2;
+   const int64_t L = lim_l, R = lim_r, pleft = min(p1x, p2x), pright = max(p1x, p2x);
+   if ((L <= pleft && pright <= R) || pright <= L || R <= pleft) return;
+   int64_t top_y = p1y, bot_y = p2y, left_y, right_y, cut[2];
+   int n = 0;
+   if (p1x <= p2x)
+   {
+      if (pleft >= L) left_y = top_y;
+      else { left_y = smr_y_for_x(p1x, p1y, p2x, p2y, L); if (smr_x_for_y(p1x, p1y, p2x, p2y, left_y) < L) left_y++; }
+      left_y = min(left_y, bot_y);
+      if (top_y < left_y) { cut[n++] = left_y; top_y = left_y; }
+      if (pright <= R) right_y = bot_y;
+      else { right_y = smr_y_for_x(p1x, p1y, p2x, p2y, R); if (smr_x_for_y(p1x, p1y, p2x, p2y, right_y) > R) right_y--; }
+      right_y = max(right_y, top_y);
+      if (bot_y > right_y) cut[n++] = right_y;
+   }
+   else
+   {
+      if (pright <= R) right_y = top_y;
+      else { right_y = smr_y_for_x(p1x, p1y, p2x, p2y, R); if (smr_x_for_y(p1x, p1y, p2x, p2y, right_y) > R) right_y++; }
+      right_y = min(right_y, bot_y);
+      if (top_y < right_y) { cut[n++] = right_y; top_y = right_y; }
+      if (pleft >= L) left_y = bot_y;
+      else { left_y = smr_y_for_x(p1x, p1y, p2x, p2y, L); if (smr_x_for_y(p1x, p1y, p2x, p2y, left_y) < L) left_y--; }
+      left_y = max(left_y, top_y);
+      if (bot_y > left_y) cut[n++] = left_y;
+   }
+   for (int k = 0; k < n; k++)
+   {
+      const int gy = smr_to_grid_y((int32_t) cut[k]);
+      if (gy <= 0 || gy % SMR_GRID_Y == 0) continue;          /* on a row's boundary: no part starts or ends inside a row */
+      const int r = gy / SMR_GRID_Y - row0;
+      if (r >= 0 && r < nrows) atomicOr(&mask[r >> 5], 1u << (r & 31));
+   }
 }
 
 /* mark the rows in which edge o starts or ends, and remember o if it spans a whole row */
@@ -1481,6 +1549,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          a.minx = a.miny = INT32_MAX; a.maxx = a.maxy = a.bin_maxx = INT32_MIN;
          a.item_flags = item_flags; a.prim_id = A.compound != 0xffffffffu ? A.compound : (uint32_t) p; a.valid = 0;
          a.clip0 = clip0; a.clip1 = clip1;
+         a.lim_l = A.lim_l; a.lim_r = A.lim_r; a.lim_on = A.lim_on && !pieces;
          A.bigacc[b] = a;
          A.prims[p] = P;                 /* edge range and colour; not valid before k_big_finish */
       }
@@ -1555,13 +1624,19 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    for (uint32_t i = lane; i < nwords; i += 64) lmask[i] = 0;
    if (lane == 0) L.nlong = 0;
    SMR_WAVE_SYNC();
+   const bool cuts = A.lim_on && !pieces && (P.minx < A.lim_l || P.maxx > A.lim_r);
    if (nitems == 1)
    {
-      if ((uint32_t) lane < P.edge_cnt) smr_setup_edge(smr_orient(e0), P.row0, P.nrows, lmask, L);
+      if ((uint32_t) lane < P.edge_cnt) { smr_setup_edge(smr_orient(e0), P.row0, P.nrows, lmask, L); if (cuts) smr_setup_cuts(e0, A.lim_l, A.lim_r, P.row0, P.nrows, lmask); }
    }
    else
    {
-      for (uint32_t idx = lane; idx < P.edge_cnt; idx += 64) smr_setup_edge(smr_orient(E[idx]), P.row0, P.nrows, lmask, L);
+      for (uint32_t idx = lane; idx < P.edge_cnt; idx += 64)
+      {
+         const smr_edge_t e = E[idx];
+         smr_setup_edge(smr_orient(e), P.row0, P.nrows, lmask, L);
+         if (cuts) smr_setup_cuts(e, A.lim_l, A.lim_r, P.row0, P.nrows, lmask);
+      }
    }
    SMR_WAVE_SYNC();
    const uint32_t nlong = L.nlong;
@@ -1774,7 +1849,9 @@ __global__ __launch_bounds__(256) void k_big_vrows(const smr_prim_t *__restrict_
             const uint32_t idx = k * 64u + (uint32_t) lane;
             if (idx < P.edge_cnt)
             {
-               const smr_oedge_t o = smr_orient(E[idx]);
+               const smr_edge_t e = E[idx];
+               const smr_oedge_t o = smr_orient(e);
+               if (a.lim_on) smr_setup_cuts(e, a.lim_l, a.lim_r, P.row0, P.nrows, m);
                if (o.dir != 0)
                {
                   if (o.ytop % SMR_GRID_Y != 0)
@@ -3824,6 +3901,13 @@ static int host_pen(double hw_pt, int dpi, std::vector<int2> &out)
    return SMR_OK;
 }
 
+/* SMR_HIP_LIMITS=0: no cuts at the page's sides (measurements; the oracle's ORC_NO_LIMITS) */
+static int limits_off(void)
+{
+   const char *e = getenv("SMR_HIP_LIMITS");
+   return e && e[0] == '0';
+}
+
 /* SMR_HIP_STROKE=polygon: every solid stroke as the stroker's polygon (measurements; the oracle's ORC_STROKE_OUTLINE=1) */
 static int stroke_polygon_always(void)
 {
@@ -4174,6 +4258,15 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SA.way_border_pix = wb_pix; SA.way_fill_pix = wf_pix; SA.W = c->W; SA.H = c->H; SA.way_clip = wc ? wc->way_clip : nullptr;
       SA.prims = prims; SA.items = items; SA.mask = maskbuf; SA.mask_cap = (uint32_t) std::min<size_t>(mask_cap, 0xffffffffu);
       SA.small = small; SA.compound = compound;
+      {
+         /* the recording surface's rectangle is the page in WHOLE pt (cairo_recording_surface_create floors / ceils the doubles of
+          * cairo_smr_init_main_image, src/smrules_cairo.c:308-330); the replay's 24.8 scale takes it to device units.  A window of
+          * an atlas is a replay at an offset: the page's sides are rarely inside it, and are left out there */
+         const int32_t sc = (int32_t) nearbyint((double) c->dpi / 72 * 256.0);
+         const int chart_w = c->win_n ? c->chart_w : c->W;
+         SA.lim_l = 0; SA.lim_r = (int32_t) (((int64_t) ((int32_t) ceil((double) chart_w * 72 / c->dpi) * 256) * sc) >> 8);
+         SA.lim_on = wc == nullptr && !limits_off();
+      }
       SA.K = K; SA.off_dots = off_dots; SA.po_border = po_border; SA.po_dots = po_dots; SA.po_open = po_open; SA.id_off = id_off;
       uint32_t *biglist;
       SMR_TRY(c->ensure(SMR_BUF_BIGLIST, ((size_t) n_prims * 2 + 2) * 4, (void **) &biglist));

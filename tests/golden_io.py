@@ -22,6 +22,10 @@ def load_scene(name):
         rules.append((st, (z[f"x{i}"], z[f"y{i}"], z[f"off{i}"], z[f"ref{i}"])))
     meta = {k: int(z[k]) for k in ("dpi", "W", "H", "bg")}
     meta["x0"], meta["y0"] = int(z["win_x0"]), int(z["win_y0"])
+    # the page the scene was rendered on (make_golden.py: full_w / full_h; default: it ends with the window): the oracle cuts
+    # polygon edges at the PAGE's sides as libcairo's replay does, so it has to know them
+    fw, fh = {"layers_translucent_600": (300, 240)}.get(name, (meta["x0"] + meta["W"], meta["y0"] + meta["H"]))
+    meta["page"] = (0, 0, fw, fh)
     return meta, rules, z["image"]
 
 

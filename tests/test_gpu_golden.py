@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def gpu_render(sa, meta, rules):
-    W, H = meta["x0"] + meta["W"], meta["y0"] + meta["H"]
+    W, H = meta["page"][2], meta["page"][3]          # the page (libcairo cuts polygon edges at its sides), the scene's rows as a band
     cv = sa.Canvas(W, H, meta["dpi"], meta["bg"], meta["y0"], meta["H"])
     for st, (x, y, off, ref) in rules:
         gs = draw_style(sa, st)
@@ -30,7 +30,7 @@ def test_golden_scene(hip, name):
     got = gpu_render(hip, meta, rules)
     assert within(got, want, 2) >= max(BARS[name][0], 0.995) and within(got, want, 0) >= BARS[name][1]
     orules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in rules]
-    o = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"])
+    o = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"], image=meta["page"])
     assert np.array_equal(got, o)
 
 
@@ -44,7 +44,7 @@ def test_golden_scene_with_every_stroke_as_the_strokers_polygon(hip, name, monke
     meta, rules, want = load_scene(name)
     got = gpu_render(hip, meta, rules)
     orules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in rules]
-    o = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"])
+    o = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"], image=meta["page"])
     assert np.array_equal(got, o)
     if name == "hairpins_300":
         assert np.array_equal(got, want)
@@ -69,7 +69,7 @@ def test_full_size_c2_windows_vs_oracle(hip):
         got = cv.read(wx, wy, S, S)
         keep = (x1b > wx - 8) & (x0b < wx + S + 8) & (y1b > wy - 8) & (y0b < wy + S + 8)
         sx, sy, soff, sref = synth.select_ways(x, y, off, ref, keep)
-        want = po.oracle_scene([(st, po.ways_from_arrays(sx, sy, soff, sref))], 300, S, S, 0xffffff, wx, wy)
+        want = po.oracle_scene([(st, po.ways_from_arrays(sx, sy, soff, sref))], 300, S, S, 0xffffff, wx, wy, image=(0, 0, W, H))
         assert np.array_equal(got, want), (wx, wy, int((got != want).sum()))
     # idempotence of the pipeline: a second identical chart gives the identical canvas (no order races)
     first = cv.read(4000, 4000, 512, 512)

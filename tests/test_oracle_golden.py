@@ -35,7 +35,7 @@ def test_rotated_bilinear_over_bit_exact():
 def test_scene_within_tolerance(name):
     meta, rules, want = load_scene(name)
     orules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in rules]
-    got = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"])
+    got = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"], image=meta["page"])
     # north_star asks for +-2/255 per channel on >= 99.5 % of the pixels; the measured bars are far tighter
     assert within(got, want, 2) >= max(BARS[name][0], 0.995)
     assert within(got, want, 0) >= BARS[name][1]
@@ -47,7 +47,7 @@ def test_far_window_pins_replay_scale_quantisation():
     meta, rules, want = load_scene("far_window_300")
     assert meta["x0"] == 15000
     orules = [(st, po.ways_from_arrays(*arrs)) for st, arrs in rules]
-    got = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"])
+    got = po.oracle_scene(orules, meta["dpi"], meta["W"], meta["H"], meta["bg"], meta["x0"], meta["y0"], image=meta["page"])
     assert within(got, want, 0) >= 0.999
 
 

@@ -40,6 +40,6 @@ for wx, wy in ((0, 0), (65536 - S, 8192 - S), (31000, 4000)):
     near = [w for w in ways if w[0].max() > wx - 80 and w[0].min() < wx + S + 80 and w[1].max() > wy - 80 and w[1].min() < wy + S + 80] if False else None
     sel = (cx > wx - 150) & (cx < wx + S + 150) & (cy > wy - 150) & (cy < wy + S + 150)
     sub = [ways[i] for i in np.nonzero(sel)[0]]
-    o = po.oracle_scene([(st, sub)], dpi, S, S, 0xffffff, wx, wy)
+    o = po.oracle_scene([(st, sub)], dpi, S, S, 0xffffff, wx, wy, image=(0, 0, W, HT))
     print("window", wx, wy, "ways", len(sub), "identical", bool(np.array_equal(g, o)), int((g != o).sum()))
 cv.close()
