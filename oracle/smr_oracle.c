@@ -956,7 +956,9 @@ static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double wid
       e = malloc(sizeof(tor_edge_t) * (ne > 0 ? ne : 1));
       if (ne > 0) orc_dash_edges(dev, n, width_pt / 2, c->dpi, dash, nd, c->cap_round, e);
    }
-   c->no_cuts = !(nd == 0 && outline_used);
+   /* a dashed stroke goes through libcairo's other stroker, which adds every dash, join and cap as a polygon of its own: those
+    * pieces ARE its edges, and are cut at the page's sides like any; the pieces of a solid stroke are ours */
+   c->no_cuts = nd == 0 && !outline_used;
    if (ne > 0) orc_layer_edges(c, e, ne, 1, col);
    c->no_cuts = 0;
    free(e);

@@ -1549,7 +1549,8 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          a.minx = a.miny = INT32_MAX; a.maxx = a.maxy = a.bin_maxx = INT32_MIN;
          a.item_flags = item_flags; a.prim_id = A.compound != 0xffffffffu ? A.compound : (uint32_t) p; a.valid = 0;
          a.clip0 = clip0; a.clip1 = clip1;
-         a.lim_l = A.lim_l; a.lim_r = A.lim_r; a.lim_on = A.lim_on && !pieces;
+         a.lim_l = A.lim_l; a.lim_r = A.lim_r;
+         a.lim_on = A.lim_on && (!pieces || (role == 0 ? A.po_border != nullptr : role == 1 ? A.po_dots != nullptr : (wf & 8) && A.po_open != nullptr));
          A.bigacc[b] = a;
          A.prims[p] = P;                 /* edge range and colour; not valid before k_big_finish */
       }
@@ -1624,7 +1625,10 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    for (uint32_t i = lane; i < nwords; i += 64) lmask[i] = 0;
    if (lane == 0) L.nlong = 0;
    SMR_WAVE_SYNC();
-   const bool cuts = A.lim_on && !pieces && (P.minx < A.lim_l || P.maxx > A.lim_r);
+   /* cuts at the page's sides: for edges that are libcairo's own -- fills, strokes as polygons, and the pieces of a DASHED stroke
+    * (its other stroker adds every dash, join and cap as a polygon of its own); not the pieces of a solid stroke */
+   const bool dashed = role == 0 ? A.po_border != nullptr : role == 1 ? A.po_dots != nullptr : (wf & 8) && A.po_open != nullptr;
+   const bool cuts = A.lim_on && (!pieces || dashed) && (P.minx < A.lim_l || P.maxx > A.lim_r);
    if (nitems == 1)
    {
       if ((uint32_t) lane < P.edge_cnt) { smr_setup_edge(smr_orient(e0), P.row0, P.nrows, lmask, L); if (cuts) smr_setup_cuts(e0, A.lim_l, A.lim_r, P.row0, P.nrows, lmask); }

@@ -34,7 +34,7 @@ def load_scene(name):
 # stroker resolves by winding cancellation (turns sharper than ~150 degrees between segments shorter than the
 # line width: the random walks of open_border / layers_translucent are full of them), see DESIGN.md deviations.
 BARS = {"c2_fill_border_300": (1.0, 0.99995), "open_border_300": (0.999, 0.998), "layers_translucent_600": (0.9993, 0.996),
-        "far_window_300": (1.0, 0.999), "dashes_300": (0.9998, 0.9995), "curves_300": (0.9995, 0.998), "hairpins_300": (0.9998, 0.9994)}
+        "far_window_300": (1.0, 0.999), "dashes_300": (1.0, 0.9999), "curves_300": (0.9995, 0.998), "hairpins_300": (0.9998, 0.9994)}
 
 
 def draw_style(sa, st, **kw):
