@@ -115,6 +115,7 @@ int orc_fill_edges(const int32_t *p, int n, tor_edge_t *out)
  * inner corner pokes through a short neighbouring segment (orc_stroke_risky below): then
  * the polygon itself is emitted (orc_stroke_outline_edges). ---- */
 
+#define ORC_POLY_MAXREFS 512
 typedef struct { int32_t x, y; } pt_t;
 static int64_t turn2(pt_t a, pt_t b, pt_t c) { return (int64_t) (b.x - a.x) * (c.y - b.y) - (int64_t) (b.y - a.y) * (c.x - b.x); }
 
@@ -463,6 +464,55 @@ int orc_stroke_edges_tan(const int32_t *xy, const int32_t *tin, const int32_t *t
       int nh = hull4(q, h);
       cnt += emit_poly(h, nh, out + cnt);
    }
+   return cnt;
+}
+
+/* the same for the stroke polygon itself (orc_stroke_outline_edges): libcairo's spline_to adds the two corners of the face at
+ * every point of a decomposed curve to its contours, and joins only where two Beziers meet */
+int orc_stroke_outline_edges_tan(const int32_t *xy, const int32_t *tin, const int32_t *tout, int m, double hw_pt, int dpi, tor_edge_t *out)
+{
+   double s = (double) dpi / 72;
+   int cnt = 0;
+   #define EDGE(a, b) do { out[cnt].x1 = (a).x; out[cnt].y1 = (a).y; out[cnt].x2 = (b).x; out[cnt].y2 = (b).y; cnt++; } while (0)
+   for (int i = 0; i + 1 < m; i++)
+   {
+      pt_t p0 = { xy[2 * i], xy[2 * i + 1] }, p1 = { xy[2 * i + 2], xy[2 * i + 3] };
+      face_t start, end;
+      compute_face(p0, tout[2 * i], tout[2 * i + 1], hw_pt, s, &start);
+      compute_face(p1, tin[2 * i + 2], tin[2 * i + 3], hw_pt, s, &end);
+      pt_t a_ccw = start.ccw, a_cw = start.cw, b_ccw = end.ccw, b_cw = end.cw;
+      if (i > 0)
+      {
+         face_t prev_end;
+         compute_face(p0, tin[2 * i], tin[2 * i + 1], hw_pt, s, &prev_end);
+         join_t j = stroke_join(&prev_end, &start);
+         if (j.kind != 0)
+         {
+            if (j.clockwise)
+            {
+               if (j.kind == 1) a_cw = j.m; else EDGE(prev_end.cw, start.cw);
+               EDGE(start.ccw, p0); EDGE(p0, prev_end.ccw);
+            }
+            else
+            {
+               if (j.kind == 1) a_ccw = j.m; else EDGE(start.ccw, prev_end.ccw);
+               EDGE(prev_end.cw, p0); EDGE(p0, start.cw);
+            }
+         }
+      }
+      else EDGE(start.ccw, start.cw);
+      if (i + 2 < m)
+      {
+         face_t nstart;
+         compute_face(p1, tout[2 * i + 2], tout[2 * i + 3], hw_pt, s, &nstart);
+         join_t j = stroke_join(&end, &nstart);
+         if (j.kind == 1) { if (j.clockwise) b_cw = j.m; else b_ccw = j.m; }
+      }
+      else EDGE(end.cw, end.ccw);
+      EDGE(a_cw, b_cw);
+      EDGE(b_ccw, a_ccw);
+   }
+   #undef EDGE
    return cnt;
 }
 
@@ -947,6 +997,7 @@ static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double wid
        * pieces / always the polygon, for measurements) */
       const char *mode = getenv("ORC_STROKE_OUTLINE");
       int outline = mode && mode[0] == '1' ? 1 : mode && mode[0] == '0' ? 0 : orc_stroke_risky(dev, n, width_pt / 2, c->dpi);
+      if (n >= ORC_POLY_MAXREFS) outline = 0;        /* the GPU path keeps ways this long in pieces (SMR_POLY_MAXREFS) */
       outline_used = outline;
       ne = outline ? orc_stroke_outline_edges(dev, n, width_pt / 2, c->dpi, e) : orc_stroke_edges(dev, n, width_pt / 2, c->dpi, e);
    }
@@ -1010,8 +1061,10 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
       else if (!closed) bw = mm2wu(2 * st->border_width_mm, c->dpi) + mm2wu(st->fill_width_mm, c->dpi);
       else bw = mm2wu(2 * st->border_width_mm, c->dpi);
       FLATTEN(orc_stroke_reach_px(bw, c->dpi));
-      int ne = m >= 2 ? orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e) : 0;
-      c->no_cuts = 1;
+      const char *om = getenv("ORC_STROKE_OUTLINE");
+      const int tan_outline = om && om[0] == '1' && m < ORC_POLY_MAXREFS;
+      int ne = m < 2 ? 0 : tan_outline ? orc_stroke_outline_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e);
+      c->no_cuts = !tan_outline;
       if (ne > 0) orc_layer_edges(c, e, ne, 1, has_border_col ? border_col : st->border_col);
       c->no_cuts = 0;
    }
@@ -1020,8 +1073,10 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
       uint32_t col = has_fill_col ? fill_col : st->fill_col;
       double fw = mm2wu(st->fill_width_mm, c->dpi);
       FLATTEN(closed ? 0.0 : orc_stroke_reach_px(fw, c->dpi));
-      int ne = m < 2 ? 0 : closed ? orc_fill_edges(pts, m, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e);
-      c->no_cuts = !closed;
+      const char *om = getenv("ORC_STROKE_OUTLINE");
+      const int tan_outline = om && om[0] == '1' && m < ORC_POLY_MAXREFS;
+      int ne = m < 2 ? 0 : closed ? orc_fill_edges(pts, m, e) : tan_outline ? orc_stroke_outline_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e);
+      c->no_cuts = !closed && !tan_outline;
       if (ne > 0) orc_layer_edges(c, e, ne, 1, col);
       c->no_cuts = 0;
    }

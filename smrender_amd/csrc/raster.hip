@@ -563,6 +563,7 @@ __global__ void k_stroke_risk(const int2 *__restrict__ pts, const int64_t *__res
    const uint8_t wf = wayflags[w];
    if (!(mode == 0 ? (wf & 2) : (wf & 8))) return;
    const int64_t a = way_off[w], b = way_off[w + 1];
+   if (b - a >= SMR_POLY_MAXREFS) return;
    if (force) { if (g == a) atomicOr(reinterpret_cast<uint32_t *>(wayflags) + (w >> 2), (mode == 0 ? 16u : 32u) << (8 * (w & 3))); return; }
    if (g + 1 >= b) return;
    const int2 p1 = pts[g], p2 = pts[g + 1];
@@ -644,7 +645,7 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
          /* a way with a poked-through join (k_stroke_risk): the stroker's polygon itself, edge by edge, filled non-zero --
           * the contour forward on the cw side, backward on the ccw side, an inner join through the vertex, a butt cap at
           * either end of the way (oracle: orc_stroke_outline_edges) */
-         const bool outline = !TAN && (wf & (mode == 0 ? 16 : 32)) != 0;
+         const bool outline = (wf & (mode == 0 ? 16 : 32)) != 0;      /* (a decomposed curve: only when every stroke is asked for as a polygon) */
          int no = 0;
          /* (straight to memory: a register array indexed by a running count would live in scratch) */
          smr_edge_t *const oline = edges + (size_t) SMR_SLOTS * g;
@@ -1196,6 +1197,7 @@ __device__ __forceinline__ void smr_setup_edge(const smr_oedge_t &o, int row0, i
 
 #define SMR_SCANCAP (64u * (SMR_ACTCAP + 1))      /* act0 / act1 of setup_lds_t as flat arrays */
 #define SMR_BIG_SLOTS 4096u   /* edge slots from which a primitive with an overflowing row-spanning list goes to k_big_rows */
+static_assert(SMR_SLOTS * SMR_POLY_MAXREFS <= SMR_BIG_SLOTS, "a stroke polygon must stay a small primitive");
 
 /* analysis of the vertex-free rows of one primitive: which of them libcairo's scan converter sub-samples after all
  * because two of the edges spanning the row cross inside it.  Used by the wavefront that sets the primitive up and,
@@ -4210,8 +4212,16 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    }
    else if (st->border_used)
    {
-      if (tin) k_stroke_edges<true><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill,
-                                                                      hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border, tin, tout, fskip);
+      if (tin)
+      {
+         /* libcairo's spline_to adds the two corners of the face at every point of a decomposed curve to its contours: the polygon
+          * is as simple to emit as for straight ways, but which curved ways NEED it (a quad that crosses itself, §7) is not worked out:
+          * on request only */
+         if (stroke_polygon_always())
+            k_stroke_risk<<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill, hw_open, hw_closed, hw_fill, st->fill_used, 1);
+         k_stroke_edges<true><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill,
+                                                                hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border, tin, tout, fskip);
+      }
       else
       {
          k_stroke_risk<<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill, hw_open, hw_closed, hw_fill, st->fill_used, stroke_polygon_always());
@@ -4224,8 +4234,13 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    if (dash_o) { DA[2].edges = edges + off_open; k_dash<true><<<blocks(n_ways, 64), 64, 0, s>>>(DA[2]); }
    else if (open_fill)
    {
-      if (tin) k_stroke_edges<true><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill,
-                                                                      hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open, tin, tout, fskip);
+      if (tin)
+      {
+         if (stroke_polygon_always())
+            k_stroke_risk<<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill, hw_open, hw_closed, hw_fill, st->fill_used, 1);
+         k_stroke_edges<true><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill,
+                                                                hw_open, hw_closed, hw_fill, st->fill_used, edges + off_open, tin, tout, fskip);
+      }
       else
       {
          k_stroke_risk<<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 1, c->dpi, hw_nofill, hw_open, hw_closed, hw_fill, st->fill_used, stroke_polygon_always());

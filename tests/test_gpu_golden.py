@@ -34,7 +34,7 @@ def test_golden_scene(hip, name):
     assert np.array_equal(got, o)
 
 
-@pytest.mark.parametrize("name", ["hairpins_300", "c2_fill_border_300", "open_border_300", "layers_translucent_600"])
+@pytest.mark.parametrize("name", ["hairpins_300", "c2_fill_border_300", "open_border_300", "layers_translucent_600", "curves_300", "dashes_300"])
 def test_golden_scene_with_every_stroke_as_the_strokers_polygon(hip, name, monkeypatch):
     """SMR_HIP_STROKE=polygon (the oracle's ORC_STROKE_OUTLINE=1): every solid stroke is filled as libcairo's stroke polygon
     itself instead of the union of its convex pieces (the default takes the polygon only for ways with a poked-through join).
@@ -50,7 +50,7 @@ def test_golden_scene_with_every_stroke_as_the_strokers_polygon(hip, name, monke
     if name in ("hairpins_300", "c2_fill_border_300"):
         assert np.array_equal(got, want)          # libcairo's image, pixel for pixel
     else:
-        assert within(got, want, 0) >= {"open_border_300": 0.9999, "layers_translucent_600": 0.9985}[name]
+        assert within(got, want, 0) >= {"open_border_300": 0.9999, "layers_translucent_600": 0.9985, "curves_300": 0.9999, "dashes_300": 0.9999}[name]
 
 
 def test_full_size_c2_windows_vs_oracle(hip):
