@@ -313,7 +313,8 @@ def test_soak_scene_whose_tiles_overflow_runs_again_with_reported_rows(hip):
     st = po.Style.from_buffer_copy(bytes(d["style"]))
     want = oracle_of([(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
     got = gpu_scene(sa, [(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
-    assert sa.lib().smr_hip_draw_status() & 1
+    if os.environ.get("SMR_HIP_STROKE") != "polygon":       # (as a polygon the stroke has a fraction of the pieces' spanning edges: nothing to report)
+        assert sa.lib().smr_hip_draw_status() & 1
     dd = po.chan_diff(got, want)
     assert dd.max() <= 12 and (dd > 0).mean() < 0.02, report(got, want)
 
