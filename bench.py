@@ -357,12 +357,13 @@ def main():
         mpx = W * chart_h / 1e6
         stage = {k: v / args.steps for k, v in stage.items()}
         # SURVEY 8d, per draw pass on one band: every canvas pixel stored once, every projected vertex and every style record read
-        # once.  The pass is two kernels now: k_cover (scan conversion, primitive by primitive: reads vertices and records) and
-        # k_raster (tiles: composites, stores the pixels)
+        # once.  The pass is k_cover (scan conversion, primitive by primitive: reads vertices and records) and the compositing of
+        # the tiles, which stores the pixels: k_blend for the tiles that hold k_cover's alpha words only, k_raster for the others
+        # (stage "raster_ms" is the two together)
         alg_cover = 16.0 * n_refs + 64.0 * n_ways
         alg_raster = 4.0 * W * H
         alg_bytes = alg_cover + alg_raster
-        dom, dom_ms, dom_bytes = ("k_cover", stage["cover_ms"], alg_cover) if stage["cover_ms"] >= stage["raster_ms"] else ("k_raster", stage["raster_ms"], alg_raster)
+        dom, dom_ms, dom_bytes = ("k_cover", stage["cover_ms"], alg_cover) if stage["cover_ms"] >= stage["raster_ms"] else ("k_blend+k_raster", stage["raster_ms"], alg_raster)
         achieved = dom_bytes / (dom_ms * 1e-3)
         stage_rate = alg_bytes / ((stage["cover_ms"] + stage["raster_ms"]) * 1e-3)
         res = {
@@ -386,10 +387,11 @@ def main():
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5), "traffic": measured_traffic(dom, args),
                          "algorithmic_bytes": dom_bytes, "ms": round(dom_ms, 3)},
-            "roofline_draw_pass": {"kernels": ["k_cover", "k_raster"], "bound": "hbm", "achieved": round(stage_rate / 1e9, 2),
+            "roofline_draw_pass": {"kernels": ["k_cover", "k_blend", "k_raster"], "bound": "hbm", "achieved": round(stage_rate / 1e9, 2),
                                    "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(stage_rate / HBM_PEAK, 5),
                                    "algorithmic_bytes": alg_bytes, "ms": round(stage["cover_ms"] + stage["raster_ms"], 3),
-                                   "traffic": (lambda a, b: None if a is None or b is None else a + b)(measured_traffic("k_cover", args), measured_traffic("k_raster", args))},
+                                   "traffic": (lambda a, b, c: None if a is None or c is None else a + (b or 0) + c)(
+                                       measured_traffic("k_cover", args), measured_traffic("k_blend", args), measured_traffic("k_raster", args))},
             "roofline_proj": {"kernel": "k_project", "bound": "hbm",
                               "achieved": round(32.0 * len(lat) / (stage["proj_ms"] * 1e-3) / 1e9, 2) if stage["proj_ms"] > 0 else None,
                               "peak": HBM_PEAK / 1e9, "unit": "GB/s"},

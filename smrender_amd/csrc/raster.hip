@@ -2127,6 +2127,7 @@ __global__ void k_set_u32(uint32_t *p, const uint32_t *v) { *p = *v; }
 /* per-tile sort of the scattered item indices (ascending = drawing order), then the tile's
  * work stream: one smr_thdr_t per entry with the item header, the tile's bits of the
  * primitive's row mask and the primitive's pixel extents relative to the tile */
+#define SMR_TILE_PURE 0x80000000u      /* tile_cnt: the tile's stream holds alpha words only */
 #define SORT_LDS 4096        /* most entries of a tile sorted in LDS; beyond, the same network runs in global memory */
 struct sort_args_t
 {
@@ -2143,6 +2144,7 @@ struct sort_args_t
    const uint2 *drows;        /* k_cover's strip table (primitives with SMR_PF_DELTA) */
    uint32_t *tile_cnt;        /* [n_tiles] entries of the tile's work stream (entries that bring nothing are left out) */
    int vec;                   /* a sparse rule: every wavefront looks at 64 tiles at once and sorts the few that hold anything */
+   uint32_t pure_bit;         /* SMR_TILE_PURE, or 0 when every tile goes to k_raster: ORed into tile_cnt of a tile whose stream is k_cover's alpha words only */
 };
 
 /* SORT_WAVES independent wavefronts per workgroup, one tile each (a chart of 4 M tiles is 4 M one-wave workgroups otherwise,
@@ -2231,6 +2233,7 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
    const uint32_t first_prim = *A.first_prim;
    const unsigned long long lt_mask = (1ull << lane) - 1ull;
    uint32_t kept = 0, last_prim = 0xffffffffu;
+   bool other = false;         /* an entry that is not an alpha word: the tile is k_raster's */
    for (uint32_t i0 = 0; i0 < n; i0 += 64)
    {
       const uint32_t i = i0 + lane;
@@ -2278,11 +2281,12 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
          if (it.prim == prev || nw == 0 || x0 + nw <= col0 || x0 >= col0 + SMR_TW) keep = false;
       }
       const unsigned long long km = __ballot(keep);
+      if (__ballot(keep && !(P.flags & SMR_PF_DELTA))) other = true;
       if (keep) A.hdrs[beg + kept + (uint32_t) __popcll(km & lt_mask)] = h;
       kept += (uint32_t) __popcll(km);
       if (valid && in_lds && n >= 2) A.entries[beg + i] = idx;
    }
-   if (lane == 0) A.tile_cnt[tile] = kept;
+   if (lane == 0) A.tile_cnt[tile] = kept | (kept && !other ? A.pure_bit : 0u);
    SMR_WAVE_SYNC();            /* the next tile of this wavefront reuses the LDS block */
    }
 }
@@ -2300,6 +2304,8 @@ struct raster_args_t
    uint32_t *canvas;          /* band pixels, stride W */
    uint32_t *status;
    uint32_t *tile_ctr;        /* [8 * xcd]: next tile of the XCD's columns, zero at launch */
+   uint32_t *blend_ctr;       /* the same for k_blend */
+   uint32_t strided;          /* k_raster<false>: no queue, wavefront i of an XCD looks at the tiles i, i + waves, ... of its columns (the pure ones are k_blend's) */
    int W, band_y0, band_h, TX;
    uint32_t n_tiles;
    uint32_t chunk;            /* tiles a wavefront takes from its XCD's queue with one atomic */
@@ -2487,30 +2493,41 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
     * load per tile varies, and a static share leaves wavefronts idle at the end of the launch */
    const uint32_t ktotal = ncol * TYt;
    uint32_t *const ctr = BIG ? A.tile_ctr : A.tile_ctr + 8u * xcd;
+   /* without the queue (A.strided): the lanes of wavefront i look at the tiles i + (64 r + lane) * waves of the XCD's columns in
+    * round r, so that neighbouring tiles, which tend to cost alike, go to different wavefronts */
+   const bool strided = !BIG && A.strided != 0u;
+   const uint32_t wx = (gridDim.x >> 3) * SMR_RASTER_WAVES, wi = (blockIdx.x >> 3) * SMR_RASTER_WAVES + wave;
+   const uint32_t kstride = strided ? wx : 1u;
+   uint32_t round = 0;
    for (;;)
    {
    uint32_t k0 = 0;
-   if (lane == 0) k0 = atomicAdd(ctr, BIG ? 1u : A.chunk);
-   k0 = __builtin_amdgcn_readfirstlane(k0);
+   if (strided) { k0 = round * 64u * wx + wi; round++; }
+   else
+   {
+      if (lane == 0) k0 = atomicAdd(ctr, BIG ? 1u : A.chunk);
+      k0 = __builtin_amdgcn_readfirstlane(k0);
+   }
    if (k0 >= (BIG ? A.ovf_n : ktotal)) break;
-   const uint32_t k1 = BIG ? k0 + 1u : min(k0 + A.chunk, ktotal);
+   const uint32_t k1 = BIG ? k0 + 1u : strided ? ktotal : min(k0 + A.chunk, ktotal);
    /* a sparse rule leaves most tiles empty: the lanes look at 64 tiles of the chunk at once, and only those with entries are visited */
-   for (uint32_t kb = k0; kb < k1; kb += 64u)
+   for (uint32_t kb = k0; kb < k1; kb += strided ? ktotal : 64u)
    {
    unsigned long long todo = 1ull;
    if (!BIG)
    {
-      const uint32_t kl = kb + (uint32_t) lane;
-      todo = __ballot(kl < k1 && A.tile_cnt[(uint32_t) (kl % TYt) * A.TX + (xcd + 8u * (kl / TYt))] != 0u);
+      const uint32_t kl = kb + (uint32_t) lane * kstride;
+      const uint32_t tc = kl < k1 ? A.tile_cnt[(uint32_t) (kl % TYt) * A.TX + (xcd + 8u * (kl / TYt))] : 0u;
+      todo = __ballot(tc != 0u && !(tc & SMR_TILE_PURE));      /* (a pure tile is k_blend's) */
    }
    while (todo)
    {
-      const uint32_t kg = kb + (uint32_t) __ffsll((long long) todo) - 1u;
+      const uint32_t kg = kb + ((uint32_t) __ffsll((long long) todo) - 1u) * kstride;
       todo &= todo - 1ull;
       /* the overflowed tiles come from the list (one queue: they are few), the others from the XCD's columns */
       const uint32_t tile = BIG ? A.ovf_list[kg] : (uint32_t) (kg % TYt) * A.TX + (xcd + 8u * (kg / TYt));
       const int tx = (int) (tile % (uint32_t) A.TX), ty = (int) (tile / (uint32_t) A.TX);
-      const uint32_t beg = A.tile_off[tile], end = beg + A.tile_cnt[tile];
+      const uint32_t beg = A.tile_off[tile], end = beg + (A.tile_cnt[tile] & ~SMR_TILE_PURE);
       if (beg == end) continue;
       COUNT(0);
       const int32_t X0 = tx * SMR_TW * 256, X1 = X0 + SMR_TW * 256;
@@ -3045,6 +3062,114 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
 #ifdef SMR_COUNT_PROFILE
    if (lane == 0) for (int i = 0; i < 24; i++) atomicAdd((unsigned long long *) (A.status + 190) + i, cnts[i]);
 #endif
+}
+
+/* Tiles whose stream holds nothing but k_cover's alpha words (SMR_TILE_PURE: on a chart of small polygons nearly all of them)
+ * need none of k_raster's machinery: no lists, no cells, no LDS.  One wavefront per tile reads the tile's headers 64 at a time,
+ * every lane its column's word of each entry, four entries in flight, and blends the four rows into the layer in registers:
+ * the statements of k_raster's own branch for such an entry, so the pixels are the same.  Twice k_raster's wavefronts per SIMD. */
+#define SMR_BLEND_WAVES 4
+__global__ __launch_bounds__(64 * SMR_BLEND_WAVES) void k_blend(raster_args_t A)
+{
+   const int lane = threadIdx.x & 63;
+   const uint32_t xcd = blockIdx.x & 7u;                /* k_raster's tile order: an XCD walks its tile columns top to bottom */
+   const uint32_t TYt = A.n_tiles / A.TX;
+   const uint32_t ncol = ((uint32_t) A.TX + 7u - xcd) >> 3;
+   const uint32_t ktotal = ncol * TYt;
+   /* the tiles are handed out dynamically: with k_raster's static share this kernel took 14.6 ms instead of 11.3 on C2 (and with
+    * sixteen queues per XCD instead of one the same 11.0: the queue's atomics are not what it waits for) */
+   uint32_t *const ctr = A.blend_ctr + 8u * xcd;
+   for (;;)
+   {
+      uint32_t k0 = 0;
+      if (lane == 0) k0 = atomicAdd(ctr, A.chunk);
+      k0 = __builtin_amdgcn_readfirstlane(k0);
+      if (k0 >= ktotal) break;                         /* (every wavefront gets here: the queue only grows) */
+      const uint32_t k1 = min(k0 + A.chunk, ktotal);
+      for (uint32_t kb = k0; kb < k1; kb += 64u)
+      {
+         const uint32_t kl = kb + (uint32_t) lane;
+         const uint32_t tc = kl < k1 ? A.tile_cnt[(uint32_t) (kl % TYt) * A.TX + (xcd + 8u * (kl / TYt))] : 0u;
+         unsigned long long todo = __ballot((tc & SMR_TILE_PURE) != 0u);
+         while (todo)
+         {
+            const uint32_t kg = kb + (uint32_t) __ffsll((long long) todo) - 1u;
+            todo &= todo - 1ull;
+            const uint32_t tile = (uint32_t) (kg % TYt) * A.TX + (xcd + 8u * (kg / TYt));
+            const int tx = (int) (tile % (uint32_t) A.TX), ty = (int) (tile / (uint32_t) A.TX);
+            const uint32_t beg = A.tile_off[tile], end = beg + (A.tile_cnt[tile] & ~SMR_TILE_PURE);
+            const int px = tx * SMR_TW + lane;
+            uint32_t layer[SMR_TH] = { 0, 0, 0, 0 };
+            if (A.direct)
+            {
+#pragma unroll
+               for (int r = 0; r < SMR_TH; r++)
+                  if (px < A.W && ty * SMR_TH + r < A.band_h) layer[r] = A.canvas[(size_t) (ty * SMR_TH + r) * A.W + px];
+            }
+            uint32_t cur = 0xffffffffu;
+            for (uint32_t bbase = beg; bbase < end; bbase += 64u)
+            {
+               uint4 hb0 = make_uint4(0u, 0xffffffffu, 0u, 0u);
+               uint32_t hinfo = 0;
+               const uint32_t k = bbase + (uint32_t) lane;
+               if (k < end)
+               {
+                  const uint4 *hp = reinterpret_cast<const uint4 *>(&A.hdrs[k]);
+                  hb0 = hp[0]; hinfo = hp[1].w;
+               }
+               const int n = (int) min(64u, end - bbase);
+               for (int j0 = 0; j0 < n; j0 += 4)
+               {
+                  uint32_t a4[4], prim[4], color[4], first[4];
+#pragma unroll
+                  for (int u = 0; u < 4; u++)
+                  {
+                     a4[u] = 0; prim[u] = 0xffffffffu; color[u] = 0; first[u] = 0;
+                     if (j0 + u < n)
+                     {
+                        const uint32_t eo = __builtin_amdgcn_readlane(hb0.x, j0 + u), info = __builtin_amdgcn_readlane(hinfo, j0 + u);
+                        prim[u] = __builtin_amdgcn_readlane(hb0.y, j0 + u); color[u] = __builtin_amdgcn_readlane(hb0.w, j0 + u);
+                        first[u] = (__builtin_amdgcn_readlane(hb0.z, j0 + u) >> 16) & 1u;
+                        const uint32_t i = (uint32_t) (px - smr_strip_x0(info));
+                        if (i < smr_strip_n(info)) a4[u] = A.alpha[(size_t) eo + i];
+                     }
+                  }
+#pragma unroll
+                  for (int u = 0; u < 4; u++)
+                  {
+                     if (j0 + u >= n || prim[u] == cur) continue;      /* (further entries of a primitive bring nothing) */
+                     cur = prim[u];
+                     if (!__ballot(a4[u] != 0)) continue;
+                     const uint32_t spix = color[u];
+                     const bool lerp = (spix >> 24) == 255u || (first[u] && !A.direct);
+#pragma unroll
+                     for (int r = 0; r < SMR_TH; r++)
+                     {
+                        const uint32_t a = (a4[u] >> (8 * r)) & 255u;
+                        if (!__ballot(a != 0)) continue;
+                        if (lerp && !__ballot(a != 255u && a != 0)) layer[r] = a ? spix : layer[r];      /* no edge pixel on the row */
+                        else if (a) layer[r] = lerp ? smr_blend_lerp(spix, a, layer[r]) : smr_blend_over_mask(spix, a, layer[r]);
+                     }
+                  }
+               }
+            }
+            /* pop_group_to_source + paint: layer OVER canvas */
+            if (px < A.W)
+            {
+#pragma unroll
+               for (int r = 0; r < SMR_TH; r++)
+               {
+                  const int row = ty * SMR_TH + r;
+                  if (row < A.band_h && (layer[r] || A.direct))
+                  {
+                     uint32_t *d = A.canvas + (size_t) row * A.W + px;
+                     *d = A.direct ? layer[r] : smr_blend_over(layer[r], *d);
+                  }
+               }
+            }
+         }
+      }
+   }
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -3963,6 +4088,13 @@ static bool smr_cover_enabled()
    return !(e && *e == '0');
 }
 
+/* SMR_HIP_BLEND=0 sends the tiles that hold alpha words only through k_raster too (A/B timing) */
+static bool blend_enabled()
+{
+   const char *e = getenv("SMR_HIP_BLEND");
+   return !(e && *e == '0');
+}
+
 static uint64_t big_slots_max()
 {
    const char *e = getenv("SMR_HIP_DEBUG_BIG_SLOTS");
@@ -4000,13 +4132,13 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    SMR_TRY(c->ensure(SMR_BUF_PTS, (size_t) n_refs * sizeof(int2), (void **) &pts));
    SMR_TRY(c->ensure(SMR_BUF_REFWAY, (size_t) n_refs * 4, (void **) &refway));
    SMR_TRY(c->ensure(SMR_BUF_WAYFLAGS, (size_t) n_ways + 4, (void **) &wayflags));      /* k_stroke_risk sets a byte through its aligned word */
-   SMR_TRY(c->ensure(SMR_BUF_SMALL, 1024, (void **) &small));     /* [0] any_open_fill [1] first_prim [2] status [3] entries [4] mask words */
+   SMR_TRY(c->ensure(SMR_BUF_SMALL, 2048, (void **) &small));     /* [0] any_open_fill [1] first_prim [2] status [3] entries [4] mask words */
    SMR_TRY(c->ensure(SMR_BUF_PRIMS, ((size_t) n_prims + 1) * sizeof(smr_prim_t), (void **) &prims));
    const uint32_t compound = mode == SMR_PASS_COMPOUND ? (uint32_t) n_prims : 0xffffffffu;
    const uint32_t cwords = mode == SMR_PASS_COMPOUND ? (uint32_t) (c->H + 31) / 32 + 1 : 0;
    SMR_TRY(c->ensure(SMR_BUF_ITEMS, (size_t) n_items * sizeof(smr_item_t), (void **) &items));
    uint32_t init_small[8] = { 0, 0xffffffffu, 0, 0, 0, 0xffffffffu, 0, 0 };     /* [5] first stroked way, [6] scan totals */
-   SMR_HIP(hipMemsetAsync(small, 0, 1024, s));                  /* [64 + 8 * xcd]: k_raster's tile queues, [128 + 8 * xcd]: k_prim_setup's */
+   SMR_HIP(hipMemsetAsync(small, 0, 2048, s));                  /* [64 + 8 * xcd]: k_raster's tile queues, [128 + 8 * xcd]: k_prim_setup's, [256 + 8 * xcd]: k_blend's */
    SMR_HIP(hipMemcpyAsync(small, init_small, sizeof(init_small), hipMemcpyHostToDevice, s));
 
    const int TB = 256;
@@ -4421,6 +4553,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       while (cap < h_small[7] && cap < SORT_LDS) cap <<= 1;       /* h_small[7]: entries of the fullest tile (k_scan_block) */
       SO.lds_cap = cap;
       SO.vec = (uint64_t) n_entries * 16ull < n_tiles ? 1 : 0;
+      SO.pure_bit = alpha && blend_enabled() ? SMR_TILE_PURE : 0u;
       const uint32_t nwork = SO.vec ? (n_tiles + 63u) / 64u : n_tiles;
       k_tile_sort<<<(nwork + SORT_WAVES - 1) / SORT_WAVES, 64 * SORT_WAVES, (size_t) SORT_WAVES * cap * 4, s>>>(SO);
    }
@@ -4437,6 +4570,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    raster_args_t A;
    A.prims = prims; A.hdrs = hdrs; A.edges = edges; A.tile_off = tile_off; A.tile_cnt = tile_cnt;
    A.tile_ctr = &small[64];       /* zero since the memset at the top of the pass */
+   A.blend_ctr = &small[256];
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
    A.chunk = n_entries >= 8ull * n_tiles ? SMR_TILE_CHUNK : n_entries >= 2ull * n_tiles ? 2 * SMR_TILE_CHUNK : n_entries * 16ull >= n_tiles ? 4 * SMR_TILE_CHUNK : 64;
@@ -4452,6 +4586,16 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       {
          SMR_TRY(c->ensure(SMR_BUF_SNAPSHOT, (size_t) c->W * c->band_h * 4, (void **) &snapshot));
          SMR_HIP(hipMemcpyAsync(snapshot, c->pix, (size_t) c->W * c->band_h * 4, hipMemcpyDeviceToDevice, s));
+      }
+      /* the tiles that hold alpha words only (they and k_raster's are disjoint: the order of the two launches is free; side by
+       * side on two streams they took longer than one after the other, measured).  k_raster then finds its tiles without the
+       * queue: what is left to it is little, and the queue's atomics on eight addresses would be most of its time */
+      A.strided = 0;
+      if (alpha && blend_enabled())
+      {
+         unsigned bwg = std::min<unsigned>((n_tiles + SMR_BLEND_WAVES - 1) / SMR_BLEND_WAVES, 256u * 8u);
+         k_blend<<<(bwg + 7u) & ~7u, 64 * SMR_BLEND_WAVES, 0, s>>>(A);
+         A.strided = 1;
       }
       k_raster<false><<<nwg, 64 * SMR_RASTER_WAVES, 0, s>>>(A);
    }

@@ -715,3 +715,25 @@ def test_hairpin_ways_take_the_strokers_polygon(hip, case):
         c = po.cairo_scene([(st, po.ways_from_arrays(*arrs))], dpi, W, H, 0xffffff)
         d = po.chan_diff(g, c)[2:-2, 2:-2]        # (the image's last row and column: the translucent layer's own edge)
         assert (d > 0).mean() < 0.004 and (d > 64).sum() <= 4, ((d > 0).sum(), d.max(), (d > 64).sum())
+
+
+@pytest.mark.parametrize("style", ["fill+border", "translucent"])
+def test_alpha_word_tiles_composite_alike_in_both_kernels(hip, style, monkeypatch):
+    """tiles whose stream holds k_cover's alpha words only are composited by k_blend, the others by k_raster: with
+    SMR_HIP_BLEND=0 (every tile through k_raster) and SMR_HIP_COVER=0 (no alpha words at all) the chart is the same, and the
+    oracle's; two rules on one canvas, bands included (the second rule meets the first one's pixels)"""
+    sa = hip
+    W, H = 700, 520
+    rules = [(STYLES[style], synth.synth_ways(900, W, H, seed=31, rmin=3.0, rmax=40.0)),
+             (STYLES["translucent"], synth.synth_ways(300, W, H, seed=32, rmin=3.0, rmax=70.0))]
+    want = oracle_of(rules, 300, W, H, 0xfff0e0d0)
+    got = gpu_scene(sa, rules, 300, W, H, 0xfff0e0d0)
+    assert np.array_equal(got, want), report(got, want)
+    for var in ("SMR_HIP_BLEND", "SMR_HIP_COVER"):
+        monkeypatch.setenv(var, "0")
+        other = gpu_scene(sa, rules, 300, W, H, 0xfff0e0d0)
+        monkeypatch.delenv(var)
+        assert np.array_equal(other, got), (var, report(other, got))
+    for y0, h in ((0, 200), (200, 320)):
+        band = gpu_scene(sa, rules, 300, W, H, 0xfff0e0d0, y0, h)
+        assert np.array_equal(band, want[y0:y0 + h]), report(band, want[y0:y0 + h])
