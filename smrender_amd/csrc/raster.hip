@@ -3099,12 +3099,16 @@ __global__ __launch_bounds__(64 * SMR_BLEND_WAVES) void k_blend(raster_args_t A)
             const int tx = (int) (tile % (uint32_t) A.TX), ty = (int) (tile / (uint32_t) A.TX);
             const uint32_t beg = A.tile_off[tile], end = beg + (A.tile_cnt[tile] & ~SMR_TILE_PURE);
             const int px = tx * SMR_TW + lane;
-            uint32_t layer[SMR_TH] = { 0, 0, 0, 0 };
-            if (A.direct)
+            /* (four names, not an array: the compiler copied the whole array wherever two paths of a row met) */
+            uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+            if (A.direct && px < A.W)
             {
-#pragma unroll
-               for (int r = 0; r < SMR_TH; r++)
-                  if (px < A.W && ty * SMR_TH + r < A.band_h) layer[r] = A.canvas[(size_t) (ty * SMR_TH + r) * A.W + px];
+               const uint32_t *cp = A.canvas + (size_t) (ty * SMR_TH) * A.W + px;
+               const int nr = A.band_h - ty * SMR_TH;
+               if (nr > 0) l0 = cp[0];
+               if (nr > 1) l1 = cp[A.W];
+               if (nr > 2) l2 = cp[2 * (size_t) A.W];
+               if (nr > 3) l3 = cp[3 * (size_t) A.W];
             }
             uint32_t cur = 0xffffffffu;
             for (uint32_t bbase = beg; bbase < end; bbase += 64u)
@@ -3142,30 +3146,29 @@ __global__ __launch_bounds__(64 * SMR_BLEND_WAVES) void k_blend(raster_args_t A)
                      if (!__ballot(a4[u] != 0)) continue;
                      const uint32_t spix = color[u];
                      const bool lerp = (spix >> 24) == 255u || (first[u] && !A.direct);
-#pragma unroll
-                     for (int r = 0; r < SMR_TH; r++)
-                     {
-                        const uint32_t a = (a4[u] >> (8 * r)) & 255u;
-                        if (!__ballot(a != 0)) continue;
-                        if (lerp && !__ballot(a != 255u && a != 0)) layer[r] = a ? spix : layer[r];      /* no edge pixel on the row */
-                        else if (a) layer[r] = lerp ? smr_blend_lerp(spix, a, layer[r]) : smr_blend_over_mask(spix, a, layer[r]);
-                     }
+                     /* k_raster's statements for such an entry, the blends without their per-lane shortcuts (the arithmetic gives
+                      * the same for a = 0 and a = 255: smr_blend_lerp_all) */
+#define SMR_BLEND_ROW(L, R) do { \
+                        const uint32_t a = (a4[u] >> (8 * (R))) & 255u; \
+                        if (__ballot(a != 0)) \
+                        { \
+                           if (!lerp) L = smr_blend_over_mask_all(spix, a, L); \
+                           else if (!__ballot(a != 255u && a != 0)) L = a ? spix : L;      /* no edge pixel on the row */ \
+                           else L = smr_blend_lerp_all(spix, a, L); \
+                        } } while (0)
+                     SMR_BLEND_ROW(l0, 0); SMR_BLEND_ROW(l1, 1); SMR_BLEND_ROW(l2, 2); SMR_BLEND_ROW(l3, 3);
+#undef SMR_BLEND_ROW
                   }
                }
             }
             /* pop_group_to_source + paint: layer OVER canvas */
             if (px < A.W)
             {
-#pragma unroll
-               for (int r = 0; r < SMR_TH; r++)
-               {
-                  const int row = ty * SMR_TH + r;
-                  if (row < A.band_h && (layer[r] || A.direct))
-                  {
-                     uint32_t *d = A.canvas + (size_t) row * A.W + px;
-                     *d = A.direct ? layer[r] : smr_blend_over(layer[r], *d);
-                  }
-               }
+               uint32_t *cp = A.canvas + (size_t) (ty * SMR_TH) * A.W + px;
+               const int nr = A.band_h - ty * SMR_TH;
+#define SMR_BLEND_OUT(L, R) do { if (nr > (R) && (L || A.direct)) { uint32_t *d = cp + (size_t) (R) * A.W; *d = A.direct ? L : smr_blend_over(L, *d); } } while (0)
+               SMR_BLEND_OUT(l0, 0); SMR_BLEND_OUT(l1, 1); SMR_BLEND_OUT(l2, 2); SMR_BLEND_OUT(l3, 3);
+#undef SMR_BLEND_OUT
             }
          }
       }

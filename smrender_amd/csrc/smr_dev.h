@@ -262,6 +262,26 @@ __device__ __forceinline__ uint32_t smr_blend_lerp(uint32_t s, uint32_t a, uint3
    return smr_pk_join(rb, ag);
 }
 
+/* the same two without their shortcuts, for code that runs them on whole wavefronts: pixman's MUL_UN8 gives x for x * 255 and
+ * 0 for x * 0 (with either rounding constant), so a = 255 and a = 0 come out as s and d by the arithmetic itself */
+__device__ __forceinline__ uint32_t smr_blend_lerp_all(uint32_t s, uint32_t a, uint32_t d)
+{
+   const smr_u16x2 a2 = smr_pk(a * 0x10001u), ia2 = smr_pk(SMR_RB - a * 0x10001u);
+   const smr_u16x2 rb = smr_pk_addsat(smr_pk_mul(smr_pk_rb(s), a2, 0x7f), smr_pk_mul(smr_pk_rb(d), ia2, 0x7f));
+   const smr_u16x2 ag = smr_pk_addsat(smr_pk_mul(smr_pk_ag(s), a2, 0x7f), smr_pk_mul(smr_pk_ag(d), ia2, 0x7f));
+   return smr_pk_join(rb, ag);
+}
+
+__device__ __forceinline__ uint32_t smr_blend_over_mask_all(uint32_t s, uint32_t m, uint32_t d)
+{
+   const smr_u16x2 m2 = smr_pk(m * 0x10001u);
+   const smr_u16x2 srb = smr_pk_mul(smr_pk_rb(s), m2, 0x80), sag = smr_pk_mul(smr_pk_ag(s), m2, 0x80);
+   const smr_u16x2 ia2 = smr_pk((255u - (smr_unpk(sag) >> 16)) * 0x10001u);
+   const smr_u16x2 rb = smr_pk_addsat(srb, smr_pk_mul(smr_pk_rb(d), ia2, 0x80));
+   const smr_u16x2 ag = smr_pk_addsat(sag, smr_pk_mul(smr_pk_ag(d), ia2, 0x80));
+   return smr_pk_join(rb, ag);
+}
+
 __device__ __forceinline__ uint32_t smr_blend_over_mask(uint32_t s, uint32_t m, uint32_t d)
 {
    smr_u16x2 srb = smr_pk_rb(s), sag = smr_pk_ag(s);
