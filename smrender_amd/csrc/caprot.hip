@@ -282,15 +282,16 @@ __global__ __launch_bounds__(64 * SMR_CAPROT_MAXWAVES) void k_caprot(caprot_args
                if (tl == tr && tl == bl && tl == br) s = tl;      /* the weights sum to 2^16: four equal pixels give themselves */
                else
                {
-                  const uint32_t wxy = distx * disty, wxiy = distx * (256 - disty), wixy = (256 - distx) * disty,
-                                 wixiy = (256 - distx) * (256 - disty);
-#pragma unroll
-                  for (int sh = 0; sh < 32; sh += 8)
-                  {
-                     uint32_t f = ((tl >> sh) & 0xff) * wixiy + ((tr >> sh) & 0xff) * wxiy +
-                                  ((bl >> sh) & 0xff) * wixy + ((br >> sh) & 0xff) * wxy;
-                     s |= ((f >> 16) & 0xff) << sh;
-                  }
+                  /* pixman's f = tl (256-dx)(256-dy) + tr dx (256-dy) + bl (256-dx) dy + br dx dy per channel is, in integers,
+                   * (256-dy) (tl (256-dx) + tr dx) + dy (bl (256-dx) + br dx): the inner sums are below 2^16 (the two weights add
+                   * up to 256), so they are worked out two channels at a time in the packed 16-bit ALU; the outer one in 32 bits */
+                  const smr_u16x2 wx = smr_pk(distx * 0x10001u), wix = smr_pk((256u - distx) * 0x10001u);
+                  const uint32_t t_rb = smr_unpk(smr_pk_rb(tl) * wix + smr_pk_rb(tr) * wx), t_ag = smr_unpk(smr_pk_ag(tl) * wix + smr_pk_ag(tr) * wx);
+                  const uint32_t b_rb = smr_unpk(smr_pk_rb(bl) * wix + smr_pk_rb(br) * wx), b_ag = smr_unpk(smr_pk_ag(bl) * wix + smr_pk_ag(br) * wx);
+                  const uint32_t wiy = 256u - disty;
+                  const uint32_t fb = (t_rb & 0xffffu) * wiy + (b_rb & 0xffffu) * disty, fr = (t_rb >> 16) * wiy + (b_rb >> 16) * disty;
+                  const uint32_t fg = (t_ag & 0xffffu) * wiy + (b_ag & 0xffffu) * disty, fa = (t_ag >> 16) * wiy + (b_ag >> 16) * disty;
+                  s = ((fb >> 16) & 0xffu) | ((fg >> 8) & 0xff00u) | (fr & 0xff0000u) | ((fa << 8) & 0xff000000u);
                }
             }
             /* OVER onto what the previous angle left in dst */
