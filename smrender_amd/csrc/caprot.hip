@@ -217,6 +217,9 @@ __global__ __launch_bounds__(64 * SMR_CAPROT_MAXWAVES) void k_caprot(caprot_args
       if (!fg_skip || A.fg)
       {
          uint32_t kbit = 1;
+         /* the transform of the lane's place in its block, once per angle: a block then adds one uniform term (below) */
+         const int Xl = __mul24(M.m[0][0], lane & 15) + __mul24(M.m[0][1], lane >> 4);
+         const int Yl = __mul24(M.m[1][0], lane & 15) + __mul24(M.m[1][1], lane >> 4);
          /* (block row, block column) of this wavefront's blocks: uniform, kept by running sums instead of a division per block */
          int brow = wave / nbc, bcol = wave - brow * nbc;
          const int drow = nwaves / nbc, dcol = nwaves - drow * nbc;
@@ -244,9 +247,11 @@ __global__ __launch_bounds__(64 * SMR_CAPROT_MAXWAVES) void k_caprot(caprot_args
             if (small)
             {
                /* 24-bit multiplies: |m| <= 2^16 (16.16 of a sine), the pixel indices are below 2^13 */
-               const int X = __mul24(M.m[0][0], M.xoff + c0 + col) + __mul24(M.m[0][1], line + M.yoff) + (M.m[0][2] + ((M.m[0][0] + M.m[0][1] + 1) >> 1));
-               const int Y = __mul24(M.m[1][0], M.xoff + c0 + col) + __mul24(M.m[1][1], line + M.yoff) + (M.m[1][2] + ((M.m[1][0] + M.m[1][1] + 1) >> 1));
-               const int x1 = X - 0x8000, y1 = Y - 0x8000;
+               /* (the products are exact in 32 bits, so the block's uniform part, which the scalar unit works out, and the lane's
+                * part add up to the same X and Y) */
+               const int ucol = M.xoff + c0 + 16 * bcol, uline = 4 * brow + M.yoff;
+               const int x1 = Xl + (M.m[0][0] * ucol + M.m[0][1] * uline + (M.m[0][2] + ((M.m[0][0] + M.m[0][1] + 1) >> 1)) - 0x8000);
+               const int y1 = Yl + (M.m[1][0] * ucol + M.m[1][1] * uline + (M.m[1][2] + ((M.m[1][0] + M.m[1][1] + 1) >> 1)) - 0x8000);
                distx = (uint32_t) ((x1 >> 9) & 0x7f) << 1; disty = (uint32_t) ((y1 >> 9) & 0x7f) << 1;
                ix = x1 >> 16; iy = y1 >> 16;
             }
@@ -263,11 +268,14 @@ __global__ __launch_bounds__(64 * SMR_CAPROT_MAXWAVES) void k_caprot(caprot_args
                ix = (int) (x1 >> 16); iy = (int) (y1 >> 16);
             }
             uint32_t s = 0;
-            if (!(ix >= A.r || ix + 1 < 0 || iy >= A.r || iy + 1 < 0))
+            const int gx = ox + ix, gy = oy + iy - A.band_y0;
+            /* all four inside the cut-out, the chart and this band (0 <= v && v + 1 < n as one unsigned compare each) */
+            const bool inside4 = (uint32_t) ix < (uint32_t) (A.r - 1) && (uint32_t) iy < (uint32_t) (A.r - 1) &&
+                                 (uint32_t) gx < (uint32_t) (A.W - 1) && (uint32_t) gy < (uint32_t) (A.band_h - 1);
+            if (inside4 || !(ix >= A.r || ix + 1 < 0 || iy >= A.r || iy + 1 < 0))
             {
                uint32_t tl, tr, bl, br;
-               const int gx = ox + ix, gy = oy + iy - A.band_y0;
-               if (ix >= 0 && ix + 1 < A.r && iy >= 0 && iy + 1 < A.r && gx >= 0 && gx + 1 < A.W && gy >= 0 && gy + 1 < A.band_h)
+               if (inside4)
                {
                   /* all four inside the cut-out, the chart and this band (nearly every sample): one address */
                   const uint32_t *q0 = A.canvas + (__umul24((uint32_t) gy, (uint32_t) A.W) + (uint32_t) gx);      /* gy < 2^16, W <= 2^16 */
