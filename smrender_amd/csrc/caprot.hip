@@ -228,8 +228,8 @@ __global__ __launch_bounds__(64 * SMR_CAPROT_MAXWAVES) void k_caprot(caprot_args
             if (bcol >= nbc) { bcol -= nbc; brow++; }
             const int line = 4 * brow + (lane >> 4), col = 16 * bcol + (lane & 15);
             if (col >= cw || line >= A.fg_h) continue;
-            const int q = line * cw + col;
-            const int p = line * A.fg_w + c0 + col;
+            const int q = __mul24(line, cw) + col;                 /* (plane sizes are far below 2^23: a full 32-bit multiply is four passes) */
+            const int p = __mul24(line, A.fg_w) + c0 + col;
             int psr = sr, psg = sg, psb = sb;
             double plum = lum_s;
             if (A.fg)
