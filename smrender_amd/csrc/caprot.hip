@@ -135,8 +135,9 @@ __device__ __forceinline__ int smr_div30(int n) { return (int) (__umul24((uint32
 
 __device__ __forceinline__ void smr_bw_stretch(uint32_t col, int &r, int &g, int &b)
 {
-   int R = (col >> 16) & 0xff, G = (col >> 8) & 0xff, B = col & 0xff, S = 2 * (R + G + B) + 15;
-   r = smr_div30(S + 24 * R); g = smr_div30(S + 24 * G); b = smr_div30(S + 24 * B);
+   /* smr_div30(S + 24 c) = ((S + 24 c) * 8739) >> 18 with the common part multiplied once (all below 2^27) */
+   const uint32_t R = (col >> 16) & 0xff, G = (col >> 8) & 0xff, B = col & 0xff, S8 = __umul24(2 * (R + G + B) + 15, 8739u);
+   r = (int) ((__umul24(R, 24u * 8739u) + S8) >> 18); g = (int) ((__umul24(G, 24u * 8739u) + S8) >> 18); b = (int) ((__umul24(B, 24u * 8739u) + S8) >> 18);
 }
 
 /* T[v] = (double) v / 255.0, the IEEE quotient itself, from a table in LDS: three fp64 divisions per pixel and angle were a
@@ -231,12 +232,14 @@ __global__ __launch_bounds__(64 * SMR_CAPROT_MAXWAVES) void k_caprot(caprot_args
             const int q = __mul24(line, cw) + col;                 /* (plane sizes are far below 2^23: a full 32-bit multiply is four passes) */
             const int p = __mul24(line, A.fg_w) + c0 + col;
             int psr = sr, psg = sg, psb = sb;
+            int pk = __mul24(2125, sr) + __mul24(7154, sg) + __mul24(721, sb);      /* the plane pixel's side of the metric's difference */
             double plum = lum_s;
             if (A.fg)
             {
                uint32_t fp = A.fg[p];
                if (smr_transp(fp)) continue;            /* transparent plane pixel: never counted */
                smr_bw_stretch(fp, psr, psg, psb);
+               pk = __mul24(2125, psr) + __mul24(7154, psg) + __mul24(721, psb);
                plum = smr_lum(T, psr, psg, psb);
             }
             /* pixman: transform the scanline start (pixel centre), then step by the first matrix column.  The start is
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(64 * SMR_CAPROT_MAXWAVES) void k_caprot(caprot_args
             if (smr_transp(d)) { dst[q] = SMR_TRANSPIX; rawmask &= ~kbit; continue; }
             int dr, dg, db;
             smr_bw_stretch(d, dr, dg, db);
-            const int k = __mul24(2125, dr - psr) + __mul24(7154, dg - psg) + __mul24(721, db - psb);
+            const int k = __mul24(2125, dr) + __mul24(7154, dg) + __mul24(721, db) - pk;
             ksum += (uint32_t) (k < 0 ? -k : k);
             cnt++;
             if (lazy) { dst[q] = d; rawmask |= kbit; }
