@@ -32,7 +32,8 @@ enum
 };
 
 /* ---- life cycle ------------------------------------------------------------------ */
-int smr_hip_init(int device);                 /* selects the device, creates the stream */
+int smr_hip_init(int device);                 /* selects the device, creates the stream (and a second one the draw pass forks its binning onto
+                                                * and joins again before it returns: callers only ever see the first) */
 int smr_hip_shutdown(void);
 const char *smr_hip_last_error(void);
 int smr_hip_device_name(char *buf, size_t len);

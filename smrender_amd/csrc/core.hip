@@ -31,7 +31,13 @@ extern "C" int smr_hip_init(int device)
    if (!smr_g.init || smr_g.device != device)
    {
       if (smr_g.stream) { hipStreamDestroy(smr_g.stream); smr_g.stream = nullptr; }
+      if (smr_g.stream2) { hipStreamDestroy(smr_g.stream2); smr_g.stream2 = nullptr; }
+      if (smr_g.ev_fork) { hipEventDestroy(smr_g.ev_fork); smr_g.ev_fork = nullptr; }
+      if (smr_g.ev_join) { hipEventDestroy(smr_g.ev_join); smr_g.ev_join = nullptr; }
       SMR_HIP(hipStreamCreateWithFlags(&smr_g.stream, hipStreamNonBlocking));
+      SMR_HIP(hipStreamCreateWithFlags(&smr_g.stream2, hipStreamNonBlocking));
+      SMR_HIP(hipEventCreateWithFlags(&smr_g.ev_fork, hipEventDisableTiming));
+      SMR_HIP(hipEventCreateWithFlags(&smr_g.ev_join, hipEventDisableTiming));
    }
    SMR_TRY(smr_caprot_scratch_setup(device));      /* with `device` current: every GPU has its own copy of the array */
    smr_g.device = device;
@@ -45,8 +51,12 @@ extern "C" int smr_hip_shutdown(void)
    if (smr_g.init)
    {
       hipStreamSynchronize(smr_g.stream);
+      hipStreamSynchronize(smr_g.stream2);
       hipStreamDestroy(smr_g.stream);
-      smr_g.stream = nullptr;
+      hipStreamDestroy(smr_g.stream2);
+      hipEventDestroy(smr_g.ev_fork); hipEventDestroy(smr_g.ev_join);
+      smr_g.stream = smr_g.stream2 = nullptr;
+      smr_g.ev_fork = smr_g.ev_join = nullptr;
       smr_g.init = false;
    }
    return SMR_OK;

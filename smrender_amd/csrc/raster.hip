@@ -2087,27 +2087,28 @@ __global__ __launch_bounds__(256) void k_scan_block(const uint32_t *__restrict__
 
 __global__ __launch_bounds__(1024) void k_scan_sums(uint32_t *__restrict__ sums, uint32_t nb, uint32_t *__restrict__ total)
 {
-   /* single block, serial over chunks of 1024 */
+   /* single block, serial over chunks of its size (256 threads in a draw pass: four wavefronts find room on a CU beside
+    * k_cover's, sixteen do not, and the whole binning waited for k_cover's last wavefront) */
    __shared__ uint32_t s[1024];
    __shared__ uint32_t carry;
-   uint32_t t = threadIdx.x;
+   const uint32_t t = threadIdx.x, B = blockDim.x;
    if (t == 0) carry = 0;
    __syncthreads();
-   for (uint32_t base = 0; base < nb; base += 1024)
+   for (uint32_t base = 0; base < nb; base += B)
    {
       uint32_t i = base + t, v = i < nb ? sums[i] : 0;
       s[t] = v;
       __syncthreads();
-      for (int d = 1; d < 1024; d <<= 1)
+      for (uint32_t d = 1; d < B; d <<= 1)
       {
-         uint32_t x = t >= (uint32_t) d ? s[t - d] : 0;
+         uint32_t x = t >= d ? s[t - d] : 0;
          __syncthreads();
          s[t] += x;
          __syncthreads();
       }
       if (i < nb) sums[i] = carry + s[t] - v;
       __syncthreads();
-      if (t == 1023) carry += s[1023];
+      if (t == B - 1) carry += s[B - 1];
       __syncthreads();
    }
    if (t == 0) *total = carry;
@@ -4091,6 +4092,13 @@ static bool smr_cover_enabled()
    return !(e && *e == '0');
 }
 
+/* SMR_HIP_OVERLAP=0 runs a pass's binning after k_cover instead of beside it (A/B timing) */
+static bool overlap_enabled()
+{
+   const char *e = getenv("SMR_HIP_OVERLAP");
+   return !(e && *e == '0');
+}
+
 /* SMR_HIP_BLEND=0 sends the tiles that hold alpha words only through k_raster too (A/B timing) */
 static bool blend_enabled()
 {
@@ -4494,8 +4502,18 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    uint32_t *alpha = nullptr;
    uint2 *drows = nullptr;
    uint32_t *cvctr = &small[40];
+   /* The binning below needs the items, which are final, and nothing of k_cover's; k_cover is arithmetic, the binning atomics:
+    * with k_cover in the pass the binning runs beside it on the second stream (sb) and joins before the tiles are sorted.
+    * SMR_HIP_OVERLAP=0: one after the other (A/B timing). */
+   hipStream_t sb = s;
    if (mode != SMR_PASS_COMPOUND && !c->strict_rows && smr_cover_enabled() && h_small[11])
    {
+      if (overlap_enabled())
+      {
+         sb = smr_g.stream2;
+         SMR_HIP(hipEventRecord(smr_g.ev_fork, s));
+         SMR_HIP(hipStreamWaitEvent(sb, smr_g.ev_fork, 0));
+      }
       /* k_prim_setup has added up what the eligible primitives need at most (h_small[11] strips, h_small[12..13] alpha words);
        * on top of it the blocks the wavefronts take and do not use up.  An arena that runs out (beyond 2^32 words) leaves the
        * remaining primitives to k_raster's own path */
@@ -4525,14 +4543,14 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    SMR_TRY(c->ensure(SMR_BUF_COUNTS, (size_t) n_tiles * 4, (void **) &counts));
    SMR_TRY(c->ensure(SMR_BUF_TILEOFF, ((size_t) n_tiles + 1) * 4, (void **) &tile_off));
    SMR_TRY(c->ensure(SMR_BUF_SUMS, (size_t) nb_scan * 4, (void **) &sums));
-   SMR_HIP(hipMemsetAsync(counts, 0, (size_t) n_tiles * 4, s));
-   k_bin<false><<<blocks(n_items, TB), TB, 0, s>>>(items, n_items, c->W, c->band_y0, c->band_h, TX, counts, nullptr, nullptr);
-   k_scan_block<<<nb_scan, 256, 0, s>>>(counts, tile_off, sums, n_tiles, &small[7]);
-   k_scan_sums<<<1, 1024, 0, s>>>(sums, nb_scan, &small[3]);
-   k_scan_add<<<nb_scan, 256, 0, s>>>(tile_off, sums, n_tiles);
-   k_set_u32<<<1, 1, 0, s>>>(&tile_off[n_tiles], &small[3]);
-   SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
-   SMR_HIP(hipStreamSynchronize(s));
+   SMR_HIP(hipMemsetAsync(counts, 0, (size_t) n_tiles * 4, sb));
+   k_bin<false><<<blocks(n_items, TB), TB, 0, sb>>>(items, n_items, c->W, c->band_y0, c->band_h, TX, counts, nullptr, nullptr);
+   k_scan_block<<<nb_scan, 256, 0, sb>>>(counts, tile_off, sums, n_tiles, &small[7]);
+   k_scan_sums<<<1, 256, 0, sb>>>(sums, nb_scan, &small[3]);
+   k_scan_add<<<nb_scan, 256, 0, sb>>>(tile_off, sums, n_tiles);
+   k_set_u32<<<1, 1, 0, sb>>>(&tile_off[n_tiles], &small[3]);
+   SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, sb));      /* (k_cover's counters are words 40 and up) */
+   SMR_HIP(hipStreamSynchronize(sb));
    const uint32_t n_entries = h_small[3];
    /* what the geometry kernels refused is reported before a pixel is touched */
    if (h_small[2] & SMR_ST_CURVE_DEPTH)
@@ -4541,9 +4559,15 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       return smr_fail(SMR_E_UNSUPPORTED, "draw: a closed way of explicit Bezier knots (curve=2) must be p0, (c1, c2, p) * m, p0 (the way was not drawn)");
    uint32_t *entries;
    SMR_TRY(c->ensure(SMR_BUF_ENTRIES, ((size_t) n_entries + 1) * 4, (void **) &entries));
-   SMR_HIP(hipMemsetAsync(counts, 0, (size_t) n_tiles * 4, s));
-   k_bin<true><<<blocks(n_items, TB), TB, 0, s>>>(items, n_items, c->W, c->band_y0, c->band_h, TX, counts, tile_off, entries);
+   SMR_HIP(hipMemsetAsync(counts, 0, (size_t) n_tiles * 4, sb));
+   k_bin<true><<<blocks(n_items, TB), TB, 0, sb>>>(items, n_items, c->W, c->band_y0, c->band_h, TX, counts, tile_off, entries);
    SMR_HIP(hipGetLastError());
+   if (sb != s)
+   {
+      /* joined at once: whatever follows on the first stream, an error path's too, comes after the binning */
+      SMR_HIP(hipEventRecord(smr_g.ev_join, sb));
+      SMR_HIP(hipStreamWaitEvent(s, smr_g.ev_join, 0));
+   }
    smr_thdr_t *hdrs;
    uint32_t *tile_cnt;
    SMR_TRY(c->ensure(SMR_BUF_TILECNT, (size_t) n_tiles * 4, (void **) &tile_cnt));

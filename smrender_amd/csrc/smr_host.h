@@ -14,6 +14,10 @@ struct smr_global_t
    bool init = false;
    int device = -1;
    hipStream_t stream = nullptr;
+   /* the binning of a draw pass (atomics, no arithmetic) runs beside k_cover (arithmetic, no memory traffic to speak of): a second
+    * stream, forked from and joined to the first by two events */
+   hipStream_t stream2 = nullptr;
+   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
    smr_proj_t proj;
    bool have_proj = false;
    bool profiling = false;
