@@ -729,7 +729,7 @@ def test_alpha_word_tiles_composite_alike_in_both_kernels(hip, style, monkeypatc
     want = oracle_of(rules, 300, W, H, 0xfff0e0d0)
     got = gpu_scene(sa, rules, 300, W, H, 0xfff0e0d0)
     assert np.array_equal(got, want), report(got, want)
-    for var in ("SMR_HIP_BLEND", "SMR_HIP_COVER"):
+    for var in ("SMR_HIP_BLEND", "SMR_HIP_COVER", "SMR_HIP_OVERLAP"):      # (the last: the binning after k_cover instead of beside it)
         monkeypatch.setenv(var, "0")
         other = gpu_scene(sa, rules, 300, W, H, 0xfff0e0d0)
         monkeypatch.delenv(var)
