@@ -223,6 +223,12 @@ typedef struct
    int32_t border_ndash, fill_ndash;
    double border_dash[4], fill_dash[4];
    double curve_factor;                     /* curve_factor=, the reference's default is DIV_PART 0.2 (src/smrender_dev.h:114; act_draw_ini :625-631) */
+   int32_t evenodd;                         /* 1: closed ways (and the compound of a directional rule) are filled with libcairo's EVEN_ODD rule
+                                               instead of WINDING.  The reference never selects it (no cairo_set_fill_rule in
+                                               src/smrules_cairo.c: :1012 and :1134-1138 fill with the default); it is here because the
+                                               rasterizer is specified with both rules, pinned on libcairo's cairo_set_fill_rule.  Strokes
+                                               are unaffected (a stroke's polygon is always filled non-zero) */
+   int32_t pad_;
 } smr_draw_style_t;
 enum { SMR_STYLE_SOLID = 0, SMR_STYLE_DASHED = 1, SMR_STYLE_DOTTED = 2, SMR_STYLE_TRANSPARENT = 3, SMR_STYLE_PIPE = 4, SMR_STYLE_ROUNDDOT = 5 };
 

@@ -58,6 +58,7 @@ FN(void, cairo_set_line_cap, (cairo_t*, int))
 FN(void, cairo_set_dash, (cairo_t*, const double*, int, double))
 FN(void, cairo_stroke, (cairo_t*))
 FN(void, cairo_fill, (cairo_t*))
+FN(void, cairo_set_fill_rule, (cairo_t*, int))
 FN(void, cairo_scale, (cairo_t*, double, double))
 FN(void, cairo_translate, (cairo_t*, double, double))
 FN(void, cairo_rotate, (cairo_t*, double))
@@ -101,7 +102,7 @@ int cd_init(const char *path)
    LOAD(cairo_push_group); LOAD(cairo_pop_group_to_source); LOAD(cairo_new_sub_path);
    LOAD(cairo_move_to); LOAD(cairo_line_to); LOAD(cairo_curve_to); LOAD(cairo_rectangle);
    LOAD(cairo_set_line_width); LOAD(cairo_set_line_cap); LOAD(cairo_set_dash);
-   LOAD(cairo_stroke); LOAD(cairo_fill); LOAD(cairo_scale); LOAD(cairo_translate);
+   LOAD(cairo_stroke); LOAD(cairo_fill); LOAD(cairo_set_fill_rule); LOAD(cairo_scale); LOAD(cairo_translate);
    LOAD(cairo_rotate); LOAD(cairo_save); LOAD(cairo_restore); LOAD(cairo_set_operator);
    LOAD(cairo_status); LOAD(cairo_surface_status); LOAD(cairo_version_string); LOAD(cairo_surface_write_to_png);
    LOAD(cairo_font_options_create); LOAD(cairo_font_options_set_hint_metrics); LOAD(cairo_set_font_options);
@@ -186,6 +187,10 @@ void cd_stroke(uint32_t col, double width_pt)
    p_cairo_set_line_width(rule_, width_pt);
    p_cairo_stroke(rule_);
 }
+
+/* CAIRO_FILL_RULE_WINDING = 0 (libcairo's default, the only one the reference uses), CAIRO_FILL_RULE_EVEN_ODD = 1: on the current
+ * rule's context, for the even-odd extension of the rasterizer */
+void cd_set_fill_rule(int evenodd) { p_cairo_set_fill_rule(rule_, evenodd ? 1 : 0); }
 
 void cd_fill(uint32_t col)
 {
@@ -272,6 +277,10 @@ int cd_cut_out(double x_pt, double y_pt, double r_pt, double dpi, uint32_t *out,
 
 /* direct (no recording surface) variant used for micro-probes: draw a polygon in
  * device px straight onto an image */
+/* fill rule of the next cd_direct_fill calls (0 winding = libcairo's default, 1 even-odd) */
+static int direct_rule_;
+void cd_set_direct_fill_rule(int evenodd) { direct_rule_ = evenodd ? 1 : 0; }
+
 int cd_direct_fill(const double *xy, int n, uint32_t col, uint32_t bg, int W, int H, uint32_t *out)
 {
    cairo_surface_t *img = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, W, H);
@@ -279,6 +288,7 @@ int cd_direct_fill(const double *xy, int n, uint32_t col, uint32_t bg, int W, in
    set_color(c, bg); p_cairo_paint(c);
    p_cairo_new_sub_path(c);
    for (int i = 0; i < n; i++) p_cairo_line_to(c, xy[2 * i], xy[2 * i + 1]);
+   p_cairo_set_fill_rule(c, direct_rule_);
    set_color(c, col); p_cairo_fill(c);
    p_cairo_destroy(c);
    p_cairo_surface_flush(img);

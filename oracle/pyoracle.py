@@ -33,7 +33,7 @@ class Style(C.Structure):
                 ("fill_width_mm", C.c_double), ("border_width_mm", C.c_double), ("ignore_open", C.c_int),
                 ("border_style", C.c_int), ("fill_style", C.c_int), ("border_ndash", C.c_int), ("fill_ndash", C.c_int),
                 ("border_dash", C.c_double * 4), ("fill_dash", C.c_double * 4),
-                ("curve", C.c_int), ("curve_fact", C.c_double)]
+                ("curve", C.c_int), ("curve_fact", C.c_double), ("evenodd", C.c_int)]
 
     SOLID, DASHED, DOTTED, TRANSPARENT, PIPE, ROUNDDOT = range(6)
     DEFAULT_DASH = {1: (7.0, 3.0), 4: (7.0, 3.0), 2: (1.0,), 5: (0.0, 2.0)}      # parse_dash_style, src/smrparse.c:1077-1102
@@ -53,6 +53,12 @@ class Style(C.Structure):
         """copy with curve=1 (curve_factor default: DIV_PART, src/smrender_dev.h:114)"""
         s = Style.from_buffer_copy(bytes(self))
         s.curve, s.curve_fact = 1, factor
+        return s
+
+    def with_evenodd(self, on=1):
+        """copy whose closed ways are filled with CAIRO_FILL_RULE_EVEN_ODD (an extension: the reference keeps libcairo's default)"""
+        s = Style.from_buffer_copy(bytes(self))
+        s.evenodd = int(on)
         return s
 
     def with_knots(self):
@@ -136,6 +142,8 @@ def cairo():
         L.cd_poly_curve.argtypes = [C.c_double, C.c_double, C.c_void_p, C.c_int]
         L.cd_stroke.argtypes = [C.c_uint32, C.c_double]
         L.cd_fill.argtypes = [C.c_uint32]
+        L.cd_set_fill_rule.argtypes = [C.c_int]
+        L.cd_set_direct_fill_rule.argtypes = [C.c_int]
         L.cd_render.argtypes = [C.c_double] + [C.c_int] * 4 + [C.c_void_p]
         L.cd_save_png.argtypes = [C.c_double, C.c_int, C.c_int, C.c_char_p]
         L.cd_write_png_data.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_char_p]
@@ -216,6 +224,7 @@ def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0, image=None):
     c = L.orc_canvas_new(x0, y0, W, H, dpi, bg)
     s1 = Style(st.fill_used, 0, st.fill_col, 0, st.fill_width_mm, st.border_width_mm, st.ignore_open)
     s1.curve, s1.curve_fact = st.curve, st.curve_fact
+    s1.evenodd = st.evenodd
     if image is not None:
         L.orc_canvas_set_image(c, *image)
     L.orc_rule_begin(c)
@@ -255,7 +264,7 @@ def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0, image=None):
     L.orc_rule_begin(c)
     if edges:
         e = np.ascontiguousarray(np.concatenate(edges))
-        L.orc_layer_edges(c, P(e), len(e), 1, st.fill_col)
+        L.orc_layer_edges(c, P(e), len(e), 0 if st.evenodd else 1, st.fill_col)
     L.orc_rule_end(c)
     out = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (H, W)).copy()
     L.orc_canvas_free(c)
@@ -278,6 +287,7 @@ def cairo_directional(st, ways, dpi, W, H, bg):
             L.cd_stroke(st.fill_col, mm2wu(st.fill_width_mm, dpi))
     L.cd_rule_end()
     L.cd_rule_begin()
+    L.cd_set_fill_rule(int(st.evenodd))
     for x, y, closed in ways:
         if closed:
             xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
@@ -345,6 +355,7 @@ def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None, befo
     L.cd_begin(fw, fh, bg)
     for st, ways in rules:
         L.cd_rule_begin()
+        L.cd_set_fill_rule(int(st.evenodd))
         for x, y, closed in ways:
             if len(x) < 2 or (not closed and st.ignore_open):
                 continue

@@ -91,6 +91,7 @@ typedef struct
    double border_dash[4], fill_dash[4];
    int curve;            /* curve=1: the way as a chain of Beziers (cairo_smr_poly_curve, src/smrules_cairo.c:697-749) */
    double curve_fact;    /* curve_factor=, default DIV_PART 0.2 (src/smrender_dev.h:114) */
+   int evenodd;          /* cairo_fill under CAIRO_FILL_RULE_EVEN_ODD (the reference never sets a fill rule: an extension pinned on libcairo) */
 } orc_draw_style_t;
 
 /* render_poly_line (src/smrules_cairo.c:953-1016) for one way given projected px coords */

@@ -428,7 +428,7 @@ static uint32_t cap_color_pixel(uint32_t c)
 {
    double r = (double) ((c >> 16) & 0xff) / 255.0, g = (double) ((c >> 8) & 0xff) / 255.0, b = (double) (c & 0xff) / 255.0;
    double a = 1.0 - (double) (((c & 0x7f000000u) >> 23) & 0xff) / 255.0;
-   auto d2s = [](double d) { uint32_t i = (uint32_t) (d * 65536); i -= (i >> 16); return i; };
+   auto d2s = [](double d) { return (uint32_t) (uint16_t) (d * 65535.0 + 0.5); };      /* _cairo_color_double_to_short of libcairo 1.16 */
    return ((d2s(a) >> 8) << 24) | ((d2s(r * a) >> 8) << 16) | ((d2s(g * a) >> 8) << 8) | (d2s(b * a) >> 8);
 }
 

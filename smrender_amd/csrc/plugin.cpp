@@ -366,6 +366,8 @@ static int draw_ini(smr_smrule_t *r)
    }
    d->st.directional = H.get_param_bool("directional", r->act);
    d->st.ignore_open = H.get_param_bool("ignore_open", r->act);
+   /* not a parameter of the reference's draw (it fills with libcairo's default rule, :1012, :1134-1138): an extension of this back end */
+   d->st.evenodd = H.get_param_bool("evenodd", r->act);
    /* DRAW_TRANSPARENT parses but draws solid (cairo_smr_dash has no case for it) */
    if (d->st.fill_style == 3) d->st.fill_style = 0;
    if (d->st.border_style == 3) d->st.border_style = 0;

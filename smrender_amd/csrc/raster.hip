@@ -1000,7 +1000,7 @@ __global__ void k_color_pixels(const uint32_t *__restrict__ col, int64_t n, uint
    uint32_t c = col[i];
    double r = (double) ((c >> 16) & 0xff) / 255.0, g = (double) ((c >> 8) & 0xff) / 255.0, b = (double) (c & 0xff) / 255.0;
    double a = 1.0 - (double) (((c & 0x7f000000u) >> 23) & 0xff) / 255.0;
-   auto d2s = [](double d) { uint32_t i = (uint32_t) (d * 65536); i -= (i >> 16); return i; };
+   auto d2s = [](double d) { return (uint32_t) (uint16_t) (d * 65535.0 + 0.5); };      /* _cairo_color_double_to_short of libcairo 1.16 */
    pix[i] = ((d2s(a) >> 8) << 24) | ((d2s(r * a) >> 8) << 16) | ((d2s(g * a) >> 8) << 8) | (d2s(b * a) >> 8);
 }
 
@@ -1072,6 +1072,7 @@ struct setup_args_t
    struct smr_bigacc_t *bigacc;                        /* [biglist entry] what those kernels need of them */
    const int2 *way_clip;                               /* [n_ways] rows [x, y) a way's primitives may touch: its window of an atlas (smr_hip_draw_windows); NULL: the chart */
    int32_t lim_l, lim_r; int lim_on;                   /* the replay's clip box, left and right side, 24.8 (smr_setup_cuts) */
+   int evenodd;                                        /* fill polygons take libcairo's EVEN_ODD rule (smr_draw_style_t.evenodd) */
 };
 
 struct setup_lds_t
@@ -1540,7 +1541,9 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    }
    if (!on) { if (lane == 0) A.prims[p] = P; return; }
    const smr_edge_t *E = A.edges + P.edge_off;
-   const uint32_t item_flags = SMR_PF_VALID | (pieces ? SMR_PF_PIECES : 0u) | (nitems > 1 ? SMR_PF_MULTI : 0u);
+   /* (the rule of cairo_fill only: a stroke's polygon, pieces or not, is filled non-zero whatever the context's fill rule) */
+   const uint32_t item_flags = SMR_PF_VALID | (pieces ? SMR_PF_PIECES : 0u) | (nitems > 1 ? SMR_PF_MULTI : 0u) |
+                               (A.evenodd && role == 2 && (wf & 4) ? SMR_PF_EVENODD : 0u);
    if (P.edge_cnt >= SMR_BIG_SLOTS && A.biglist)
    {
       if (lane == 0)
@@ -2011,12 +2014,12 @@ __global__ __launch_bounds__(64) void k_compound_rows(const smr_edge_t *__restri
    if (__ballot(viol) && lane == 0) atomicOr(&mask[r >> 5], 1u << (r & 31));
 }
 
-__global__ void k_compound_init(smr_prim_t *prims, uint32_t compound, uint64_t edge_off, uint32_t edge_cnt, uint32_t color, int H)
+__global__ void k_compound_init(smr_prim_t *prims, uint32_t compound, uint64_t edge_off, uint32_t edge_cnt, uint32_t color, int H, int evenodd)
 {
    smr_prim_t P;
    P.edge_off = edge_off; P.edge_cnt = edge_cnt; P.color = color;
    P.minx = P.miny = INT32_MAX; P.maxx = P.maxy = INT32_MIN;
-   P.flags = SMR_PF_VALID | SMR_PF_MULTI; P.mask_off = 0; P.row0 = 0; P.nrows = H; P.drow_off = 0; P.pad_[0] = P.pad_[1] = P.pad_[2] = 0;
+   P.flags = SMR_PF_VALID | SMR_PF_MULTI | (evenodd ? SMR_PF_EVENODD : 0u); P.mask_off = 0; P.row0 = 0; P.nrows = H; P.drow_off = 0; P.pad_[0] = P.pad_[1] = P.pad_[2] = 0;
    prims[compound] = P;
 }
 
@@ -3699,7 +3702,7 @@ static uint32_t host_color_pixel(uint32_t c)
 {
    double r = (double) ((c >> 16) & 0xff) / 255.0, g = (double) ((c >> 8) & 0xff) / 255.0, b = (double) (c & 0xff) / 255.0;
    double a = 1.0 - (double) (((c & 0x7f000000u) >> 23) & 0xff) / 255.0;
-   auto d2s = [](double d) { uint32_t i = (uint32_t) (d * 65536); i -= (i >> 16); return i; };
+   auto d2s = [](double d) { return (uint32_t) (uint16_t) (d * 65535.0 + 0.5); };      /* _cairo_color_double_to_short of libcairo 1.16 */
    return ((d2s(a) >> 8) << 24) | ((d2s(r * a) >> 8) << 16) | ((d2s(g * a) >> 8) << 8) | (d2s(b * a) >> 8);
 }
 
@@ -4419,7 +4422,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SA.border_pix = host_color_pixel(st->border_col); SA.fill_pix = host_color_pixel(st->fill_col);
       SA.way_border_pix = wb_pix; SA.way_fill_pix = wf_pix; SA.W = c->W; SA.H = c->H; SA.way_clip = wc ? wc->way_clip : nullptr;
       SA.prims = prims; SA.items = items; SA.mask = maskbuf; SA.mask_cap = (uint32_t) std::min<size_t>(mask_cap, 0xffffffffu);
-      SA.small = small; SA.compound = compound;
+      SA.small = small; SA.compound = compound; SA.evenodd = st->evenodd != 0;
       {
          /* the recording surface's rectangle is the page in WHOLE pt (cairo_recording_surface_create floors / ceils the doubles of
           * cairo_smr_init_main_image, src/smrules_cairo.c:308-330); the replay's 24.8 scale takes it to device units.  A window of
@@ -4447,7 +4450,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          SMR_HIP(hipMemsetAsync(maskbuf, 0, (size_t) cwords * 4, s));
          SMR_HIP(hipMemsetAsync(covered, 0, (size_t) cwords * 4, s));
          SMR_HIP(hipMemcpyAsync(&small[4], &cwords, 4, hipMemcpyHostToDevice, s));
-         k_compound_init<<<1, 1, 0, s>>>(prims, compound, off_fill, (uint32_t) n_refs, host_color_pixel(st->fill_col), c->H);
+         k_compound_init<<<1, 1, 0, s>>>(prims, compound, off_fill, (uint32_t) n_refs, host_color_pixel(st->fill_col), c->H, st->evenodd != 0);
       }
       int mask_words = (c->H + 31) / 32 + 1;
       /* at least 8 takes per wavefront before the chunks grow: few primitives (a chart's 50 contour lines) go one by one */

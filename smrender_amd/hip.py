@@ -33,7 +33,13 @@ class DrawStyle(C.Structure):
                 ("ignore_open", C.c_int32), ("fill_style", C.c_int32), ("border_style", C.c_int32),
                 ("curve", C.c_int32), ("directional", C.c_int32), ("direct", C.c_int32),
                 ("border_ndash", C.c_int32), ("fill_ndash", C.c_int32),
-                ("border_dash", C.c_double * 4), ("fill_dash", C.c_double * 4), ("curve_factor", C.c_double)]
+                ("border_dash", C.c_double * 4), ("fill_dash", C.c_double * 4), ("curve_factor", C.c_double),
+                ("evenodd", C.c_int32), ("pad_", C.c_int32)]
+
+    def set_evenodd(self, on=1):
+        """closed ways filled with libcairo's EVEN_ODD rule (not selectable in the reference: see include/smr_hip.h)"""
+        self.evenodd = int(on)
+        return self
 
     def set_dashes(self, border=(), fill=()):
         self.border_ndash, self.fill_ndash = len(border), len(fill)

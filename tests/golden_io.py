@@ -4,7 +4,8 @@ import numpy as np
 from oracle import pyoracle as po
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-SCENES = ["c2_fill_border_300", "open_border_300", "layers_translucent_600", "far_window_300", "dashes_300", "curves_300", "hairpins_300"]
+SCENES = ["c2_fill_border_300", "open_border_300", "layers_translucent_600", "far_window_300", "dashes_300", "curves_300", "hairpins_300",
+          "evenodd_300"]
 
 
 def load_scene(name):
@@ -19,6 +20,8 @@ def load_scene(name):
                 st.border_dash[k], st.fill_dash[k] = float(sf[2 + k]), float(sf[6 + k])
         if len(si) > 9 and int(si[9]):
             st.curve, st.curve_fact = int(si[9]), float(sf[10])
+        if len(si) > 10:
+            st.evenodd = int(si[10])
         rules.append((st, (z[f"x{i}"], z[f"y{i}"], z[f"off{i}"], z[f"ref{i}"])))
     meta = {k: int(z[k]) for k in ("dpi", "W", "H", "bg")}
     meta["x0"], meta["y0"] = int(z["win_x0"]), int(z["win_y0"])
@@ -34,7 +37,8 @@ def load_scene(name):
 # stroker resolves by winding cancellation (turns sharper than ~150 degrees between segments shorter than the
 # line width: the random walks of open_border / layers_translucent are full of them), see DESIGN.md deviations.
 BARS = {"c2_fill_border_300": (1.0, 0.99995), "open_border_300": (0.999, 0.998), "layers_translucent_600": (0.9993, 0.996),
-        "far_window_300": (1.0, 0.999), "dashes_300": (1.0, 0.9999), "curves_300": (0.9995, 0.998), "hairpins_300": (0.9998, 0.9994)}
+        "far_window_300": (1.0, 0.999), "dashes_300": (1.0, 0.9999), "curves_300": (0.9995, 0.998), "hairpins_300": (0.9998, 0.9994),
+        "evenodd_300": (1.0, 0.9999)}
 
 
 def draw_style(sa, st, **kw):
@@ -45,6 +49,7 @@ def draw_style(sa, st, **kw):
         gs.set_knots()
     elif st.curve:
         gs.set_curve(st.curve_fact)
+    gs.set_evenodd(st.evenodd)
     return gs.set_dashes([st.border_dash[i] for i in range(st.border_ndash)], [st.fill_dash[i] for i in range(st.fill_ndash)])
 
 

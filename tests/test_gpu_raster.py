@@ -737,3 +737,78 @@ def test_alpha_word_tiles_composite_alike_in_both_kernels(hip, style, monkeypatc
     for y0, h in ((0, 200), (200, 320)):
         band = gpu_scene(sa, rules, 300, W, H, 0xfff0e0d0, y0, h)
         assert np.array_equal(band, want[y0:y0 + h]), report(band, want[y0:y0 + h])
+
+
+def _star_ways(n_ways, W, H, seed, rmax=50.0, big=0):
+    """closed ways that cross themselves ({n/k} stars, closed random walks); `big` of them with thousands of nodes"""
+    rng = np.random.default_rng(seed)
+    ways = []
+    for i in range(n_ways):
+        cx, cy, r = rng.uniform(0.2 * W, 0.8 * W), rng.uniform(0.2 * H, 0.8 * H), rng.uniform(6, rmax)
+        if i < big:
+            n = 4500 + 200 * i; k = 7
+            t = 2 * np.pi * k * np.arange(n) / n + rng.uniform(0, 6)
+            rr = 0.35 * min(W, H) * (0.6 + 0.4 * np.cos(11 * 2 * np.pi * np.arange(n) / n))
+            cx, cy = W / 2, H / 2
+        elif i % 3 == 2:
+            n = int(rng.integers(5, 12))
+            x, y = cx + rng.uniform(-r, r, n), cy + rng.uniform(-r, r, n)
+            ways.append((np.append(x, x[0]), np.append(y, y[0]), True))
+            continue
+        else:
+            n = int(rng.choice([5, 7, 8, 9, 11])); k = 2 if n < 8 else 4 if n == 9 else 3
+            t = rng.uniform(0, 6) + 2 * np.pi * k * np.arange(n) / n * rng.choice([-1, 1])
+            rr = r * rng.uniform(0.8, 1.0, n)
+        x, y = cx + rr * np.cos(t), cy + rr * np.sin(t)
+        ways.append((np.append(x, x[0]), np.append(y, y[0]), True))
+    return ways
+
+
+@pytest.mark.parametrize("col,bcol", [(0x4080c0, 0x000000), (0x40c04020, 0x30102030), (0xc04020, None)])
+def test_even_odd_fill_rule_bit_exact(hip, col, bcol, monkeypatch):
+    """smr_draw_style_t.evenodd (libcairo's CAIRO_FILL_RULE_EVEN_ODD; the reference keeps the default rule, see the header):
+    self-crossing ways through k_cover + k_blend, through k_raster alone (SMR_HIP_COVER=0), in bands, and against the same
+    ways under the winding rule (the pictures must differ)"""
+    sa = hip
+    W, H = 520, 400
+    ways = _star_ways(120, W, H, seed=11)
+    arrs = _ways_to_arrays(ways)
+    st = po.Style(1, 1 if bcol is not None else 0, col, bcol or 0, 0, 0.12, 0).with_evenodd()
+    want = oracle_of([(st, arrs)], 300, W, H, 0xffffff)
+    got = gpu_scene(sa, [(st, arrs)], 300, W, H, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
+    st_w = po.Style(1, 1 if bcol is not None else 0, col, bcol or 0, 0, 0.12, 0)
+    assert (gpu_scene(sa, [(st_w, arrs)], 300, W, H, 0xffffff) != got).sum() > 2000
+    monkeypatch.setenv("SMR_HIP_COVER", "0")
+    other = gpu_scene(sa, [(st, arrs)], 300, W, H, 0xffffff)
+    monkeypatch.delenv("SMR_HIP_COVER")
+    assert np.array_equal(other, got), report(other, got)
+    for y0, h in ((0, 140), (140, 260)):
+        band = gpu_scene(sa, [(st, arrs)], 300, W, H, 0xffffff, y0, h)
+        assert np.array_equal(band, want[y0:y0 + h]), report(band, want[y0:y0 + h])
+
+
+def test_even_odd_long_primitives_and_compound(hip):
+    """the rule reaches the long-primitive path (a self-crossing way of ~5 000 nodes: k_big_* + k_raster's own scan conversion)
+    and the ONE polygon of a directional rule (all closed ways together, even-odd: overlapping ways cancel)"""
+    sa = hip
+    W, H = 640, 480
+    ways = _star_ways(3, W, H, seed=3, big=2)
+    arrs = _ways_to_arrays(ways)
+    st = po.Style(1, 0, 0x4080c0, 0, 0, 0, 0).with_evenodd()
+    want = oracle_of([(st, arrs)], 300, W, H, 0xffffff)
+    got = gpu_scene(sa, [(st, arrs)], 300, W, H, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
+    ways = _star_ways(60, W, H, seed=4, rmax=90.0)
+    st = po.Style(1, 0, 0x30c0d8f0, 0, 0.3, 0, 0).with_evenodd()
+    want = po.oracle_directional(st, ways, 300, W, H, 0xffffff)
+    x, y, off, ref = _ways_to_arrays(ways)
+    cv = sa.Canvas(W, H, 300, 0xffffff)
+    gs = draw_style(sa, st, directional=1)
+    cv.draw(gs, sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off),
+            sa.DeviceArray.from_numpy(ref), len(off) - 1, len(ref))
+    got = cv.read()
+    cv.close()
+    assert np.array_equal(got, want), report(got, want)
+    st_w = po.Style(1, 0, 0x30c0d8f0, 0, 0.3, 0, 0)
+    assert (po.oracle_directional(st_w, ways, 300, W, H, 0xffffff) != want).sum() > 2000

@@ -21,6 +21,29 @@ def test_tor_scan_converter_bit_exact():
     assert n_edge_px > 3000
 
 
+def test_tor_scan_converter_even_odd_bit_exact():
+    """CAIRO_FILL_RULE_EVEN_ODD (cairo_set_fill_rule): random self-crossing polygons, libcairo's own coverage.  The reference never
+    selects this rule; it pins the rasterizer's second rule (north_star) on libcairo itself."""
+    z = np.load(os.path.join(GOLDEN, "tor_kat_evenodd.npz"))
+    n_diff_rule = 0
+    for i in range(int(z["n"])):
+        xy, want = z[f"xy{i}"], z[f"a{i}"]
+        p = np.array([[po.orc().orc_fixed_from_double(float(v)) for v in row] for row in xy], np.int32)
+        e = np.concatenate([p, np.roll(p, -1, 0)], 1)
+        got = po.tor_coverage(e, want.shape[1], want.shape[0], nonzero=0)
+        assert np.array_equal(got, want), f"polygon {i}"
+        n_diff_rule += int((po.tor_coverage(e, want.shape[1], want.shape[0], nonzero=1) != want).sum())
+    assert n_diff_rule > 500           # the polygons do tell the two rules apart
+
+
+def test_colour_to_premultiplied_pixel_as_libcairo():
+    """0xTTRRGGBB -> cairo_set_source_rgba -> the 8-bit premultiplied source pixel: libcairo 1.16 rounds d * 65535 to nearest
+    (_cairo_color_double_to_short); an older form of that function gives another channel value for ~0.8 % of translucent colours"""
+    z = np.load(os.path.join(GOLDEN, "color_pixels.npz"))
+    for col, want in zip(z["col"].tolist(), z["rgb_over_black"].tolist()):
+        assert (po.orc().orc_color_pixel(col) & 0xffffff) == want, hex(col)
+
+
 def test_rotated_bilinear_over_bit_exact():
     z = np.load(os.path.join(GOLDEN, "rot_paint.npz"))
     for t in range(int(z["n"])):
