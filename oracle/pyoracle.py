@@ -61,6 +61,12 @@ class Style(C.Structure):
         s.evenodd = int(on)
         return s
 
+    @classmethod
+    def from_saved(cls, raw):
+        """a Style from the bytes a fixture holds (tests/golden/soak_scene*.npz): fields added since then are zero"""
+        raw = bytes(raw)
+        return cls.from_buffer_copy(raw + b"\0" * max(0, C.sizeof(cls) - len(raw)))
+
     def with_knots(self):
         """copy with curve=2: a way's points are p0 and (c1, c2, p) triples, the path cairo_smr_wavy records (:752-840)"""
         s = Style.from_buffer_copy(bytes(self))

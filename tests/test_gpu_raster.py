@@ -293,7 +293,7 @@ def test_soak_scene_with_a_wide_curved_stroke(hip):
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene4.npz"))
     x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
     W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
-    st = po.Style.from_buffer_copy(bytes(d["style"]))
+    st = po.Style.from_saved(d["style"])
     want = oracle_of([(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
     got = gpu_scene(sa, [(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
     assert np.array_equal(got, want), report(got, want)
@@ -310,7 +310,7 @@ def test_soak_scene_whose_tiles_overflow_runs_again_with_reported_rows(hip):
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene1_37.npz"))
     x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
     W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
-    st = po.Style.from_buffer_copy(bytes(d["style"]))
+    st = po.Style.from_saved(d["style"])
     want = oracle_of([(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
     got = gpu_scene(sa, [(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
     if os.environ.get("SMR_HIP_STROKE") != "polygon":       # (as a polygon the stroke has a fraction of the pieces' spanning edges: nothing to report)
@@ -331,7 +331,7 @@ def test_soak_scene_with_one_pixel_dots(hip):
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene21_2.npz"))
     x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
     W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
-    st = po.Style.from_buffer_copy(bytes(d["style"]))
+    st = po.Style.from_saved(d["style"])
     r1 = np.ascontiguousarray(ref[off[17]:off[18]]); o1 = np.array([0, len(r1)], np.int64)
     for arrs in ((x, y, o1, r1), (x, y, off, ref)):
         want = oracle_of([(st, arrs)], dpi, W, H, 0xffffff)
@@ -422,7 +422,7 @@ def test_soak_scene_directional_rule_with_a_way_beside_the_chart(hip):
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene70_37_directional.npz"))
     x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
     W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
-    st = po.Style.from_buffer_copy(bytes(d["style"]))
+    st = po.Style.from_saved(d["style"])
     ways = po.ways_from_arrays(x, y, off, ref)
     want = po.oracle_directional(st, ways, dpi, W, H, 0xffffff)
     cv = sa.Canvas(W, H, dpi, 0xffffff)
@@ -440,7 +440,7 @@ def test_soak_scene_with_a_span_that_ends_right_of_the_tile(hip):
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", "soak_scene38_49.npz"))
     x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
     W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
-    st = po.Style.from_buffer_copy(bytes(d["style"]))
+    st = po.Style.from_saved(d["style"])
     want = oracle_of([(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
     got = gpu_scene(hip, [(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
     assert np.array_equal(got, want), report(got, want)
@@ -456,7 +456,7 @@ def test_soak_scenes_with_segments_that_run_straight_back(hip, scene):
     d = np.load(os.path.join(os.path.dirname(__file__), "golden", scene + ".npz"))
     x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
     W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
-    st = po.Style.from_buffer_copy(bytes(d["style"]))
+    st = po.Style.from_saved(d["style"])
     want = oracle_of([(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
     got = gpu_scene(hip, [(st, (x, y, off, ref))], dpi, W, H, 0xffffff)
     assert np.array_equal(got, want), report(got, want)

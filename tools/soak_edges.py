@@ -11,7 +11,7 @@ sa.init(0)
 d = np.load(sys.argv[1]); w = int(sys.argv[2]); tag = sys.argv[3]
 x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
 W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
-st = po.Style.from_buffer_copy(bytes(d["style"]))
+st = po.Style.from_saved(d["style"])
 r1 = np.ascontiguousarray(ref[off[w]:off[w + 1]]); o1 = np.array([0, len(r1)], np.int64)
 cv = sa.Canvas(W, H, dpi, 0xffffff)
 cv.draw(draw_style(sa, st), *(sa.DeviceArray.from_numpy(a) for a in (x, y, o1, r1)), 1, len(r1))

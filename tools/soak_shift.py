@@ -10,7 +10,7 @@ sa.init(0)
 d = np.load(sys.argv[1]); w = int(sys.argv[2])
 x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
 W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
-st = po.Style.from_buffer_copy(bytes(d["style"]))
+st = po.Style.from_saved(d["style"])
 r1 = np.ascontiguousarray(ref[off[w]:off[w + 1]]); o1 = np.array([0, len(r1)], np.int64)
 for tag, dy, HH in (("as is", 0, H), ("taller", 0, H + 30), ("up 10", -10, H), ("up 1", -1, H), ("down 3 taller", 3, H + 30), ("H+1", 0, H + 1), ("H+2", 0, H + 2)):
     yy = y + dy

@@ -11,7 +11,7 @@ sa.init(0)
 d = np.load(sys.argv[1]); w = int(sys.argv[2])
 x, y, off, ref = d["x"], d["y"], d["off"], d["ref"]
 W, H, dpi = int(d["W"]), int(d["H"]), int(d["dpi"])
-st0 = po.Style.from_buffer_copy(bytes(d["style"]))
+st0 = po.Style.from_saved(d["style"])
 r_all = np.ascontiguousarray(ref[off[w]:off[w + 1]])
 
 
