@@ -123,25 +123,87 @@ extern "C" int smr_hip_set_projection(const smr_proj_t *p)
    return SMR_OK;
 }
 
-/* HBM-bound stream: 16 B in, 16 B out (+ optional 9 B) per node, two nodes per lane so
- * that every load/store is a 16-byte access */
+/* asinh(tan(phi)), the Mercator ordinate of src/rdata.c:223, without the C library's tan and asinh (some 400 fp64 instructions
+ * per node, which made the kernel ALU-bound at 3 TB/s): with h = phi / 2,
+ *    asinh(tan phi) = ln tan(pi/4 + h) = ln((cos h + sin h) / (cos h - sin h)),
+ * sin h and cos h on |h| <= pi/4 need no range reduction (fdlibm's kernel polynomials, < 1 ulp there), and the logarithm's own
+ * reduction ln(S / C) = e ln 2 + 2 atanh(t), t = (S - C 2^e) / (S + C 2^e) with |t| <= 0.172, takes the ONE division of the whole
+ * evaluation (fdlibm's log: 2 atanh(t) = 2 t + t R(t^2), seven coefficients).  Accurate to a few ulp of the result for
+ * |lat| < 89.9 degrees (the difference cos h - sin h cancels towards the poles, where the projection itself is singular and
+ * the reference's own libm is no better); beyond that the C library's functions are called as before. */
+__device__ __forceinline__ double smr_rcp_div(double a, double b, double rb)
+{
+   /* a / b, correctly rounded, from rb = RN(1 / b) computed once (Markstein): one multiply and two FMAs instead of the ~30
+    * instructions of the IEEE division sequence */
+   const double q = a * rb;
+   return fma(fma(-q, b, a), rb, q);
+}
+
+__device__ __attribute__((noinline)) double smr_mercator_libm(double lat_deg) { return asinh(tan(lat_deg * M_PI / 180.0)); }
+
+__device__ __forceinline__ double smr_mercator(double lat_deg)
+{
+   if (!(fabs(lat_deg) < 89.9)) return smr_mercator_libm(lat_deg);
+   const double h = lat_deg * (M_PI / 360.0), z = h * h;
+   /* (explicit FMAs: the file is built with -ffp-contract=off, and Horner steps as separate multiplies and adds are twice the work) */
+   double sp = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+   sp = fma(z, sp, 2.75573137070700676789e-06); sp = fma(z, sp, -1.98412698298579493134e-04);
+   sp = fma(z, sp, 8.33333333332248946124e-03); sp = fma(z, sp, -1.66666666666666324348e-01);
+   const double sh = fma(h * z, sp, h);
+   double cp = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+   cp = fma(z, cp, -2.75573143513906633035e-07); cp = fma(z, cp, 2.48015872894767294178e-05);
+   cp = fma(z, cp, -1.38888888888741095749e-03); cp = fma(z, cp, 4.16666666666666019037e-02);
+   cp *= z;
+   const double hz = 0.5 * z, w = 1.0 - hz;
+   const double ch = w + fma(z, cp, (1.0 - w) - hz);
+   const double S = ch + sh;
+   double C = ch - sh;
+   int e = __builtin_amdgcn_frexp_exp(S) - __builtin_amdgcn_frexp_exp(C);
+   C = ldexp(C, e);                                   /* S / C in (1/2, 2) */
+   if (S > C * M_SQRT2) { e++; C *= 2.0; }
+   else if (S * M_SQRT2 < C) { e--; C *= 0.5; }
+   /* (near the equator e == 0, and S - C = 2 sin h would cancel to 1e-16 absolute: taken from sin h and cos h themselves) */
+   const double num = e == 0 ? 2.0 * sh : S - C;
+   const double den = e == 0 ? 2.0 * ch : S + C, rd = __builtin_amdgcn_rcp(den);
+   double r = fma(fma(-den, rd, 1.0), rd, rd);
+   r = fma(fma(-den, r, 1.0), r, r);
+   const double t = smr_rcp_div(num, den, r), t2 = t * t;
+   double R = fma(t2, 1.479819860511658591e-01, 1.531383769920937332e-01);
+   R = fma(t2, R, 1.818357216161805012e-01); R = fma(t2, R, 2.222219843214978396e-01); R = fma(t2, R, 2.857142874366239149e-01);
+   R = fma(t2, R, 3.999999999940941908e-01); R = fma(t2, R, 6.666666666666735130e-01);
+   R *= t2;
+   const double de = (double) e;
+   return fma(de, 6.93147180369123816490e-01, fma(t, R, fma(de, 1.90821492927058770002e-10, 2.0 * t)));
+}
+
+/* HBM-bound stream: 16 B in, 16 B out (+ optional 9 B) per node, two nodes per lane so that every load/store is a 16-byte
+ * access.  x = (lon - lon0) * w / wc and the division by lath_len keep the reference's operations (src/rdata.c:221-225) and their
+ * IEEE results, through reciprocals computed once on the host */
+struct proj_rcp_t { double r_wc, r_len; };
+
 __global__ __launch_bounds__(256) void k_project(const double *__restrict__ lat, const double *__restrict__ lon, int64_t n,
-                                                 smr_proj_t P, double *__restrict__ x, double *__restrict__ y,
+                                                 smr_proj_t P, proj_rcp_t Q, double *__restrict__ x, double *__restrict__ y,
                                                  int32_t *__restrict__ ix, int32_t *__restrict__ iy, uint8_t *__restrict__ on)
 {
    const int64_t npair = n >> 1;
    int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    const int64_t stride = (int64_t) gridDim.x * blockDim.x;
+   auto px = [&](double lo) { return smr_rcp_div((lo - P.lon0) * P.w, P.wc, Q.r_wc); };
+   auto py = [&](double la) { return P.h * (0.5 - smr_rcp_div(smr_mercator(la) - P.lath, P.lath_len, Q.r_len)); };
    for (; i < npair; i += stride)
    {
-      double2 la = reinterpret_cast<const double2 *>(lat)[i], lo = reinterpret_cast<const double2 *>(lon)[i];
-      double2 xo, yo;
-      xo.x = (lo.x - P.lon0) * P.w / P.wc;
-      xo.y = (lo.y - P.lon0) * P.w / P.wc;
-      yo.x = P.h * (0.5 - (asinh(tan(la.x * M_PI / 180.0)) - P.lath) / P.lath_len);
-      yo.y = P.h * (0.5 - (asinh(tan(la.y * M_PI / 180.0)) - P.lath) / P.lath_len);
-      reinterpret_cast<double2 *>(x)[i] = xo;
-      reinterpret_cast<double2 *>(y)[i] = yo;
+      /* streamed once: non-temporal, so that 1 GB of coordinates does not push the canvas and the edge arena out of the L2s */
+      typedef double smr_d2 __attribute__((ext_vector_type(2)));
+      const smr_d2 la_ = __builtin_nontemporal_load(reinterpret_cast<const smr_d2 *>(lat) + i);
+      const smr_d2 lo_ = __builtin_nontemporal_load(reinterpret_cast<const smr_d2 *>(lon) + i);
+      double2 la, lo, xo, yo;
+      la.x = la_.x; la.y = la_.y; lo.x = lo_.x; lo.y = lo_.y;
+      xo.x = px(lo.x); xo.y = px(lo.y);
+      yo.x = py(la.x); yo.y = py(la.y);
+      smr_d2 xo_, yo_;
+      xo_.x = xo.x; xo_.y = xo.y; yo_.x = yo.x; yo_.y = yo.y;
+      __builtin_nontemporal_store(xo_, reinterpret_cast<smr_d2 *>(x) + i);
+      __builtin_nontemporal_store(yo_, reinterpret_cast<smr_d2 *>(y) + i);
       if (ix) reinterpret_cast<int2 *>(ix)[i] = make_int2((int) round(xo.x), (int) round(xo.y));
       if (iy) reinterpret_cast<int2 *>(iy)[i] = make_int2((int) round(yo.x), (int) round(yo.y));
       if (on)
@@ -156,8 +218,8 @@ __global__ __launch_bounds__(256) void k_project(const double *__restrict__ lat,
    {
       int64_t k = n - 1;
       double la = lat[k], lo = lon[k];
-      double xo = (lo - P.lon0) * P.w / P.wc;
-      double yo = P.h * (0.5 - (asinh(tan(la * M_PI / 180.0)) - P.lath) / P.lath_len);
+      double xo = px(lo);
+      double yo = py(la);
       x[k] = xo; y[k] = yo;
       if (ix) ix[k] = (int) round(xo);
       if (iy) iy[k] = (int) round(yo);
@@ -197,7 +259,9 @@ extern "C" int smr_hip_project(const double *d_lat, const double *d_lon, int64_t
       return smr_fail(SMR_E_INVAL, "project: arrays must be 16-byte aligned (ix/iy 8, onpage 2)");
    smr_timer_t T(smr_g.profiling);
    T.mark(smr_g.stream);
-   k_project<<<stream_grid((n + 1) / 2, 256), 256, 0, smr_g.stream>>>(d_lat, d_lon, n, smr_g.proj, d_x, d_y, d_ix, d_iy, d_onpage);
+   proj_rcp_t Q;
+   Q.r_wc = 1.0 / smr_g.proj.wc; Q.r_len = 1.0 / smr_g.proj.lath_len;
+   k_project<<<stream_grid((n + 1) / 2, 256), 256, 0, smr_g.stream>>>(d_lat, d_lon, n, smr_g.proj, Q, d_x, d_y, d_ix, d_iy, d_onpage);
    SMR_HIP(hipGetLastError());
    T.mark(smr_g.stream);
    if (smr_g.profiling) smr_g.last.proj_ms = T.ms(0, 1);

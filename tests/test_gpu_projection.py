@@ -137,3 +137,28 @@ def test_poly_area_matches_the_hosts(hip):
         assert abs(area[w] - har) <= 1e-9 and abs(clat[w] - hlat) <= 4e-9 / abs(har) and abs(clon[w] - hlon) <= 4e-9 / abs(har), w
         seen_cw += har < 0; seen_ccw += har > 0
     assert seen_cw > 5 and seen_ccw > 5
+
+
+def test_project_keeps_the_references_ieee_results_where_it_can(hip):
+    """x = (lon - lon0) * w / wc is a multiply and a division in the reference (src/rdata.c:222): the kernel's reciprocal form
+    gives the same IEEE doubles.  y goes through the kernel's own evaluation of asinh(tan(lat)) (one division, no libm call):
+    a few ulp of the ordinate at every latitude, the equator (where a difference of sums would cancel), latitudes beyond
+    89.9 degrees (the C library's path, as the reference computes them) and the seam between the two included."""
+    sa = hip
+    p, op = _setup(sa, 10.0, -30.0, 3.0e7, 20000.0, 30000.0, 300)
+    rng = np.random.default_rng(11)
+    lat = np.concatenate([rng.uniform(-89.99, 89.99, 300001), [0.0, 1e-12, -1e-12, 1e-7, 89.9, -89.9, 89.899999, 89.95, -89.95, 45.0, -45.0],
+                          rng.uniform(-1e-6, 1e-6, 1000)])
+    lon = rng.uniform(-180, 180, lat.size)
+    d_lat, d_lon = sa.DeviceArray.from_numpy(lat), sa.DeviceArray.from_numpy(lon)
+    d_x, d_y = sa.DeviceArray(lat.shape, np.float64), sa.DeviceArray(lat.shape, np.float64)
+    sa.project(d_lat, d_lon, d_x, d_y)
+    x, y, _, _, _ = po.project(op, lat, lon)
+    gx, gy = d_x.numpy(), d_y.numpy()
+    assert np.array_equal(gx, x)
+    # the ordinate m = asinh(tan(lat)): y = h * (0.5 - (m - lath) / lath_len), so an error of e in m is h * e / lath_len px
+    m_err = np.abs(gy - y) * op.lath_len / op.h
+    m = np.arcsinh(np.tan(np.radians(lat)))
+    assert np.max(m_err / np.maximum(np.abs(m), 1.0)) < 4e-15          # towards the poles both evaluations lose digits
+    mid = np.abs(lat) < 80
+    assert np.max(m_err[mid]) < 1.5e-15
