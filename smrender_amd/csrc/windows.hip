@@ -29,19 +29,28 @@ struct win_box_t { double x0, y0, x1, y1; };
 
 /* one thread per way: its box in chart pixels */
 __global__ void k_win_bbox(const double *__restrict__ x, const double *__restrict__ y, const int64_t *__restrict__ way_off,
-                           const int32_t *__restrict__ ref, int64_t n_ways, int64_t n_nodes, win_box_t *__restrict__ wb)
+                           const int32_t *__restrict__ ref, int64_t n_ways, int64_t n_nodes, double curve_f, win_box_t *__restrict__ wb)
 {
    const int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    if (w >= n_ways) return;
    win_box_t b = { 1e300, 1e300, -1e300, -1e300 };
    const int64_t a = way_off[w], e = way_off[w + 1];
+   double lmax = 0, px = 0, py = 0;
+   bool have = false;
    if (e - a >= 2)
       for (int64_t g = a; g < e; g++)
       {
          int64_t node = ref ? (int64_t) ref[g] : g;
          if (node < 0 || node >= n_nodes) continue;          /* reported by the draw pass itself */
-         b.x0 = fmin(b.x0, x[node]); b.x1 = fmax(b.x1, x[node]); b.y0 = fmin(b.y0, y[node]); b.y1 = fmax(b.y1, y[node]);
+         const double vx = x[node], vy = y[node];
+         b.x0 = fmin(b.x0, vx); b.x1 = fmax(b.x1, vx); b.y0 = fmin(b.y0, vy); b.y1 = fmax(b.y1, vy);
+         if (have) lmax = fmax(lmax, hypot(vx - px, vy - py));
+         px = vx; py = vy; have = true;
       }
+   /* curve=1: a Bezier's control points lie curve_factor times the length of their segment beyond its ends (control_points,
+    * src/bspline_ctrl.c:64-105: lgt * f along the tangent), and the curve inside the hull of its four knots: the way's box grows
+    * by the longest segment's share (a long segment's curve can pass a window that its nodes' box misses) */
+   if (curve_f > 0 && b.x0 <= b.x1) { const double m = curve_f * lmax + 0.25; b.x0 -= m; b.y0 -= m; b.x1 += m; b.y1 += m; }
    wb[w] = b;
 }
 
@@ -253,7 +262,8 @@ static int draw_windows_range(smr_canvas_t *c, const smr_draw_style_t *st, const
    const int64_t n_ways = b->n_ways;
    const int n_win = k1 - k0;
    /* the windows grown by the rule's reach */
-   const double reach = style_reach_px(st, c->dpi) * (st->curve ? 4.0 : 1.0);
+   const double reach = style_reach_px(st, c->dpi);
+   const double curve_f = st->curve == 1 ? (st->curve_factor > 0 ? st->curve_factor : 0.2) : 0.0;      /* (curve=2: the knots are nodes themselves) */
    win_box_t *wb, *win;
    SMR_TRY(c->ensure(SMR_BUF_WIN_WB, (size_t) n_ways * sizeof(win_box_t), (void **) &wb));
    SMR_TRY(c->ensure(SMR_BUF_WIN_BOX, (size_t) c->win_n * sizeof(win_box_t), (void **) &win));
@@ -265,7 +275,7 @@ static int draw_windows_range(smr_canvas_t *c, const smr_draw_style_t *st, const
       SMR_HIP(hipMemcpyAsync(win, h.data(), (size_t) c->win_n * sizeof(win_box_t), hipMemcpyHostToDevice, s));
       SMR_HIP(hipStreamSynchronize(s));          /* h goes out of scope */
    }
-   k_win_bbox<<<(unsigned) ((n_ways + 255) / 256), 256, 0, s>>>(b->d_x, b->d_y, b->d_way_off, b->d_ref, n_ways, b->n_nodes, wb);
+   k_win_bbox<<<(unsigned) ((n_ways + 255) / 256), 256, 0, s>>>(b->d_x, b->d_y, b->d_way_off, b->d_ref, n_ways, b->n_nodes, curve_f, wb);
    const unsigned nblk = (unsigned) ((n_ways + SMR_WIN_WAYS_PER_BLOCK - 1) / SMR_WIN_WAYS_PER_BLOCK);
    const uint64_t nslots = (uint64_t) nblk * n_win;
    if (nslots > 0x3fffffffull) return smr_fail(SMR_E_CAPACITY, "draw_windows: %lld ways x %d windows", (long long) n_ways, n_win);

@@ -181,3 +181,40 @@ def test_windows_at_whole_pixel_offsets_are_crops_of_the_chart(hip):
         assert d.max() <= 6, (k, int(d.max()))
         same += int((d == 0).sum()); tot += d.size
     assert same / tot >= 0.995, same / tot
+
+
+def test_a_long_curved_segment_reaches_a_window_its_nodes_box_misses(hip):
+    """curve=1: a Bezier bulges out of its way's node box by up to curve_factor times the segment's length (control_points,
+    src/bspline_ctrl.c:64-105).  A closed way of four nodes 700 px apart with curve_factor 0.5 bulges some 180 px beyond its box: a
+    window put on the bulge, outside the box by more than the stroke's reach, must still hold the curve (the window's pairs
+    are found from the box grown by that share), like the oracle's shifted render of the same way."""
+    sa = hip
+    from golden_io import draw_style
+    L = po.orc()
+    L.orc_canvas_set_shift.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    Wc, Hc = 1200, 1000
+    wx = np.array([250.0, 950.0, 950.0, 250.0, 250.0]); wy = np.array([200.0, 200.0, 800.0, 800.0, 200.0])
+    sty = po.Style(1, 1, 0x4080c0, 0x000000, 0, 0.2, 0).with_curve(0.5)
+    X, Y = wx[:4].copy(), wy[:4].copy()
+    OFF, REF = np.array([0, 5], np.int64), np.array([0, 1, 2, 3, 0], np.int32)
+    r = 61
+    # (measured on the oracle: the shape reaches y = 12 .. 988 at x = 600 and x = 88 .. 1111 at y = 500, i.e. 160-190 px beyond the box)
+    cx, cy = np.array([600.3, 1111.2, 600.7]), np.array([12.4, 500.6, 988.3])      # on the bulge above, right of and below the box
+    D = sa.DeviceArray.from_numpy
+    at = sa.Canvas.windows(Wc, Hc, DPI, 0xfff8e0, cx, cy, r)
+    at.draw_windows(draw_style(sa, sty), D(X), D(Y), D(OFF), D(REF), 1, 5)
+    img = at.read()
+    at.close()
+    r_pt = r * 72 / DPI
+    for k in range(3):
+        c = L.orc_canvas_new(0, 0, r, r, DPI, 0xfff8e0)
+        L.orc_canvas_set_shift(c, -cx[k] * 72 / DPI + r_pt / 2, -cy[k] * 72 / DPI + r_pt / 2)
+        L.orc_rule_begin(c)
+        L.orc_draw_way(c, C.byref(sty), po.P(wx), po.P(wy), 5, 1, 0, 0, 0, 0)
+        L.orc_rule_end(c)
+        want = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (r, r)).copy()
+        L.orc_canvas_free(c)
+        got = img[k * at.window_pitch:k * at.window_pitch + r]
+        assert len(np.unique(want)) > 3, k                    # the bulge does cross the window
+        d = po.chan_diff(got, want); d = d.max(axis=-1) if d.ndim == 3 else d
+        assert (d > 0).sum() <= 4 and d.max() <= 1, (k, int((d > 0).sum()), int(d.max()))
