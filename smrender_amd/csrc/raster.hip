@@ -3309,6 +3309,65 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
          SMR_WAVE_SYNC();
       }
 
+      /* ---- cells -> alpha (k_raster's flush: prefix sum of cover, area, libcairo's extents), the four rows of a column in
+       * one word; lane = column, two sweeps for a primitive wider than 64 cells; then the strip's words and its table entry.
+       * cells = the strip's first row, rstride ints from row to row, ncell of them per row ---- */
+      auto emit_strip = [&](const int crow, int *const cells, const int rstride, const int ncell, const uint32_t rows)
+      {
+         uint32_t a4lo = 0u, a4hi = 0u;
+#pragma unroll
+         for (int r = 0; r < SMR_TH; r++)
+         {
+            if (!((rows >> r) & 1u)) continue;
+            int *const crowp = cells + r * rstride;
+            int carry = 0;
+            auto sweep = [&](const int i, uint32_t &a4)
+            {
+               const int v = i < ncell ? crowp[i] : 0;
+               if (!__ballot(v != 0) && carry == 0) return;
+               if (v) crowp[i] = 0;
+               int c = smr_delta_cover(v);
+               const int ua = smr_delta_area(v);
+               c = (__ballot(c != 0) ? smr_wave_scan(c) : 0) + carry;
+               carry = __builtin_amdgcn_readlane(c, 63);
+               const int area = c * 512 - ua;
+               int a = (area + (area << 4) + 256) >> 9;
+               a = a < 0 ? 0 : a > 255 ? 255 : a;
+               if (i < 1 || i > wp - 2) a = 0;           /* libcairo composites inside the primitive's pixel extents only */
+               a4 |= (uint32_t) a << (8 * r);
+            };
+            sweep(lane, a4lo);
+            if (wp > 64) sweep(lane + 64, a4hi);
+         }
+         {
+            const unsigned long long m0 = __ballot(a4lo != 0), m1 = __ballot(a4hi != 0);
+            uint2 entry = make_uint2(0u, 0u);
+            if ((m0 | m1) && !bad)
+            {
+               const int xlo = m0 ? __ffsll((long long) m0) - 1 : 63 + __ffsll((long long) m1);
+               const int xhi = m1 ? 127 - __clzll((long long) m1) : 63 - __clzll((long long) m0);
+               const uint32_t n = (uint32_t) (xhi - xlo + 1);
+               uint32_t abase = 0;
+               if (n > dleft)
+               {
+                  uint32_t b = 0;
+                  if (lane == 0) b = atomicAdd(&A.ctr[1], SMR_CV_DBLOCK);
+                  b = __builtin_amdgcn_readfirstlane(b);
+                  if ((uint64_t) b + SMR_CV_DBLOCK > A.alpha_cap) bad = true;
+                  else { dpos = b; dleft = SMR_CV_DBLOCK; }
+               }
+               if (!bad)
+               {
+                  abase = dpos; dpos += n; dleft -= n;
+                  if (lane >= xlo && lane <= xhi) A.alpha[abase + (uint32_t) (lane - xlo)] = a4lo;
+                  if (lane + 64 >= xlo && lane + 64 <= xhi) A.alpha[abase + (uint32_t) (lane + 64 - xlo)] = a4hi;
+                  entry = make_uint2(abase, smr_strip_pack(cx0 + xlo, (int) n));
+               }
+            }
+            if (!bad && lane == 0) A.drows[rbase + (uint32_t) ((crow - cr_first) >> 2)] = entry;
+         }
+      };
+
       CVTICK(0);
       for (int crow = cr_first; crow < dr1 && !bad; crow += SMR_TH)
       {
@@ -3619,59 +3678,7 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
          SMR_WAVE_SYNC();
 
          CVTICK(5);
-         /* ---- cells -> alpha (k_raster's flush: prefix sum of cover, area, libcairo's extents), the four rows of a column in
-          * one word; lane = column, two sweeps for a primitive wider than 64 cells ---- */
-         uint32_t a4lo = 0u, a4hi = 0u;
-#pragma unroll
-         for (int r = 0; r < SMR_TH; r++)
-         {
-            if (!(((partial | full_bits) >> r) & 1u)) continue;
-            int carry = 0;
-            auto sweep = [&](const int i, uint32_t &a4)
-            {
-               const int v = L.cell[r][i];
-               if (!__ballot(v != 0) && carry == 0) return;
-               if (v) L.cell[r][i] = 0;
-               int c = smr_delta_cover(v);
-               const int ua = smr_delta_area(v);
-               c = (__ballot(c != 0) ? smr_wave_scan(c) : 0) + carry;
-               carry = __builtin_amdgcn_readlane(c, 63);
-               const int area = c * 512 - ua;
-               int a = (area + (area << 4) + 256) >> 9;
-               a = a < 0 ? 0 : a > 255 ? 255 : a;
-               if (i < 1 || i > wp - 2) a = 0;           /* libcairo composites inside the primitive's pixel extents only */
-               a4 |= (uint32_t) a << (8 * r);
-            };
-            sweep(lane, a4lo);
-            if (wp > 64) sweep(lane + 64, a4hi);
-         }
-         {
-            const unsigned long long m0 = __ballot(a4lo != 0), m1 = __ballot(a4hi != 0);
-            uint2 entry = make_uint2(0u, 0u);
-            if ((m0 | m1) && !bad)
-            {
-               const int xlo = m0 ? __ffsll((long long) m0) - 1 : 63 + __ffsll((long long) m1);
-               const int xhi = m1 ? 127 - __clzll((long long) m1) : 63 - __clzll((long long) m0);
-               const uint32_t n = (uint32_t) (xhi - xlo + 1);
-               uint32_t abase = 0;
-               if (n > dleft)
-               {
-                  uint32_t b = 0;
-                  if (lane == 0) b = atomicAdd(&A.ctr[1], SMR_CV_DBLOCK);
-                  b = __builtin_amdgcn_readfirstlane(b);
-                  if ((uint64_t) b + SMR_CV_DBLOCK > A.alpha_cap) bad = true;
-                  else { dpos = b; dleft = SMR_CV_DBLOCK; }
-               }
-               if (!bad)
-               {
-                  abase = dpos; dpos += n; dleft -= n;
-                  if (lane >= xlo && lane <= xhi) A.alpha[abase + (uint32_t) (lane - xlo)] = a4lo;
-                  if (lane + 64 >= xlo && lane + 64 <= xhi) A.alpha[abase + (uint32_t) (lane + 64 - xlo)] = a4hi;
-                  entry = make_uint2(abase, smr_strip_pack(cx0 + xlo, (int) n));
-               }
-            }
-            if (!bad && lane == 0) A.drows[rbase + (uint32_t) ((crow - cr_first) >> 2)] = entry;
-         }
+         emit_strip(crow, &L.cell[0][0], SMR_CV_WC, SMR_CV_WC, partial | full_bits);
          SMR_WAVE_SYNC();
          CVTICK(6);
       }
