@@ -383,7 +383,7 @@ def main():
             "nodes_per_s": round(n_nodes / (stage["proj_ms"] * 1e-3), 1) if stage["proj_ms"] > 0 else None,
             "stage_ms": {k: round(v, 3) for k, v in stage.items()},
             "counts": {"prims": tm["n_prims"], "edge_slots": tm["n_edges"], "tile_refs": tm["n_tile_refs"], "tiles": tm["n_tiles"],
-                       "cover_prims": tm["n_cover_prims"], "cover_left": tm["n_cover_left"], "deltas": tm["n_deltas"]},
+                       "cover_prims": tm["n_cover_prims"], "cover_left": tm["n_cover_left"], "deltas": tm["n_deltas"], "cover_linear": tm["n_cover_linear"]},
             "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 5), "traffic": measured_traffic(dom, args),
                          "algorithmic_bytes": dom_bytes, "ms": round(dom_ms, 3)},

@@ -334,6 +334,7 @@ typedef struct
    float cover_ms;                                /* draw: scan conversion of the small primitives, primitive by primitive (k_cover) */
    uint32_t n_cover_prims, n_cover_left;          /* primitives k_cover handled / had to leave to the tile rasterizer */
    uint32_t n_deltas;                             /* coverage cells k_cover wrote */
+   uint32_t n_cover_linear;                       /* of n_cover_prims: fills that took k_cover's crossing-by-crossing path (simple polygons) */
 } smr_timings_t;
 int smr_hip_set_profiling(int on);
 int smr_hip_timings(smr_timings_t *t);

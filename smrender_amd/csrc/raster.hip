@@ -3205,6 +3205,7 @@ struct cover_args_t
    uint32_t *ctr;             /* [0] next primitive [1] alpha words taken [2] strips taken [3] primitives done [4] primitives left to k_raster */
    int band_y0, band_h;
    uint32_t chunk;            /* primitives a wavefront takes from the queue with one atomic: SMR_CV_CHUNK on a full chart, fewer when the rule is small */
+   uint32_t linear;           /* fills that pass the star test take the crossing-by-crossing path (SMR_HIP_LINEAR=0: none does) */
 };
 
 struct cover_lds_t
@@ -3215,6 +3216,16 @@ struct cover_lds_t
    int gy[SMR_CV_MAXGROUPS][2];      /* sub-row extent of each group of 64 edge slots */
    int own[64];
 };
+
+/* the linear path of k_cover keeps the cells of a whole chunk of rows where the strip path keeps four rows, its lists and
+ * its row edges: cell, bucket and redge are contiguous (asserted), SMR_CV_POOL ints; the last SMR_CV_AUX of them hold, per row of
+ * the chunk, the number of edges spanning it when it is an exact row and the first SMR_CV_C0 of their positions */
+#define SMR_CV_POOL ((int) ((sizeof(int) * SMR_TH * SMR_CV_WC + sizeof(uint16_t) * SMR_NSUB * SMR_BKS + sizeof(int) * SMR_TH * SMR_CV_SL * 5) / sizeof(int)))
+#define SMR_CV_C0 6
+#define SMR_CV_ROWS 64
+#define SMR_CV_AUX (SMR_CV_ROWS * (1 + SMR_CV_C0))
+static_assert(offsetof(cover_lds_t, bucket) == sizeof(int) * SMR_TH * SMR_CV_WC && offsetof(cover_lds_t, redge) % 4 == 0 &&
+              offsetof(cover_lds_t, gy) == sizeof(int) * SMR_CV_POOL, "the linear path's pool is cell + bucket + redge");
 
 __device__ __forceinline__ int smr_wave_scan_max(int v)
 {
@@ -3242,7 +3253,7 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
    for (int r = 0; r < SMR_TH; r++) { L.cell[r][lane] = 0; L.cell[r][lane + 64] = 0; }
    SMR_WAVE_SYNC();
    uint32_t dpos = 0, dleft = 0, rpos = 0, rleft = 0;      /* this wavefront's blocks of the two arenas */
-   uint32_t n_done = 0, n_left = 0;
+   uint32_t n_done = 0, n_left = 0, n_lin = 0;
 #ifdef SMR_CV_PROFILE
    unsigned long long cvp[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, cvt = __builtin_amdgcn_s_memtime();
 #define CVTICK(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); cvp[i] += t_ - cvt; cvt = t_; } while (0)
@@ -3368,8 +3379,191 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
          }
       };
 
+
+      /* ---- fills that are simple polygons: every crossing counts by itself ----
+       * The scan converter's spans are a function of the winding number along a sample line.  Where that number is only ever 0
+       * or s (one sign for the whole polygon: a simple polygon), a crossing whose direction is s starts a span and any other
+       * ends one, whatever lies left of it: the sorted lists, the walk and the per-row order of the exact rows fall away, and
+       * (edge, row) pairs on the lanes add their crossings straight to the cells -- the sub-rows of a pair one after the other
+       * in its lane, x by the scan converter's own DDA (quotient and remainder of one sub-row's step).  Libcairo's two rules
+       * that look at neighbours hold by themselves: spans that touch merge (their two crossings cancel in one cell), and an
+       * exact row's span that ends where the next begins continues -- which the sums do not reproduce, so a row with more than
+       * two spanning edges must have them at different positions, else the primitive takes the strip path below.
+       * Simple is tested as star-shaped: every edge turns the same way about the box's centre and the boundary goes round it
+       * once (two edges straddle the centre's row).  Polygons that are not (an L, a river) take the strip path; so do
+       * primitives of more than 64 edge slots (the cells' packed fields hold 64 crossings of one cell and sub-row). */
+      bool linear_done = false;
+      if (A.linear && !pieces && ngroups == 1)
+      {
+         const int ccx = (int) (((int64_t) P.minx + P.maxx) >> 1), ccy = (int) (((int64_t) P.miny + P.maxy) >> 1);
+         const int ax = e0.x1 - ccx, ay = e0.y1 - ccy, bx = e0.x2 - ccx, by = e0.y2 - ccy;
+         const bool real = (uint32_t) lane < P.edge_cnt && (e0.x1 != e0.x2 || e0.y1 != e0.y2);
+         const bool inr = ((uint32_t) (ax + 32768) | (uint32_t) (ay + 32768) | (uint32_t) (bx + 32768) | (uint32_t) (by + 32768)) < 65536u;
+         const int crs = ax * by - bx * ay;                  /* |.| < 2^31 whenever inr */
+         const unsigned long long m_real = __ballot(real), m_pos = __ballot(real && crs > 0), m_neg = __ballot(real && crs < 0);
+         const unsigned long long m_out = __ballot(real && !inr);
+         const unsigned long long m_str = __ballot(real && ((ay <= 0 && by > 0) || (by <= 0 && ay > 0)));
+         const bool star = m_real && !m_out && (m_pos == m_real || m_neg == m_real) && __popcll(m_str) == 2;
+         if (star)
+         {
+            const int sg = m_pos == m_real ? -1 : 1;         /* a crossing of direction sg opens a span */
+            const smr_oedge_t o = smr_orient(e0);
+            int *const pool = &L.cell[0][0];
+            int *const rowcnt = pool + (SMR_CV_POOL - SMR_CV_AUX), *const c0l = rowcnt + SMR_CV_ROWS;
+            const int stride = wp;
+            int R = ((SMR_CV_POOL - SMR_CV_AUX) / stride) & ~(SMR_TH - 1);
+            if (R > SMR_CV_ROWS) R = SMR_CV_ROWS;
+            /* one sub-row's step of x: floor(1024 dxs / D) and the remainder */
+            int qs = 0, rs = 0;
+            if (o.dir != 0 && o.dxs != 0)
+            {
+               const int n = 1024 * o.dxs;
+               qs = (int) floor((double) n * smr_rcp((double) o.D));
+               rs = n - qs * o.D;
+               if (rs < 0) { qs--; rs += o.D; } else if (rs >= o.D) { qs++; rs -= o.D; }
+            }
+            /* the row mask, a word per lane (a star inside +-128 px has at most 8) */
+            uint32_t mw = 0;
+            if ((uint32_t) lane < (((uint32_t) P.nrows + 31u) >> 5)) mw = A.mask[P.mask_off + lane];
+            bool fail = false;
+            for (int c0r = cr_first; c0r < dr1 && !bad && !fail; c0r += R)
+            {
+               const int c1r = min(c0r + R, dr1), nr = c1r - c0r;
+               for (int i = 2 * lane; i < nr * stride; i += 128) *reinterpret_cast<int2 *>(pool + i) = make_int2(0, 0);
+               rowcnt[lane] = 0;
+               SMR_WAVE_SYNC();
+               const int ys_lo = max(o.ytop, max(c0r, dr0) * SMR_GRID_Y), ys_hi = min(o.ybot, c1r * SMR_GRID_Y);
+               const int ra = ys_lo / SMR_GRID_Y;
+               const int np = (o.dir != 0 && ys_hi > ys_lo) ? (ys_hi - 1) / SMR_GRID_Y - ra + 1 : 0;
+               const int incl = smr_wave_scan(np), excl = incl - np;
+               const int total = __builtin_amdgcn_readlane(incl, 63);
+               bool oob = false;
+               for (int base = 0; base < total; base += 64)
+               {
+                  L.own[lane] = INT32_MIN;
+                  SMR_WAVE_SYNC();
+                  if (np > 0)
+                  {
+                     const int first = excl - base;
+                     if (first >= 0 && first < 64) L.own[first] = lane;
+                     else if (first < 0 && incl > base) L.own[0] = lane;
+                  }
+                  SMR_WAVE_SYNC();
+                  const int own = smr_wave_scan_max(L.own[lane]);
+                  const bool valid = base + lane < total;
+                  const int ad = (valid ? own : lane) << 2;
+                  const int s_p1x = __builtin_amdgcn_ds_bpermute(ad, o.p1x), s_p1y = __builtin_amdgcn_ds_bpermute(ad, o.p1y);
+                  const int s_dxs = __builtin_amdgcn_ds_bpermute(ad, o.dxs), s_D = __builtin_amdgcn_ds_bpermute(ad, o.D);
+                  const int s_ytop = __builtin_amdgcn_ds_bpermute(ad, o.ytop), s_ybot = __builtin_amdgcn_ds_bpermute(ad, o.ybot);
+                  const int s_qs = __builtin_amdgcn_ds_bpermute(ad, qs), s_rs = __builtin_amdgcn_ds_bpermute(ad, rs);
+                  const int sgn = __builtin_amdgcn_ds_bpermute(ad, o.dir) * sg;
+                  const int row = __builtin_amdgcn_ds_bpermute(ad, ra) + (base + lane - __builtin_amdgcn_ds_bpermute(ad, excl));
+                  const int rr = row - P.row0, rs0 = row * SMR_GRID_Y;
+                  const uint32_t mword = (uint32_t) __builtin_amdgcn_ds_bpermute(valid ? (rr >> 5) << 2 : 0, (int) mw);
+                  const bool sub = (mword >> (rr & 31)) & 1u;
+                  int *const crow = pool + (row - c0r) * stride;
+                  if (valid && sub)
+                  {
+                     const int s0 = max(s_ytop, rs0), s1 = min(s_ybot, rs0 + SMR_GRID_Y);
+                     int32_t q, rem;
+                     smr_edge_qr(256 - 30ll * s_p1y, 2 * s_dxs, s_D, smr_rcp((double) s_D), s0, q, rem);
+                     const int half = s_D >> 1;
+                     for (int ys = s0; ys < s1; ys++)
+                     {
+                        const int rel = s_p1x + q + (rem >= half && s_dxs != 0 ? 1 : 0) - X0;
+                        atomicAdd(&crow[rel >> 8], smr_delta_pack(sgn, sgn * 2 * (rel & 255)));
+                        q += s_qs; rem += s_rs;
+                        if (rem >= s_D) { q++; rem -= s_D; }
+                     }
+                  }
+                  else if (valid && s_ytop <= rs0 && s_ybot >= rs0 + SMR_GRID_Y)
+                  {
+                     /* an exact row: libcairo's cell_list_render_edge for this edge, as in the strip path below */
+                     int32_t q1, r1, q2, r2;
+                     const int64_t ec = 256 - 30ll * s_p1y;
+                     const double inv = smr_rcp((double) s_D);
+                     smr_edge_qr(ec, 2 * s_dxs, s_D, inv, rs0, q1, r1);
+                     smr_edge_qr(ec, 2 * s_dxs, s_D, inv, rs0 + SMR_GRID_Y, q2, r2);
+                     const int64_t nn = (int64_t) s_dxs * 1024;
+                     int64_t dq = (int64_t) trunc((double) nn * inv);
+                     int64_t dr = nn - dq * s_D;
+                     if (nn >= 0) { if (dr < 0) { dq--; dr += s_D; } else if (dr >= s_D) { dq++; dr -= s_D; } }
+                     else { if (dr > 0) { dq++; dr -= s_D; } else if (dr <= -(int64_t) s_D) { dq--; dr += s_D; } }
+                     const int32_t hq = (int32_t) (dq / 2), hr = (int32_t) (dr / 2);
+                     q1 += s_p1x; q2 += s_p1x;
+                     const int c0 = q1 + (r1 >= (s_D >> 1) ? 1 : 0);
+                     q1 -= hq; r1 -= hr;
+                     if (r1 < 0) { --q1; r1 += s_D; } else if (r1 >= s_D) { ++q1; r1 -= s_D; }
+                     q2 -= hq; r2 -= hr;
+                     if (r2 < 0) { --q2; r2 += s_D; } else if (r2 >= s_D) { ++q2; r2 -= s_D; }
+                     q1 -= X0; q2 -= X0;
+                     const int pos = atomicAdd(&rowcnt[row - c0r], 1);
+                     if (pos < SMR_CV_C0) c0l[(row - c0r) * SMR_CV_C0 + pos] = c0;
+                     int ix1 = q1 >> 8, ix2 = q2 >> 8, fx1 = q1 & 255, fx2 = q2 & 255;
+                     if (min(ix1, ix2) < 0 || max(ix1, ix2) >= stride) oob = true;
+                     else if (ix1 == ix2) atomicAdd(&crow[ix1], smr_delta_pack(sgn * SMR_GRID_Y, sgn * (fx1 + fx2) * SMR_GRID_Y));
+                     else
+                     {
+                        const bool sw = ix2 < ix1;
+                        const int32_t qa = sw ? q2 : q1, rra = sw ? r2 : r1, qb = sw ? q1 : q2, rrb = sw ? r1 : r2;
+                        if (sw) { int t = ix1; ix1 = ix2; ix2 = t; t = fx1; fx1 = fx2; fx2 = t; }
+                        const int64_t dx = (int64_t) (qb - qa) * s_D + (rrb - rra);
+                        const int64_t tmp0 = ((int64_t) (256 - fx1) * s_D - rra) * SMR_GRID_Y;
+                        const int64_t step = (int64_t) (SMR_GRID_Y * 256) * s_D;
+                        const double idx = smr_rcp(smr_i64_to_f64(dx));
+                        int ylast = 0;
+                        for (int k = ix1; k <= ix2; k++)
+                        {
+                           int yhi = SMR_GRID_Y;
+                           if (k != ix2)
+                           {
+                              const int64_t n = tmp0 + (int64_t) (k - ix1) * step;
+                              yhi = (int) (smr_i64_to_f64(n) * idx);
+                              const int64_t rm = n - (int64_t) yhi * dx;
+                              if (rm < 0) yhi--; else if (rm >= dx) yhi++;
+                           }
+                           const int cov = yhi - ylast;
+                           const int fac = k == ix1 ? 256 + fx1 : k == ix2 ? fx2 : 256;
+                           if (cov) atomicAdd(&crow[k], smr_delta_pack(sgn * cov, sgn * cov * fac));
+                           ylast = yhi;
+                        }
+                     }
+                  }
+               }
+               SMR_WAVE_SYNC();
+               /* exact rows: two spanning edges are a span by themselves; more must all stand at different positions */
+               {
+                  bool dup = false;
+                  const int cnt = lane < nr ? rowcnt[lane] : 0;
+                  if (cnt > SMR_CV_C0 || (cnt & 1)) dup = true;
+                  else if (cnt > 2)
+                     for (int i = 1; i < cnt; i++)
+                        for (int j = 0; j < i; j++)
+                           if (c0l[lane * SMR_CV_C0 + i] == c0l[lane * SMR_CV_C0 + j]) dup = true;
+                  if (__ballot(dup || oob)) fail = true;
+               }
+               if (fail)
+               {
+                  for (int i = 2 * lane; i < nr * stride; i += 128) *reinterpret_cast<int2 *>(pool + i) = make_int2(0, 0);
+                  SMR_WAVE_SYNC();
+                  break;
+               }
+               for (int crow = c0r; crow < c1r && !bad; crow += SMR_TH)
+               {
+                  uint32_t rows = 0;
+#pragma unroll
+                  for (int r = 0; r < SMR_TH; r++) if (crow + r >= dr0 && crow + r < dr1) rows |= 1u << r;
+                  emit_strip(crow, pool + (crow - c0r) * stride, stride, stride, rows);
+               }
+               SMR_WAVE_SYNC();
+            }
+            linear_done = !fail;
+            if (linear_done && !bad) n_lin++;
+         }
+      }
+
       CVTICK(0);
-      for (int crow = cr_first; crow < dr1 && !bad; crow += SMR_TH)
+      for (int crow = cr_first; crow < dr1 && !bad && !linear_done; crow += SMR_TH)
       {
          /* the strip's rows: sub-sampled (bit of the row mask set), exact (clear), or not the primitive's */
          uint32_t partial, full_bits;
@@ -3696,7 +3890,7 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
       n_done++;
    }
    }
-   if (lane == 0) { if (n_done) atomicAdd(&A.ctr[3], n_done); if (n_left) atomicAdd(&A.ctr[4], n_left); }
+   if (lane == 0) { if (n_done) atomicAdd(&A.ctr[3], n_done); if (n_left) atomicAdd(&A.ctr[4], n_left); if (n_lin) atomicAdd(&A.ctr[5], n_lin); }
 #ifdef SMR_CV_PROFILE
    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd((unsigned long long *) (A.ctr + 6) + i, cvp[i]);
 #endif
@@ -4110,6 +4304,13 @@ static bool overlap_enabled()
 }
 
 /* SMR_HIP_BLEND=0 sends the tiles that hold alpha words only through k_raster too (A/B timing) */
+/* SMR_HIP_LINEAR=0: no fill takes k_cover's crossing-by-crossing path (A/B timing, parity of the two paths) */
+static bool linear_enabled()
+{
+   const char *e = getenv("SMR_HIP_LINEAR");
+   return !(e && *e == '0');
+}
+
 static bool blend_enabled()
 {
    const char *e = getenv("SMR_HIP_BLEND");
@@ -4541,7 +4742,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       cover_args_t CV;
       CV.prims = prims; CV.n_prims = (uint32_t) n_prims; CV.edges = edges; CV.mask = maskbuf;
       CV.alpha = alpha; CV.alpha_cap = (uint32_t) acap; CV.drows = drows; CV.drow_cap = (uint32_t) rcap;
-      CV.ctr = cvctr; CV.band_y0 = c->band_y0; CV.band_h = c->band_h; CV.chunk = cv_chunk;
+      CV.ctr = cvctr; CV.band_y0 = c->band_y0; CV.band_h = c->band_h; CV.chunk = cv_chunk; CV.linear = linear_enabled() ? 1u : 0u;
       k_cover<<<nwg, 64 * SMR_CV_WAVES, 0, s>>>(CV);
       SMR_HIP(hipGetLastError());
    }
@@ -4688,9 +4889,9 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       smr_timings_t &t = smr_g.last;
       t.edges_ms = T.ms(0, 1); t.prims_ms = T.ms(1, 2); t.cover_ms = T.ms(2, 3); t.bin_ms = T.ms(3, 4); t.raster_ms = T.ms(4, 5); t.total_ms = T.ms(0, 5);
       t.n_prims = (uint64_t) n_prims; t.n_edges = n_edges; t.n_tile_refs = n_entries; t.n_tiles = n_tiles;
-      uint32_t cv[5] = { 0, 0, 0, 0, 0 };
+      uint32_t cv[6] = { 0, 0, 0, 0, 0, 0 };
       if (alpha) hipMemcpy(cv, cvctr, sizeof(cv), hipMemcpyDeviceToHost);
-      t.n_deltas = cv[1]; t.n_cover_prims = cv[3]; t.n_cover_left = cv[4];
+      t.n_deltas = cv[1]; t.n_cover_prims = cv[3]; t.n_cover_left = cv[4]; t.n_cover_linear = cv[5];
 #ifdef SMR_CV_PROFILE
       {
          unsigned long long pr[8]; double tot = 0;

@@ -73,7 +73,7 @@ class Timings(C.Structure):
     _fields_ = [("proj_ms", C.c_float), ("edges_ms", C.c_float), ("prims_ms", C.c_float), ("bin_ms", C.c_float),
                 ("raster_ms", C.c_float), ("caprot_ms", C.c_float), ("total_ms", C.c_float),
                 ("n_prims", C.c_uint64), ("n_edges", C.c_uint64), ("n_tile_refs", C.c_uint64), ("n_tiles", C.c_uint64),
-                ("cover_ms", C.c_float), ("n_cover_prims", C.c_uint32), ("n_cover_left", C.c_uint32), ("n_deltas", C.c_uint32)]
+                ("cover_ms", C.c_float), ("n_cover_prims", C.c_uint32), ("n_cover_left", C.c_uint32), ("n_deltas", C.c_uint32), ("n_cover_linear", C.c_uint32)]
 
 
 class PngStats(C.Structure):

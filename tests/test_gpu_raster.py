@@ -729,7 +729,7 @@ def test_alpha_word_tiles_composite_alike_in_both_kernels(hip, style, monkeypatc
     want = oracle_of(rules, 300, W, H, 0xfff0e0d0)
     got = gpu_scene(sa, rules, 300, W, H, 0xfff0e0d0)
     assert np.array_equal(got, want), report(got, want)
-    for var in ("SMR_HIP_BLEND", "SMR_HIP_COVER", "SMR_HIP_OVERLAP"):      # (the last: the binning after k_cover instead of beside it)
+    for var in ("SMR_HIP_BLEND", "SMR_HIP_COVER", "SMR_HIP_OVERLAP", "SMR_HIP_LINEAR"):      # (OVERLAP: the binning after k_cover instead of beside it; LINEAR: no fill takes k_cover's crossing-by-crossing path)
         monkeypatch.setenv(var, "0")
         other = gpu_scene(sa, rules, 300, W, H, 0xfff0e0d0)
         monkeypatch.delenv(var)
@@ -812,3 +812,88 @@ def test_even_odd_long_primitives_and_compound(hip):
     assert np.array_equal(got, want), report(got, want)
     st_w = po.Style(1, 0, 0x30c0d8f0, 0, 0.3, 0, 0)
     assert (po.oracle_directional(st_w, ways, 300, W, H, 0xffffff) != want).sum() > 2000
+
+
+def _shape_ways(W, H, seed):
+    """closed ways that try the two fill paths of k_cover: rectangles on whole and half pixels (vertical edges, rows without a
+    vertex, crossings that tie), stars with deep teeth (exact rows with four and six spanning edges), L and U shapes and
+    spirals (not star-shaped: the strip path), slivers, tiny polygons inside one pixel, polygons 120 px wide and 200 px tall"""
+    rng = np.random.default_rng(seed)
+    ways = []
+
+    def add(x, y):
+        ways.append((np.append(x, x[0]), np.append(y, y[0]), True))
+    for i in range(260):
+        cx, cy = rng.uniform(0, W), rng.uniform(0, H)
+        kind = i % 13
+        if kind == 0:        # rectangle on the pixel grid
+            w, h = rng.integers(1, 40), rng.integers(1, 40)
+            x0, y0 = np.floor(cx), np.floor(cy)
+            add(np.array([x0, x0 + w, x0 + w, x0]), np.array([y0, y0, y0 + h, y0 + h]))
+        elif kind == 1:      # rectangle on half pixels, clockwise
+            w, h = rng.integers(1, 30) + 0.5, rng.integers(1, 30) + 0.5
+            x0, y0 = np.floor(cx) + 0.5, np.floor(cy) + 0.5
+            add(np.array([x0, x0, x0 + w, x0 + w]), np.array([y0, y0 + h, y0 + h, y0]))
+        elif kind in (2, 3): # star with deep teeth: long radial edges, rows without a vertex crossed four and six times
+            n = int(rng.choice([6, 8, 10, 14])); r = rng.uniform(20, 60)
+            t = rng.uniform(0, 6) + 2 * np.pi * np.arange(n) / n
+            rr = np.where(np.arange(n) % 2, r, r * rng.uniform(0.15, 0.5))
+            add(cx + rr * np.cos(t), cy + rr * np.sin(t))
+        elif kind == 4:      # L shape
+            a, b = rng.uniform(10, 50), rng.uniform(3, 9)
+            add(cx + np.array([0, a, a, b, b, 0]), cy + np.array([0, 0, b, b, a, a]))
+        elif kind == 5:      # U shape: two arms on the same rows
+            a, b = rng.uniform(12, 50), rng.uniform(2, 5)
+            add(cx + np.array([0, b, b, a - b, a - b, a, a, 0]), cy + np.array([0, 0, a - b, a - b, 0, 0, a, a]))
+        elif kind == 6:      # spiral
+            n = 40; t = np.linspace(0, 5 * np.pi, n); r = 2 + 3 * t
+            xo, yo = cx + r * np.cos(t), cy + r * np.sin(t)
+            xi, yi = cx + (r - 2.5) * np.cos(t), cy + (r - 2.5) * np.sin(t)
+            add(np.concatenate([xo, xi[::-1]]), np.concatenate([yo, yi[::-1]]))
+        elif kind == 7:      # sliver
+            L_, a = rng.uniform(20, 100), rng.uniform(0, 6)
+            add(cx + np.array([0, L_ * np.cos(a), 0.3 * np.sin(a)]), cy + np.array([0, L_ * np.sin(a), -0.3 * np.cos(a)]))
+        elif kind == 8:      # inside one pixel
+            n = int(rng.integers(3, 30)); t = np.sort(rng.uniform(0, 2 * np.pi, n))
+            add(cx + 0.4 * rng.uniform(0.3, 1, n) * np.cos(t), cy + 0.4 * rng.uniform(0.3, 1, n) * np.sin(t))
+        elif kind == 9:      # wide and tall ellipse of 60 nodes
+            n = 60; t = 2 * np.pi * np.arange(n) / n
+            add(cx + 59 * np.cos(t) * rng.uniform(0.9, 1, n), cy + 100 * np.sin(t) * rng.uniform(0.9, 1, n))
+        elif kind == 10:     # convex polygon with many collinear points on its sides
+            x0, y0, w, h = cx, cy, rng.uniform(10, 60), rng.uniform(10, 60)
+            k = 6
+            xs = np.concatenate([x0 + w * np.arange(k) / k, np.full(k, x0 + w), x0 + w - w * np.arange(k) / k, np.full(k, x0)])
+            ys = np.concatenate([np.full(k, y0), y0 + h * np.arange(k) / k, np.full(k, y0 + h), y0 + h - h * np.arange(k) / k])
+            add(xs, ys)
+        else:                # C2's own generator shape, either orientation
+            n = int(rng.integers(4, 64)); r = rng.uniform(3, 62)
+            t = 2 * np.pi * np.arange(n) / n * rng.choice([-1, 1]) + rng.uniform(0, 6)
+            rr = r * rng.uniform(0.7, 1.0, n)
+            add(cx + rr * np.cos(t), cy + rr * np.sin(t))
+    return ways
+
+
+@pytest.mark.parametrize("col", [0xc04020, 0x40c04020])
+@pytest.mark.parametrize("dpi", [300, 97])
+def test_fill_paths_of_k_cover_agree_with_the_oracle_and_with_each_other(hip, col, dpi, monkeypatch):
+    """k_cover fills a star-shaped polygon crossing by crossing (no lists, no sort) and everything else strip by strip: both must be
+    the oracle's pixels, on shapes chosen to sit on the border between the two and on the rules that look at neighbouring
+    crossings (touching spans, exact rows whose span ends where the next begins)"""
+    sa = hip
+    W, H = 640, 520
+    arrs = _ways_to_arrays(_shape_ways(W, H, seed=dpi))
+    st = po.Style(1, 0, col, 0, 0, 0, 0)
+    want = oracle_of([(st, arrs)], dpi, W, H, 0xffffff)
+    sa.lib().smr_hip_set_profiling(1)
+    got = gpu_scene(sa, [(st, arrs)], dpi, W, H, 0xffffff)
+    tm = sa.timings()
+    sa.lib().smr_hip_set_profiling(0)
+    assert np.array_equal(got, want), report(got, want)
+    assert 0.4 * tm["n_cover_prims"] < tm["n_cover_linear"] < 0.9 * tm["n_cover_prims"], tm      # both paths were taken
+    monkeypatch.setenv("SMR_HIP_LINEAR", "0")
+    other = gpu_scene(sa, [(st, arrs)], dpi, W, H, 0xffffff)
+    assert np.array_equal(other, got), report(other, got)
+    monkeypatch.delenv("SMR_HIP_LINEAR")
+    for y0, h in ((0, 203), (203, 317)):
+        band = gpu_scene(sa, [(st, arrs)], dpi, W, H, 0xffffff, y0, h)
+        assert np.array_equal(band, want[y0:y0 + h]), report(band, want[y0:y0 + h])
