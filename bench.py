@@ -334,15 +334,20 @@ def main():
             sa.sync()
             t0 = time.perf_counter()
             ang2 = np.zeros(args.captions)
+            at = None
+            d2 = sa.DeviceArray((per,), np.float64)
             for k0 in range(0, args.captions, per):
                 k1 = min(args.captions, k0 + per)
-                at = sa.Canvas.windows(W, chart_h, args.dpi, 0xffffff, cx[k0:k1], cy[k0:k1], r_px, float(np.hypot(fg_w, fg_h)))
+                if at is None:      # one atlas for the whole scan, set up again per batch (smr_hip_windows_reset)
+                    at = sa.Canvas.windows(W, chart_h, args.dpi, 0xffffff, cx[k0:k1], cy[k0:k1], r_px, float(np.hypot(fg_w, fg_h)))
+                else:
+                    at.reset_windows(cx[k0:k1], cy[k0:k1], r_px, float(np.hypot(fg_w, fg_h)))
                 at.draw_windows(style, d_x, d_y, d_off, d_ref, n_ways, n_refs)
                 ax, ay = at.window_anchors()
-                d2 = sa.DeviceArray((k1 - k0,), np.float64)
                 at.caprot(sa.DeviceArray.from_numpy(ax), sa.DeviceArray.from_numpy(ay), k1 - k0, fg_w, fg_h, fg_x, 0x000000, 0.0, 1.0, d2)
                 sa.sync()
-                ang2[k0:k1] = d2.numpy()
+                ang2[k0:k1] = d2.numpy()[:k1 - k0]
+            if at is not None:
                 at.close()
             t_rep = time.perf_counter() - t0
             sa.set_profiling(True)

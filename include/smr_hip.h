@@ -313,6 +313,10 @@ typedef struct
    const double *cx, *cy;          /* [n] HOST: the captions' anchors in chart px (geo2pxf) */
 } smr_windows_t;
 int smr_hip_windows_create(int chart_w, int chart_h, int dpi, uint32_t bgcolor, const smr_windows_t *w, smr_canvas_t **atlas);
+/* the same atlas for the next batch of captions of the same chart: at most as many windows as it was created for, the largest as
+ * wide as the atlas; pixels and window tables are set up again, the canvas and its work buffers stay (no hipMalloc / hipFree
+ * between batches) */
+int smr_hip_windows_reset(smr_canvas_t *atlas, const smr_windows_t *w);
 int smr_hip_draw_windows(smr_canvas_t *atlas, const smr_draw_style_t *st, const smr_draw_batch_t *b);
 /* call after the last draw into the atlas: it also clears what the rules left beyond the chart's rectangle (the reference's
  * recording has the chart's extents), then returns the anchors to scan at */

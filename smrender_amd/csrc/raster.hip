@@ -3899,7 +3899,10 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
 /* ------------------------------------------------------------------------------------ */
 /* host side                                                                             */
 /* ------------------------------------------------------------------------------------ */
-static uint32_t host_color_pixel(uint32_t c)
+static uint32_t host_color_pixel(uint32_t c) { return smr_color_pixel(c); }
+
+/* 0xTTRRGGBB -> the premultiplied ARGB32 pixel libcairo makes of cairo_set_source_rgba (src/smrules_cairo.c:271-274) */
+uint32_t smr_color_pixel(uint32_t c)
 {
    double r = (double) ((c >> 16) & 0xff) / 255.0, g = (double) ((c >> 8) & 0xff) / 255.0, b = (double) (c & 0xff) / 255.0;
    double a = 1.0 - (double) (((c & 0x7f000000u) >> 23) & 0xff) / 255.0;
@@ -3960,6 +3963,8 @@ extern "C" int smr_hip_canvas_destroy(smr_canvas_t *c)
    if (c->d_win_shift) hipFree(c->d_win_shift);
    if (c->d_win_box) hipFree(c->d_win_box);
    if (c->d_win_clip) hipFree(c->d_win_clip);
+   if (c->d_grid_off) hipFree(c->d_grid_off);
+   if (c->d_grid_win) hipFree(c->d_grid_win);
    if (c->halo_above) hipFree(c->halo_above);
    if (c->halo_below) hipFree(c->halo_below);
    for (auto &b : c->buf) if (b.p) hipFree(b.p);

@@ -40,7 +40,7 @@ enum { SMR_BUF_PTS, SMR_BUF_WAYFLAGS, SMR_BUF_SMALL, SMR_BUF_PRIMS, SMR_BUF_EDGE
        SMR_BUF_TILEOFF, SMR_BUF_SUMS, SMR_BUF_ENTRIES, SMR_BUF_CAP0, SMR_BUF_CAP1, SMR_BUF_REFWAY, SMR_BUF_ITEMS, SMR_BUF_MASK, SMR_BUF_HDRS, SMR_BUF_COVERED, SMR_BUF_DASH, SMR_BUF_PEN,
        SMR_BUF_CURVE_CNT, SMR_BUF_FPTS, SMR_BUF_FTIN, SMR_BUF_FTOUT, SMR_BUF_FREFWAY, SMR_BUF_FWAYOFF, SMR_BUF_FSKIP, SMR_BUF_BIGLIST, SMR_BUF_BIGACC, SMR_BUF_CURVEFIX, SMR_BUF_SNAPSHOT, SMR_BUF_OVFLIST, SMR_BUF_BIGBUCKET, SMR_BUF_DELTAS, SMR_BUF_DROWS, SMR_BUF_TILECNT, SMR_BUF_BLIT,
        SMR_BUF_WIN_WB, SMR_BUF_WIN_BOX, SMR_BUF_WIN_CNT, SMR_BUF_WIN_SUMS, SMR_BUF_WIN_TOT, SMR_BUF_WIN_IWAY, SMR_BUF_WIN_IWIN, SMR_BUF_WIN_IOFF, SMR_BUF_WIN_X, SMR_BUF_WIN_Y,
-       SMR_BUF_WIN_REF, SMR_BUF_WIN_NODEWIN, SMR_BUF_WIN_WAYOFF, SMR_BUF_WIN_CLIP, SMR_BUF_WIN_FCOL, SMR_BUF_WIN_BCOL, SMR_BUF_MAX };
+       SMR_BUF_WIN_REF, SMR_BUF_WIN_NODEWIN, SMR_BUF_WIN_WAYOFF, SMR_BUF_WIN_CLIP, SMR_BUF_WIN_FCOL, SMR_BUF_WIN_BCOL, SMR_BUF_WIN_KEYS, SMR_BUF_WIN_KEYS2, SMR_BUF_WIN_TMP, SMR_BUF_MAX };
 
 struct smr_devbuf_t { void *p = nullptr; size_t cap = 0; };
 
@@ -55,6 +55,9 @@ struct smr_canvas
     * its replay (atlas placement included) and its box on the chart in px */
    int win_n = 0, win_size = 0, win_pitch = 0, chart_w = 0, chart_h = 0;
    int2 *d_win_shift = nullptr, *d_win_clip = nullptr; void *d_win_box = nullptr;
+   int win_cap = 0;                         /* windows the atlas has rows and tables for (smr_hip_windows_reset) */
+   /* a uniform grid over the chart (cells of grid_cell px from (-grid_cell, -grid_cell) on): per cell the windows whose box meets it */
+   uint32_t *d_grid_off = nullptr, *d_grid_win = nullptr; int grid_nx = 0, grid_ny = 0, grid_cell = 0; size_t grid_win_cap = 0;
    std::vector<int> win_sizes;
    std::vector<double> win_ox, win_oy;      /* each window's corner on the chart, px */
    int own_y0 = -1, own_h = 0;         /* smr_hip_canvas_extend: the rows whose captions this canvas scans (-1: the band itself) */
@@ -85,6 +88,7 @@ struct smr_win_ctx_t { const int32_t *node_win; const int2 *win_shift; const int
  * (buf[n] = total, which also comes back) */
 int smr_draw_instances(smr_canvas *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, const smr_win_ctx_t *wc);
 int smr_scan_u32(uint32_t *buf, uint32_t n, uint32_t *sums, uint32_t *total_dev, uint32_t *total);
+uint32_t smr_color_pixel(uint32_t smr_col);      /* raster.hip: 0xTTRRGGBB -> premultiplied ARGB32 source pixel */
 
 /* HIP-event stage timer on the library stream (only active when profiling is on) */
 struct smr_timer_t

@@ -107,7 +107,7 @@ EXPORTS = [
     "smr_hip_canvas_create", "smr_hip_canvas_destroy", "smr_hip_canvas_clear", "smr_hip_canvas_trim", "smr_hip_canvas_read", "smr_hip_canvas_device",
     "smr_hip_canvas_set_halo", "smr_hip_canvas_set_halo_device", "smr_hip_canvas_extend", "smr_hip_canvas_clone", "smr_hip_canvas_blit",
     "smr_hip_canvas_write_png", "smr_hip_canvas_write_tiles", "smr_hip_canvas_write_kap",
-    "smr_hip_windows_create", "smr_hip_draw_windows", "smr_hip_windows_anchors", "smr_hip_blit_windows",
+    "smr_hip_windows_create", "smr_hip_windows_reset", "smr_hip_draw_windows", "smr_hip_windows_anchors", "smr_hip_blit_windows",
     "smr_hip_objects_create", "smr_hip_objects_destroy", "smr_hip_objects_info", "smr_hip_objects_match",
     "smr_hip_objects_select_ways", "smr_hip_objects_select_nodes",
     "smr_hip_poly_area", "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
@@ -153,6 +153,7 @@ def lib():
         L.smr_hip_windows_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
         L.smr_hip_draw_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.smr_hip_windows_anchors.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.smr_hip_windows_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.smr_hip_blit_windows.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
         L.smr_hip_canvas_write_png.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_void_p]
         L.smr_hip_canvas_write_tiles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int,
@@ -371,6 +372,16 @@ class Canvas:
         o._n_above = o._n_below = 0
         o.n_windows, o.window_sizes, o.window_pitch = len(cx), sizes, pitch
         return o
+
+    def reset_windows(self, cx, cy, size, r_px=None):
+        """the same atlas for another batch of anchors (smr_hip_windows_reset): no more windows than it was created for, the
+        same size; nothing is allocated or freed"""
+        cx, cy = np.ascontiguousarray(cx, np.float64), np.ascontiguousarray(cy, np.float64)
+        sizes = np.ascontiguousarray(np.broadcast_to(np.asarray(size, np.int32), cx.shape))
+        rp = None if r_px is None else np.ascontiguousarray(np.broadcast_to(np.asarray(r_px, np.float64), cx.shape))
+        w = _Windows(len(cx), sizes.ctypes.data, None if rp is None else rp.ctypes.data, cx.ctypes.data, cy.ctypes.data)
+        _chk(lib().smr_hip_windows_reset(self.h, C.byref(w)))
+        self.n_windows, self.window_sizes = len(cx), sizes
 
     def draw_windows(self, style, d_x, d_y, d_way_off, d_ref, n_ways, n_refs, d_fill_col=None, d_border_col=None):
         """the rule (as draw() took it for the chart) into every window of this atlas it reaches (smr_hip_draw_windows)"""

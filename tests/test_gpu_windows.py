@@ -224,3 +224,30 @@ def test_a_long_curved_segment_reaches_a_window_its_nodes_box_misses(hip):
         d = po.chan_diff(got, want); d = d.max(axis=-1) if d.ndim == 3 else d
         assert len(np.unique(got[inside])) > 3, k
         assert (d[inside] > 0).sum() <= 4 and d[inside].max() <= 1, (k, int((d[inside] > 0).sum()), int(d[inside].max()))
+
+
+@pytest.mark.parametrize("bg", [0xfff8e0, 0x30c0d8f0])
+@pytest.mark.parametrize("dpi", [300, 127])
+def test_the_background_of_a_window_is_the_draw_passs_rectangle(hip, bg, dpi, monkeypatch):
+    """the chart's background reaches the windows through a closed form of what the scan converter makes of the chart's
+    rectangle (k_win_bgfill) instead of a draw pass per atlas: both must give the same pixels, in windows inside the chart, over
+    each of its edges and corners, beyond it altogether, with whole-pixel and fractional anchors, opaque and translucent"""
+    sa = hip
+    Wc, Hc, r = 500, 400, 77
+    rng = np.random.default_rng(5)
+    cx = np.concatenate([rng.uniform(-30, Wc + 30, 40), [0.0, 0.0, Wc, Wc, 250.0, 250.5, -100.0, 38.5, Wc - 38.5, 10.25]])
+    cy = np.concatenate([rng.uniform(-30, Hc + 30, 40), [0.0, Hc, 0.0, Hc, 200.0, 38.5, 200.0, Hc - 38.5, 12.75, Hc + 20.0]])
+    at = sa.Canvas.windows(Wc, Hc, dpi, bg, cx, cy, r)
+    got = at.read()
+    at.reset_windows(cx[::-1].copy(), cy[::-1].copy(), r)           # and again through smr_hip_windows_reset, other anchors
+    got_rev = at.read()
+    at.close()
+    monkeypatch.setenv("SMR_HIP_WINBG", "draw")
+    at = sa.Canvas.windows(Wc, Hc, dpi, bg, cx, cy, r)
+    want = at.read()
+    at.close()
+    assert np.array_equal(got, want), int((got != want).sum())
+    assert len(np.unique(want)) > 20                                 # anti-aliased edges are in the picture
+    p = at.window_pitch
+    for k in range(len(cx)):
+        assert np.array_equal(got_rev[(len(cx) - 1 - k) * p:(len(cx) - 1 - k) * p + r], want[k * p:k * p + r]), k
