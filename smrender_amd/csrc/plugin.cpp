@@ -94,6 +94,9 @@ struct plugin_t
    smr_proj_t proj;
    int W = 0, H = 0, dpi = 0, band_y0 = 0, band_h = 0;
    uint32_t bg = 0xffffff;
+   /* the guard box (chart px and degrees): a way with a node beyond it is clipped to it before it goes to the device, whose edge
+    * arithmetic is exact for |coordinates| < 2^20 px only (far_clip below) */
+   double gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0, glon0 = 0, glon1 = 0, glat0 = 0, glat1 = 0;
 };
 static plugin_t P;
 
@@ -155,6 +158,18 @@ static int env_int(const char *name, int def)
 
 /* called from every _ini.  rdata is complete at that time (init_rendering_window runs before
  * the rules are parsed: src/smrender.c:1134 vs :1190). */
+/* geo2pxf's Mercator branch and pxf2geo (src/rdata.c:221-225, :68-72) with the host's libm, for the few ways far_clip touches */
+static void host_geo2pxf(double lon, double lat, double *x, double *y)
+{
+   *x = (lon - P.proj.lon0) * P.proj.w / P.proj.wc;
+   *y = P.proj.h * (0.5 - (asinh(tan(lat * M_PI / 180.0)) - P.proj.lath) / P.proj.lath_len);
+}
+static void host_pxf2geo(double x, double y, double *lon, double *lat)
+{
+   *lon = x * P.proj.wc / P.proj.w + P.proj.lon0;
+   *lat = atan(sinh(P.proj.lath_len * (0.5 - y / P.proj.h) + P.proj.lath)) * 180.0 / M_PI;
+}
+
 static int plugin_setup(void)
 {
    host_resolve();
@@ -187,6 +202,13 @@ static int plugin_setup(void)
    }
    /* the pixel grid of cairo_smr_image_surface_from_bg, src/smrules_cairo.c:344 */
    P.W = (int) round(rd->w); P.H = (int) round(rd->h); P.dpi = rd->dpi;
+   {
+      const double G = 524288.0;        /* 2^19 px around the chart: nothing that far is ever seen, and every coordinate stays below 2^20 */
+      P.gx0 = -G; P.gy0 = -G; P.gx1 = rd->w + G; P.gy1 = rd->h + G;
+      double la, lo;
+      host_pxf2geo(P.gx0, P.gy0, &lo, &la); P.glon0 = lo; P.glat1 = la;
+      host_pxf2geo(P.gx1, P.gy1, &lo, &la); P.glon1 = lo; P.glat0 = la;
+   }
    P.band_y0 = env_int("SMR_HIP_BAND_Y0", 0);
    P.band_h = env_int("SMR_HIP_BAND_H", P.H - P.band_y0);
    uint32_t bg = 0xffffff;
@@ -407,6 +429,8 @@ static int draw_ini(smr_smrule_t *r)
    return 0;
 }
 
+static void far_clip(struct draw_rule_t *d, size_t node0, size_t ref0, bool closed, const smr_osm_obj_t *obj);      /* below, before draw_main */
+
 /* coord_diffp, src/smath.c:34-52: bearing (degrees, 0 = north, clockwise, in [0, 360)) and orthodrome distance (degrees) */
 static void wavy_diff(double slat, double slon, double tlat, double tlon, double *bearing, double *dist)
 {
@@ -550,9 +574,21 @@ static int draw_way(draw_rule_t *d, const smr_osm_way_t *w)
       emitted++;
    }
    if (d->lat.size() > 0x7fffff00u) { plog(SMR_LOG_ERR, "draw: more than 2^31 nodes in one rule"); return -1; }
+   bool far = false;
+   if (d->st.curve == 0)
+      for (size_t k = (size_t) first; k < d->lat.size() && !far; k++)
+         far = !(d->lon[k] >= P.glon0 && d->lon[k] <= P.glon1 && d->lat[k] >= P.glat0 && d->lat[k] <= P.glat1);
+   if (far)
+   {
+      plog(SMR_LOG_DEBUG, "way %lld reaches more than 2^19 px beyond the chart: clipped to that box", (long long) w->obj.id);
+      far_clip(d, (size_t) first, (size_t) d->way_off.back(), closed && emitted >= 4, &w->obj);
+   }
+   else
+   {
    d->way_off.push_back((int64_t) d->ref.size());
    if (d->fill_cs.key) d->fill_col.push_back(color_by_cs(&w->obj, &d->fill_cs));
    if (d->border_cs.key) d->border_col.push_back(color_by_cs(&w->obj, &d->border_cs));
+   }
    if (closed && d->st.directional && fabs(ar) > d->max_area)
    {
       d->max_area = fabs(ar); d->max_cw = ar < 0;
@@ -564,6 +600,98 @@ static int draw_way(draw_rule_t *d, const smr_osm_way_t *w)
       d->min_col = d->fill_cs.key ? d->fill_col.back() : d->fill_cs.col;
    }
    return 0;
+}
+
+/* A way with a node 2^19 px or more beyond the chart (a coastline, a border or a ferry line that runs on for hundreds of
+ * kilometres past a large-scale chart) cannot go to the device as it is: its edge arithmetic is exact below 2^20 px, and
+ * smr_hip_draw refuses the whole rule otherwise.  The reference draws such a way (libcairo's 24.8 holds +-35 M px at 300 dpi,
+ * and clips), so the plugin clips it here, in chart px with the host's libm: a closed way as a polygon against the guard box
+ * (Sutherland-Hodgman: what lies on the box's sides is half a million pixels from the chart), an open way into the runs of
+ * its segments that lie inside the box.  Vertices that stay keep their coordinates; the cuts are new nodes (pxf2geo of the cut,
+ * which geo2pxf takes back to within 1e-9 px).  What is seen on the chart is the same line: a segment that is cut keeps its
+ * direction to within the 24.8 rounding of its new end point.  Straight ways only: a curve's control points depend on the
+ * neighbouring nodes (a far node of a curve=1 way still ends in smr_hip_draw's refusal of the rule). */
+struct far_pt_t { double x, y, lat, lon; bool orig; };
+
+static void far_clip(draw_rule_t *d, size_t node0, size_t ref0, bool closed, const smr_osm_obj_t *obj)
+{
+   std::vector<far_pt_t> v;
+   const size_t nref = d->ref.size() - ref0;
+   for (size_t i = 0; i < nref - (closed ? 1 : 0); i++)
+   {
+      const int32_t k = d->ref[ref0 + i];
+      far_pt_t q; q.lat = d->lat[(size_t) k]; q.lon = d->lon[(size_t) k]; q.orig = true;
+      host_geo2pxf(q.lon, q.lat, &q.x, &q.y);
+      v.push_back(q);
+   }
+   d->lat.resize(node0); d->lon.resize(node0); d->ref.resize(ref0);
+   auto emit = [&](const std::vector<far_pt_t> &u, bool as_closed)
+   {
+      const int32_t first = (int32_t) d->lat.size();
+      for (const far_pt_t &q : u)
+      {
+         double la = q.lat, lo = q.lon;
+         if (!q.orig) host_pxf2geo(q.x, q.y, &lo, &la);
+         d->ref.push_back((int32_t) d->lat.size());
+         d->lat.push_back(la); d->lon.push_back(lo);
+      }
+      if (as_closed) d->ref.push_back(first);
+      d->way_off.push_back((int64_t) d->ref.size());
+      if (d->fill_cs.key) d->fill_col.push_back(color_by_cs(obj, &d->fill_cs));
+      if (d->border_cs.key) d->border_col.push_back(color_by_cs(obj, &d->border_cs));
+   };
+   auto cut = [](const far_pt_t &a, const far_pt_t &b, double t) { far_pt_t q; q.x = a.x + t * (b.x - a.x); q.y = a.y + t * (b.y - a.y); q.lat = q.lon = 0; q.orig = false; return q; };
+   if (closed)
+   {
+      /* one side of the box after the other: inside(p), and where the segment meets the side */
+      for (int side = 0; side < 4 && !v.empty(); side++)
+      {
+         auto val = [&](const far_pt_t &q) { return side == 0 ? q.x - P.gx0 : side == 1 ? P.gx1 - q.x : side == 2 ? q.y - P.gy0 : P.gy1 - q.y; };
+         std::vector<far_pt_t> u;
+         for (size_t i = 0; i < v.size(); i++)
+         {
+            const far_pt_t &a = v[i], &b = v[(i + 1) % v.size()];
+            const double fa = val(a), fb = val(b);
+            if (fa >= 0) u.push_back(a);
+            if ((fa >= 0) != (fb >= 0))
+            {
+               far_pt_t q = cut(a, b, fa / (fa - fb));
+               if (side < 2) q.x = side == 0 ? P.gx0 : P.gx1; else q.y = side == 2 ? P.gy0 : P.gy1;      /* on the side, exactly */
+               u.push_back(q);
+            }
+         }
+         v.swap(u);
+      }
+      if (v.size() >= 3) emit(v, true);
+      return;
+   }
+   std::vector<far_pt_t> run;
+   for (size_t i = 0; i + 1 < v.size(); i++)
+   {
+      /* Liang-Barsky: the part t0 .. t1 of the segment inside the box */
+      const far_pt_t &a = v[i], &b = v[i + 1];
+      double t0 = 0, t1 = 1;
+      const double dx = b.x - a.x, dy = b.y - a.y;
+      const double pp[4] = { -dx, dx, -dy, dy }, qq[4] = { a.x - P.gx0, P.gx1 - a.x, a.y - P.gy0, P.gy1 - a.y };
+      bool out = false;
+      for (int k = 0; k < 4 && !out; k++)
+      {
+         if (pp[k] == 0) { if (qq[k] < 0) out = true; continue; }
+         const double t = qq[k] / pp[k];
+         if (pp[k] < 0) { if (t > t1) out = true; else if (t > t0) t0 = t; }
+         else { if (t < t0) out = true; else if (t < t1) t1 = t; }
+      }
+      if (out || !(t0 < t1)) { if (run.size() >= 2) emit(run, false); run.clear(); continue; }
+      if (t0 > 0 || run.empty())
+      {
+         if (run.size() >= 2) emit(run, false);
+         run.clear();
+         run.push_back(t0 > 0 ? cut(a, b, t0) : a);
+      }
+      run.push_back(t1 < 1 ? cut(a, b, t1) : b);
+      if (t1 < 1) { emit(run, false); run.clear(); }
+   }
+   if (run.size() >= 2) emit(run, false);
 }
 
 static int draw_main(smr_smrule_t *r, smr_osm_obj_t *o)
