@@ -95,7 +95,7 @@ struct plugin_t
    int W = 0, H = 0, dpi = 0, band_y0 = 0, band_h = 0;
    uint32_t bg = 0xffffff;
    /* the guard box (chart px and degrees): a way with a node beyond it is clipped to it before it goes to the device, whose edge
-    * arithmetic is exact for |coordinates| < 2^20 px only (far_clip below) */
+    * arithmetic is exact for edges of less than 139 000 px of height only (far_clip below) */
    double gx0 = 0, gy0 = 0, gx1 = 0, gy1 = 0, glon0 = 0, glon1 = 0, glat0 = 0, glat1 = 0;
 };
 static plugin_t P;
@@ -203,7 +203,8 @@ static int plugin_setup(void)
    /* the pixel grid of cairo_smr_image_surface_from_bg, src/smrules_cairo.c:344 */
    P.W = (int) round(rd->w); P.H = (int) round(rd->h); P.dpi = rd->dpi;
    {
-      const double G = 524288.0;        /* 2^19 px around the chart: nothing that far is ever seen, and every coordinate stays below 2^20 */
+      const double G = 32768.0 - 8.0;   /* a little inside SMR_FAR_PX (smr_dev.h: what the device accepts; a cut comes back from pxf2geo and geo2pxf
+                                           to within 1e-9 px of the box's side): nothing that far is ever seen, and the device's edge arithmetic stays exact */
       P.gx0 = -G; P.gy0 = -G; P.gx1 = rd->w + G; P.gy1 = rd->h + G;
       double la, lo;
       host_pxf2geo(P.gx0, P.gy0, &lo, &la); P.glon0 = lo; P.glat1 = la;
@@ -580,7 +581,7 @@ static int draw_way(draw_rule_t *d, const smr_osm_way_t *w)
          far = !(d->lon[k] >= P.glon0 && d->lon[k] <= P.glon1 && d->lat[k] >= P.glat0 && d->lat[k] <= P.glat1);
    if (far)
    {
-      plog(SMR_LOG_DEBUG, "way %lld reaches more than 2^19 px beyond the chart: clipped to that box", (long long) w->obj.id);
+      plog(SMR_LOG_DEBUG, "way %lld reaches more than 32768 px beyond the chart: clipped to that box", (long long) w->obj.id);
       far_clip(d, (size_t) first, (size_t) d->way_off.back(), closed && emitted >= 4, &w->obj);
    }
    else
@@ -602,11 +603,12 @@ static int draw_way(draw_rule_t *d, const smr_osm_way_t *w)
    return 0;
 }
 
-/* A way with a node 2^19 px or more beyond the chart (a coastline, a border or a ferry line that runs on for hundreds of
- * kilometres past a large-scale chart) cannot go to the device as it is: its edge arithmetic is exact below 2^20 px, and
- * smr_hip_draw refuses the whole rule otherwise.  The reference draws such a way (libcairo's 24.8 holds +-35 M px at 300 dpi,
- * and clips), so the plugin clips it here, in chart px with the host's libm: a closed way as a polygon against the guard box
- * (Sutherland-Hodgman: what lies on the box's sides is half a million pixels from the chart), an open way into the runs of
+/* A way with a node 32 768 px or more beyond the chart (a coastline, a border or a ferry line that runs on for hundreds of
+ * kilometres past a large-scale chart) cannot go to the device as it is: its edge arithmetic is exact for edges of less than
+ * 139 000 px of height, and smr_hip_draw refuses the whole rule otherwise.  The reference draws such a way (libcairo's 24.8
+ * holds +-35 M px at 300 dpi -- though its scan converter's own 64-bit products overflow for an edge of more than ~130 000 px in
+ * both directions, and what it then paints is not the line), so the plugin clips it here, in chart px with the host's libm: a closed way as a polygon against the guard box
+ * (Sutherland-Hodgman: what lies on the box's sides is 32 768 px from the chart), an open way into the runs of
  * its segments that lie inside the box.  Vertices that stay keep their coordinates; the cuts are new nodes (pxf2geo of the cut,
  * which geo2pxf takes back to within 1e-9 px).  What is seen on the chart is the same line: a segment that is cut keeps its
  * direction to within the 24.8 rounding of its new end point.  Straight ways only: a curve's control points depend on the

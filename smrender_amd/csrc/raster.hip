@@ -30,7 +30,7 @@ __device__ __forceinline__ int64_t smr_find_way(const int64_t *__restrict__ way_
 }
 
 __global__ void k_dev_points(const double *__restrict__ x, const double *__restrict__ y,
-                             const int32_t *__restrict__ ref, int64_t n_refs, int64_t n_nodes, int dpi, int32_t sfix,
+                             const int32_t *__restrict__ ref, int64_t n_refs, int64_t n_nodes, int dpi, int32_t sfix, double far_x, double far_y,
                              const int64_t *__restrict__ way_off, int64_t n_ways,
                              int2 *__restrict__ pts, int32_t *__restrict__ refway, uint32_t *__restrict__ status,
                              const int32_t *__restrict__ node_win, const int2 *__restrict__ win_shift)
@@ -42,9 +42,10 @@ __global__ void k_dev_points(const double *__restrict__ x, const double *__restr
       int64_t node = ref ? (int64_t) ref[g] : g;
       /* a ref outside the node arrays: reported (SMR_E_INVAL before anything is drawn), and nothing is read out of bounds */
       if (node < 0 || node >= n_nodes) { atomicOr(status, SMR_ST_BADBATCH); node = 0; }
-      /* the edge arithmetic is exact while |coordinates| < 2^20 px (smr_edge_cell); a node further off the chart (or not a
-       * number) is reported instead of wrapping around in the 24.8 conversion below */
-      if (!(fabs(x[node]) < 1048576.0) || !(fabs(y[node]) < 1048576.0)) atomicOr(status, SMR_ST_FARAWAY);
+      /* the edge arithmetic is exact while an edge's 60 * dy (24.8) fits 31 bits and its numerators 63 (smr_orient, smr_edge_cell):
+       * 139 000 px of height.  A node more than SMR_FAR_PX beyond the chart (or not a number) is reported instead of wrapping
+       * around; nothing out there is ever seen, so a caller clips such ways first (the plugin does: far_clip) */
+      if (!(x[node] >= -SMR_FAR_PX && x[node] <= far_x) || !(y[node] >= -SMR_FAR_PX && y[node] <= far_y)) atomicOr(status, SMR_ST_FARAWAY);
       double xp = x[node] * 72 / dpi, yp = y[node] * 72 / dpi;      /* rdata_px_unit(.., U_PT) */
       int32_t fx = (int32_t) rint(xp * 256.0), fy = (int32_t) rint(yp * 256.0);
       int2 p;
@@ -4373,7 +4374,9 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    int32_t sfix = (int32_t) nearbyint((double) c->dpi / 72 * 256.0);
    {
       unsigned nb = blocks(n_refs, TB); if (nb > 65536u * 4) nb = 65536u * 4;
-      k_dev_points<<<nb, TB, 0, s>>>(b->d_x, b->d_y, b->d_ref, n_refs, b->n_nodes, c->dpi, sfix, b->d_way_off, n_ways, pts, refway, &small[2],
+      /* (a window of an atlas holds chart coordinates: its nodes are far from the atlas's own rows, the shift takes them there) */
+      const double far_x = (double) (c->win_n ? c->chart_w : c->W) + SMR_FAR_PX, far_y = (double) (c->win_n ? c->chart_h : c->H) + SMR_FAR_PX;
+      k_dev_points<<<nb, TB, 0, s>>>(b->d_x, b->d_y, b->d_ref, n_refs, b->n_nodes, c->dpi, sfix, far_x, far_y, b->d_way_off, n_ways, pts, refway, &small[2],
                                      wc ? wc->node_win : nullptr, wc ? wc->win_shift : nullptr);
    }
    k_way_info<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, b->d_ref, n_ways, n_refs, st->border_used, st->fill_used,
@@ -4387,7 +4390,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       return smr_fail(SMR_E_INVAL, "draw: bad batch: d_way_off must start at 0, ascend and end at n_refs (%lld), every ref must lie in [0, n_nodes = %lld)",
                       (long long) b->n_refs, (long long) b->n_nodes);
    if (h_small[2] & SMR_ST_FARAWAY)
-      return smr_fail(SMR_E_CAPACITY, "draw: a node of the batch lies 2^20 px or more from the chart's origin (or is not a number); the rule was not drawn");
+      return smr_fail(SMR_E_CAPACITY, "draw: a node of the batch lies more than %d px beyond the chart (or is not a number); the rule was not drawn: clip such ways first", (int) SMR_FAR_PX);
 
    double hw_nofill = mm2wu(st->border_width_mm, c->dpi) / 2;
    double hw_open = (mm2wu(2 * st->border_width_mm, c->dpi) + mm2wu(st->fill_width_mm, c->dpi)) / 2;

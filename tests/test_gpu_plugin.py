@@ -902,3 +902,50 @@ def test_cap_tags_from_the_references_own_cutouts(chart_replay):
     # and the crop convention gives other tags for some of them: the two paths really differ on this chart
     crop, _ = oracle_caption_tags(plugin_canvas(sa), names, px, py, 1.6, 0x203040, 1.0)
     assert sum(crop[k][0] != want[k][0] for k in range(n)) >= 1
+
+
+def test_a_way_with_a_node_far_off_the_chart_is_clipped_not_refused(chart):
+    """a coastline or ferry line that runs on for a thousand kilometres past a large-scale chart: libsmr_hip's edge arithmetic is
+    exact for edges of less than 139 000 px of height, and smr_hip_draw refuses a batch with a node more than 32 768 px beyond
+    the chart; the reference draws the way.  The plugin clips such ways to that box before they reach the device (far_clip):
+    the rule is drawn, and what is seen of the far ways is the line they are.  The expectation is the oracle's picture of the
+    SAME lines with their far ends pulled in to 20 000 px (along the line: the visible part is the same): with the far ends
+    where they are libcairo's own scan converter overflows its 64-bit products (an edge of more than ~130 000 px in both
+    directions) and paints a horizontal line instead of the sloped one, which the oracle, restating that arithmetic, does too."""
+    sa, proj = chart
+    from smrender_amd import synth
+    # a closed way with one corner 1.5 M px east, an open way that crosses the chart and ends 2 M px north-west, near ways around them
+    fx = np.array([100.0, 300.0, 1.5e6, 100.0]); fy = np.array([50.0, 250.0, 150.0, 50.0])
+    ox_ = np.array([350.0, 200.0, 60.0, -2.0e6]); oy_ = np.array([280.0, 200.0, 120.0, -1.2e6])
+    near = po.synth_ways(30, W, H, seed=5)
+    ways_px = [(fx, fy, True), (ox_, oy_, False)]
+    base = _next_id[0]; _next_id[0] += 1000
+    wids = []
+    k = base
+    for x, y, closed in ways_px:
+        n = len(x) - 1 if closed else len(x)
+        lat, lon = synth.px_to_geo(proj, x[:n], y[:n])
+        ids = np.arange(k, k + n); k += n
+        hs.add_nodes(ids, lat, lon)
+        hs.add_way(k, np.append(ids, ids[0]) if closed else ids); wids.append(k); k += 1
+    nwids, noways = load_ways(sa, proj, near)
+    wids = wids + list(nwids)
+    assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.2", wids) == 0, sa.lib().smr_hip_last_error()
+    got = plugin_canvas(sa)
+    st = po.Style(1, 1, 0x4080c0, 0x000000, 0, 0.2, 0)
+
+    def pulled(ax, ay, bx, by, dist=20000.0):        # the point of the segment a -> b that lies `dist` px from a
+        t = dist / np.hypot(bx - ax, by - ay)
+        return ax + t * (bx - ax), ay + t * (by - ay)
+    # the triangle's far corner becomes two points, one on each of its sides (the same two lines across the chart)
+    p1, p2 = pulled(300.0, 250.0, 1.5e6, 150.0), pulled(100.0, 50.0, 1.5e6, 150.0)
+    q = pulled(60.0, 120.0, -2.0e6, -1.2e6)
+    far = [(np.array([100.0, 300.0, p1[0], p2[0], 100.0]), np.array([50.0, 250.0, p1[1], p2[1], 50.0]), True),
+           (np.array([350.0, 200.0, 60.0, q[0]]), np.array([280.0, 200.0, 120.0, q[1]]), False)]
+    want = po.oracle_scene([(st, far + noways)], DPI, W, H, 0xfff8e0)
+    d = po.chan_diff(got, want)
+    assert (got != 0xfffff8e0).sum() > 20000                       # the far triangle covers a good part of the chart
+    if os.environ.get("SMR_TEST_DUMP") and (d > 0).sum() > 40:
+        np.savez(os.path.join(os.environ["SMR_TEST_DUMP"], "far.npz"), got=got, want=want)
+    # the cuts are new end points: the lines keep their direction to within the 24.8 rounding of those (an AA level here and there)
+    assert (d > 0).sum() <= 40 and d.max() <= 8, (int((d > 0).sum()), int(d.max()))

@@ -625,7 +625,7 @@ def test_directional_rule_of_knot_ways(hip):
 
 def test_bad_batches_are_refused_before_anything_is_drawn(hip):
     """smr_hip_draw checks the device-side batch itself (the way table starts at 0, ascends, ends at n_refs; every ref inside
-    the node arrays; no node 2^20 px or more away, where the 24.8 edge arithmetic would wrap): SMR_E_INVAL / SMR_E_CAPACITY,
+    the node arrays; no node more than 32 768 px beyond the chart, where an edge's 60 * dy no longer fits the 31 bits of the 24.8 edge arithmetic): SMR_E_INVAL / SMR_E_CAPACITY,
     the canvas untouched, and the next good rule draws as if nothing had happened."""
     sa = hip
     W, H = 96, 80
