@@ -51,6 +51,16 @@ def make_band(args, band, n_bands):
     return xs, ys, offs, refs
 
 
+def caption_anchors(n, rank, W, H, band_y0):
+    """C4's anchors of one rank: a jittered grid over its band, in chart px"""
+    rng = np.random.default_rng(4321 + rank)
+    side = int(np.ceil(np.sqrt(n)))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side))
+    cx = ((gx.ravel()[:n] + rng.uniform(0.2, 0.8, n)) * W / side)
+    cy = ((gy.ravel()[:n] + rng.uniform(0.2, 0.8, n)) * H / side) + band_y0
+    return cx, cy
+
+
 def measured_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/<round>_hbm_traffic.json,
     collected by tools/profile_round.sh in separate rocprofv3 --pmc runs of this same command and
@@ -222,6 +232,9 @@ def main():
     ap.add_argument("--strong", action="store_true", help="strong scaling: ONE chart of --strong-size^2 px (north_star's 32k target: 1 M ways / 10 M nodes) "
                                                           "split into one row band per GPU; value = the chart's Mpx / max-over-ranks time")
     ap.add_argument("--strong-size", type=int, default=32768)
+    ap.add_argument("--halo", choices=("auto", "host"), default="auto", help="N>1 caption scan: 'host' stages the halo strips through host memory "
+                                                                            "instead of RCCL on views of the canvas")
+    ap.add_argument("--dump", default=None, help="directory: every rank writes band_<rank>.npz (its band's pixels, its captions' anchors and angles)")
     args = ap.parse_args()
 
     from smrender_amd import dist as smrdist
@@ -297,20 +310,23 @@ def main():
         halo_path = None
         if world > 1:
             halo = r_px // 2 + 2
-            try:
-                # strips straight from the canvas band in HBM over RCCL into device buffers (no host round trip)
-                grp.exchange_halo_device(cv, halo)
-                halo_path = "device"
-            except Exception as e:      # noqa: BLE001  (first contact with a real multi-GPU node: fall back, say so)
-                print(f"rank {rank}: device halo exchange failed ({e}); host-staged exchange", file=sys.stderr)
+            # strips straight from the canvas band in HBM over RCCL into device buffers (no host round trip); the host-staged
+            # exchange is the path of a gloo group (SMR_DIST_BACKEND=gloo: ranks that share a GPU, tests/test_gpu_a_two_ranks.py)
+            # and the fallback if the device exchange fails on a node
+            halo_path = "device" if grp.device.type == "cuda" and args.halo != "host" else "host"
+            if halo_path == "device":
+                try:
+                    grp.exchange_halo_device(cv, halo)
+                except Exception as e:      # noqa: BLE001
+                    print(f"rank {rank}: device halo exchange failed ({e}); host-staged exchange", file=sys.stderr)
+                    halo_path = "host (device exchange failed)"
+            # every rank must take the same path: the exchanges are collective
+            if grp.sum(0.0 if halo_path == "device" else 1.0) > 0 and halo_path == "device":
+                halo_path = "host (device exchange failed on another rank)"
+            if halo_path != "device":
                 above, below = grp.exchange_halo(cv.read(0, 0, W, min(halo, H)), cv.read(0, max(0, H - halo), W, min(halo, H)), halo)
                 cv.set_halo(above, below)
-                halo_path = "host"
-        rng = np.random.default_rng(4321 + rank)
-        side = int(np.ceil(np.sqrt(args.captions)))
-        gx, gy = np.meshgrid(np.arange(side), np.arange(side))
-        cx = ((gx.ravel()[:args.captions] + rng.uniform(0.2, 0.8, args.captions)) * W / side)
-        cy = ((gy.ravel()[:args.captions] + rng.uniform(0.2, 0.8, args.captions)) * H / side) + band_y0
+        cx, cy = caption_anchors(args.captions, rank, W, H, band_y0)
         d_cx, d_cy = sa.DeviceArray.from_numpy(cx), sa.DeviceArray.from_numpy(cy)
         d_ang = sa.DeviceArray((args.captions,), np.float64)
         cv.caprot(d_cx, d_cy, args.captions, fg_w, fg_h, fg_x, 0x000000, 0.0, 1.0, d_ang)      # warm-up
@@ -356,6 +372,11 @@ def main():
                              "captions": args.captions, "atlases": (args.captions + per - 1) // per, "seconds": round(t_rep, 3),
                              "captions_per_s": round(args.captions / t_rep, 1),
                              "tags_differing_from_the_crop_scan": int((tag(ang) != tag(ang2)).sum())}
+
+    if args.dump:
+        os.makedirs(args.dump, exist_ok=True)
+        np.savez(os.path.join(args.dump, f"band_{rank}.npz"), y0=band_y0, h=H, pixels=cv.read(), n_ways=n_ways,
+                 cx=cx if cap is not None else np.zeros(0), cy=cy if cap is not None else np.zeros(0), angles=ang if cap is not None else np.zeros(0))
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3

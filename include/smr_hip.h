@@ -278,8 +278,9 @@ typedef struct
  * [n * num_steps] raw per-angle differences (dv_diff before weighting). */
 int smr_hip_caprot(smr_canvas_t *c, const smr_cap_batch_t *b, double *d_angle, double *d_dv);
 int smr_hip_caprot_steps(int fg_w, int fg_h, int dpi, int *num_steps, int *r_px);
-/* smr_hip_caprot for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc.  No counterpart in the reference.  Same arguments, same kernel, same results; the scan's only scratch
+/* smr_hip_caprot for callers that cannot allocate: tight serving loops, harnesses that forbid hipMalloc.  (It is NOT safe under
+ * stream capture: it synchronises the library's stream and copies its tables from pageable host memory.)  No counterpart in the
+ * reference.  Same arguments, same kernel, same results; the scan's only scratch
  * (the per-batch tables: one rotation matrix, angle and weight factor per trial angle) sits in a static device array of
  * SMR_CAPROT_NOALLOC_MAX_STEPS entries (48 KiB on every GPU the library was initialised on, until the process ends) instead
  * of the canvas's grow-only work buffers, so the call makes no hipMalloc / hipFree whatever it is given.  More trial angles

@@ -522,8 +522,8 @@ extern "C" int smr_hip_caprot(smr_canvas_t *c, const smr_cap_batch_t *b, double 
 }
 
 /* ------------------------------------------------------------------------------------ */
-/* smr_hip_caprot_noalloc: the same scan for callers that cannot allocate (code under HIP  */
-/* graph capture, tight serving loops, harnesses that forbid hipMalloc).  The scan's only   */
+/* smr_hip_caprot_noalloc: the same scan for callers that cannot allocate (tight serving   */
+/* loops, harnesses that forbid hipMalloc; not capture-safe: it syncs).  The scan's only    */
 /* scratch, the per-batch tables (rotation matrices, angles, weight factors), lives in a    */
 /* file-scope device array instead of the canvas's grow-only buffers; the host copies are   */
 /* file-scope too.  Each GPU holds its own copy of the array at its own address: the        */

@@ -84,6 +84,9 @@ static void plog(int level, const char *fmt, ...)
    else fprintf(stderr, "libsmr_hip[%d]: %s\n", level, buf);
 }
 
+/* angle=majoraxis is this value in the reference's struct actCaption (src/smrender_dev.h:76, parse_auto_rot src/smrparse.c:1064-1066) */
+#define SMR_MAJORAXIS 720.0
+
 /* ---------------------------------------------------------------------------------------- */
 /* the chart: device, projection, canvas (one per process)                                  */
 /* ---------------------------------------------------------------------------------------- */
@@ -779,13 +782,14 @@ static int draw_fini(smr_smrule_t *r)
          b.d_way_fill_col = (const uint32_t *) fc;
          b.d_way_border_col = (const uint32_t *) bc;
          ok = smr_hip_draw(P.canvas, &d->st, &b) == SMR_OK;
-         if (keep)
+         if (keep && ok)
          {
+            /* only what is on the chart may appear in the cut-outs: a rule whose draw failed is not replayed */
             kept_.emplace_back();
-            kept_.back().st = d->st; kept_.back().b = b;        /* freed by kept_release, drawn or not */
+            kept_.back().st = d->st; kept_.back().b = b;        /* freed by kept_release */
          }
       }
-      else if (keep) { void *q[6] = { x, y, off, ref, fc, bc }; for (void *v : q) if (v) smr_hip_free(v); }
+      if (keep && !ok) { void *q[6] = { x, y, off, ref, fc, bc }; for (void *v : q) if (v) smr_hip_free(v); }
       if (ok) ok = smr_hip_sync() == SMR_OK;
       if (!ok) { plog(SMR_LOG_ERR, "draw: %s", smr_hip_last_error()); ret = -1; }
       else if (smr_hip_draw_status() & SMR_DRAW_DEGRADED_ROWS)
@@ -977,12 +981,13 @@ static int cap_ini(smr_smrule_t *r)
    if ((s = H.get_param("angle", &angle, r->act)) != nullptr)
    {
       if (!strcasecmp(s, "auto")) { autorot = true; angle = 0; }
-      else if (!strcasecmp(s, "majoraxis"))
-      {
-         plog(SMR_LOG_ERR, "cap: angle=majoraxis is not implemented on the GPU path; use the built-in cap");
-         return 1;
-      }
+      else if (!strcasecmp(s, "majoraxis")) angle = SMR_MAJORAXIS;          /* a closed way's caption runs along its longest diagonal (cap_way) */
       else angle = fmod(angle, 360.0);
+   }
+   if (angle == SMR_MAJORAXIS && !H.get_object)
+   {
+      plog(SMR_LOG_ERR, "cap: angle=majoraxis needs the host symbol get_object");
+      return -1;
    }
    const char *akey = H.get_param("anglekey", nullptr, r->act);
    if (akey != nullptr && autorot)
@@ -1078,8 +1083,58 @@ static int cap_ini(smr_smrule_t *r)
 
 static void strupper(char *s) { for (; *s; s++) if (*s >= 'a' && *s <= 'z') *s -= 32; }
 
+/* fmod2, src/smath.c:78-82 */
+static double fmod2(double a, double n) { a = fmod(a, n); return a < 0 ? a + n : a; }
+
+/* coord_diffp, src/smath.c:34-52: orthodrome distance and bearing (degrees, 0 = north, clockwise) from src to dst */
+static void coord_diff_deg(double slat, double slon, double dlat_, double dlon_, double *dist, double *bearing)
+{
+   const double r = M_PI / 180.0;
+   const double dlat = dlat_ - slat, dlon = (dlon_ - slon) * cos((slat + dlat_) / 2.0 * r);
+   *bearing = fmod2(atan2(dlon, dlat) / r, 360.0);
+   *dist = acos(sin(slat * r) * sin(dlat_ * r) + cos(slat * r) * cos(dlat_ * r) * cos((dlon_ - slon) * r)) / r;
+}
+
+/* farthest_node, src/smrules_cairo.c:1151-1180: the index of the way's node farthest from (lat, lon); -1 if none is farther than 0 */
+static int farthest_node(double lat, double lon, const smr_osm_way_t *w, double *dist, double *bearing)
+{
+   int ref = -1;
+   *dist = 0; *bearing = 0;
+   for (int i = 0; i < w->ref_cnt; i++)
+   {
+      const smr_osm_node_t *n = (const smr_osm_node_t *) H.get_object(SMR_OSM_NODE, w->ref[i]);
+      if (n == nullptr) continue;
+      double d, b;
+      coord_diff_deg(lat, lon, n->lat, n->lon, &d, &b);
+      if (d > *dist) { *dist = d; *bearing = b; ref = i; }
+   }
+   return ref;
+}
+
+/* area_axis, src/smrules_cairo.c:1183-1240: walks from node 0 to the node farthest from it, from there to the node farthest
+ * from that one, ... until the distance stops growing; *a = the bearing of the longest hop found */
+static int area_axis(const smr_osm_way_t *w, double *a)
+{
+   if (w->ref_cnt < 2) return -1;
+   double fdist = 0, fbearing = 0;
+   int last = 0;
+   for (int guard = 0; guard <= w->ref_cnt; guard++)        /* the distance grows strictly with every hop: at most ref_cnt of them */
+   {
+      const smr_osm_node_t *n = (const smr_osm_node_t *) H.get_object(SMR_OSM_NODE, w->ref[last]);
+      if (n == nullptr) return -1;                          /* the reference spins here for ever */
+      double dist, bearing;
+      const int nref = farthest_node(n->lat, n->lon, w, &dist, &bearing);
+      if (nref == 0) break;
+      if (nref == -1) return -1;
+      if (dist <= fdist) break;
+      last = nref; fdist = dist; fbearing = bearing;
+   }
+   *a = fbearing;
+   return 0;
+}
+
 /* the part of cap_coord (:2202-2281) that runs before find_angle: extents -> plane geometry */
-static int cap_collect(cap_rule_t *cap, double size_mm, double lat, double lon, const smr_bstring_t *str, smr_osm_obj_t *o)
+static int cap_collect(cap_rule_t *cap, double size_mm, double angle_deg, double lat, double lon, const smr_bstring_t *str, smr_osm_obj_t *o)
 {
    if (size_mm == 0.0) return 0;
    std::string buf(str->buf, (size_t) str->len);
@@ -1116,7 +1171,7 @@ static int cap_collect(cap_rule_t *cap, double size_mm, double lat, double lon, 
       int m;
       if (cap->akey != nullptr && (m = H.match_attr(o, cap->akey, nullptr)) >= 0)
          it.fixed_a = strtod(std::string(o->otag[m].v.buf, (size_t) o->otag[m].v.len).c_str(), nullptr) * M_PI / 180.0;
-      it.fixed_a += (360 - cap->angle) * M_PI / 180.0;
+      it.fixed_a += (360 - angle_deg) * M_PI / 180.0;
    }
    it.col = color_by_cs(o, &cap->cs);
    it.tw = tx.width + tx.x_bearing; it.hgt = fmax(tx.height, fe.ascent + fe.descent); it.ascent = fe.ascent;
@@ -1140,7 +1195,7 @@ static int cap_main(smr_smrule_t *r, smr_osm_obj_t *o)
    if (o->type == SMR_OSM_NODE)
    {
       const smr_osm_node_t *nd = (const smr_osm_node_t *) o;
-      return cap_collect(cap, cap->size, nd->lat, nd->lon, &o->otag[n].v, o);
+      return cap_collect(cap, cap->size, cap->angle, nd->lat, nd->lon, &o->otag[n].v, o);
    }
    if (o->type == SMR_OSM_WAY)
    {
@@ -1160,7 +1215,16 @@ static int cap_main(smr_smrule_t *r, smr_osm_obj_t *o)
          if (cap->min_auto_size != 0.0 && size < cap->min_auto_size)
             size = area_mm2 < cap->min_area_size ? 0.0 : cap->min_auto_size;
       }
-      return cap_collect(cap, size, c.lat, c.lon, &o->otag[n].v, o);
+      double angle = cap->angle;
+      if (angle == SMR_MAJORAXIS)
+      {
+         /* :2431-2441: the bearing of the way's longest diagonal as a math angle, turned to read upright.  A way whose axis
+          * cannot be found keeps 720 here, as the reference's tmp_cap.angle does, and so ends at 90 */
+         (void) area_axis(w, &angle);
+         angle = fmod2(90 - angle, 360);
+         if (angle > 90 && angle <= 270) angle -= 180.0;
+      }
+      return cap_collect(cap, size, angle, c.lat, c.lon, &o->otag[n].v, o);
    }
    return 1;
 }
@@ -1832,12 +1896,8 @@ static int img_ini(smr_smrule_t *r)
          g->weight = fmin(fmax(g->weight, -1.0), 1.0);
          (void) H.get_param("phase", &g->phase, r->act);
       }
-      else if (!strcasecmp("majoraxis", val))
-      {
-         plog(SMR_LOG_ERR, "img: angle=majoraxis is not implemented on the GPU path; use the built-in img");
-         CR.surface_destroy(g->img); delete g;
-         return 1;
-      }
+      /* only cap_way looks at MAJORAXIS (:2431): img_place turns by 360 - 720 degrees, a full turn */
+      else if (!strcasecmp("majoraxis", val)) g->angle = SMR_MAJORAXIS;
       else g->angle = fmod(g->angle, 360.0);
    }
    g->akey = H.get_param("anglekey", nullptr, r->act);

@@ -3942,7 +3942,11 @@ extern "C" int smr_hip_canvas_clone(smr_canvas_t *c, smr_canvas_t **out)
    n->own_y0 = c->own_y0; n->own_h = c->own_h;
    size_t bytes = (size_t) c->W * c->band_h * 4;
    if (hipMalloc(&n->pix, bytes) != hipSuccess) { delete n; return smr_fail(SMR_E_NOMEM, "canvas_clone: hipMalloc %zu bytes", bytes); }
-   SMR_HIP(hipMemcpyAsync(n->pix, c->pix, bytes, hipMemcpyDeviceToDevice, smr_g.stream));
+   if (hipMemcpyAsync(n->pix, c->pix, bytes, hipMemcpyDeviceToDevice, smr_g.stream) != hipSuccess)
+   {
+      smr_hip_canvas_destroy(n);
+      return smr_fail(SMR_E_HIP, "canvas_clone: copy of %zu bytes failed", bytes);
+   }
    *out = n;
    return SMR_OK;
 }
@@ -4065,9 +4069,15 @@ extern "C" int smr_hip_canvas_extend(smr_canvas_t *c, smr_canvas_t **out)
    const size_t row = (size_t) c->W * 4;
    if (hipMalloc(&n->pix, row * n->band_h) != hipSuccess) { delete n; return smr_fail(SMR_E_NOMEM, "canvas_extend: hipMalloc %zu bytes", row * n->band_h); }
    hipStream_t s = smr_g.stream;
-   if (c->n_above) SMR_HIP(hipMemcpyAsync(n->pix, c->halo_above, row * c->n_above, hipMemcpyDeviceToDevice, s));
-   SMR_HIP(hipMemcpyAsync(n->pix + (size_t) c->n_above * c->W, c->pix, row * c->band_h, hipMemcpyDeviceToDevice, s));
-   if (c->n_below) SMR_HIP(hipMemcpyAsync(n->pix + (size_t) (c->n_above + c->band_h) * c->W, c->halo_below, row * c->n_below, hipMemcpyDeviceToDevice, s));
+   bool ok = true;
+   if (c->n_above) ok = hipMemcpyAsync(n->pix, c->halo_above, row * c->n_above, hipMemcpyDeviceToDevice, s) == hipSuccess;
+   ok = ok && hipMemcpyAsync(n->pix + (size_t) c->n_above * c->W, c->pix, row * c->band_h, hipMemcpyDeviceToDevice, s) == hipSuccess;
+   if (ok && c->n_below) ok = hipMemcpyAsync(n->pix + (size_t) (c->n_above + c->band_h) * c->W, c->halo_below, row * c->n_below, hipMemcpyDeviceToDevice, s) == hipSuccess;
+   if (!ok)
+   {
+      smr_hip_canvas_destroy(n);
+      return smr_fail(SMR_E_HIP, "canvas_extend: copy of the band and its halo strips failed");
+   }
    *out = n;
    return SMR_OK;
 }

@@ -244,11 +244,13 @@ class Group:
         counts[self.rank, 0], counts[self.rank, 1] = top_rows.shape[0], bottom_rows.shape[0]
         dist.all_reduce(counts)
         ops, bufs = [], {}
-        if self.rank > 0 and (int(counts[self.rank - 1, 1]) > 0 or top_rows.shape[0] > 0):
+        # (both sides of a boundary decide alike, as in exchange_halo_device: a pair exchanges only if both have rows; a rank
+        # with an empty band, bands(), posts nothing and is sent nothing)
+        if self.rank > 0 and int(counts[self.rank - 1, 1]) > 0 and top_rows.shape[0] > 0:
             bufs["above"] = torch.empty((int(counts[self.rank - 1, 1]), W), dtype=torch.int32, device=self.device)
             ops.append(dist.P2POp(dist.isend, to_t(top_rows), self.rank - 1))
             ops.append(dist.P2POp(dist.irecv, bufs["above"], self.rank - 1))
-        if self.rank < self.world - 1 and (int(counts[self.rank + 1, 0]) > 0 or bottom_rows.shape[0] > 0):
+        if self.rank < self.world - 1 and int(counts[self.rank + 1, 0]) > 0 and bottom_rows.shape[0] > 0:
             bufs["below"] = torch.empty((int(counts[self.rank + 1, 0]), W), dtype=torch.int32, device=self.device)
             ops.append(dist.P2POp(dist.isend, to_t(bottom_rows), self.rank + 1))
             ops.append(dist.P2POp(dist.irecv, bufs["below"], self.rank + 1))

@@ -208,6 +208,35 @@ print("rank", g.rank, "ok")
 '''
 
 
+EMPTY_BAND_WORKER = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.environ["SMR_ROOT"])
+from smrender_amd import dist
+g = dist.Group("gloo")
+W, H, halo = 64, 12, 6
+full = (np.arange(W * H, dtype=np.uint32) * 2654435761 % 16777216).reshape(H, W)
+bands = dist.bands(H, g.world)                      # 4 ranks, 3 tile rows: the last rank's band is empty
+assert bands[-1][1] == 0 and all(h > 0 for _, h in bands[:-1])
+y0, h = bands[g.rank]
+mine = full[y0:y0 + h]
+above, below = g.exchange_halo(mine[:halo], mine[max(0, h - halo):], halo)
+if h == 0:
+    assert above is None and below is None          # nothing posted to or by a rank without rows
+else:
+    lo, hi = bands[g.rank - 1] if g.rank > 0 else (0, 0), bands[g.rank + 1] if g.rank + 1 < g.world else (0, 0)
+    if lo[1] > 0:
+        assert np.array_equal(above, full[max(lo[0], y0 - halo):y0])
+    else:
+        assert above is None
+    if hi[1] > 0:
+        assert np.array_equal(below, full[y0 + h:min(y0 + h + halo, hi[0] + hi[1])])
+    else:
+        assert below is None
+g.barrier(); g.close()
+print("rank", g.rank, "ok")
+'''
+
+
 def _run(tmp_path, text, world, port, extra_env=None):
     script = tmp_path / "worker.py"
     script.write_text(text)
@@ -237,6 +266,13 @@ def test_captions_on_re_rasterised_cutouts_need_no_halo(tmp_path):
     anchored in its band, and the levels' angles are summed over the ranks as before; 3 ranks give the angles of the
     one-after-the-other scan with every way of the chart"""
     _run(tmp_path, WIN_WORKER, 3, 29523, {"SMR_TEST_H": "300"})
+
+
+def test_halo_exchange_with_an_empty_band(tmp_path):
+    """more ranks than tile rows: the last rank has no rows, posts nothing and is sent nothing (Group.exchange_halo pairs
+    neighbours only if both have rows, like exchange_halo_device); the others get their neighbours' strips, shorter than
+    the halo where a band is"""
+    _run(tmp_path, EMPTY_BAND_WORKER, 4, 29525)
 
 
 def test_two_gloo_ranks(tmp_path):

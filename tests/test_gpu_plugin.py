@@ -821,6 +821,109 @@ def test_cap_with_given_angles_and_background_boxes(chart):
     assert (plugin_canvas(sa) != mid).sum() > 1000
 
 
+def _area_axis_angle(lat, lon):
+    """cap_way's angle=majoraxis (src/smrules_cairo.c:2431-2441) over area_axis (:1183-1240), farthest_node (:1151-1180) and
+    coord_diffp (src/smath.c:34-52), restated for the test: hop to the farthest node until the distance stops growing; the
+    last hop's bearing as a math angle, turned to read upright."""
+    def diff(i, j):
+        dlat = lat[j] - lat[i]
+        dlon = (lon[j] - lon[i]) * np.cos(np.radians((lat[i] + lat[j]) / 2))
+        b = np.fmod(np.degrees(np.arctan2(dlon, dlat)), 360.0)
+        b = b + 360 if b < 0 else b
+        c = np.sin(np.radians(lat[i])) * np.sin(np.radians(lat[j])) + np.cos(np.radians(lat[i])) * np.cos(np.radians(lat[j])) * np.cos(np.radians(lon[j] - lon[i]))
+        return np.degrees(np.arccos(c)), b
+    last, fd, fb = 0, 0.0, 0.0
+    ang = 720.0
+    while True:
+        best, bd, bb = -1, 0.0, 0.0
+        for j in range(len(lat)):
+            d, b = diff(last, j)
+            if d > bd:
+                best, bd, bb = j, d, b
+        if best == -1:
+            break
+        if best == 0 or bd <= fd:
+            ang = fb
+            break
+        last, fd, fb = best, bd, bb
+    a = np.fmod(90 - ang, 360.0)
+    a = a + 360 if a < 0 else a
+    return a - 180.0 if 90 < a <= 270 else a
+
+
+def test_cap_along_the_major_axis_of_closed_ways(chart):
+    """cap angle=majoraxis (parse_auto_rot src/smrparse.c:1064-1066, cap_way :2431-2441): the caption of a closed way runs along
+    its longest diagonal.  Long thin areas at known headings; the picture is compared with libcairo drawing the same captions at
+    the angles of the restated area_axis, and those angles with the headings the areas were made at."""
+    sa, proj = chart
+    from smrender_amd import synth
+    from golden_io import within
+    cd = po.cairo()
+    if cd is None:
+        pytest.skip("libcairo not loadable")
+    arrs = po.synth_ways(40, W, H, seed=87)
+    wids, oways = load_ways(sa, proj, arrs)
+    assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", wids) == 0
+    rng = np.random.default_rng(77)
+    n, m = 6, 16
+    heads = [10.0, 75.0, 120.0, 200.0, 265.0, 330.0]           # math angles of the long axis, degrees, y up
+    cap_ids, names, cen, want_a = [], [], [], []
+    for k in range(n):
+        ccx, ccy = 90 + (k % 3) * (W - 180) / 2, 90 + (k // 3) * (H - 180)
+        t = np.arange(m) * 2 * np.pi / m + 0.1
+        ex, ey = 60 * np.cos(t), 12 * np.sin(t)
+        h = np.radians(heads[k])
+        x, y = ccx + ex * np.cos(h) - ey * np.sin(h), ccy - (ex * np.sin(h) + ey * np.cos(h))
+        lat, lon = synth.px_to_geo(proj, x, y)
+        base = _next_id[0]; _next_id[0] += m + 2
+        ids = base + np.arange(m)
+        hs.add_nodes(ids, lat, lon)
+        hs.add_way(base + m, np.append(ids, ids[0]), f"name=Axis {k}")
+        cap_ids.append(base + m); names.append(f"Axis {k}")
+        clat, clon, _ = hs.poly_area(base + m)
+        cen.append((clat, clon))
+        a = _area_axis_angle(np.append(lat, lat[0]), np.append(lon, lon[0]))
+        want_a.append(a)
+        up = (heads[k] + 90) % 180 - 90                          # the heading folded into (-90, 90]
+        assert abs((a - up + 90) % 180 - 90) < 8, (k, a, up)     # 16 nodes: the diagonal is within a node's spacing of the axis
+    size_mm, col = 2.0, 0x000000
+    params = f"key=name;size={size_mm};angle=majoraxis;color=black;halign=center;font=serif"
+    before = plugin_canvas(sa)
+    assert hs.apply_rule(sa.lib(), "cap", hs.OSM_WAY, params, cap_ids) == 0, sa.lib().smr_hip_last_error()
+    got = plugin_canvas(sa)
+    assert hs.get_tag(hs.OSM_WAY, cap_ids[0], "name:autoangle") is None
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    px, py, _, _, _ = po.project(op, np.array([c[0] for c in cen]), np.array([c[1] for c in cen]))
+    xoff = size_mm * 72 / 25.4 / 2
+
+    def captions(L):
+        L.cd_rule_begin()
+        for k in range(n):
+            a = np.radians(360 - want_a[k])
+            geo = np.zeros(3, np.int32)
+            L.cd_caption_geometry(b"serif", size_mm, names[k].encode(), xoff, xoff, 1, W * 72 / DPI, H * 72 / DPI, po.P(geo))
+            met = np.zeros(4); L.cd_last_metrics(po.P(met))
+            tw, asc, desc, th = met
+            hgt = max(th, asc + desc)
+            assert L.cd_show_caption(b"serif", size_mm, names[k].encode(), px[k] * 72 / DPI, py[k] * 72 / DPI, a, -tw / 2, hgt / 2, col) == 0
+        L.cd_rule_end()
+
+    style = po.Style(1, 1, 0x4080c0, 0, 0, 0.1, 0)
+    want = po.cairo_scene([(style, oways)], DPI, W, H, 0xfff8e0, before_render=captions)
+    assert (got != before).sum() > 1500
+    assert within(got, want) >= 0.995, within(got, want)
+    e = po.chan_diff(got, want)
+    e = e.max(axis=-1) if e.ndim == 3 else e
+    ink = got != before
+    assert (e[ink] <= 2).mean() >= 0.97, float((e[ink] <= 2).mean())
+
+    # a node rule with angle=majoraxis turns by a full turn (cap_coord :2356 with cap->angle == 720)
+    base = _next_id[0]; _next_id[0] += 2
+    lat, lon = synth.px_to_geo(proj, np.array([W / 2.0]), np.array([H / 2.0]))
+    hs.add_nodes(np.array([base]), lat, lon, ["name=Turn"])
+    assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, "key=name;size=2;angle=majoraxis;color=black;font=serif", np.array([base])) == 0
+
+
 def reference_caption_tags(rules, names, px, py, size_mm, col, weight, bg=0xfff8e0):
     """cap_coord the reference's way with the REAL libcairo: the chart's rules recorded (oracle/cairo_drive.c), then per caption, in
     object order, cairo_smr_cut_out's replay at the anchor's sub-pixel offset (cd_cut_out, src/smrules_cairo.c:1511-1533),

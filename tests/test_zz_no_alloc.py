@@ -10,14 +10,21 @@ from oracle import pyoracle as po
 pytestmark = pytest.mark.gpu
 
 
-def _scan(sa, cv, fn, cx, cy, fg_w, fg_h, fg_x, col, phase, weight):
+def _scan(sa, cv, fn, cx, cy, fg_w, fg_h, fg_x, col, phase, weight, free=None):
     n, _ = sa.caprot_steps(fg_w, fg_h, cv.dpi)
     d_ang = sa.DeviceArray((len(cx),), np.float64)
     d_dv = sa.DeviceArray((len(cx), n), np.float64)
     # poison the outputs: a call that wrote nothing must not pass
     sa.lib().smr_hip_memcpy_h2d(d_ang.ptr, np.full(len(cx), -7.0).ctypes.data, 8 * len(cx))
-    fn(sa.DeviceArray.from_numpy(cx), sa.DeviceArray.from_numpy(cy), len(cx), fg_w, fg_h, fg_x, col, phase, weight, d_ang, d_dv)
+    d_cx, d_cy = sa.DeviceArray.from_numpy(cx), sa.DeviceArray.from_numpy(cy)
     sa.sync()
+    if free is not None:
+        import torch
+        before = torch.cuda.mem_get_info(0)[0]
+    fn(d_cx, d_cy, len(cx), fg_w, fg_h, fg_x, col, phase, weight, d_ang, d_dv)
+    sa.sync()
+    if free is not None:
+        free.append((before, torch.cuda.mem_get_info(0)[0]))
     return d_ang.numpy(), d_dv.numpy()
 
 
@@ -35,7 +42,10 @@ def test_noalloc_equals_caprot_on_two_calls_in_a_row(hip):
         (17, rng.uniform(-5, W + 5, 17), rng.uniform(-5, H + 5, 17), 48, 10, 24, 0x203040, 90.0, -0.5),      # smaller: 17 captions, 13 angles
     ]
     want = [_scan(sa, cv, cv.caprot, cx, cy, *rest) for _, cx, cy, *rest in calls]
-    got = [_scan(sa, cv, cv.caprot_noalloc, cx, cy, *rest) for _, cx, cy, *rest in calls]
+    free = []
+    got = [_scan(sa, cv, cv.caprot_noalloc, cx, cy, *rest, free=free) for _, cx, cy, *rest in calls]
+    # "allocates nothing": the device's free memory (hipMemGetInfo) is the same before and after each call
+    assert len(free) == 2 and all(a == b for a, b in free), free
     assert sa.caprot_steps(48, 10, 300)[0] < sa.caprot_steps(90, 14, 300)[0]
     for (wa, wd), (ga, gd) in zip(want, got):
         assert np.array_equal(ga, wa)
