@@ -305,6 +305,28 @@ const char *hs_get_tag(int type, int64_t id, const char *key)
    return buf;
 }
 
+/* refs of a way / position of a node / the ids the next new node and way will get (for the objects that cap fontbox=1 and
+ * mkarea=1 add through malloc_node / malloc_way / put_object) */
+int hs_way_refs(int64_t id, int64_t *out, int cap)
+{
+   osm_way_t *w = get_object(OSM_WAY, id);
+   if (w == NULL) return -1;
+   for (int i = 0; i < w->ref_cnt && i < cap; i++) out[i] = w->ref[i];
+   return w->ref_cnt;
+}
+
+int hs_node_pos(int64_t id, double *latlon)
+{
+   osm_node_t *n = get_object(OSM_NODE, id);
+   if (n == NULL) return -1;
+   latlon[0] = n->lat; latlon[1] = n->lon;
+   return n->obj.tag_cnt;
+}
+
+/* unique_node_id / unique_way_id hand out descending ids and have no peek: take one and say which comes next */
+int64_t hs_next_node_id(void) { return unique_node_id() - 1; }
+int64_t hs_next_way_id(void) { return unique_way_id() - 1; }
+
 /* ---- match tags and the executor's filter (for smr_hip_objects_match) ----
  * A rule as init_rule leaves it (src/smrparse.c:365-467): oo->otag[] = the patterns with their markers stripped, act->stag[] =
  * their kinds, act->flags = ACTION_OPEN_WAY / ACTION_CLOSED_WAY from the rule way's own refs (check_way_type :340-351).

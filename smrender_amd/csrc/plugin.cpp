@@ -53,6 +53,13 @@ struct host_api_t
    double (*rdata_square_nm)(void) = nullptr;
    const smr_osm_way_t *(*page_way)(void) = nullptr;
    int (*parse_length_mm_array)(const char *, double *, int) = nullptr;
+   /* objects the rules add to the host's data (cap fontbox=1, angle=auto mkarea=1): libsmrender/osm_inplace.h:132-139, smrender.h:81 */
+   smr_osm_node_t *(*malloc_node)(short) = nullptr;
+   smr_osm_way_t *(*malloc_way)(short, int) = nullptr;
+   void (*osm_node_default)(smr_osm_node_t *) = nullptr;
+   void (*osm_way_default)(smr_osm_way_t *) = nullptr;
+   int (*put_object)(smr_osm_obj_t *) = nullptr;
+   bool can_make_objects() const { return malloc_node && malloc_way && osm_node_default && osm_way_default && put_object; }
 };
 static host_api_t H;
 
@@ -69,6 +76,8 @@ static void host_resolve(void)
    host_sym(H.poly_area, "poly_area"); host_sym(H.rdata_square_mm, "rdata_square_mm");
    host_sym(H.rdata_square_nm, "rdata_square_nm"); host_sym(H.page_way, "page_way");
    host_sym(H.parse_length_mm_array, "parse_length_mm_array");
+   host_sym(H.malloc_node, "malloc_node"); host_sym(H.malloc_way, "malloc_way"); host_sym(H.osm_node_default, "osm_node_default");
+   host_sym(H.osm_way_default, "osm_way_default"); host_sym(H.put_object, "put_object");
    H.resolved = true;
 }
 
@@ -920,6 +929,7 @@ struct cap_rule_t
    double angle = 0, bgbox_scale = 1.2;
    const char *akey = nullptr;
    bool fill_used = false;
+   bool fontbox = false, mkarea = false;      /* objects for the host's data: cap_geo_rect (:2114-2176), dv_mkarea (:1772-1801) */
    col_spec_t fill_cs;
    bool have_auto_col = false; uint32_t auto_col = 0;      /* auto_ctx's source: the colour of the FIRST object act_cap_main sees, matched or not (:2455-2459) */
    void *sfc = nullptr, *ctx = nullptr;
@@ -995,10 +1005,14 @@ static int cap_ini(smr_smrule_t *r)
       plog(SMR_LOG_NOTICE, "anglekey=%s overrides angle=auto", akey);
       autorot = false; angle = 0;
    }
-   if (H.get_param_bool("fontbox", r->act))
+   /* fontbox=1 (act_cap_ini :1291) and mkarea=1 (parse_auto_rot, src/smrparse.c:1062: read with angle=auto only) add nodes and ways
+    * to the host's data through the host's own malloc_node / malloc_way / put_object */
+   const bool fontbox = H.get_param_bool("fontbox", r->act) != 0;
+   const bool mkarea = autorot && H.get_param_bool("mkarea", r->act) != 0;
+   if ((fontbox || mkarea) && !H.can_make_objects())
    {
-      plog(SMR_LOG_ERR, "cap: fontbox=1 adds objects to the host's data, which the GPU path does not; use the built-in cap");
-      return 1;
+      plog(SMR_LOG_ERR, "cap: fontbox=1 / mkarea=1 need the host symbols malloc_node, malloc_way, osm_node_default, osm_way_default, put_object");
+      return -1;
    }
    if (!H.match_attr || !H.realloc_tags)
    {
@@ -1015,7 +1029,7 @@ static int cap_ini(smr_smrule_t *r)
    if (cairo_load() != 0) return -1;
 
    cap_rule_t *cap = new cap_rule_t();
-   cap->autorot = autorot; cap->angle = angle; cap->akey = akey;
+   cap->autorot = autorot; cap->angle = angle; cap->akey = akey; cap->fontbox = fontbox; cap->mkarea = mkarea;
    (void) H.get_param("bgbox_scale", &cap->bgbox_scale, r->act);
    if ((s = H.get_param("fillcolor", nullptr, r->act)) != nullptr) { parse_col_spec(s, &cap->fill_cs); cap->fill_used = true; }
    if ((s = H.get_param("font", nullptr, r->act)) != nullptr) cap->font = s;
@@ -1382,8 +1396,9 @@ struct atlas_set_t
       return 0;
    }
 
+   /* dv (optional): per caption the raw per-angle differences of its scan (dv_diff before dv_weight), for mkarea */
    template <typename PlaneFn>
-   int scan(int lv, PlaneFn plane_of, double phase, double weight, std::vector<double> &angle)
+   int scan(int lv, PlaneFn plane_of, double phase, double weight, std::vector<double> &angle, std::vector<std::vector<double>> *dv = nullptr)
    {
       for (atlas_t &a : atlases)
       {
@@ -1400,17 +1415,26 @@ struct atlas_set_t
             const size_t m = idx.size();
             std::vector<double> gx(m), gy(m), out(m);
             for (size_t k = 0; k < m; k++) { gx[k] = a.ax[idx[k] - a.i0]; gy[k] = a.ay[idx[k] - a.i0]; }
-            dbuf_t dx, dy, dfg, dang;
+            dbuf_t dx, dy, dfg, dang, ddv;
+            int steps = 0, rr = 0;
+            smr_hip_caprot_steps(w_px, h_px, P.dpi, &steps, &rr);
             bool ok = dx.put(gx.data(), m * 8) == 0 && dy.put(gy.data(), m * 8) == 0 && dfg.put(plane.data(), plane.size() * 4) == 0 && dang.alloc(m * 8) == 0;
+            if (ok && dv) ok = ddv.alloc(m * (size_t) steps * 8) == 0;
             if (ok)
             {
                smr_cap_batch_t b;
                memset(&b, 0, sizeof(b));
                b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) m;
                b.fg_w = w_px; b.fg_h = h_px; b.fg_x = 0; b.phase_deg = phase; b.weight = weight; b.d_fg = (const uint32_t *) dfg.p;
-               ok = smr_hip_caprot(a.c, &b, (double *) dang.p, nullptr) == SMR_OK;
+               ok = smr_hip_caprot(a.c, &b, (double *) dang.p, dv ? (double *) ddv.p : nullptr) == SMR_OK;
             }
             if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, m * 8) == SMR_OK;
+            if (ok && dv)
+            {
+               std::vector<double> all(m * (size_t) steps);
+               ok = smr_hip_memcpy_d2h(all.data(), ddv.p, all.size() * 8) == SMR_OK;
+               for (size_t k = 0; k < m && ok; k++) (*dv)[items[idx[k]].id].assign(all.begin() + k * steps, all.begin() + (k + 1) * steps);
+            }
             if (!ok) return -1;
             for (size_t k = 0; k < m; k++) angle[items[idx[k]].id] = out[k];
          }
@@ -1531,6 +1555,87 @@ static int cap_draw_glyphs(const cap_rule_t *cap, const std::vector<double> &cx,
    return flush();
 }
 
+/* cap_geo_rect, src/smrules_cairo.c:2114-2176 (fontbox=1): the caption's box, NOT rotated, as a closed way of four new nodes in the
+ * host's data; way and nodes carry the object's tags and smrender:fontbox=yes.  x, y: the text's origin on the page in pt */
+static int cap_geo_rect(const cap_rule_t *cap, double x, double y, double width, double height, double desc, const smr_osm_obj_t *o)
+{
+   const double ws = width * cap->bgbox_scale, hs = height * cap->bgbox_scale;
+   smr_osm_way_t *w = H.malloc_way((short) (o->tag_cnt + 2), 5);
+   if (w == nullptr) return -1;
+   H.osm_way_default(w);
+   /* the object's tags behind generator=smrender, or over it when the object has that tag itself */
+   const int i0 = H.match_attr(o, "generator", "smrender") == -1;
+   memcpy(&w->obj.otag[i0], o->otag, sizeof(*o->otag) * (size_t) o->tag_cnt);
+   w->obj.tag_cnt = (short) (o->tag_cnt + i0);
+   static char k_fontbox[] = "smrender:fontbox", v_yes[] = "yes";
+   struct smr_otag &t = w->obj.otag[w->obj.tag_cnt];
+   t.k.buf = k_fontbox; t.k.len = (int) strlen(k_fontbox); t.v.buf = v_yes; t.v.len = (int) strlen(v_yes);
+   w->obj.tag_cnt++;
+   for (int i = 0; i < 4; i++)
+   {
+      smr_osm_node_t *n = H.malloc_node(w->obj.tag_cnt);
+      if (n == nullptr) return -1;
+      H.osm_node_default(n);
+      memcpy(n->obj.otag, w->obj.otag, sizeof(*w->obj.otag) * (size_t) w->obj.tag_cnt);
+      n->obj.tag_cnt = w->obj.tag_cnt;
+      double x0 = x + (width - ws) * .5, y0 = y + (height - hs) * .5 + desc;
+      if (i == 1 || i == 2) x0 += ws;
+      if (i == 2 || i == 3) y0 += hs;
+      host_pxf2geo(x0 * P.dpi / 72, y0 * P.dpi / 72, &n->lon, &n->lat);      /* rdata_unit_px(.., U_PT) */
+      H.put_object(&n->obj);
+      w->ref[i] = n->obj.id;
+   }
+   w->ref[4] = w->ref[0];
+   H.put_object(&w->obj);
+   return 0;
+}
+
+/* dv_mkarea, src/smrules_cairo.c:1772-1801 (angle=auto;mkarea=1): the scan's weighted, quantised differences as a closed way around
+ * the caption's anchor, one new node per trial angle at r * dv_quant from it (r in pt taken as px, as the reference does), each
+ * tagged smrender:autorot:angle="<bearing>;<percent>".  dv: the raw differences of smr_hip_caprot; dv_weight (:1813-1821) and
+ * dv_quantize (:1868-1890) are applied here as find_angle does before it calls dv_mkarea (:1997-2000) */
+static int cap_mkarea(const cap_rule_t *cap, const cap_item_t &, double cx_px, double cy_px, double r, const std::vector<double> &dv)
+{
+   const int cnt = (int) dv.size();
+   std::vector<double> diff(dv), ang((size_t) cnt), quant((size_t) cnt);
+   const double phase = cap->phase * M_PI / 180.0;
+   double a = 0;
+   for (int i = 0; i < cnt; i++, a += 2 * M_PI / cnt)       /* dv_sample's running sum (:1842) */
+   {
+      ang[(size_t) i] = a;
+      if (cap->weight < 0.0) diff[(size_t) i] = 1.0 - diff[(size_t) i];
+      diff[(size_t) i] *= 1.0 - (1.0 - fabs(cap->weight)) * (1.0 - cos(a * 2.0 + phase)) / 2.0;
+   }
+   double mn = 1.0, mx = 0.0;
+   for (double d : diff) { if (d > mx) mx = d; if (d < mn) mn = d; }
+   for (int i = 0; i < cnt; i++)
+   {
+      quant[(size_t) i] = (diff[(size_t) i] - mn) / (mx - mn);
+      if (std::isnan(quant[(size_t) i])) quant[(size_t) i] = 1.0;
+   }
+   smr_osm_way_t *w = H.malloc_way(1, cnt + 1);
+   if (w == nullptr) return -1;
+   H.osm_way_default(w);
+   static char k_angle[] = "smrender:autorot:angle";
+   for (int i = 0; i < cnt; i++)
+   {
+      smr_osm_node_t *n = H.malloc_node(2);
+      if (n == nullptr) return -1;
+      H.osm_node_default(n);
+      w->ref[i] = n->obj.id;
+      host_pxf2geo(cx_px + r * quant[(size_t) i] * cos(2 * M_PI - ang[(size_t) i]), cy_px + r * quant[(size_t) i] * sin(2 * M_PI - ang[(size_t) i]), &n->lon, &n->lat);
+      char buf[32];
+      snprintf(buf, sizeof(buf), "%.1f;%.1f", fmod2((M_PI_2 - ang[(size_t) i]) * 180.0 / M_PI, 360), quant[(size_t) i] * 100);
+      char *v = strdup(buf);                               /* lives as long as the node, like the reference's */
+      n->obj.otag[1].k.buf = k_angle; n->obj.otag[1].k.len = (int) strlen(k_angle);
+      n->obj.otag[1].v.buf = v; n->obj.otag[1].v.len = (int) strlen(v);
+      H.put_object(&n->obj);
+   }
+   w->ref[cnt] = w->ref[0];
+   H.put_object(&w->obj);
+   return 0;
+}
+
 static int cap_fini(smr_smrule_t *r)
 {
    cap_rule_t *cap = (cap_rule_t *) r->data;
@@ -1540,6 +1645,7 @@ static int cap_fini(smr_smrule_t *r)
    std::vector<double> angle(n_all, 0.0), cx(n_all), cy(n_all), reach(n_all, 1.0);
    std::vector<int> fw(n_all), fh(n_all), level;
    std::vector<short> final_pos(n_all);
+   std::vector<std::vector<double>> dvraw(cap->mkarea ? n_all : 0);
    int n_levels = 0;
    smr_canvas_t *autoc = nullptr;
    size_t n_groups = 0, n_atlases = 0;
@@ -1597,7 +1703,7 @@ static int cap_fini(smr_smrule_t *r)
             if (atl.build(todo, level) != 0) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
             n_atlases = atl.atlases.size();
          }
-         if (ret == 0 && atl.scan(lv, plane_of, cap->phase, cap->weight, angle) != 0) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
+         if (ret == 0 && atl.scan(lv, plane_of, cap->phase, cap->weight, angle, cap->mkarea ? &dvraw : nullptr) != 0) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; }
       }
       else
       {
@@ -1619,9 +1725,12 @@ static int cap_fini(smr_smrule_t *r)
             const size_t n = idx.size();
             std::vector<double> gx(n), gy(n), out(n);
             for (size_t k = 0; k < n; k++) { gx[k] = cx[idx[k]]; gy[k] = cy[idx[k]]; }
-            dbuf_t dx, dy, dfg, dang;
+            dbuf_t dx, dy, dfg, dang, ddv;
+            int steps = 0, rr = 0;
+            smr_hip_caprot_steps(w_px, h_px, P.dpi, &steps, &rr);
             bool ok = dx.put(gx.data(), n * 8) == 0 && dy.put(gy.data(), n * 8) == 0 && dfg.put(plane.data(), plane.size() * 4) == 0 &&
                       dang.alloc(n * 8) == 0;
+            if (ok && cap->mkarea) ok = ddv.alloc(n * (size_t) steps * 8) == 0;
             if (ok)
             {
                smr_cap_batch_t b;
@@ -1629,9 +1738,15 @@ static int cap_fini(smr_smrule_t *r)
                b.d_cx = (const double *) dx.p; b.d_cy = (const double *) dy.p; b.n = (int64_t) n;
                b.fg_w = w_px; b.fg_h = h_px; b.fg_x = 0; b.col = first.col; b.phase_deg = cap->phase; b.weight = cap->weight;
                b.d_fg = (const uint32_t *) dfg.p;
-               ok = smr_hip_caprot(autoc, &b, (double *) dang.p, nullptr) == SMR_OK;
+               ok = smr_hip_caprot(autoc, &b, (double *) dang.p, cap->mkarea ? (double *) ddv.p : nullptr) == SMR_OK;
             }
             if (ok) ok = smr_hip_memcpy_d2h(out.data(), dang.p, n * 8) == SMR_OK;
+            if (ok && cap->mkarea)
+            {
+               std::vector<double> all(n * (size_t) steps);
+               ok = smr_hip_memcpy_d2h(all.data(), ddv.p, all.size() * 8) == SMR_OK;
+               for (size_t k = 0; k < n && ok; k++) dvraw[idx[k]].assign(all.begin() + k * steps, all.begin() + (k + 1) * steps);
+            }
             if (!ok) { plog(SMR_LOG_ERR, "cap: %s", smr_hip_last_error()); ret = -1; break; }
             for (size_t k = 0; k < n; k++) angle[idx[k]] = out[k];
          }
@@ -1707,6 +1822,19 @@ static int cap_fini(smr_smrule_t *r)
          snprintf(val, sizeof(val), "%.1f", angle[i] * 180.0 / M_PI);
          add_tag(it.o, cap->key, "autoangle", val);
          add_tag(it.o, cap->key, "autoalign", (final_pos[i] & SMR_POS_E) ? "east" : (final_pos[i] & SMR_POS_W) ? "west" : "center");
+      }
+   /* what the rule adds to the host's data, caption by caption in object order as cap_coord does (find_angle's area first) */
+   if (ret == 0 && (cap->mkarea || cap->fontbox))
+      for (size_t i = 0; i < n_all; i++)
+      {
+         const cap_item_t &it = cap->items[i];
+         if (cap->mkarea && !dvraw[i].empty()) cap_mkarea(cap, it, cx[i], cy[i], hypot((double) fw[i], (double) fh[i]) * 72 / P.dpi, dvraw[i]);
+         if (cap->fontbox)
+         {
+            double ox, oy;
+            pos_offset(final_pos[i], it.tw, it.hgt, cap->xoff, cap->yoff, &ox, &oy);
+            cap_geo_rect(cap, cx[i] * 72 / P.dpi + ox, cy[i] * 72 / P.dpi + oy, it.tw, -it.hgt, it.descent, it.o);
+         }
       }
    if (ret == 0 && (!cap->hide || cap->fill_used) && n_all && cap_draw_glyphs(cap, cx, cy, angle, final_pos) != SMR_OK)
    {

@@ -38,6 +38,10 @@ def host():
         L.hs_synth_world.argtypes = [C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_void_p, C.c_void_p]
         L.hs_object_ptrs.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.hs_set_visible.argtypes = [C.c_int, C.c_int64, C.c_int]
+        L.hs_way_refs.argtypes = [C.c_int64, C.c_void_p, C.c_int]
+        L.hs_node_pos.argtypes = [C.c_int64, C.c_void_p]
+        L.hs_next_node_id.restype = C.c_int64
+        L.hs_next_way_id.restype = C.c_int64
         L.rdata_square_mm.restype = C.c_double
         L.rdata_square_nm.restype = C.c_double
         _hs = L
@@ -80,6 +84,25 @@ def add_rel(rid, ways):
 def get_tag(obj_type, oid, key):
     v = host().hs_get_tag(obj_type, int(oid), key.encode())
     return None if v is None else v.decode()
+
+
+def way_refs(wid):
+    """refs of a way in the host's data, or None"""
+    out = np.zeros(4096, np.int64)
+    n = host().hs_way_refs(int(wid), out.ctypes.data, len(out))
+    return None if n < 0 else out[:n].copy()
+
+
+def node_pos(nid):
+    """(lat, lon, tag count) of a node in the host's data, or None"""
+    out = np.zeros(2)
+    n = host().hs_node_pos(int(nid), out.ctypes.data)
+    return None if n < 0 else (out[0], out[1], n)
+
+
+def next_ids():
+    """(id of the next node, id of the next way) the host's malloc_node / malloc_way + osm_*_default will hand out"""
+    return int(host().hs_next_node_id()), int(host().hs_next_way_id())
 
 
 def poly_area(wid):

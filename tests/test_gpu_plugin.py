@@ -924,6 +924,121 @@ def test_cap_along_the_major_axis_of_closed_ways(chart):
     assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, "key=name;size=2;angle=majoraxis;color=black;font=serif", np.array([base])) == 0
 
 
+def test_cap_fontbox_adds_the_captions_boxes_to_the_hosts_data(chart):
+    """cap fontbox=1 (cap_coord :2371-2374, cap_geo_rect src/smrules_cairo.c:2114-2176): every caption leaves a closed way of four
+    new nodes in the host's data -- the text's box on the page, scaled by bgbox_scale about its middle and NOT rotated -- with
+    the object's tags and smrender:fontbox=yes; made through the host's own malloc_way / malloc_node / put_object."""
+    sa, proj = chart
+    from smrender_amd import synth
+    cd = po.cairo()
+    if cd is None:
+        pytest.skip("libcairo (text extents) not loadable")
+    n = 3
+    cx, cy = np.array([80.3, 200.7, 310.1]), np.array([60.2, 150.9, 90.4])
+    lat, lon = synth.px_to_geo(proj, cx, cy)
+    base = _next_id[0]; _next_id[0] += n + 1
+    nids = base + np.arange(n)
+    names = ["Box A", "Second", "C"]
+    hs.add_nodes(nids, lat, lon, [f"name={t};kind=test" for t in names])
+    size_mm, scale = 2.5, 1.5
+    node0, way0 = hs.next_ids()
+    params = f"key=name;size={size_mm};angle=30;color=black;halign=east;valign=north;font=serif;fontbox=1;bgbox_scale={scale};hide=1"
+    assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, params, nids) == 0, sa.lib().smr_hip_last_error()
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    px, py, _, _, _ = po.project(op, lat, lon)
+    xoff = size_mm * 72 / 25.4 / 2
+    for k in range(n):
+        refs = hs.way_refs(way0 - k)
+        assert refs is not None and len(refs) == 5 and refs[4] == refs[0], k
+        assert list(refs[:4]) == [node0 - 4 * k - i for i in range(4)]
+        assert hs.get_tag(hs.OSM_WAY, way0 - k, "smrender:fontbox") == "yes"
+        assert hs.get_tag(hs.OSM_WAY, way0 - k, "name") == names[k] and hs.get_tag(hs.OSM_WAY, way0 - k, "kind") == "test"
+        assert hs.get_tag(hs.OSM_WAY, way0 - k, "generator") == "smrender"
+        assert hs.get_tag(hs.OSM_NODE, refs[2], "smrender:fontbox") == "yes" and hs.get_tag(hs.OSM_NODE, refs[2], "name") == names[k]
+        geo = np.zeros(3, np.int32)
+        cd.cd_caption_geometry(b"serif", size_mm, names[k].encode(), xoff, xoff, 1, W * 72 / DPI, H * 72 / DPI, po.P(geo))
+        met = np.zeros(4); cd.cd_last_metrics(po.P(met))
+        tw, asc, desc, th = met
+        hgt = max(th, asc + desc)
+        # pos_offset (:1478-1508) for east + north, then cap_geo_rect's corners in pt
+        X, Y = px[k] * 72 / DPI + xoff, py[k] * 72 / DPI - xoff
+        wdt, h = tw, -hgt
+        ws, hsc = wdt * scale, h * scale
+        x0, y0 = X + (wdt - ws) / 2, Y + (h - hsc) / 2 + desc
+        want = [(x0, y0), (x0 + ws, y0), (x0 + ws, y0 + hsc), (x0, y0 + hsc)]
+        for i in range(4):
+            la, lo, _ = hs.node_pos(refs[i])
+            gx, gy, _, _, _ = po.project(op, np.array([la]), np.array([lo]))
+            assert abs(gx[0] - want[i][0] * DPI / 72) < 1e-6 and abs(gy[0] - want[i][1] * DPI / 72) < 1e-6, (k, i)
+
+
+def test_cap_mkarea_adds_the_scans_diagram_to_the_hosts_data(chart):
+    """cap angle=auto;mkarea=1 (parse_auto_rot src/smrparse.c:1062, find_angle :1999-2000, dv_mkarea :1772-1801): per caption a closed
+    way of num_steps new nodes around the anchor, node i at r * dv_quant[i] in the direction of trial angle i, tagged
+    smrender:autorot:angle=<bearing>;<percent>.  dv_quant from the oracle's find_angle on the same cut-out (crop convention of this
+    chart fixture)."""
+    sa, proj = chart
+    from smrender_amd import synth
+    cd, L = po.cairo(), po.orc()
+    if cd is None:
+        pytest.skip("libcairo (text extents) not loadable")
+    wids, oways = load_ways(sa, proj, po.synth_ways(90, W, H, seed=91))
+    assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", wids) == 0
+    img = plugin_canvas(sa)
+    n = 2
+    cx, cy = np.array([120.4, 260.8]), np.array([100.3, 170.6])
+    lat, lon = synth.px_to_geo(proj, cx, cy)
+    base = _next_id[0]; _next_id[0] += n + 1
+    nids = base + np.arange(n)
+    names = ["Area One", "Two"]
+    hs.add_nodes(nids, lat, lon, [f"name={t}" for t in names])
+    size_mm, weight, phase = 2.0, 0.6, 20.0
+    node0, way0 = hs.next_ids()
+    params = f"key=name;size={size_mm};angle=auto;mkarea=1;color=black;halign=east;font=serif;weight={weight};phase={phase};hide=1"
+    assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, params, nids) == 0, sa.lib().smr_hip_last_error()
+    op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
+    px, py, _, _, _ = po.project(op, lat, lon)
+    xoff = size_mm * 72 / 25.4 / 2
+    crnd = lambda v: int(np.sign(v) * np.floor(abs(v) + 0.5))
+    nid = node0
+    for k in range(n):
+        geo = np.zeros(3, np.int32)
+        cd.cd_caption_geometry(b"serif", size_mm, names[k].encode(), xoff, xoff, 1, W * 72 / DPI, H * 72 / DPI, po.P(geo))
+        pw, ph, pxx = [int(v) for v in geo]
+        fw, fh = crnd(pw * DPI / 72), crnd(ph * DPI / 72)
+        fg = np.zeros((fh, fw), np.uint32)
+        assert cd.cd_plane(pw, ph, pxx, 0, DPI, po.P(fg)) == 0
+        r = C.c_int()
+        steps = L.orc_num_steps(fw, fh, DPI, C.byref(r)); r = r.value
+        ox, oy = crnd(px[k] - r / 2.0), crnd(py[k] - r / 2.0)
+        cut = np.zeros((r, r), np.uint32)
+        xs0, ys0, xs1, ys1 = max(ox, 0), max(oy, 0), min(ox + r, W), min(oy + r, H)
+        cut[ys0 - oy:ys1 - oy, xs0 - ox:xs1 - ox] = img[ys0:ys1, xs0:xs1]
+        dv = np.zeros(steps)
+        L.orc_find_angle(po.P(cut), r, po.P(fg), fw, fh, steps, phase, weight, po.P(dv))
+        # dv_weight (:1813-1821), dv_quantize (:1868-1890)
+        ang = np.zeros(steps); a = 0.0
+        for i in range(steps):
+            ang[i] = a; a += 2 * np.pi / steps
+        d = dv * (1.0 - (1.0 - abs(weight)) * (1.0 - np.cos(ang * 2.0 + np.radians(phase))) / 2.0)
+        q = (d - d.min()) / (d.max() - d.min())
+        refs = hs.way_refs(way0 - k)
+        assert refs is not None and len(refs) == steps + 1 and refs[-1] == refs[0], (k, None if refs is None else len(refs), steps)
+        assert list(refs[:steps]) == [nid - i for i in range(steps)]
+        nid -= steps
+        rr = np.hypot(fw, fh) * 72 / DPI              # find_angle's r in pt, added to px as the reference does (its FIXME)
+        for i in range(steps):
+            la, lo, ntag = hs.node_pos(refs[i])
+            assert ntag == 2
+            gx, gy, _, _, _ = po.project(op, np.array([la]), np.array([lo]))
+            assert abs(gx[0] - (px[k] + rr * q[i] * np.cos(2 * np.pi - ang[i]))) < 1e-6, (k, i)
+            assert abs(gy[0] - (py[k] + rr * q[i] * np.sin(2 * np.pi - ang[i]))) < 1e-6, (k, i)
+            b = np.fmod(np.degrees(np.pi / 2 - ang[i]), 360.0)
+            b = b + 360 if b < 0 else b
+            assert hs.get_tag(hs.OSM_NODE, refs[i], "smrender:autorot:angle") == "%.1f;%.1f" % (b, q[i] * 100), (k, i)
+        assert q.max() == 1.0 and q.min() == 0.0 and len(np.unique(q)) > steps // 2
+
+
 def reference_caption_tags(rules, names, px, py, size_mm, col, weight, bg=0xfff8e0):
     """cap_coord the reference's way with the REAL libcairo: the chart's rules recorded (oracle/cairo_drive.c), then per caption, in
     object order, cairo_smr_cut_out's replay at the anchor's sub-pixel offset (cd_cut_out, src/smrules_cairo.c:1511-1533),
