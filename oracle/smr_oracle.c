@@ -753,6 +753,41 @@ int orc_dash_edges(const int32_t *xy, int n, double hw_pt, int dpi, const double
    return D.cnt;
 }
 
+/* A solid stroke with ROUND caps (add_cap / add_fan of cairo-path-stroke-polygon.c put the pen's vertices between the two corners
+ * of the path's first and last face): the pieces of orc_stroke_edges -- always the pieces, never the polygon itself -- and, as the
+ * dasher's round caps are cut, a fan of quads over the pen's vertices beyond the first segment's start and the last one's end */
+int orc_stroke_edges_round(const int32_t *xy, int n, double hw_pt, int dpi, tor_edge_t *out)
+{
+   int cnt = orc_stroke_edges(xy, n, hw_pt, dpi, out);
+   dasher_t D;
+   D.s = (double) dpi / 72; D.hw = hw_pt; D.round_cap = 1; D.out = out; D.cnt = cnt;
+   D.npen = orc_pen(hw_pt, dpi, D.pvx, D.pvy, ORC_PEN_MAX);
+   if (D.npen < 0) return -1;
+   for (int i = 0; i < D.npen; i++)
+   {
+      int pr = i == 0 ? D.npen - 1 : i - 1, nx = i + 1 == D.npen ? 0 : i + 1;
+      D.pcw[i].dx = D.pvx[i] - D.pvx[pr]; D.pcw[i].dy = D.pvy[i] - D.pvy[pr];
+      D.pccw[i].dx = D.pvx[nx] - D.pvx[i]; D.pccw[i].dy = D.pvy[nx] - D.pvy[i];
+   }
+   int has_first = 0;
+   dface_t first, last;
+   for (int i = 0; i + 1 < n; i++)
+   {
+      pt_t p1 = { xy[2 * i], xy[2 * i + 1] }, p2 = { xy[2 * i + 2], xy[2 * i + 3] };
+      if (p1.x == p2.x && p1.y == p2.y) continue;
+      face_t f;
+      compute_face(p1, p2.x - p1.x, p2.y - p1.y, hw_pt, D.s, &f);
+      dface_t d;
+      d.ccw = f.ccw; d.cw = f.cw; d.point = p1; d.ux = f.sx; d.uy = f.sy; d.dev.dx = p2.x - p1.x; d.dev.dy = p2.y - p1.y;
+      if (!has_first) { first = d; has_first = 1; }
+      last = d;
+      last.point = p2;
+      last.ccw.x += d.dev.dx; last.ccw.y += d.dev.dy; last.cw.x += d.dev.dx; last.cw.y += d.dev.dy;
+   }
+   if (has_first) { d_cap_leading(&D, &first); d_cap_trailing(&D, &last); }
+   return D.cnt;
+}
+
 /* ---------------- colour + compositing ---------------- */
 
 static uint32_t d2s(double d)   /* _cairo_color_double_to_short as libcairo 1.16 has it (cairo-color.c): round to nearest of d * 65535.
@@ -985,13 +1020,20 @@ static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double wid
    double dash[4], l = 0;
    int nd = 0;
    for (; nd < len && nd < 4; nd++) { dash[nd] = mm2wu(bwidth_mm, c->dpi) * ds[nd]; l += dash[nd]; }
+   const int was_round = c->cap_round;
    if (style == 5) c->cap_round = 1;
    if (style == 4) { c->cap_round = 1; dash[0] = 0; dash[1] = l; nd = 2; }
    tor_edge_t *e;
-   int ne, outline_used = 0;
-   if (nd == 0)
+   int ne, outline_used = 0, solid = nd == 0;
+   /* a solid stroke on a context whose caps an earlier stroke of the rule has switched to round (:909-921, never undone): the
+    * stroke's pieces and a half disc over the pen's vertices at either end (orc_stroke_edges_round) */
+   if (nd == 0 && c->cap_round)
    {
-      /* a solid stroke with round caps would take libcairo's other stroker: not restated */
+      e = malloc(sizeof(tor_edge_t) * (8 * n + 4 * ORC_PEN_MAX));
+      ne = orc_stroke_edges_round(dev, n, width_pt / 2, c->dpi, e);
+   }
+   else if (nd == 0)
+   {
       e = malloc(sizeof(tor_edge_t) * 8 * n);
       /* the polygon itself for a way with a poked-through join, its pieces otherwise (ORC_STROKE_OUTLINE=0 / 1: always the
        * pieces / always the polygon, for measurements) */
@@ -1009,10 +1051,12 @@ static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double wid
    }
    /* a dashed stroke goes through libcairo's other stroker, which adds every dash, join and cap as a polygon of its own: those
     * pieces ARE its edges, and are cut at the page's sides like any; the pieces of a solid stroke are ours */
-   c->no_cuts = nd == 0 && !outline_used;
+   c->no_cuts = solid && !outline_used;
    if (ne > 0) orc_layer_edges(c, e, ne, 1, col);
    c->no_cuts = 0;
    free(e);
+   /* ORC_NO_STICKY_CAPS=1 (tests: that the stickiness matters in their scenes): the caps go back to what they were */
+   { const char *ns = getenv("ORC_NO_STICKY_CAPS"); if (ns && ns[0] == '1') c->cap_round = was_round; }
 }
 
 /* render_poly_line with curve=1 (cairo_smr_poly -> cairo_smr_poly_curve, :926-937): border stroke, then fill /

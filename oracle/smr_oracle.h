@@ -39,6 +39,7 @@ void orc_pt_to_dev(const double *xy_pt, int64_t n, int dpi, int32_t *xy_dev);
  * butt caps, miter joins (limit 10).  hw_pt = half line width in pt.  Returns #edges,
  * out needs room for 8*(n-1) edges. */
 int orc_stroke_edges(const int32_t *xy_dev, int n, double hw_pt, int dpi, tor_edge_t *out);
+int orc_stroke_edges_round(const int32_t *xy_dev, int n, double hw_pt, int dpi, tor_edge_t *out);   /* + round caps; out: 8 n + 4 ORC_PEN_MAX */
 /* the same poly-line stroked with a dash array (lengths in pt, offset 0) and butt or round caps:
  * libcairo's cairo-path-stroke.c dasher.  out == NULL: only counts.  Returns #edges (-1: pen too large). */
 #define ORC_PEN_MAX 256

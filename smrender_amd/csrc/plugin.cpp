@@ -411,11 +411,9 @@ static int draw_ini(smr_smrule_t *r)
    d->st.border_ndash = parse_dashes(H.get_param("bdash", nullptr, r->act), d->st.border_dash);
 
    const char *why = nullptr;
-   if (d->st.fill_used && (d->st.fill_style == SMR_STYLE_PIPE || d->st.fill_style == SMR_STYLE_ROUNDDOT))
-      why = "style=pipe|rounddot (round caps on the fill strokes of open ways)";
-   else if (d->st.curve != 0 && ((d->st.border_used && (d->st.border_style != 0 || d->st.border_ndash)) ||
+   if (d->st.curve != 0 && ((d->st.border_used && (d->st.border_style != 0 || d->st.border_ndash)) ||
                                  (d->st.fill_used && (d->st.fill_style != 0 || d->st.fill_ndash))))
-      why = "dashed strokes along curves (curve=1 or wavy=1 with style/bstyle/dash/bdash)";
+      why = "dashed or round-capped strokes along curves (curve=1 or wavy=1 with style/bstyle/dash/bdash)";
    else if (H.get_param("file", nullptr, r->act)) why = "image pattern fill (file=)";
    if (why)
    {

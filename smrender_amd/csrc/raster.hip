@@ -67,7 +67,8 @@ enum { SMR_PASS_NORMAL = 0, SMR_PASS_OPEN = 1, SMR_PASS_COMPOUND = 2 };
  * bit3 fill-as-stroke (open way) */
 __global__ void k_way_info(const int64_t *__restrict__ way_off, const int32_t *__restrict__ ref, int64_t n_ways, int64_t n_refs,
                            int border_used, int fill_used, int ignore_open, int mode, uint8_t *__restrict__ wayflags,
-                           uint32_t *__restrict__ any_open_fill, uint32_t *__restrict__ first_stroked, uint32_t *__restrict__ status)
+                           uint32_t *__restrict__ any_open_fill, uint32_t *__restrict__ first_stroked, uint32_t *__restrict__ first_open,
+                           uint32_t *__restrict__ status)
 {
    int64_t w = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
    if (w >= n_ways) return;
@@ -99,6 +100,7 @@ __global__ void k_way_info(const int64_t *__restrict__ way_off, const int32_t *_
    wayflags[w] = f;
    if (f & 8) atomicOr(any_open_fill, 1u);
    if (first_stroked && (f & 2)) atomicMin(first_stroked, (uint32_t) w);
+   if (first_open && (f & 8)) atomicMin(first_open, (uint32_t) w);
 }
 
 /* fill polygon: edge g = pts[g] -> pts[g+1]; the slot of the last ref closes the polygon
@@ -753,6 +755,65 @@ __device__ __forceinline__ int smr_slope_cmp(int32_t adx, int32_t ady, int32_t b
    return 0;
 }
 
+/* The pieces of segment g -> g + 1 of a straight way's solid stroke, as k_stroke_edges<false> cuts them (slots 0..3: the join at
+ * the segment's first point, 4..7: the segment's quad with its mitered corners); never the stroker's polygon itself.  loc comes
+ * zeroed; false for a degenerate segment.  For k_dash's solid strokes with round caps (oracle: orc_stroke_edges + the caps). */
+__device__ bool smr_stroke_ref_pieces(const int2 *__restrict__ pts, int64_t a, int64_t b, int64_t g, double hw, double s, smr_edge_t *loc,
+                                      smr_face_t &start_face, int32_t &ddx_out, int32_t &ddy_out)
+{
+   const int2 p1 = pts[g], p2 = pts[g + 1];
+   if (p1.x == p2.x && p1.y == p2.y) return false;
+   const int32_t ddx = p2.x - p1.x, ddy = p2.y - p1.y;
+   const smr_face_t start = smr_face(p1, ddx, ddy, hw, s);
+   int2 c_ccw0 = start.ccw, c_cw0 = start.cw;
+   int2 c_ccw1 = make_int2(start.ccw.x + ddx, start.ccw.y + ddy), c_cw1 = make_int2(start.cw.x + ddx, start.cw.y + ddy);
+   int64_t k = g - 1;
+   int2 q0 = p1;
+   bool have = false;
+   while (k >= a)
+   {
+      q0 = pts[k];
+      if (q0.x != p1.x || q0.y != p1.y) { have = true; break; }
+      k--;
+   }
+   if (have)
+   {
+      const smr_face_t cur = smr_face(p1, p1.x - q0.x, p1.y - q0.y, hw, s);
+      const smr_join_t j = smr_join(cur, start, p1);
+      const int2 in_inner = j.clockwise ? cur.ccw : cur.cw, out_inner = j.clockwise ? start.ccw : start.cw;
+      const int2 in_outer = j.clockwise ? cur.cw : cur.ccw, out_outer = j.clockwise ? start.cw : start.ccw;
+      if (j.kind == 1)
+      {
+         if (j.clockwise) c_cw0 = j.m; else c_ccw0 = j.m;
+         int2 q[3] = { p1, in_inner, out_inner };
+         smr_emit_poly(q, 3, loc);
+      }
+      else if (j.kind == 2)
+      {
+         int2 q[4] = { p1, in_outer, out_outer, in_inner };
+         smr_emit_poly(q, 4, loc);
+      }
+   }
+   k = g + 2;
+   have = false;
+   while (k < b)
+   {
+      q0 = pts[k];
+      if (q0.x != p2.x || q0.y != p2.y) { have = true; break; }
+      k++;
+   }
+   if (have)
+   {
+      const smr_face_t end = smr_face(p2, ddx, ddy, hw, s), nstart = smr_face(p2, q0.x - p2.x, q0.y - p2.y, hw, s);
+      const smr_join_t j = smr_join(end, nstart, p2);
+      if (j.kind == 1) { if (j.clockwise) c_cw1 = j.m; else c_ccw1 = j.m; }
+   }
+   int2 q[4] = { c_ccw0, c_ccw1, c_cw1, c_cw0 };
+   smr_emit_poly(q, 4, loc + 4);
+   start_face = start; ddx_out = ddx; ddy_out = ddy;
+   return true;
+}
+
 struct dash_args_t
 {
    const int2 *pts; const int64_t *way_off; const uint8_t *wayflags; int64_t n_ways;
@@ -760,7 +821,10 @@ struct dash_args_t
    int dpi, fill_used;
    double hw_nofill, hw_open, hw_closed, hw_fill;       /* half widths in pt (the dots' already scaled) */
    double dash[4]; int ndash;                           /* pt */
-   int cap_mode;                   /* 0 butt, 1 round, 2 round except on the rule's first stroked way (pipe) */
+   int cap_mode;                   /* 0 butt, 1 round, 2 round except on the rule's first stroked way (pipe), 3 round on the ways after
+                                      *first_way (the first open way, whose fill stroke of style pipe / rounddot switches the rule's caps) */
+   int round_only;                 /* ways whose caps are butt have no pieces here: their solid stroke is k_stroke_edges' */
+   int solid;                      /* no dashes: the pieces of the solid stroke (smr_stroke_ref_pieces) and a round cap at either end */
    const uint32_t *first_way;
    const int2 *pen; int pen_off[3], pen_n[3];           /* pens of the nofill / open / closed width (fill stroke: [0]) */
    uint32_t *piece_cnt;            /* count pass */
@@ -785,6 +849,15 @@ struct smr_dasher_t
          smr_edge_t *o = out + 4 * (size_t) cnt;
          o[0] = tmp[0]; o[1] = tmp[1]; o[2] = tmp[2]; o[3] = tmp[3];
       }
+      cnt++;
+   }
+   /* four slots as they come (a piece smr_emit_poly has wound already); an empty group is no piece */
+   __device__ __forceinline__ void raw4(const smr_edge_t *e)
+   {
+      bool any = false;
+      for (int i = 0; i < 4; i++) any = any || e[i].x1 != 0 || e[i].y1 != 0 || e[i].x2 != 0 || e[i].y2 != 0;
+      if (!any) return;
+      if (out) { smr_edge_t *o = out + 4 * (size_t) cnt; o[0] = e[0]; o[1] = e[1]; o[2] = e[2]; o[3] = e[3]; }
       cnt++;
    }
    __device__ __forceinline__ int2 pv(int i) const { return pen[i]; }
@@ -887,15 +960,43 @@ __global__ void k_dash(dash_args_t A)
    const bool on = A.mode == 1 ? (wf & 8) != 0 : (wf & 2) != 0;
    smr_dasher_t D;
    D.cnt = 0; D.out = nullptr;
-   if (on)
+   if (on && !(A.round_only && !(A.cap_mode == 1 || (A.cap_mode == 2 && (uint32_t) w != *A.first_way) || (A.cap_mode == 3 && (uint32_t) w > *A.first_way))))
    {
       const int64_t a = A.way_off[w], b = A.way_off[w + 1];
       const int cls = A.mode == 1 || !A.fill_used ? 0 : ((wf & 1) ? 2 : 1);
       D.hw = A.mode == 1 ? A.hw_fill : (!A.fill_used ? A.hw_nofill : ((wf & 1) ? A.hw_closed : A.hw_open));
       D.s = (double) A.dpi / 72;
-      D.round = A.cap_mode == 1 || (A.cap_mode == 2 && (uint32_t) w != *A.first_way);
+      D.round = A.cap_mode == 1 || (A.cap_mode == 2 && (uint32_t) w != *A.first_way) || (A.cap_mode == 3 && (uint32_t) w > *A.first_way);
       D.pen = A.pen + A.pen_off[cls]; D.npen = A.pen_n[cls];
       if (EMIT) D.out = A.edges + 4 * (size_t) A.piece_off[w];
+      if (A.solid)
+      {
+         /* a solid stroke whose caps are round: its pieces, then the half disc over the pen's vertices at the first segment's
+          * start (the face turned round) and at the last segment's end (add_cap / add_fan of cairo-path-stroke-polygon.c) */
+         bool has_first = false;
+         smr_face_t ff, lf; int32_t fdx = 0, fdy = 0, ldx = 0, ldy = 0;
+         ff.ccw = ff.cw = lf.ccw = lf.cw = make_int2(0, 0);
+         int2 fpt = make_int2(0, 0), lpt = make_int2(0, 0);
+         for (int64_t g = a; g + 1 < b; g++)
+         {
+            smr_edge_t loc[8];
+            smr_edge_t z; z.x1 = z.y1 = z.x2 = z.y2 = 0;
+            for (int i = 0; i < 8; i++) loc[i] = z;
+            smr_face_t sf; int32_t ddx, ddy;
+            if (!smr_stroke_ref_pieces(A.pts, a, b, g, D.hw, D.s, loc, sf, ddx, ddy)) continue;
+            D.raw4(loc); D.raw4(loc + 4);
+            if (!has_first) { has_first = true; ff = sf; fdx = ddx; fdy = ddy; fpt = A.pts[g]; }
+            lf = sf; lf.ccw.x += ddx; lf.ccw.y += ddy; lf.cw.x += ddx; lf.cw.y += ddy; ldx = ddx; ldy = ddy; lpt = A.pts[g + 1];
+         }
+         if (D.round && has_first)
+         {
+            int cs, ce;
+            if (D.fan_range(-fdx, -fdy, cs, ce)) D.round_cap(ff.cw, ff.ccw, fpt, cs, ce);
+            if (D.fan_range(ldx, ldy, cs, ce)) D.round_cap(lf.ccw, lf.cw, lpt, cs, ce);
+         }
+         if (!EMIT) A.piece_cnt[w] = D.cnt;
+         return;
+      }
       /* _cairo_stroker_dash_start, offset 0 */
       int di = 0; bool dash_on = true;
       double dash_remain = A.dash[0];
@@ -1074,6 +1175,11 @@ struct setup_args_t
    const int2 *way_clip;                               /* [n_ways] rows [x, y) a way's primitives may touch: its window of an atlas (smr_hip_draw_windows); NULL: the chart */
    int32_t lim_l, lim_r; int lim_on;                   /* the replay's clip box, left and right side, 24.8 (smr_setup_cuts) */
    int evenodd;                                        /* fill polygons take libcairo's EVEN_ODD rule (smr_draw_style_t.evenodd) */
+   /* solid strokes with round caps (the rule's caps are sticky, src/smrules_cairo.c:909-921) come as piece lists of the dasher with
+    * one endless dash: they stay OUR pieces (no cuts at the page's sides).  mix_border: only the ways after small[14] (the first
+    * open way) have such a list, at off_border_po; the others keep the plain layout at off_border */
+   int solid_border, solid_open, mix_border;
+   uint64_t off_border_po;
 };
 
 struct setup_lds_t
@@ -1513,7 +1619,8 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    /* strokes keep 8 slots per ref (or 4 per dash piece), empty ones zeroed; a solid stroke of a way with a poked-through join
     * (k_stroke_risk) holds the stroker's polygon in them and is filled non-zero like a fill polygon */
    const bool sparse = role != 2 || (wf & 8);
-   const bool pieces = sparse && !(role == 0 ? (wf & 16) != 0 && !A.po_border : role == 2 ? (wf & 32) != 0 && !A.po_open : false);
+   const uint32_t *const pob = A.po_border && !(A.mix_border && (uint32_t) w <= A.small[14]) ? A.po_border : nullptr;
+   const bool pieces = sparse && !(role == 0 ? (wf & 16) != 0 && !pob : role == 2 ? (wf & 32) != 0 && !A.po_open : false);
    /* libcairo limits a polygon to the image it renders into; for a window of an atlas that image is the window's rows */
    const int clip0 = A.way_clip ? A.way_clip[w].x : 0, clip1 = A.way_clip ? A.way_clip[w].y : A.H;
    smr_prim_t P;
@@ -1527,7 +1634,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          if (po) { P.edge_off = off + 4ull * po[w]; P.edge_cnt = 4u * (po[w + 1] - po[w]); }
          else { P.edge_off = off + (uint64_t) SMR_SLOTS * a; P.edge_cnt = (uint32_t) (SMR_SLOTS * n); }
       };
-      if (role == 0) stroke_range(A.off_border, A.po_border);
+      if (role == 0) stroke_range(pob ? A.off_border_po : A.off_border, pob);
       else if (role == 1) stroke_range(A.off_dots, A.po_dots);
       else if (wf & 4) { P.edge_off = A.off_fill + (uint64_t) a; P.edge_cnt = (uint32_t) n; }
       else stroke_range(A.off_open, A.po_open);
@@ -1556,7 +1663,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          a.item_flags = item_flags; a.prim_id = A.compound != 0xffffffffu ? A.compound : (uint32_t) p; a.valid = 0;
          a.clip0 = clip0; a.clip1 = clip1;
          a.lim_l = A.lim_l; a.lim_r = A.lim_r;
-         a.lim_on = A.lim_on && (!pieces || (role == 0 ? A.po_border != nullptr : role == 1 ? A.po_dots != nullptr : (wf & 8) && A.po_open != nullptr));
+         a.lim_on = A.lim_on && (!pieces || (role == 0 ? pob != nullptr && !A.solid_border : role == 1 ? A.po_dots != nullptr : (wf & 8) && A.po_open != nullptr && !A.solid_open));
          A.bigacc[b] = a;
          A.prims[p] = P;                 /* edge range and colour; not valid before k_big_finish */
       }
@@ -1633,7 +1740,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    SMR_WAVE_SYNC();
    /* cuts at the page's sides: for edges that are libcairo's own -- fills, strokes as polygons, and the pieces of a DASHED stroke
     * (its other stroker adds every dash, join and cap as a polygon of its own); not the pieces of a solid stroke */
-   const bool dashed = role == 0 ? A.po_border != nullptr : role == 1 ? A.po_dots != nullptr : (wf & 8) && A.po_open != nullptr;
+   const bool dashed = role == 0 ? pob != nullptr && !A.solid_border : role == 1 ? A.po_dots != nullptr : (wf & 8) && A.po_open != nullptr && !A.solid_open;
    const bool cuts = A.lim_on && (!pieces || dashed) && (P.minx < A.lim_l || P.maxx > A.lim_r);
    if (nitems == 1)
    {
@@ -4286,8 +4393,6 @@ int smr_draw_instances(smr_canvas_t *c, const smr_draw_style_t *st, const smr_dr
    if (!c || !st || !b) return smr_fail(SMR_E_INVAL, "draw: NULL argument");
    if (st->fill_style < 0 || st->fill_style > 5 || st->border_style < 0 || st->border_style > 5)
       return smr_fail(SMR_E_INVAL, "draw: unknown style %d / %d", st->fill_style, st->border_style);
-   if (st->fill_used && (st->fill_style == SMR_STYLE_PIPE || st->fill_style == SMR_STYLE_ROUNDDOT))
-      return smr_fail(SMR_E_UNSUPPORTED, "draw: style=pipe|rounddot on the fill of open ways leaves round caps on every later stroke of the rule: not implemented on the GPU path");
    if (st->curve < 0 || st->curve > 2) return smr_fail(SMR_E_INVAL, "draw: curve mode %d", st->curve);
    if (st->curve == 1 && !(st->curve_factor > 0 && st->curve_factor < 100)) return smr_fail(SMR_E_INVAL, "draw: curve_factor %g", st->curve_factor);
    if (st->directional && st->fill_used)
@@ -4355,6 +4460,11 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    SMR_TRY(dash_spec(st->fill_used ? st->fill_style : 0, st->fill_dash, st->fill_ndash, st->border_width_mm, c->dpi, &dso));
    const bool pipe = st->border_used && st->border_style == SMR_STYLE_PIPE;
    const bool round_border = st->border_used && (st->border_style == SMR_STYLE_ROUNDDOT || pipe);
+   /* the fill stroke of an open way with style=pipe is the dots alone: cairo_smr_dash(DRAW_PIPE) sets {0, sum} and round caps (:915-920);
+    * with style=pipe|rounddot it switches the rule's context to round caps for good (:909-921), and the border strokes of every
+    * LATER way have them */
+   const bool round_fill = st->fill_used && (st->fill_style == SMR_STYLE_PIPE || st->fill_style == SMR_STYLE_ROUNDDOT);
+   if (st->fill_used && st->fill_style == SMR_STYLE_PIPE) { dso.n = 2; dso.d[0] = 0; dso.d[1] = dso.sum; dso.d[2] = dso.d[3] = 0; }
    const int K = pipe ? 3 : 2;
    if (pipe && mode == SMR_PASS_COMPOUND) return smr_fail(SMR_E_INVAL, "draw: internal: compound pass with a border");
    const int64_t n_ways = b->n_ways, n_prims = K * n_ways;
@@ -4378,6 +4488,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    uint32_t init_small[8] = { 0, 0xffffffffu, 0, 0, 0, 0xffffffffu, 0, 0 };     /* [5] first stroked way, [6] scan totals */
    SMR_HIP(hipMemsetAsync(small, 0, 2048, s));                  /* [64 + 8 * xcd]: k_raster's tile queues, [128 + 8 * xcd]: k_prim_setup's, [256 + 8 * xcd]: k_blend's */
    SMR_HIP(hipMemcpyAsync(small, init_small, sizeof(init_small), hipMemcpyHostToDevice, s));
+   SMR_HIP(hipMemsetAsync(&small[14], 0xff, 4, s));             /* [14] first open way with a fill stroke */
 
    const int TB = 256;
    auto blocks = [](int64_t n, int tb) { return (unsigned) ((n + tb - 1) / tb); };
@@ -4390,7 +4501,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
                                      wc ? wc->node_win : nullptr, wc ? wc->win_shift : nullptr);
    }
    k_way_info<<<blocks(n_ways, TB), TB, 0, s>>>(b->d_way_off, b->d_ref, n_ways, n_refs, st->border_used, st->fill_used,
-                                                st->ignore_open, mode, wayflags, &small[0], &small[5], &small[2]);
+                                                st->ignore_open, mode, wayflags, &small[0], &small[5], &small[14], &small[2]);
    uint32_t h_small[16];         /* [8] tiles left to k_raster<true>, [9] most entries of one of them, [10] that kernel's queue */
    SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
@@ -4406,8 +4517,16 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    double hw_open = (mm2wu(2 * st->border_width_mm, c->dpi) + mm2wu(st->fill_width_mm, c->dpi)) / 2;
    double hw_closed = mm2wu(2 * st->border_width_mm, c->dpi) / 2;
    double hw_fill = mm2wu(st->fill_width_mm, c->dpi) / 2;
-   if (open_fill && round_border && dso.n == 0)
-      return smr_fail(SMR_E_UNSUPPORTED, "draw: bstyle=rounddot|pipe leaves round caps on the solid fill strokes of open ways: not implemented on the GPU path");
+   /* a SOLID stroke with round caps: the dasher with one endless dash (quad per segment, wedge per join, a fan per cap; oracle:
+    * stroke_styled).  Fill strokes after a round border: all of them (a way's border comes before its fill stroke).  Border strokes
+    * after a round fill stroke: those of the ways after the first open way; the others stay k_stroke_edges' */
+   const bool solid_open = open_fill && round_border && dso.n == 0;
+   const bool solid_border = st->border_used && dsb.n == 0 && round_fill && open_fill;
+   const dash_spec_t endless = { 1, { SMR_DASH_ENDLESS, 0, 0, 0 }, SMR_DASH_ENDLESS };
+   if (solid_open) dso = endless;
+   if (solid_border) dsb = endless;
+   const int cap_b = st->border_style == SMR_STYLE_ROUNDDOT ? 1 : pipe ? 2 : round_fill && open_fill ? 3 : 0;
+   const int cap_o = round_border || round_fill ? 1 : 0;
 
    /* dashed strokes: count the pieces of every way, place them with a scan */
    const bool dash_b = st->border_used && dsb.n > 0, dash_o = open_fill && dso.n > 0;
@@ -4416,7 +4535,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    if (st->curve != 0)
    {
       if (dash_b || dash_o)
-         return smr_fail(SMR_E_UNSUPPORTED, "draw: a dashed stroke along a curve (curve=1 with style/bstyle/dash/bdash) is not implemented on the GPU path");
+         return smr_fail(SMR_E_UNSUPPORTED, "draw: a dashed or round-capped stroke along a curve (curve=1 with style/bstyle/dash/bdash) is not implemented on the GPU path");
       uint32_t *ccnt, *sums; int2 *fpts; int32_t *frefway; int64_t *fway_off;
       SMR_TRY(c->ensure(SMR_BUF_CURVE_CNT, ((size_t) n_refs + 1) * 4, (void **) &ccnt));
       SMR_TRY(c->ensure(SMR_BUF_SUMS, ((size_t) n_refs / SCAN_B + 2) * 4, (void **) &sums));
@@ -4504,7 +4623,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       for (int i = 0; i < 7; i++)
       {
          pen_off[i] = (int) pens.size(); pen_n[i] = 0;
-         const bool need = i < 3 ? (dash_b && round_border) : i < 6 ? pipe : (dash_o && round_border);
+         const bool need = i < 3 ? (dash_b && cap_b != 0) : i < 6 ? pipe : (dash_o && cap_o != 0);
          if (need) { SMR_TRY(host_pen(pw[i], c->dpi, pens)); pen_n[i] = (int) pens.size() - pen_off[i]; }
       }
       int2 *d_pen;
@@ -4516,7 +4635,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          A.dpi = c->dpi; A.fill_used = st->fill_used;
          A.hw_nofill = hw_nofill * scale; A.hw_open = hw_open * scale; A.hw_closed = hw_closed * scale; A.hw_fill = hw_fill;
          for (int i = 0; i < 4; i++) A.dash[i] = ds.d[i];
-         A.ndash = ds.n; A.cap_mode = cap_mode; A.first_way = &small[5]; A.pen = d_pen;
+         A.ndash = ds.n; A.cap_mode = cap_mode; A.first_way = cap_mode == 3 ? &small[14] : &small[5]; A.pen = d_pen; A.round_only = 0; A.solid = 0;
          for (int i = 0; i < 3; i++) { A.pen_off[i] = pen_off[dmode == 1 ? 6 : pen0 + i]; A.pen_n[i] = pen_n[dmode == 1 ? 6 : pen0 + i]; }
          A.piece_cnt = nullptr; A.piece_off = nullptr; A.edges = nullptr;
       };
@@ -4526,7 +4645,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       if (dash_b)
       {
          dash_spec_t d1 = dsb;
-         fill_args(DA[0], 0, d1, st->border_style == SMR_STYLE_ROUNDDOT ? 1 : pipe ? 2 : 0, 0, 1.0);
+         fill_args(DA[0], 0, d1, cap_b, 0, 1.0);
+         DA[0].round_only = solid_border ? 1 : 0; DA[0].solid = solid_border ? 1 : 0;
          po_border = dbuf;
          DA[0].piece_cnt = po_border;
          k_dash<false><<<blocks(n_ways, 64), 64, 0, s>>>(DA[0]);
@@ -4548,7 +4668,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       }
       if (dash_o)
       {
-         fill_args(DA[2], 1, dso, round_border ? 1 : 0, 0, 1.0);
+         fill_args(DA[2], 1, dso, cap_o, 0, 1.0);
+         DA[2].solid = solid_open ? 1 : 0;
          po_open = dbuf + 2 * stride;
          DA[2].piece_cnt = po_open;
          k_dash<false><<<blocks(n_ways, 64), 64, 0, s>>>(DA[2]);
@@ -4567,7 +4688,9 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
 
    /* edge arena: [border strokes: 8/ref or 4/piece][the pipe's dots][fill polygons: 1/ref][open-way fill strokes] */
    uint64_t off_border = 0;
-   uint64_t off_dots = !st->border_used ? 0 : dash_b ? 4ull * tot_b : (uint64_t) SMR_SLOTS * n_refs;
+   /* (solid_border: the plain layout of every way, then the piece lists of the ways with round caps) */
+   const uint64_t off_border_po = solid_border ? (uint64_t) SMR_SLOTS * n_refs : 0;
+   uint64_t off_dots = !st->border_used ? 0 : dash_b ? off_border_po + 4ull * tot_b : (uint64_t) SMR_SLOTS * n_refs;
    uint64_t off_fill = off_dots + 4ull * tot_d;
    uint64_t off_open = off_fill + (st->fill_used ? (uint64_t) n_refs : 0);
    uint64_t n_edges = off_open + (!open_fill ? 0 : dash_o ? 4ull * tot_o : (uint64_t) SMR_SLOTS * n_refs);
@@ -4578,11 +4701,11 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
 
    if (dash_b)
    {
-      DA[0].edges = edges + off_border;
+      DA[0].edges = edges + off_border + off_border_po;
       k_dash<true><<<blocks(n_ways, 64), 64, 0, s>>>(DA[0]);
       if (pipe) { DA[1].edges = edges + off_dots; k_dash<true><<<blocks(n_ways, 64), 64, 0, s>>>(DA[1]); }
    }
-   else if (st->border_used)
+   if (st->border_used && (!dash_b || solid_border))
    {
       if (tin)
       {
@@ -4659,6 +4782,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          SA.lim_on = wc == nullptr && !limits_off();
       }
       SA.K = K; SA.off_dots = off_dots; SA.po_border = po_border; SA.po_dots = po_dots; SA.po_open = po_open; SA.id_off = id_off;
+      SA.solid_border = solid_border; SA.solid_open = solid_open; SA.mix_border = solid_border; SA.off_border_po = off_border + off_border_po;
       uint32_t *biglist;
       SMR_TRY(c->ensure(SMR_BUF_BIGLIST, ((size_t) n_prims * 2 + 2) * 4, (void **) &biglist));
       SMR_HIP(hipMemsetAsync(biglist, 0, 4, s));

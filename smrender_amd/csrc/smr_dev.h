@@ -88,6 +88,7 @@ struct __attribute__((aligned(16))) smr_thdr_t
                                    exact whole-row path, which holds SMR_ROWCAP of them per tile (draw_pass keeps a copy of the canvas) */
 #define SMR_ST_BADBATCH 128u    /* the way table does not start at 0 / ascend / end at n_refs, or a ref lies outside [0, n_nodes) */
 #define SMR_ST_FARAWAY 256u     /* a node more than SMR_FAR_PX beyond the chart: beyond what the edge arithmetic holds exactly */
+#define SMR_DASH_ENDLESS 1e12   /* pt: the one dash of a solid stroke that goes through the dasher for its round caps (oracle: ORC_DASH_ENDLESS) */
 #define SMR_FAR_PX 32768.0      /* with charts of up to 65 536 px an edge then spans less than the 139 000 px whose 60 * dy (24.8) fit 31 bits */
 #define SMR_ST_DEGRADED 8u      /* a compound row with more than SMR_ROWCAP spanning edges was sub-sampled */
 

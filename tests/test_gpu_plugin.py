@@ -99,8 +99,28 @@ def test_draw_relation_members_and_key_colours(chart):
 
 def test_unsupported_draw_styles_are_refused_loudly(chart):
     sa, proj = chart
-    for params in ("color=red;style=rounddot", "color=red;wavy=1;style=dashed", "bcolor=red;curve=1;bstyle=dashed"):
+    for params in ("color=red;wavy=1;style=dashed", "bcolor=red;curve=1;bstyle=dashed"):
         assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, []) == 2001      # "Rule will be ignored"
+
+
+@pytest.mark.parametrize("params,style", [
+    ("color=#c04020;width=0.5;bcolor=black;bwidth=0.2;style=pipe", dict(fill_style=4)),
+    ("color=#c04020;width=0.4;bcolor=#204060;bwidth=0.15;style=rounddot", dict(fill_style=5)),
+    ("color=#4080c0;width=0.5;bcolor=black;bwidth=0.15;bstyle=rounddot", dict(border_style=5))])
+def test_rules_whose_caps_stay_round_through_the_action_api(chart, params, style):
+    """style=pipe|rounddot on fill strokes and solid strokes after a round-capped one (cairo_smr_dash :909-921: the rule's context
+    keeps CAIRO_LINE_CAP_ROUND): accepted by act_draw_ini and drawn as the oracle does (pinned on libcairo in test_oracle_cairo.py)"""
+    from test_oracle_cairo import _sticky_scene
+    from test_gpu_raster import _ways_to_arrays
+    sa, proj = chart
+    wids, oways = load_ways(sa, proj, _ways_to_arrays(_sticky_scene(W, H, 7)))
+    rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, wids)
+    assert rc == 0, sa.lib().smr_hip_last_error()
+    col = lambda k: int(params.split(k + "=#")[1][:6], 16) if k + "=#" in params else 0
+    w = lambda k: float(params.split(";" + k + "=")[1].split(";")[0])
+    st = po.Style(1, 1, col("color"), col("bcolor"), w("width"), w("bwidth"), 0).with_dash(**style)
+    want = po.oracle_scene([(st, oways)], DPI, W, H, 0xfff8e0)
+    assert np.array_equal(plugin_canvas(sa), want)
 
 
 @pytest.mark.parametrize("params,style", [

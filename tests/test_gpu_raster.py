@@ -503,6 +503,26 @@ def test_dashed_strokes_bit_exact(hip, case):
     assert (got != 0xffffffff).sum() > 2000
 
 
+@pytest.mark.parametrize("case", ["rounddot-border+solid-fill-stroke", "pipe-border+solid-fill-stroke", "solid-border+pipe-fill-stroke",
+                                  "solid-border+rounddot-fill-stroke", "dashed-border+rounddot-fill-stroke", "no-border+pipe-fill-stroke"])
+def test_sticky_round_caps_bit_exact(hip, case):
+    """the rule's caps stay round once a rounddot / pipe stroke has set them (cairo_smr_dash :909-921): solid fill strokes after a
+    round border, solid or dashed borders of the ways after the first open way's round fill stroke, the dots of style=pipe on a
+    fill stroke; whole canvas and two bands, against the oracle (pinned on libcairo: test_oracle_cairo.py::test_sticky_round_caps)"""
+    from test_oracle_cairo import STICKY_CASES, _sticky_scene
+    st = STICKY_CASES[case]
+    W, H = 240, 200
+    ways = _sticky_scene(W, H, 7)
+    arrs = _ways_to_arrays(ways)
+    want = po.oracle_scene([(st, ways)], 300, W, H, 0xffffff)
+    got = gpu_scene(hip, [(st, arrs)], 300, W, H, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
+    assert (got != 0xffffffff).sum() > 5000
+    for y0, h in ((0, 96), (96, 104)):
+        band = gpu_scene(hip, [(st, arrs)], 300, W, H, 0xffffff, y0, h)
+        assert np.array_equal(band, want[y0:y0 + h]), (y0, report(band, want[y0:y0 + h]))
+
+
 def test_dash_styles_the_gpu_path_refuses(hip):
     sa = hip
     x, y, off, ref = _ways_to_arrays([(np.array([3.0, 40.0, 50.0]), np.array([4.0, 30.0, 8.0]), False)])
@@ -510,8 +530,7 @@ def test_dash_styles_the_gpu_path_refuses(hip):
     args = (sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off),
             sa.DeviceArray.from_numpy(ref), 1, len(ref))
     S = po.Style
-    for st in (S(1, 0, 0, 0, 0.3, 0, 0).with_dash(fill_style=S.ROUNDDOT),                  # round caps on fill strokes
-               S(1, 1, 0, 0, 0.3, 0.1, 0).with_dash(border_style=S.PIPE),                   # solid fill stroke after round caps
+    for st in (S(1, 1, 0, 0, 0.3, 0.1, 0).with_curve().with_dash(border_style=S.DASHED),   # dashes along a curve
                S(0, 1, 0, 0, 0, 0.1, 0).with_dash(border_style=S.DASHED, border_dash=(0, 0))):   # libcairo: invalid dash
         with pytest.raises(sa.SmrHipError):
             cv.draw(draw_style(sa, st), *args)

@@ -150,6 +150,17 @@ DASH_CASES = {
     "dashed-fill-stroke": po.Style(1, 1, 0x4080c0, 0x000000, 0.3, 0.1, 0).with_dash(fill_style=1),
 }
 
+# the rule's caps are sticky (cairo_smr_dash :909-921 sets CAIRO_LINE_CAP_ROUND and nothing sets it back): strokes that come after a
+# rounddot / pipe stroke on the same context have round caps, solid ones included
+STICKY_CASES = {
+    "rounddot-border+solid-fill-stroke": po.Style(1, 1, 0x4080c0, 0x000000, 0.5, 0.15, 0).with_dash(border_style=5),
+    "pipe-border+solid-fill-stroke": po.Style(1, 1, 0x4080c0, 0x103050, 0.4, 0.15, 0).with_dash(border_style=4),
+    "solid-border+pipe-fill-stroke": po.Style(1, 1, 0xc04020, 0x000000, 0.5, 0.2, 0).with_dash(fill_style=4),
+    "solid-border+rounddot-fill-stroke": po.Style(1, 1, 0xc04020, 0x204060, 0.4, 0.15, 0).with_dash(fill_style=5),
+    "dashed-border+rounddot-fill-stroke": po.Style(1, 1, 0x208040, 0x000000, 0.4, 0.15, 0).with_dash(border_style=1, fill_style=5),
+    "no-border+pipe-fill-stroke": po.Style(1, 0, 0x208040, 0, 0.6, 0.2, 0).with_dash(fill_style=4),
+}
+
 
 @pytest.mark.parametrize("case", list(DASH_CASES))
 def test_dashed_strokes(case):
@@ -165,6 +176,44 @@ def test_dashed_strokes(case):
     assert touched.sum() > 5000
     # bit-identical but for one near-reversal (bevel) join of the scene whose vertex sits on a sample-row boundary
     assert (d > 0).sum() <= 0.0008 * touched.sum(), ((d > 2).sum(), (d > 0).sum(), d.max())
+
+
+def _sticky_scene(W, H, seed):
+    """closed ways first (their borders come before any open way's fill stroke), then open and closed ones mixed"""
+    rng = np.random.default_rng(seed)
+    x, y, off, ref = po.synth_ways(7, W, H, seed=seed, rmin=10.0, rmax=0.2 * W)
+    closed = po.ways_from_arrays(x, y, off, ref)
+    ways = closed[:2]
+    for k in range(5):
+        n = int(rng.integers(2, 8))
+        ways.append((rng.uniform(8, W - 8, n), rng.uniform(8, H - 8, n), False))
+        ways.append(closed[2 + k])
+    return ways
+
+
+@pytest.mark.parametrize("case", list(STICKY_CASES))
+def test_sticky_round_caps(case):
+    """solid strokes with round caps (the polygon stroker's add_cap / add_fan) restated as the dasher's pieces with one endless
+    dash, and the order in which the rule's strokes switch the caps, against the real libcairo driven with the reference's
+    call sequence (render_poly_line :953-1016)"""
+    st = STICKY_CASES[case]
+    W, H = 240, 200
+    ways = _sticky_scene(W, H, 7)
+    a = po.oracle_scene([(st, ways)], 300, W, H, 0xffffff)
+    b = po.cairo_scene([(st, ways)], 300, W, H, 0xffffff)
+    d = po.chan_diff(a, b)
+    touched = (a != 0xffffffff) | (b != 0xffffffff)
+    assert touched.sum() > 5000
+    assert (d > 2).sum() <= 0.002 * touched.sum() and (d > 0).sum() <= 0.02 * touched.sum(), ((d > 2).sum(), (d > 0).sum(), d.max(), touched.sum())
+    # and the caps are there: without the stickiness (every stroke with the caps its own style asks for) the picture differs
+    import os
+    os.environ["ORC_NO_STICKY_CAPS"] = "1"
+    try:
+        c = po.oracle_scene([(st, ways)], 300, W, H, 0xffffff)
+    finally:
+        del os.environ["ORC_NO_STICKY_CAPS"]
+    if case != "no-border+pipe-fill-stroke":
+        assert (po.chan_diff(c, b) > 2).sum() > 20 * max(1, (d > 2).sum()), ((po.chan_diff(c, b) > 2).sum(), (d > 2).sum())
 
 
 # ---- curve=1 -------------------------------------------------------------------------------------------------------
