@@ -246,6 +246,13 @@ typedef struct
 } smr_draw_batch_t;
 
 int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b);
+/* The image fill of a rule (draw file=..., img on ways): render_poly_line src/smrules_cairo.c:989-997 / img_fill :2742-2751 fill
+ * the CLOSED ways with a surface pattern that img_ini :2691-2704 sets up -- CAIRO_EXTEND_REPEAT, matrix scale(dpi / 72), i.e. one
+ * image pixel per chart pixel, the image's top-left pixel on the chart's -- in a group of the rule's own, which act_draw_fini
+ * :1081 pops BEFORE the rule's colours: call this first, smr_hip_draw after.  pattern: pat_w x pat_h premultiplied ARGB32 pixels
+ * in HOST memory (the image as img_ini leaves it: scaled, transparency applied).  Of the style only directional, evenodd and curve
+ * count; open ways draw nothing.  A rotated pattern (angle=) is not implemented: the caller refuses it. */
+int smr_hip_draw_pattern(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, const uint32_t *pattern, int32_t pat_w, int32_t pat_h);
 /* Flags about the last smr_hip_draw of this process.  SMR_DRAW_DEGRADED_ROWS: some pixel row of a polygon held no
  * vertex but more spanning edges than the exact whole-row coverage path keeps (64); such rows were sub-sampled on the
  * 15-row grid instead, so their anti-aliasing may differ from libcairo's by a few levels.  No counterpart in the

@@ -59,6 +59,14 @@ FN(void, cairo_set_dash, (cairo_t*, const double*, int, double))
 FN(void, cairo_stroke, (cairo_t*))
 FN(void, cairo_fill, (cairo_t*))
 FN(void, cairo_set_fill_rule, (cairo_t*, int))
+typedef struct { double xx, yx, xy, yy, x0, y0; } cd_matrix_t;       /* cairo_matrix_t */
+FN(cairo_pattern_t*, cairo_pattern_create_for_surface, (cairo_surface_t*))
+FN(void, cairo_pattern_set_matrix, (cairo_pattern_t*, const cd_matrix_t*))
+FN(void, cairo_pattern_set_extend, (cairo_pattern_t*, int))
+FN(void, cairo_pattern_destroy, (cairo_pattern_t*))
+FN(void, cairo_set_source, (cairo_t*, cairo_pattern_t*))
+FN(void, cairo_matrix_init_scale, (cd_matrix_t*, double, double))
+FN(void, cairo_matrix_rotate, (cd_matrix_t*, double))
 FN(void, cairo_scale, (cairo_t*, double, double))
 FN(void, cairo_translate, (cairo_t*, double, double))
 FN(void, cairo_rotate, (cairo_t*, double))
@@ -108,6 +116,8 @@ int cd_init(const char *path)
    LOAD(cairo_font_options_create); LOAD(cairo_font_options_set_hint_metrics); LOAD(cairo_set_font_options);
    LOAD(cairo_font_options_destroy); LOAD(cairo_select_font_face); LOAD(cairo_set_font_size);
    LOAD(cairo_font_extents); LOAD(cairo_text_extents);
+   LOAD(cairo_pattern_create_for_surface); LOAD(cairo_pattern_set_matrix); LOAD(cairo_pattern_set_extend); LOAD(cairo_pattern_destroy);
+   LOAD(cairo_set_source); LOAD(cairo_matrix_init_scale); LOAD(cairo_matrix_rotate);
    return 0;
 }
 
@@ -191,6 +201,33 @@ void cd_stroke(uint32_t col, double width_pt)
 /* CAIRO_FILL_RULE_WINDING = 0 (libcairo's default, the only one the reference uses), CAIRO_FILL_RULE_EVEN_ODD = 1: on the current
  * rule's context, for the even-odd extension of the rasterizer */
 void cd_set_fill_rule(int evenodd) { p_cairo_set_fill_rule(rule_, evenodd ? 1 : 0); }
+
+/* img_ini's pattern (src/smrules_cairo.c:2691-2704) as the source of the current rule's context: the image (w x h premultiplied
+ * ARGB32, copied) as a surface pattern with the matrix scale(1 / PX2PT_SCALE) . rotate(angle) and CAIRO_EXTEND_REPEAT;
+ * cd_fill_source fills the current path with it (img_fill :2742-2751, render_poly_line :989-997) */
+static cairo_surface_t *pat_sfc_;
+int cd_set_source_pattern(const uint32_t *pix, int w, int h, double dpi, double angle_deg)
+{
+   if (pat_sfc_) { p_cairo_surface_destroy(pat_sfc_); pat_sfc_ = NULL; }
+   pat_sfc_ = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, w, h);
+   if (p_cairo_surface_status(pat_sfc_)) return -1;
+   p_cairo_surface_flush(pat_sfc_);
+   unsigned char *d = p_cairo_image_surface_get_data(pat_sfc_);
+   int stride = p_cairo_image_surface_get_stride(pat_sfc_);
+   for (int y = 0; y < h; y++) memcpy(d + (size_t) y * stride, pix + (size_t) y * w, (size_t) w * 4);
+   p_cairo_surface_mark_dirty(pat_sfc_);
+   cairo_pattern_t *pat = p_cairo_pattern_create_for_surface(pat_sfc_);
+   cd_matrix_t m;
+   p_cairo_matrix_init_scale(&m, dpi / 72, dpi / 72);
+   p_cairo_matrix_rotate(&m, angle_deg * M_PI / 180);
+   p_cairo_pattern_set_matrix(pat, &m);
+   p_cairo_pattern_set_extend(pat, 1 /* CAIRO_EXTEND_REPEAT */);
+   p_cairo_set_source(rule_, pat);
+   p_cairo_pattern_destroy(pat);
+   return p_cairo_status(rule_);
+}
+
+void cd_fill_source(void) { p_cairo_fill(rule_); }
 
 void cd_fill(uint32_t col)
 {

@@ -98,6 +98,7 @@ def orc():
         L.orc_curve_path.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p, C.c_void_p]
         L.orc_curve_flatten.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_canvas_set_image.argtypes = [C.c_void_p] + [C.c_int] * 4
+        L.orc_canvas_set_pattern.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.orc_stroke_edges_tan.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
         L.orc_color_pixel.argtypes = [C.c_uint32]
         L.orc_color_pixel.restype = C.c_uint32
@@ -149,6 +150,7 @@ def cairo():
         L.cd_stroke.argtypes = [C.c_uint32, C.c_double]
         L.cd_fill.argtypes = [C.c_uint32]
         L.cd_set_fill_rule.argtypes = [C.c_int]
+        L.cd_set_source_pattern.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
         L.cd_set_direct_fill_rule.argtypes = [C.c_int]
         L.cd_render.argtypes = [C.c_double] + [C.c_int] * 4 + [C.c_void_p]
         L.cd_save_png.argtypes = [C.c_double, C.c_int, C.c_int, C.c_char_p]
@@ -220,6 +222,69 @@ def oracle_scene(rules, dpi, W, H, bg, x0=0, y0=0, image=None):
     out = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (H, W)).copy()
     L.orc_canvas_free(c)
     return out
+
+
+def oracle_pattern_scene(before, pattern_rule, after, dpi, W, H, bg, x0=0, y0=0):
+    """rules `before`, then ONE rule with an image fill, then rules `after`.  pattern_rule = (Style, ways, pattern[h, w] uint32
+    premultiplied ARGB32): the rule's closed ways filled with the image in a group of its own (render_poly_line :989-997), popped
+    before the rule's own group (act_draw_fini :1081-1082); with Style.directional-like use see oracle_directional(pattern=)."""
+    L = orc()
+    c = L.orc_canvas_new(x0, y0, W, H, dpi, bg)
+
+    def plain(rules):
+        for st, ways in rules:
+            L.orc_rule_begin(c)
+            for way in ways:
+                x, y, closed = way[:3]
+                x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+                L.orc_draw_way(c, C.byref(st), P(x), P(y), len(x), int(closed), 0, 0, 0, 0)
+            L.orc_rule_end(c)
+
+    plain(before)
+    st, ways, pat = pattern_rule
+    pat = np.ascontiguousarray(pat, np.uint32)
+    fs = Style(1, 0, 0, 0, 0, 0, 1)
+    fs.curve, fs.curve_fact, fs.evenodd = st.curve, st.curve_fact, st.evenodd
+    L.orc_canvas_set_pattern(c, P(pat), pat.shape[1], pat.shape[0])
+    L.orc_rule_begin(c)
+    for x, y, closed in ways:
+        if closed:
+            x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+            L.orc_draw_way(c, C.byref(fs), P(x), P(y), len(x), 1, 0, 0, 0, 0)
+    L.orc_rule_end(c)
+    L.orc_canvas_set_pattern(c, None, 0, 0)
+    if st.fill_used or st.border_used:
+        plain([(st, ways)])
+    plain(after)
+    out = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (H, W)).copy()
+    L.orc_canvas_free(c)
+    return out
+
+
+def cairo_pattern_scene(before, pattern_rule, after, dpi, W, H, bg):
+    """the same through the real libcairo: the image as a surface pattern with img_ini's matrix and CAIRO_EXTEND_REPEAT"""
+    L = cairo()
+    st, ways, pat = pattern_rule
+    pat = np.ascontiguousarray(pat, np.uint32)
+
+    def img_group(Ld):
+        Ld.cd_rule_begin()
+        Ld.cd_set_fill_rule(int(st.evenodd))
+        assert Ld.cd_set_source_pattern(P(pat), pat.shape[1], pat.shape[0], float(dpi), 0.0) == 0
+        for x, y, closed in ways:
+            if closed:
+                xy = np.ascontiguousarray(np.stack([np.asarray(x) * 72 / dpi, np.asarray(y) * 72 / dpi], 1))
+                Ld.cd_poly_line(P(xy), len(xy))
+                Ld.cd_fill_source()
+        Ld.cd_rule_end()
+
+    # cairo_scene records rule by rule and renders at the end: the image group goes in between through its hook
+    rules = list(before)
+    n_before = len(rules)
+    if st.fill_used or st.border_used:
+        rules.append((st, ways))
+    rules += list(after)
+    return cairo_scene(rules, dpi, W, H, bg, between=(n_before, img_group))
 
 
 def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0, image=None):
@@ -352,14 +417,16 @@ def _cairo_curve_way(L, st, xy, closed, dpi):
             L.cd_fill(st.fill_col)
 
 
-def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None, before_render=None):
+def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None, before_render=None, between=None):
     """Same scene through the real libcairo with the reference's call sequence.  before_render(L): further rules recorded
     through the driver (captions: cd_rule_begin, cd_show_caption ..., cd_rule_end) before the chart is replayed."""
     L = cairo()
     fw = (full_w or (x0 + W)) * 72 / dpi
     fh = (full_h or (y0 + H)) * 72 / dpi
     L.cd_begin(fw, fh, bg)
-    for st, ways in rules:
+    for k_rule, (st, ways) in enumerate(rules):
+        if between is not None and between[0] == k_rule:
+            between[1](L)                    # (index, fn): a group recorded through the driver before rule `index`
         L.cd_rule_begin()
         L.cd_set_fill_rule(int(st.evenodd))
         for x, y, closed in ways:
@@ -392,6 +459,8 @@ def cairo_scene(rules, dpi, W, H, bg, x0=0, y0=0, full_w=None, full_h=None, befo
                 else:
                     L.cd_fill(st.fill_col)
         L.cd_rule_end()
+    if between is not None and between[0] == len(rules):
+        between[1](L)
     if before_render is not None:
         before_render(L)
     out = np.zeros((H, W), np.uint32)

@@ -861,6 +861,7 @@ struct orc_canvas
    int cap_round;        /* line cap of the current rule's context (cairo_set_line_cap is never undone) */
    int32_t shift_x, shift_y;   /* 24.8: the translation of a replay at an offset (cairo_smr_cut_out), added to every device vertex */
    int no_cuts;          /* the edges of the next orc_layer_edges are a stroke's PIECES: their inner edges are not the polygon's, no cuts at the image's sides */
+   const uint32_t *pat; int pat_w, pat_h;   /* orc_canvas_set_pattern: the source of orc_layer_edges is this image, repeated from the chart's origin */
 };
 
 orc_canvas_t *orc_canvas_new(int x0, int y0, int W, int H, int dpi, uint32_t bgcolor)
@@ -915,6 +916,12 @@ void orc_rule_end(orc_canvas_t *c)
    for (size_t i = 0; i < (size_t) c->W * c->H; i++) c->pix[i] = blend_over(c->layer[i], c->pix[i]);
 }
 
+/* The image fill of a rule (img_ini src/smrules_cairo.c:2691-2704: cairo_pattern_create_for_surface, matrix scale(1 / PX2PT_SCALE)
+ * = one image pixel per chart pixel at angle 0, CAIRO_EXTEND_REPEAT; render_poly_line :989-997 / img_fill :2742-2751 fill the
+ * closed ways with it): while a pattern is set, orc_layer_edges takes every pixel's source from the image (premultiplied ARGB32,
+ * kept by the caller) and composites it as pixman does an image source through a mask: (s IN m) OVER d.  NULL: colours again. */
+void orc_canvas_set_pattern(orc_canvas_t *c, const uint32_t *pix, int w, int h) { c->pat = pix; c->pat_w = w; c->pat_h = h; }
+
 void orc_layer_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, uint32_t smr_col)
 {
    uint32_t s = orc_color_pixel(smr_col);
@@ -955,7 +962,14 @@ void orc_layer_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, u
          uint32_t m = c->cov[(size_t) y * bw + x];
          if (!m) continue;
          uint32_t *d = &c->layer[(size_t) (y + by0) * c->W + x + bx0];
-         *d = lerp ? blend_lerp(s, m, *d) : blend_over_mask(s, m, *d);
+         if (c->pat)
+         {
+            int u = (c->x0 + bx0 + x) % c->pat_w, v = (c->y0 + by0 + y) % c->pat_h;
+            if (u < 0) u += c->pat_w;
+            if (v < 0) v += c->pat_h;
+            *d = blend_over_mask(c->pat[(size_t) v * c->pat_w + u], m, *d);
+         }
+         else *d = lerp ? blend_lerp(s, m, *d) : blend_over_mask(s, m, *d);
       }
    c->layer_clear = 0;
 }

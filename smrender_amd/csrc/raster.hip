@@ -2406,6 +2406,15 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
 /* ------------------------------------------------------------------------------------ */
 /* the rasterizer: one wavefront per 64x4 tile                                             */
 /* ------------------------------------------------------------------------------------ */
+/* a pattern pass's source pixel at chart pixel (px, row) */
+__device__ __forceinline__ uint32_t smr_pat_pix(const uint32_t *__restrict__ pat, int w, int h, int px, int row)
+{
+   int u = px % w, v = row % h;
+   if (u < 0) u += w;
+   if (v < 0) v += h;
+   return pat[(size_t) v * w + u];
+}
+
 struct raster_args_t
 {
    const smr_prim_t *prims;
@@ -2417,6 +2426,9 @@ struct raster_args_t
    uint32_t *status;
    uint32_t *tile_ctr;        /* [8 * xcd]: next tile of the XCD's columns, zero at launch */
    uint32_t *blend_ctr;       /* the same for k_blend */
+   const uint32_t *pat;       /* a pattern pass (smr_hip_draw_pattern): every primitive's source is this premultiplied ARGB32 image, tiled from the
+                                 chart's top-left pixel (CAIRO_EXTEND_REPEAT, one image pixel per chart pixel); NULL: the primitives' colours */
+   int pat_w, pat_h;
    uint32_t strided;          /* k_raster<false>: no queue, wavefront i of an XCD looks at the tiles i, i + waves, ... of its columns (the pure ones are k_blend's) */
    int W, band_y0, band_h, TX;
    uint32_t n_tiles;
@@ -3030,6 +3042,12 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                int a = (area + (area << 4) + 256) >> 9;
                a = a < 0 ? 0 : a > 255 ? 255 : a;
                if (!col_in || !((cur_rowin >> r) & 1u)) a = 0;
+               if (A.pat)
+               {
+                  /* an image source: pixman's OVER through the coverage mask, pixel by pixel */
+                  if (a) layer[r] = smr_blend_over_mask(smr_pat_pix(A.pat, A.pat_w, A.pat_h, tx * SMR_TW + lane, row0 + r), (uint32_t) a, layer[r]);
+                  continue;
+               }
                if (lerp && !__ballot(a != 0 && a != 255)) layer[r] = a ? spix : layer[r];      /* no edge pixel on the row */
                else if (__ballot(a != 0)) COUNT(8);
                if (lerp && !__ballot(a != 0 && a != 255)) { }
@@ -3066,6 +3084,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
                   {
                      const uint32_t a = (a4 >> (8 * r)) & 255u;
                      if (!__ballot(a != 0)) continue;
+                     if (A.pat) { if (a) layer[r] = smr_blend_over_mask(smr_pat_pix(A.pat, A.pat_w, A.pat_h, tx * SMR_TW + lane, row0 + r), a, layer[r]); continue; }
                      if (lerp && !__ballot(a != 255u && a != 0)) layer[r] = a ? spix : layer[r];      /* no edge pixel on the row */
                      else if (a) layer[r] = lerp ? smr_blend_lerp(spix, a, layer[r]) : smr_blend_over_mask(spix, a, layer[r]);
                   }
@@ -3264,7 +3283,8 @@ __global__ __launch_bounds__(64 * SMR_BLEND_WAVES) void k_blend(raster_args_t A)
                         const uint32_t a = (a4[u] >> (8 * (R))) & 255u; \
                         if (__ballot(a != 0)) \
                         { \
-                           if (!lerp) L = smr_blend_over_mask_all(spix, a, L); \
+                           if (A.pat) L = smr_blend_over_mask_all(smr_pat_pix(A.pat, A.pat_w, A.pat_h, px, A.band_y0 + ty * SMR_TH + (R)), a, L); \
+                           else if (!lerp) L = smr_blend_over_mask_all(spix, a, L); \
                            else if (!__ballot(a != 255u && a != 0)) L = a ? spix : L;      /* no edge pixel on the row */ \
                            else L = smr_blend_lerp_all(spix, a, L); \
                         } } while (0)
@@ -4386,6 +4406,30 @@ int smr_scan_u32(uint32_t *buf, uint32_t n, uint32_t *sums, uint32_t *total_dev,
 
 extern "C" int smr_hip_draw(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b) { return smr_draw_instances(c, st, b, nullptr); }
 
+/* render_poly_line's image fill (src/smrules_cairo.c:989-997, img_ini :2691-2704, img_fill :2742-2751): the CLOSED ways of the batch
+ * filled with an image repeated over the page -- CAIRO_EXTEND_REPEAT, pattern matrix scale(dpi / 72): one image pixel per chart
+ * pixel, the image's top-left pixel on the chart's -- as one group of its own.  Of the style only directional and evenodd count */
+extern "C" int smr_hip_draw_pattern(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, const uint32_t *pattern, int32_t pat_w, int32_t pat_h)
+{
+   smr_g.draw_status = 0;
+   SMR_NEED_INIT();
+   if (!c || !st || !b || !pattern) return smr_fail(SMR_E_INVAL, "draw_pattern: NULL argument");
+   if (pat_w <= 0 || pat_h <= 0 || (int64_t) pat_w * pat_h > (1 << 26)) return smr_fail(SMR_E_INVAL, "draw_pattern: image of %d x %d pixels", pat_w, pat_h);
+   if (c->win_n) return smr_fail(SMR_E_UNSUPPORTED, "draw_pattern: not on an atlas of windows (the image is laid out from the chart's origin)");
+   uint32_t *d_pat;
+   SMR_TRY(c->ensure(SMR_BUF_PATTERN, (size_t) pat_w * pat_h * 4, (void **) &d_pat));
+   SMR_HIP(hipMemcpyAsync(d_pat, pattern, (size_t) pat_w * pat_h * 4, hipMemcpyHostToDevice, smr_g.stream));
+   SMR_HIP(hipStreamSynchronize(smr_g.stream));             /* the caller's pixels may go */
+   smr_draw_style_t s2;
+   memset(&s2, 0, sizeof(s2));
+   s2.fill_used = 1; s2.fill_col = 0; s2.ignore_open = 1; s2.directional = st->directional; s2.evenodd = st->evenodd;
+   s2.curve = st->curve; s2.curve_factor = st->curve_factor;
+   c->pat = d_pat; c->pat_w = pat_w; c->pat_h = pat_h;
+   const int rc = smr_draw_instances(c, &s2, b, nullptr);
+   c->pat = nullptr; c->pat_w = c->pat_h = 0;
+   return rc;
+}
+
 int smr_draw_instances(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, const smr_win_ctx_t *wc)
 {
    smr_g.draw_status = 0;
@@ -4956,6 +5000,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    A.chunk = n_entries >= 8ull * n_tiles ? SMR_TILE_CHUNK : n_entries >= 2ull * n_tiles ? 2 * SMR_TILE_CHUNK : n_entries * 16ull >= n_tiles ? 4 * SMR_TILE_CHUNK : 64;
    A.direct = st->direct != 0;
    A.ovf_list = ovf_list; A.ovf_cnt = &small[8]; A.ovf_n = 0; A.big_bucket = nullptr; A.big_cap = 0; A.alpha = alpha;
+   A.pat = c->pat; A.pat_w = c->pat_w; A.pat_h = c->pat_h;
    {
       /* persistent grid: enough workgroups to fill every CU at the kernel's LDS/register occupancy */
       unsigned nwg = std::min<unsigned>((n_tiles + SMR_RASTER_WAVES - 1) / SMR_RASTER_WAVES, 256u * 8u);

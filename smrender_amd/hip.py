@@ -110,7 +110,7 @@ EXPORTS = [
     "smr_hip_windows_create", "smr_hip_windows_reset", "smr_hip_draw_windows", "smr_hip_windows_anchors", "smr_hip_blit_windows",
     "smr_hip_objects_create", "smr_hip_objects_destroy", "smr_hip_objects_info", "smr_hip_objects_match",
     "smr_hip_objects_select_ways", "smr_hip_objects_select_nodes",
-    "smr_hip_poly_area", "smr_hip_draw", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
+    "smr_hip_poly_area", "smr_hip_draw", "smr_hip_draw_pattern", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
     "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
     "act_draw_ini", "act_draw_main", "act_draw_fini", "act_cap_ini", "act_cap_main", "act_cap_fini",
@@ -161,6 +161,7 @@ def lib():
         L.smr_hip_canvas_write_kap.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_void_p]
         L.smr_hip_canvas_device.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
         L.smr_hip_draw.argtypes = [C.c_void_p, C.POINTER(DrawStyle), C.POINTER(_DrawBatch)]
+        L.smr_hip_draw_pattern.argtypes = [C.c_void_p, C.POINTER(DrawStyle), C.POINTER(_DrawBatch), C.c_void_p, C.c_int32, C.c_int32]
         L.smr_hip_debug_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.smr_hip_caprot.argtypes = [C.c_void_p, C.POINTER(_CapBatch), C.c_void_p, C.c_void_p]
         L.smr_hip_caprot_noalloc.argtypes = [C.c_void_p, C.POINTER(_CapBatch), C.c_void_p, C.c_void_p]
@@ -354,6 +355,12 @@ class Canvas:
         b = _DrawBatch(d_x.ptr, d_y.ptr, int(np.prod(d_x.shape)), d_way_off.ptr, d_ref.ptr if d_ref else None,
                        n_ways, n_refs, d_fill_col.ptr if d_fill_col else None, d_border_col.ptr if d_border_col else None)
         _chk(lib().smr_hip_draw(self.h, C.byref(style), C.byref(b)))
+
+    def draw_pattern(self, style, pattern, d_x, d_y, d_way_off, d_ref, n_ways, n_refs):
+        """the image fill of a rule (smr_hip_draw_pattern): pattern = [h, w] uint32 premultiplied ARGB32 pixels in host memory"""
+        pattern = np.ascontiguousarray(pattern, np.uint32)
+        b = _DrawBatch(d_x.ptr, d_y.ptr, int(np.prod(d_x.shape)), d_way_off.ptr, d_ref.ptr if d_ref else None, n_ways, n_refs, None, None)
+        _chk(lib().smr_hip_draw_pattern(self.h, C.byref(style), C.byref(b), pattern.ctypes.data, pattern.shape[1], pattern.shape[0]))
 
     @classmethod
     def windows(cls, chart_w, chart_h, dpi, bgcolor, cx, cy, size, r_px=None):

@@ -916,3 +916,42 @@ def test_fill_paths_of_k_cover_agree_with_the_oracle_and_with_each_other(hip, co
     for y0, h in ((0, 203), (203, 317)):
         band = gpu_scene(sa, [(st, arrs)], dpi, W, H, 0xffffff, y0, h)
         assert np.array_equal(band, want[y0:y0 + h]), report(band, want[y0:y0 + h])
+
+
+@pytest.mark.parametrize("alpha,style", [(255, po.Style(0, 0, 0, 0, 0, 0, 0)), (140, po.Style(0, 1, 0, 0x000000, 0, 0.2, 0)),
+                                         (200, po.Style(1, 1, 0x604080c0, 0x102030, 0.3, 0.15, 0))])
+def test_image_fill_bit_exact(hip, alpha, style):
+    """smr_hip_draw_pattern (render_poly_line's image fill, src/smrules_cairo.c:989-997): the closed ways filled with the repeated
+    image in a group below the rule's own; against the oracle (pinned on libcairo's surface pattern in
+    tests/test_oracle_cairo.py::test_image_fill_of_closed_ways), whole canvas and two bands (the tiling starts at the CHART's origin)"""
+    from test_oracle_cairo import _pattern, _dash_scene, _nested_scene
+    sa = hip
+    W, H = 200, 160
+    pat = _pattern(37, 23, 3, alpha)
+    ways = _dash_scene(W, H, 11)
+    before = [(po.Style(1, 0, 0xe0f0e0, 0, 0, 0, 0), _nested_scene(W, H, 2))]
+    want = po.oracle_pattern_scene(before, (style, ways, pat), [], 300, W, H, 0xffffff)
+
+    def gpu(y0, h):
+        cv = sa.Canvas(W, H, 300, 0xffffff, y0, h)
+        def dev(ws):
+            x, y, off, ref = _ways_to_arrays(ws)
+            return (sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off.astype(np.int64)),
+                    sa.DeviceArray.from_numpy(ref.astype(np.int32)), len(off) - 1, len(ref))
+        for st, ws in before:
+            cv.draw(draw_style(sa, st), *dev(ws))
+        d = dev(ways)
+        cv.draw_pattern(draw_style(sa, style), pat, *d)
+        if style.fill_used or style.border_used:
+            cv.draw(draw_style(sa, style), *d)
+        out = cv.read()
+        cv.close()
+        return out
+
+    got = gpu(0, H)
+    assert np.array_equal(got, want), report(got, want)
+    plain = po.oracle_scene(before + ([(style, ways)] if style.fill_used or style.border_used else []), 300, W, H, 0xffffff)
+    assert (got != plain).sum() > 3000
+    for y0, h in ((0, 60), (60, 100)):
+        band = gpu(y0, h)
+        assert np.array_equal(band, want[y0:y0 + h]), (y0, report(band, want[y0:y0 + h]))

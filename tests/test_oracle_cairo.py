@@ -330,3 +330,33 @@ def test_directional_rule_of_explicit_bezier_paths():
     b = po.cairo_directional(st, ways, 300, 256, 200, 0xffffff)
     assert len(np.unique(a)) > 2
     assert np.array_equal(a, b), int((a != b).sum())
+
+
+# ---- image fills (draw file=..., img on ways) ---------------------------------------------------------------------------
+def _pattern(w, h, seed, alpha=255):
+    """a premultiplied ARGB32 image without symmetry (so that a flipped, shifted or transposed tiling shows)"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    r = (xx * 255 // max(1, w - 1)).astype(np.uint32)
+    g = (yy * 255 // max(1, h - 1)).astype(np.uint32)
+    b = rng.integers(0, 256, (h, w)).astype(np.uint32)
+    a = np.full((h, w), alpha, np.uint32)
+    pm = lambda c: (c * a + 127) // 255
+    return ((a << 24) | (pm(r) << 16) | (pm(g) << 8) | pm(b)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("alpha,style", [(255, po.Style(0, 0, 0, 0, 0, 0, 0)), (140, po.Style(0, 0, 0, 0, 0, 0, 0)),
+                                         (255, po.Style(0, 1, 0, 0x000000, 0, 0.2, 0)), (200, po.Style(1, 1, 0x604080c0, 0x102030, 0.3, 0.15, 0))])
+def test_image_fill_of_closed_ways(alpha, style):
+    """render_poly_line's image fill (:989-997, img_ini :2691-2704): the closed ways filled with a repeated surface pattern in a group
+    below the rule's own; the oracle's per-pixel (s IN m) OVER d against libcairo compositing the real pattern"""
+    W, H = 200, 160
+    pat = _pattern(37, 23, 3, alpha)
+    ways = _dash_scene(W, H, 11)
+    before = [(po.Style(1, 0, 0xe0f0e0, 0, 0, 0, 0), _nested_scene(W, H, 2))]
+    a = po.oracle_pattern_scene(before, (style, ways, pat), [], 300, W, H, 0xffffff)
+    b = po.cairo_pattern_scene(before, (style, ways, pat), [], 300, W, H, 0xffffff)
+    d = po.chan_diff(a, b)
+    plain = po.oracle_scene(before + ([(style, ways)] if style.fill_used or style.border_used else []), 300, W, H, 0xffffff)
+    assert (a != plain).sum() > 3000                          # the image is there
+    assert (d > 0).sum() <= 0.001 * d.size, ((d > 0).sum(), (d > 2).sum(), d.max())
