@@ -229,6 +229,38 @@ int cd_set_source_pattern(const uint32_t *pix, int w, int h, double dpi, double 
 
 void cd_fill_source(void) { p_cairo_fill(rule_); }
 
+/* img_ini's image (:2637-2658): the decoded w x h ARGB32 picture painted at `scale` into a new image of (int) (w * scale) x
+ * (int) (h * scale) pixels, then the transparency taken off with DEST_OUT.  out holds that many pixels; returns its width,
+ * its height in *oh */
+int cd_scaled_image(const uint32_t *pix, int w, int h, double scale, double trans, uint32_t *out, int cap, int *oh)
+{
+   cairo_surface_t *src = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, w, h);
+   p_cairo_surface_flush(src);
+   unsigned char *d = p_cairo_image_surface_get_data(src);
+   int stride = p_cairo_image_surface_get_stride(src);
+   for (int y = 0; y < h; y++) memcpy(d + (size_t) y * stride, pix + (size_t) y * w, (size_t) w * 4);
+   p_cairo_surface_mark_dirty(src);
+   const int ow = (int) (w * scale), hh = (int) (h * scale);
+   if (ow < 1 || hh < 1 || (long) ow * hh > cap) { p_cairo_surface_destroy(src); return -1; }
+   cairo_surface_t *img = p_cairo_image_surface_create(CAIRO_FORMAT_ARGB32, ow, hh);
+   cairo_t *ctx = p_cairo_create(img);
+   p_cairo_scale(ctx, scale, scale);
+   p_cairo_set_source_surface(ctx, src, 0, 0);
+   p_cairo_paint(ctx);
+   p_cairo_set_source_rgba(ctx, 0, 0, 0, trans);
+   p_cairo_set_operator(ctx, 9 /* CAIRO_OPERATOR_DEST_OUT */);
+   p_cairo_paint(ctx);
+   p_cairo_destroy(ctx);
+   p_cairo_surface_destroy(src);
+   p_cairo_surface_flush(img);
+   d = p_cairo_image_surface_get_data(img);
+   stride = p_cairo_image_surface_get_stride(img);
+   for (int y = 0; y < hh; y++) memcpy(out + (size_t) y * ow, d + (size_t) y * stride, (size_t) ow * 4);
+   p_cairo_surface_destroy(img);
+   *oh = hh;
+   return ow;
+}
+
 void cd_fill(uint32_t col)
 {
    set_color(rule_, col);

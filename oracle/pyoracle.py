@@ -151,6 +151,7 @@ def cairo():
         L.cd_fill.argtypes = [C.c_uint32]
         L.cd_set_fill_rule.argtypes = [C.c_int]
         L.cd_set_source_pattern.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double]
+        L.cd_scaled_image.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p]
         L.cd_set_direct_fill_rule.argtypes = [C.c_int]
         L.cd_render.argtypes = [C.c_double] + [C.c_int] * 4 + [C.c_void_p]
         L.cd_save_png.argtypes = [C.c_double, C.c_int, C.c_int, C.c_char_p]
@@ -287,7 +288,34 @@ def cairo_pattern_scene(before, pattern_rule, after, dpi, W, H, bg):
     return cairo_scene(rules, dpi, W, H, bg, between=(n_before, img_group))
 
 
-def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0, image=None):
+def scaled_image(pix, scale, trans=0.0):
+    """img_ini's image of a decoded picture (libcairo: paint at `scale`, DEST_OUT transparency): [h', w'] uint32"""
+    L = cairo()
+    pix = np.ascontiguousarray(pix, np.uint32)
+    h, w = pix.shape
+    out = np.zeros(int(w * scale + 1) * int(h * scale + 1), np.uint32)
+    oh = C.c_int()
+    ow = L.cd_scaled_image(P(pix), w, h, float(scale), float(trans), P(out), len(out), C.byref(oh))
+    assert ow > 0
+    return out[:ow * oh.value].reshape(oh.value, ow).copy()
+
+
+def decode_jpeg(path):
+    """[h, w] uint32 ARGB32 (alpha 255) through gdk-pixbuf, which decodes with the libjpeg the reference links (tests only)"""
+    g = C.CDLL("libgdk_pixbuf-2.0.so.0")
+    g.gdk_pixbuf_new_from_file.restype = C.c_void_p
+    g.gdk_pixbuf_new_from_file.argtypes = [C.c_char_p, C.c_void_p]
+    pb = g.gdk_pixbuf_new_from_file(path.encode(), None)
+    assert pb, path
+    geti = lambda n: getattr(g, "gdk_pixbuf_get_" + n)(C.c_void_p(pb))
+    w, h, rs, nc = geti("width"), geti("height"), geti("rowstride"), geti("n_channels")
+    g.gdk_pixbuf_get_pixels.restype = C.POINTER(C.c_ubyte)
+    raw = np.ctypeslib.as_array(g.gdk_pixbuf_get_pixels(C.c_void_p(pb)), ((h - 1) * rs + w * nc,))
+    rows = np.stack([raw[y * rs:y * rs + w * nc].reshape(w, nc) for y in range(h)]).astype(np.uint32)
+    return (0xff000000 | (rows[..., 0] << 16) | (rows[..., 1] << 8) | rows[..., 2]).astype(np.uint32)
+
+
+def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0, image=None, pattern=None):
     """One directional draw rule (act_draw_main :1039-1052, act_draw_fini :1084-1140): group 1 = the open ways,
     group 2 = ALL closed ways as one path with one non-zero fill (a page rectangle, if the reference adds
     one, is just another closed way of `ways`).  The border is off in directional mode (:674-680)."""
@@ -332,8 +360,17 @@ def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0, image=None):
             e = np.zeros((len(x), 4), np.int32)
             L.orc_fill_edges(P(dev), len(x), P(e))
             edges.append(e)
+    if pattern is not None and edges:
+        # the image's group, popped before the colours' (act_draw_fini :1131-1136, :1081-1082 for the order)
+        pattern = np.ascontiguousarray(pattern, np.uint32)
+        e = np.ascontiguousarray(np.concatenate(edges))
+        L.orc_canvas_set_pattern(c, P(pattern), pattern.shape[1], pattern.shape[0])
+        L.orc_rule_begin(c)
+        L.orc_layer_edges(c, P(e), len(e), 0 if st.evenodd else 1, 0)
+        L.orc_rule_end(c)
+        L.orc_canvas_set_pattern(c, None, 0, 0)
     L.orc_rule_begin(c)
-    if edges:
+    if edges and st.fill_used:
         e = np.ascontiguousarray(np.concatenate(edges))
         L.orc_layer_edges(c, P(e), len(e), 0 if st.evenodd else 1, st.fill_col)
     L.orc_rule_end(c)

@@ -323,7 +323,13 @@ struct draw_rule_t
    double max_area = -1; bool max_cw = false; uint32_t max_col = 0;
    double min_area = 1e300; uint32_t min_col = 0;      /* the smallest closed way: the LAST after act_draw_fini's qsort by area (:1099) */
    double wavy_deg = 0;                   /* wavy=1: wavy_length in degrees (:632-642) */
+   /* file=: the image the rule's closed ways are filled with below its colours (img_ini :2512-2712 as act_draw_ini :662-671 calls
+    * it; render_poly_line :989-997), as img_ini leaves it: scaled, transparency applied, premultiplied ARGB32 */
+   std::vector<uint32_t> pat; int pat_w = 0, pat_h = 0;
 };
+
+/* the image of a rule's file= as a pattern's pixels (defined with img below): 0, > 0 to leave the rule to the built-in action, < 0 */
+static int rule_pattern(smr_smrule_t *r, const char *who, std::vector<uint32_t> &pix, int *w, int *h);
 
 /* parse_dash_style, src/smrparse.c:1077-1102: "a:b:c:d" in mm (the host's parser knows the other units); no or
  * no valid array = 0 lengths, for which the library takes the style's default */
@@ -414,22 +420,28 @@ static int draw_ini(smr_smrule_t *r)
    if (d->st.curve != 0 && ((d->st.border_used && (d->st.border_style != 0 || d->st.border_ndash)) ||
                                  (d->st.fill_used && (d->st.fill_style != 0 || d->st.fill_ndash))))
       why = "dashed or round-capped strokes along curves (curve=1 or wavy=1 with style/bstyle/dash/bdash)";
-   else if (H.get_param("file", nullptr, r->act)) why = "image pattern fill (file=)";
    if (why)
    {
       plog(SMR_LOG_ERR, "draw: %s are not implemented on the GPU path yet; use the built-in draw for this rule", why);
       delete d;
       return 1;
    }
+   /* file= (:662-671): the closed ways are filled with the image, too */
+   if (H.get_param("file", nullptr, r->act) != nullptr)
+   {
+      const int e2 = rule_pattern(r, "draw", d->pat, &d->pat_w, &d->pat_h);
+      if (e2 > 0) { delete d; return e2; }
+      if (e2 < 0) { plog(SMR_LOG_WARN, "not using image in fill operation"); d->pat.clear(); }      /* as act_draw_ini goes on without it */
+   }
    /* check if parameter combination makes sense (:673-686) */
    if (d->st.directional)
    {
-      if (d->st.fill_used && d->st.border_used)
+      if ((d->st.fill_used || !d->pat.empty()) && d->st.border_used)
       {
          plog(SMR_LOG_WARN, "in directional mode, filling and border drawing is not supported at the same time -> disabling border");
          d->st.border_used = 0;
       }
-      if (!d->st.fill_used && d->st.border_used)
+      if (!d->st.fill_used && d->pat.empty() && d->st.border_used)
       {
          plog(SMR_LOG_NOTICE, "directional mode makes only sense with a fill operation -> disabling directional mode");
          d->st.directional = 0;
@@ -728,10 +740,9 @@ static int draw_main(smr_smrule_t *r, smr_osm_obj_t *o)
    return 1;
 }
 
-static int draw_fini(smr_smrule_t *r)
+/* everything act_draw_fini does with the ways a rule has collected (also for img on ways: a rule of nothing but an image fill) */
+static int draw_finish(draw_rule_t *d)
 {
-   draw_rule_t *d = (draw_rule_t *) r->data;
-   if (d == nullptr) return 0;
    int ret = 0;
    if (d->st.directional && d->max_area >= 0)
    {
@@ -763,7 +774,8 @@ static int draw_fini(smr_smrule_t *r)
       size_t n = d->lat.size();
       if (n & 1) { d->lat.push_back(d->lat.back()); d->lon.push_back(d->lon.back()); n++; }
       /* a rule that is kept for the caption scan's windows owns its arrays; otherwise they come from the grow-only pool */
-      const bool keep = cutout_replay() && P.band_y0 == 0 && P.band_h == P.H;
+      /* (an image fill is not replayed into the cut-outs of later caption scans: they see the rule's colours only) */
+      const bool keep = cutout_replay() && P.band_y0 == 0 && P.band_h == P.H && (d->st.fill_used || d->st.border_used);
       auto own_put = [&](int i, const void *h, size_t bytes) -> void *
       {
          if (!keep) return h ? pool_put(i, h, bytes) : pool_get(i, bytes);
@@ -788,7 +800,9 @@ static int draw_fini(smr_smrule_t *r)
          b.d_way_off = (const int64_t *) off; b.d_ref = (const int32_t *) ref; b.n_ways = n_ways; b.n_refs = n_refs;
          b.d_way_fill_col = (const uint32_t *) fc;
          b.d_way_border_col = (const uint32_t *) bc;
-         ok = smr_hip_draw(P.canvas, &d->st, &b) == SMR_OK;
+         /* the image's group is popped before the colours' (act_draw_fini :1081-1082) */
+         if (!d->pat.empty()) ok = smr_hip_draw_pattern(P.canvas, &d->st, &b, d->pat.data(), d->pat_w, d->pat_h) == SMR_OK;
+         if (ok && (d->st.fill_used || d->st.border_used)) ok = smr_hip_draw(P.canvas, &d->st, &b) == SMR_OK;
          if (keep && ok)
          {
             /* only what is on the chart may appear in the cut-outs: a rule whose draw failed is not replayed */
@@ -801,8 +815,16 @@ static int draw_fini(smr_smrule_t *r)
       if (!ok) { plog(SMR_LOG_ERR, "draw: %s", smr_hip_last_error()); ret = -1; }
       else if (smr_hip_draw_status() & SMR_DRAW_DEGRADED_ROWS)
          plog(SMR_LOG_WARN, "draw: some pixel rows with more than 64 crossing edges were sub-sampled (anti-aliasing may differ slightly)");
-      else plog(SMR_LOG_INFO, "draw: %lld ways, %lld refs rendered on the GPU", (long long) n_ways, (long long) n_refs);
+      else plog(SMR_LOG_INFO, "draw: %lld ways, %lld refs rendered on the GPU%s", (long long) n_ways, (long long) n_refs, d->pat.empty() ? "" : ", closed ways filled with the rule's image");
    }
+   return ret;
+}
+
+static int draw_fini(smr_smrule_t *r)
+{
+   draw_rule_t *d = (draw_rule_t *) r->data;
+   if (d == nullptr) return 0;
+   const int ret = draw_finish(d);
    delete d;
    r->data = nullptr;
    return ret;
@@ -848,6 +870,7 @@ struct cairo_api_t
    void (*restore)(void *);
    void (*set_operator)(void *, int);
    void *(*image_surface_create_from_png)(const char *);
+   void (*surface_mark_dirty)(void *);
    int (*surface_status)(void *);
    int (*image_surface_get_width)(void *);
    int (*image_surface_get_height)(void *);
@@ -886,6 +909,7 @@ static int cairo_load(void)
    CR_LOAD(set_source_surface, "cairo_set_source_surface"); CR_LOAD(paint, "cairo_paint");
    CR_LOAD(save, "cairo_save"); CR_LOAD(restore, "cairo_restore");
    CR_LOAD(set_operator, "cairo_set_operator"); CR_LOAD(image_surface_create_from_png, "cairo_image_surface_create_from_png");
+   CR_LOAD(surface_mark_dirty, "cairo_surface_mark_dirty");
    CR_LOAD(surface_status, "cairo_surface_status"); CR_LOAD(image_surface_get_width, "cairo_image_surface_get_width");
    CR_LOAD(image_surface_get_height, "cairo_image_surface_get_height");
    *(void **) (&CR.ft_font_face_create_for_pattern) = dlsym(CR.lib, "cairo_ft_font_face_create_for_pattern");
@@ -1909,19 +1933,55 @@ struct img_rule_t
    bool autorot = false;
    const char *akey = nullptr, *alignkey = nullptr;
    std::vector<img_item_t> items;
+   draw_rule_t *ways = nullptr;        /* img on ways (img_fill :2742-2751): a rule of nothing but an image fill of its closed ways */
+   ~img_rule_t() { delete ways; }
 };
 
-static int img_ini(smr_smrule_t *r)
+/* a JPEG through gdk-pixbuf (the reference decodes it with libjpeg itself, src/cairo_jpg.c:243-290: the same library underneath;
+ * jpeglib.h is not in this image, so its structs are out of reach) into a cairo ARGB32 image surface */
+static void *jpeg_surface(const char *name)
 {
-   int e;
-   host_resolve();
-   if ((e = plugin_setup()) != 0) return e;
-   if (r->oo->type != SMR_OSM_NODE)
+   static void *lib = nullptr;
+   static void *(*new_from_file)(const char *, void **) = nullptr;
+   static int (*get_i[4])(const void *) = { nullptr, nullptr, nullptr, nullptr };
+   static const unsigned char *(*get_pixels)(const void *) = nullptr;
+   static void (*unref)(void *) = nullptr;
+   if (!lib)
    {
-      plog(SMR_LOG_ERR, r->oo->type == SMR_OSM_WAY ? "img: on ways img is a pattern fill, which stays on the built-in path (no @libsmr_hip.so)"
-                                                    : "img() only applicable to nodes and ways");
-      return 1;
+      const char *cand[] = { getenv("SMR_HIP_LIBGDKPIXBUF"), "libgdk_pixbuf-2.0.so.0", nullptr };
+      for (int i = 0; i < 3 && !lib; i++) if (cand[i] && *cand[i]) lib = dlopen(cand[i], RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) { plog(SMR_LOG_WARN, "img: libgdk_pixbuf-2.0.so.0 (JPEG decoding) cannot be loaded: %s", dlerror()); return nullptr; }
+      *(void **) (&new_from_file) = dlsym(lib, "gdk_pixbuf_new_from_file");
+      const char *names[4] = { "gdk_pixbuf_get_width", "gdk_pixbuf_get_height", "gdk_pixbuf_get_rowstride", "gdk_pixbuf_get_n_channels" };
+      for (int i = 0; i < 4; i++) *(void **) (&get_i[i]) = dlsym(lib, names[i]);
+      *(void **) (&get_pixels) = dlsym(lib, "gdk_pixbuf_get_pixels");
+      *(void **) (&unref) = dlsym(RTLD_DEFAULT, "g_object_unref");
+      if (!new_from_file || !get_i[0] || !get_i[1] || !get_i[2] || !get_i[3] || !get_pixels || !unref) { lib = nullptr; return nullptr; }
    }
+   void *pb = new_from_file(name, nullptr);
+   if (!pb) return nullptr;
+   const int w = get_i[0](pb), h = get_i[1](pb), rs = get_i[2](pb), nc = get_i[3](pb);
+   const unsigned char *px = get_pixels(pb);
+   void *sfc = CR.image_surface_create(0 /* ARGB32 */, w, h);
+   if (CR.surface_status(sfc) != 0 || nc < 3) { unref(pb); return sfc; }
+   CR.surface_flush(sfc);
+   unsigned char *d = CR.image_surface_get_data(sfc);
+   const int stride = CR.image_surface_get_stride(sfc);
+   for (int y = 0; y < h; y++)
+   {
+      uint32_t *row = (uint32_t *) (d + (size_t) y * stride);
+      const unsigned char *q = px + (size_t) y * rs;
+      for (int x = 0; x < w; x++, q += nc) row[x] = 0xff000000u | ((uint32_t) q[0] << 16) | ((uint32_t) q[1] << 8) | q[2];      /* a JPEG has no alpha */
+   }
+   CR.surface_mark_dirty(sfc);
+   unref(pb);
+   return sfc;
+}
+
+/* the part of img_ini (:2512-2674) that makes the image: file=, scale= (times the chart's img_scale), transparency=; SVG through
+ * librsvg into a recording surface, PNG / JPEG into an ARGB32 image of w x h pixels.  0, or what img_ini is to return */
+static int img_load(smr_smrule_t *r, img_rule_t *g)
+{
    char *name;
    if ((name = H.get_param("file", nullptr, r->act)) == nullptr)
    {
@@ -1930,21 +1990,15 @@ static int img_ini(smr_smrule_t *r)
    }
    if (cairo_load() != 0) return -1;
    const size_t nl = strlen(name);
-   if (nl >= 4 && !strcasecmp(name + nl - 4, ".jpg"))
-   {
-      plog(SMR_LOG_ERR, "img: %s: JPEG symbols are decoded by the reference's own code; use the built-in img", name);
-      return 1;
-   }
-   img_rule_t *g = new img_rule_t();
    if (H.get_param("scale", &g->scale, r->act) == nullptr) g->scale = 1;
    g->scale *= H.rdata_get()->img_scale;
    if (H.get_param("transparency", &g->trans, r->act) != nullptr) g->trans = fmin(fmax(g->trans, 0.0), 1.0);
    void *ctx;
    if (nl >= 4 && !strcasecmp(name + nl - 4, ".svg"))
    {
-      if (rsvg_load() != 0) { delete g; return 1; }
+      if (rsvg_load() != 0) return 1;
       void *rh = RS.handle_new_from_file(name, nullptr);
-      if (rh == nullptr) { plog(SMR_LOG_ERR, "error opening file %s", name); delete g; return -1; }
+      if (rh == nullptr) { plog(SMR_LOG_ERR, "error opening file %s", name); return -1; }
       RS.handle_set_dpi(rh, (double) P.dpi);
       double dw = 32, dh = 32;
       if (RS.handle_get_intrinsic_size_in_pixels && RS.handle_render_document)
@@ -1978,17 +2032,18 @@ static int img_ini(smr_smrule_t *r)
       if (!ok)
       {
          plog(SMR_LOG_ERR, "rendering %s failed", name);
-         CR.destroy(ctx); CR.surface_destroy(g->img); delete g;
+         CR.destroy(ctx); CR.surface_destroy(g->img); g->img = nullptr;
          return -1;
       }
    }
    else
    {
-      void *sfc = CR.image_surface_create_from_png(name);
-      if (CR.surface_status(sfc) != 0)
+      const bool jpg = nl >= 4 && !strcasecmp(name + nl - 4, ".jpg");
+      void *sfc = jpg ? jpeg_surface(name) : CR.image_surface_create_from_png(name);
+      if (sfc == nullptr || CR.surface_status(sfc) != 0)
       {
-         plog(SMR_LOG_ERR, "cannot open file %s (cairo status %d)", name, CR.surface_status(sfc));
-         CR.surface_destroy(sfc); delete g;
+         plog(SMR_LOG_ERR, "cannot open file %s (cairo status %d)", name, sfc ? CR.surface_status(sfc) : -1);
+         if (sfc) CR.surface_destroy(sfc);
          return -1;
       }
       g->w = CR.image_surface_get_width(sfc) * g->scale; g->h = CR.image_surface_get_height(sfc) * g->scale;
@@ -1996,7 +2051,7 @@ static int img_ini(smr_smrule_t *r)
       if (CR.surface_status(g->img) != 0)
       {
          plog(SMR_LOG_ERR, "cannot create the %g x %g image of %s", g->w, g->h, name);
-         CR.surface_destroy(sfc); CR.surface_destroy(g->img); delete g;
+         CR.surface_destroy(sfc); CR.surface_destroy(g->img); g->img = nullptr;
          return -1;
       }
       ctx = CR.create(g->img);
@@ -2010,6 +2065,64 @@ static int img_ini(smr_smrule_t *r)
    CR.set_operator(ctx, 9 /* CAIRO_OPERATOR_DEST_OUT */);
    CR.paint(ctx);
    CR.destroy(ctx);
+   return 0;
+}
+
+/* the image of a way rule as the pixels of its pattern (img_ini :2689-2704: cairo_pattern_create_for_surface, matrix
+ * scale(1 / PX2PT_SCALE) . rotate(angle), CAIRO_EXTEND_REPEAT): at angle 0 one image pixel per chart pixel from the chart's origin,
+ * which smr_hip_draw_pattern lays out; a rotated or a vector (SVG) pattern is left to the built-in action */
+static int rule_pattern(smr_smrule_t *r, const char *who, std::vector<uint32_t> &pix, int *w, int *h)
+{
+   img_rule_t g;
+   const int e = img_load(r, &g);
+   if (e != 0) return e;
+   double angle = 0;
+   const char *val = H.get_param("angle", &angle, r->act);
+   if (val != nullptr && (!strcasecmp(val, "auto") || !strcasecmp(val, "majoraxis"))) angle = 0;      /* "ignoring angle=auto" (:2685-2689); 720 degrees */
+   angle = fmod(angle, 360.0);
+   int ret = 0;
+   if (g.vector) { plog(SMR_LOG_ERR, "%s: an SVG as the pattern of a way fill is not implemented on the GPU path; use the built-in %s", who, who); ret = 1; }
+   else if (angle != 0.0) { plog(SMR_LOG_ERR, "%s: a rotated pattern (angle=%g) is not implemented on the GPU path; use the built-in %s", who, angle, who); ret = 1; }
+   else if ((int) g.w < 1 || (int) g.h < 1) { plog(SMR_LOG_ERR, "%s: the scaled image is empty", who); ret = -1; }
+   else
+   {
+      *w = (int) g.w; *h = (int) g.h;
+      CR.surface_flush(g.img);
+      const unsigned char *d = CR.image_surface_get_data(g.img);
+      const int stride = CR.image_surface_get_stride(g.img);
+      pix.resize((size_t) *w * *h);
+      for (int y = 0; y < *h; y++) memcpy(&pix[(size_t) y * *w], d + (size_t) y * stride, (size_t) *w * 4);
+   }
+   if (g.img) CR.surface_destroy(g.img);
+   g.img = nullptr;
+   return ret;
+}
+
+static int img_ini(smr_smrule_t *r)
+{
+   int e;
+   host_resolve();
+   if ((e = plugin_setup()) != 0) return e;
+   if (r->oo->type != SMR_OSM_NODE && r->oo->type != SMR_OSM_WAY)
+   {
+      plog(SMR_LOG_WARN, "img() only applicable to nodes and ways");
+      return -1;
+   }
+   if (r->oo->type == SMR_OSM_WAY)
+   {
+      /* a pattern fill of the rule's closed ways (img_ini :2683-2704, act_img_main -> img_fill :2742-2751) */
+      img_rule_t *gw = new img_rule_t();
+      gw->ways = new draw_rule_t();
+      memset(&gw->ways->st, 0, sizeof(gw->ways->st));
+      gw->ways->st.ignore_open = 1;                       /* img_fill passes open ways over */
+      gw->ways->way_off.push_back(0);
+      const int e2 = rule_pattern(r, "img", gw->ways->pat, &gw->ways->pat_w, &gw->ways->pat_h);
+      if (e2 != 0) { delete gw; return e2; }
+      r->data = gw;
+      return 0;
+   }
+   img_rule_t *g = new img_rule_t();
+   if ((e = img_load(r, g)) != 0) { delete g; return e; }
 
    /* parse_auto_rot (src/smrparse.c:1033-1074) */
    char *val;
@@ -2053,6 +2166,7 @@ static int img_main(smr_smrule_t *r, smr_osm_obj_t *o)
 {
    img_rule_t *g = (img_rule_t *) r->data;
    if (g == nullptr) { plog(SMR_LOG_WARN, "r->data == NULL"); return 1; }
+   if (g->ways != nullptr) return o->type == SMR_OSM_WAY ? draw_way(g->ways, (const smr_osm_way_t *) o) : 1;      /* act_img_main :2835-2836 */
    if (o->type != SMR_OSM_NODE) return 1;
    const smr_osm_node_t *n = (const smr_osm_node_t *) o;
    img_item_t it; it.lat = n->lat; it.lon = n->lon; it.a = 0;
@@ -2090,6 +2204,13 @@ static int img_fini(smr_smrule_t *r)
 {
    img_rule_t *g = (img_rule_t *) r->data;
    if (g == nullptr) { plog(SMR_LOG_WARN, "r->data == NULL"); return 1; }
+   if (g->ways != nullptr)
+   {
+      const int e = draw_finish(g->ways);
+      delete g;
+      r->data = nullptr;
+      return e;
+   }
    int ret = 0;
    const size_t n = g->items.size();
    std::vector<double> lat(n), lon(n), cx, cy;

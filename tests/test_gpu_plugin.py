@@ -395,18 +395,77 @@ def test_cap_same_rule_captions_see_earlier_rectangles(chart):
 def test_every_shipped_draw_rule_is_accepted_or_refused_for_a_documented_reason(chart):
     """tests/golden/draw_params.txt holds the parameter strings of all `draw` actions of the reference's rulesets and test
     rules (collected by tests/golden/make_draw_params.py).  act_draw_ini must take every one of them (and _fini must run on an
-    empty rule), except the image-pattern fills (file=), which the GPU path refuses with "Rule will be ignored"."""
+    empty rule): all 82, the two image fills (file=wooded.jpg, the reference's test/wooded.jpg kept as a fixture) included."""
     import os
     sa, proj = chart
-    lines = [l.rstrip("\n") for l in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "draw_params.txt"))]
-    assert len(lines) >= 80
-    refused = []
-    for params in lines:
-        rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, [])
-        if rc != 0:
-            refused.append(params)
-            assert rc == 2001 and "file=" in params, (params, rc, sa.lib().smr_hip_last_error())
-    assert sorted(refused) == sorted(l for l in lines if "file=" in l)
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    lines = [l.rstrip("\n") for l in open(os.path.join(golden, "draw_params.txt"))]
+    assert len(lines) >= 80 and sum("file=" in l for l in lines) == 2
+    cwd = os.getcwd()
+    os.chdir(golden)                 # file= names are relative to where smrender runs
+    try:
+        for params in lines:
+            rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, [])
+            assert rc == 0, (params, rc, sa.lib().smr_hip_last_error())
+    finally:
+        os.chdir(cwd)
+
+
+@pytest.mark.parametrize("params,directional", [("file=wooded.jpg;scale=0.6", False), ("file=wooded.jpg;scale=0.6;directional=yes", True),
+                                                ("file=wooded.jpg;scale=0.4;transparency=0.35;color=#30c04020;bcolor=black;bwidth=0.15", False)])
+def test_shipped_image_fill_rules(chart, params, directional):
+    """draw file=wooded.jpg;scale=0.6[;directional=yes] (the two image fills among the shipped rules): the plugin decodes the JPEG,
+    scales it as img_ini does (libcairo), and the device fills the closed ways with it.  Expected: the oracle's image fill
+    (pinned on libcairo's surface pattern) with the pattern made by the same steps through the test's own libcairo driver."""
+    import os
+    from test_oracle_cairo import _dash_scene, _nested_scene
+    from test_gpu_raster import _ways_to_arrays
+    sa, proj = chart
+    if po.cairo() is None:
+        pytest.skip("libcairo not loadable")
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    scale = float(params.split("scale=")[1].split(";")[0])
+    trans = float(params.split("transparency=")[1].split(";")[0]) if "transparency=" in params else 0.0
+    pat = po.scaled_image(po.decode_jpeg(os.path.join(golden, "wooded.jpg")), scale, trans)
+    ways = _nested_scene(W, H, 4) if directional else _dash_scene(W, H, 9)
+    wids, oways = load_ways(sa, proj, _ways_to_arrays(ways))
+    cwd = os.getcwd()
+    os.chdir(golden)
+    try:
+        rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, wids)
+    finally:
+        os.chdir(cwd)
+    assert rc == 0, sa.lib().smr_hip_last_error()
+    if directional:
+        st = po.Style(0, 0, 0, 0, 0, 0, 0)
+        want = po.oracle_directional(st, [w for w in oways if w[2]], DPI, W, H, 0xfff8e0, pattern=pat)
+    else:
+        st = po.Style(1, 1, 0x30c04020, 0, 0, 0.15, 0) if "bcolor" in params else po.Style(0, 0, 0, 0, 0, 0, 0)
+        want = po.oracle_pattern_scene([], (st, oways, pat), [], DPI, W, H, 0xfff8e0)
+    got = plugin_canvas(sa)
+    assert (got != 0xfffff8e0).sum() > 5000
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_img_on_ways_is_an_image_fill(chart, tmp_path):
+    """img on ways (act_img_ini :2683-2704, act_img_main -> img_fill :2742-2751): the closed ways filled with the repeated image, open
+    ways passed over; a PNG at scale 1 is the pattern pixel for pixel.  A rotated pattern is left to the built-in action."""
+    from test_oracle_cairo import _dash_scene, _pattern
+    from test_gpu_raster import _ways_to_arrays
+    sa, proj = chart
+    cd = po.cairo()
+    if cd is None:
+        pytest.skip("libcairo not loadable")
+    pat = _pattern(29, 17, 5, 255)
+    png = str(tmp_path / "tile.png")
+    assert cd.cd_write_png_data(po.P(pat), 29, 17, png.encode()) == 0
+    wids, oways = load_ways(sa, proj, _ways_to_arrays(_dash_scene(W, H, 9)))
+    assert hs.apply_rule(sa.lib(), "img", hs.OSM_WAY, f"file={png}", wids) == 0, sa.lib().smr_hip_last_error()
+    want = po.oracle_pattern_scene([], (po.Style(0, 0, 0, 0, 0, 0, 0), oways, pat), [], DPI, W, H, 0xfff8e0)
+    got = plugin_canvas(sa)
+    assert np.array_equal(got, want), int((got != want).sum())
+    assert (got != 0xfffff8e0).sum() > 3000
+    assert hs.apply_rule(sa.lib(), "img", hs.OSM_WAY, f"file={png};angle=30", wids) == 2001      # "Rule will be ignored"
 
 
 REAL_RULES = [   # (parameters as a ruleset would give them, the oracle's style, directional)
@@ -740,13 +799,10 @@ def test_img_svg_symbol_and_refusals(chart, tmp_path):
     from smrender_amd import synth
     if po.cairo() is None:
         pytest.skip("libcairo not loadable")
-    f = symbol_png(tmp_path / "sym.png")
-    wids, _ = load_ways(sa, proj, po.synth_ways(5, W, H, seed=1))
-    # ways: a pattern fill, stays built-in; JPEG: the reference's own decoder; no file: refused like the reference
-    assert hs.apply_rule(sa.lib(), "img", hs.OSM_WAY, f"file={f}", wids) != 0
     nid = _next_id[0]; _next_id[0] += 2
     lat, lon = synth.px_to_geo(proj, np.array([100.0]), np.array([80.0]))
     hs.add_nodes(np.array([nid]), lat, lon)
+    # a file that is not there (PNG or JPEG), no file at all: refused like the reference; an SVG as a way's pattern: left to the built-in img
     assert hs.apply_rule(sa.lib(), "img", hs.OSM_NODE, "file=symbol.jpg", np.array([nid])) != 0
     assert hs.apply_rule(sa.lib(), "img", hs.OSM_NODE, "scale=2", np.array([nid])) != 0
     assert hs.apply_rule(sa.lib(), "img", hs.OSM_NODE, f"file={tmp_path / 'missing.png'}", np.array([nid])) != 0
@@ -758,6 +814,8 @@ def test_img_svg_symbol_and_refusals(chart, tmp_path):
     rc = hs.apply_rule(sa.lib(), "img", hs.OSM_NODE, f"file={svg}", np.array([nid]))
     if rc != 0:
         pytest.skip("librsvg not loadable on this box: " + sa.lib().smr_hip_last_error().decode())
+    wids, _ = load_ways(sa, proj, po.synth_ways(5, W, H, seed=1))
+    assert hs.apply_rule(sa.lib(), "img", hs.OSM_WAY, f"file={svg}", wids) == 2001
     got = plugin_canvas(sa)
     op = po.make_proj(45.0, 15.0, 25000.0, float(W), float(H), DPI)
     px, py, _, _, _ = po.project(op, lat, lon)
