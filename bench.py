@@ -244,7 +244,7 @@ def main():
     ap.add_argument("--ways", type=int, default=1000000)
     ap.add_argument("--size", type=int, default=16384)
     ap.add_argument("--dpi", type=int, default=300)
-    ap.add_argument("--captions", type=int, default=20000, help="C4 captions scanned after the timed region (0 = skip)")
+    ap.add_argument("--captions", type=int, default=200000, help="C4 captions scanned after the timed region (BASELINE config 4: 200 000; 0 = skip)")
     ap.add_argument("--no-replay", action="store_true", help="skip the caption scan through re-rasterised cut-outs (profiling runs: keeps the chart's own kernels apart)")
     ap.add_argument("--cpu-window", type=int, default=3072)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -356,12 +356,14 @@ def main():
         cap_ms = grp.max(sa.timings()["caprot_ms"])
         ang = d_ang.numpy()
         cap_bytes = (4.0 * r_px * r_px + 4.0 * fg_w * fg_h + 32.0) * args.captions          # SURVEY 8d per candidate
-        cap = {"captions": args.captions * world, "angles": n_steps, "cutout_px": r_px, "plane_px": [fg_w, fg_h],
-               "caprot_ms": round(cap_ms, 3), "captions_per_s": round(args.captions * world / (cap_ms * 1e-3), 1),
-               "roofline": {"kernel": "k_caprot", "bound": "hbm", "achieved": round(cap_bytes / (cap_ms * 1e-3) / 1e9, 2),
-                            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(cap_bytes / (cap_ms * 1e-3) / HBM_PEAK, 5)},
-               "distinct_angles": int(len(np.unique(ang))), "halo_exchange": halo_path,
-               "cutout": "crop of the canvas at the rounded anchor (smr_hip_caprot on the chart)"}
+        crop = {"captions": args.captions * world, "caprot_ms": round(cap_ms, 3), "captions_per_s": round(args.captions * world / (cap_ms * 1e-3), 1),
+                "roofline": {"kernel": "k_caprot", "bound": "hbm", "achieved": round(cap_bytes / (cap_ms * 1e-3) / 1e9, 2),
+                             "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(cap_bytes / (cap_ms * 1e-3) / HBM_PEAK, 5)},
+                "distinct_angles": int(len(np.unique(ang))), "halo_exchange": halo_path,
+                "cutout": "crop of the canvas at the rounded anchor (smr_hip_caprot on the chart): NOT the reference's convention, 11-13 % of the %.1f tags differ"}
+        # the headline of the scan is the reference's own convention (below, when it runs); the crop scan is the labelled alternative
+        cap = {"workload": f"C4: {args.captions} captions per GPU, {fg_w}x{fg_h} px plane, {n_steps} trial angles, {r_px} px cut-outs",
+               "angles": n_steps, "cutout_px": r_px, "plane_px": [fg_w, fg_h], "crop_alternative": crop}
         if world == 1 and not args.strong and not args.no_replay:
             # the same captions the reference's way: every cut-out re-rasterised at its anchor's sub-pixel offset (atlases of
             # windows, smr_hip_draw_windows), wall time of everything: instancing, drawing, scan
@@ -388,10 +390,10 @@ def main():
             t_rep = time.perf_counter() - t0
             sa.set_profiling(True)
             tag = lambda v: np.array(["%.1f" % (q * 180 / np.pi) for q in v])
-            cap["replay"] = {"cutout": "re-rasterised at the anchor's sub-pixel offset, as cairo_smr_cut_out replays the recording (smr_hip_draw_windows)",
-                             "captions": args.captions, "atlases": (args.captions + per - 1) // per, "seconds": round(t_rep, 3),
-                             "captions_per_s": round(args.captions / t_rep, 1),
-                             "tags_differing_from_the_crop_scan": int((tag(ang) != tag(ang2)).sum())}
+            cap.update({"cutout": "re-rasterised at the anchor's sub-pixel offset, as cairo_smr_cut_out replays the recording (smr_hip_draw_windows)",
+                        "captions": args.captions, "atlases": (args.captions + per - 1) // per, "seconds": round(t_rep, 3),
+                        "captions_per_s": round(args.captions / t_rep, 1),
+                        "tags_differing_from_the_crop_scan": int((tag(ang) != tag(ang2)).sum())})
 
     if args.dump:
         os.makedirs(args.dump, exist_ok=True)

@@ -32,7 +32,7 @@ def _launch(tmp_path, name, extra, port):
     assert len(line) == 1, r.stdout[-2000:]                      # rank 0 alone prints the line
     res = json.loads(line[0])
     assert res["n_gpus"] == 2 and res["value"] > 0
-    assert res["caption_scan"]["halo_exchange"] == "host"
+    assert res["caption_scan"]["crop_alternative"]["halo_exchange"] == "host"
     bands = [np.load(out / f"band_{k}.npz") for k in range(2)]
     return res, bands
 
