@@ -394,6 +394,9 @@ smr_canvas_t *smr_hip_plugin_canvas(void);
 /* ends the chart: frees that canvas; the next _ini starts a new chart from rdata_get() (smrender
  * itself renders one chart per process, src/smrender.c:852-1416, and never needs this) */
 int smr_hip_plugin_reset(void);
+/* diagnostics (tools/plugin_bench.py): seconds the draw rules so far spent in [0] _main (the host's get_object per ref), [2] uploads +
+ * projection, [3] smr_hip_draw, [4] the wait for it; reset != 0 clears them.  No counterpart in the reference */
+int smr_hip_plugin_stats(double *out, int n, int reset);
 
 #ifdef __cplusplus
 }

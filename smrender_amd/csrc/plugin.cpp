@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <strings.h>
+#include <time.h>
 #include <algorithm>
 #include <map>
 #include <string>
@@ -152,6 +153,17 @@ static void kept_blit(const std::vector<uint32_t> &pixels, const std::vector<smr
 extern "C" smr_canvas_t *smr_hip_plugin_canvas(void) { return P.canvas; }
 
 static void pool_release(void);
+
+/* where the plugin's draw rules spend their time (diagnostics: tools/plugin_bench.py): seconds in _main (the host's get_object per
+ * ref), in _fini before the device is asked for anything, in the uploads + projection, in smr_hip_draw, in the wait for it */
+static double pstat_[8];
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double) t.tv_sec + 1e-9 * (double) t.tv_nsec; }
+extern "C" int smr_hip_plugin_stats(double *out, int n, int reset)
+{
+   for (int i = 0; i < n && i < 8; i++) out[i] = pstat_[i];
+   if (reset) memset(pstat_, 0, sizeof(pstat_));
+   return SMR_OK;
+}
 
 extern "C" int smr_hip_plugin_reset(void)
 {
@@ -722,7 +734,7 @@ static int draw_main(smr_smrule_t *r, smr_osm_obj_t *o)
 {
    draw_rule_t *d = (draw_rule_t *) r->data;
    if (d == nullptr) return -1;
-   if (o->type == SMR_OSM_WAY) return draw_way(d, (const smr_osm_way_t *) o);
+   if (o->type == SMR_OSM_WAY) { const double t0 = now_s(); const int e = draw_way(d, (const smr_osm_way_t *) o); pstat_[0] += now_s() - t0; return e; }
    if (o->type == SMR_OSM_REL)
    {
       const smr_osm_rel_t *rel = (const smr_osm_rel_t *) o;
@@ -771,6 +783,7 @@ static int draw_finish(draw_rule_t *d)
    const int64_t n_ways = (int64_t) d->way_off.size() - 1, n_refs = (int64_t) d->ref.size();
    if (n_ways > 0 && n_refs > 0)
    {
+      const double t_up = now_s();
       size_t n = d->lat.size();
       if (n & 1) { d->lat.push_back(d->lat.back()); d->lon.push_back(d->lon.back()); n++; }
       /* a rule that is kept for the caption scan's windows owns its arrays; otherwise they come from the grow-only pool */
@@ -792,6 +805,8 @@ static int draw_finish(draw_rule_t *d)
       if (ok && d->border_cs.key) ok = (bc = own_put(7, d->border_col.data(), d->border_col.size() * 4)) != nullptr;
       if (ok) ok = smr_hip_project((const double *) lat, (const double *) lon, (int64_t) n, (double *) x, (double *) y,
                                    nullptr, nullptr, nullptr) == SMR_OK;
+      pstat_[2] += now_s() - t_up;
+      const double t_dr = now_s();
       if (ok)
       {
          smr_draw_batch_t b;
@@ -811,7 +826,10 @@ static int draw_finish(draw_rule_t *d)
          }
       }
       if (keep && !ok) { void *q[6] = { x, y, off, ref, fc, bc }; for (void *v : q) if (v) smr_hip_free(v); }
+      pstat_[3] += now_s() - t_dr;
+      const double t_sy = now_s();
       if (ok) ok = smr_hip_sync() == SMR_OK;
+      pstat_[4] += now_s() - t_sy;
       if (!ok) { plog(SMR_LOG_ERR, "draw: %s", smr_hip_last_error()); ret = -1; }
       else if (smr_hip_draw_status() & SMR_DRAW_DEGRADED_ROWS)
          plog(SMR_LOG_WARN, "draw: some pixel rows with more than 64 crossing edges were sub-sampled (anti-aliasing may differ slightly)");
@@ -1884,8 +1902,9 @@ static int cap_fini(smr_smrule_t *r)
  * recording surface); every placement is recorded with the reference's call sequence (img_place :2754-2826), replayed at
  * dpi/72 into an image on the chart's pixel grid and painted OVER the device canvas in object order (smr_hip_canvas_blit).
  * angle=auto is find_angle with the symbol as the plane (:2767-2794): one smr_hip_caprot batch for all nodes of the rule
- * (img has no auto_ctx: its symbols do not see each other, :2790 scans sfc_).  Not here: img on ways (a pattern fill,
- * img_fill :2742-2751) and JPEG files (the reference's own decoder, src/cairo_jpg.c): refused, the rule stays built-in. */
+ * (img has no auto_ctx: its symbols do not see each other, :2790 scans sfc_).  img on ways (img_fill :2742-2751) is an
+ * image fill of the closed ways on the device (draw_finish, smr_hip_draw_pattern); JPEG files are decoded by gdk-pixbuf
+ * (the reference has a decoder of its own, src/cairo_jpg.c).  Not here: SVG and rotated patterns, the rule stays built-in. */
 struct rsvg_api_t
 {
    void *lib = nullptr, *gobj = nullptr;

@@ -112,7 +112,7 @@ EXPORTS = [
     "smr_hip_objects_select_ways", "smr_hip_objects_select_nodes",
     "smr_hip_poly_area", "smr_hip_draw", "smr_hip_draw_pattern", "smr_hip_draw_status", "smr_hip_debug_edges", "smr_hip_caprot", "smr_hip_caprot_noalloc", "smr_hip_caprot_steps", "smr_hip_sync", "smr_hip_stream",
     "smr_hip_set_profiling", "smr_hip_timings", "smr_hip_malloc", "smr_hip_free",
-    "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset",
+    "smr_hip_memcpy_h2d", "smr_hip_memcpy_d2h", "smr_hip_plugin_canvas", "smr_hip_plugin_reset", "smr_hip_plugin_stats",
     "act_draw_ini", "act_draw_main", "act_draw_fini", "act_cap_ini", "act_cap_main", "act_cap_fini",
     "act_img_ini", "act_img_main", "act_img_fini", "act_hipsave_ini", "act_hipsave_main", "act_hipsave_fini",
 ]

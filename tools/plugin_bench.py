@@ -40,6 +40,10 @@ for rep in range(2):
         assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, f"color={col(r)};bcolor=black;bwidth=0.1", wids) == 0
     sa.sync()
     t_plugin = time.perf_counter() - t0
+    import ctypes as C
+    st8 = (C.c_double * 8)()
+    sa.lib().smr_hip_plugin_stats(st8, 8, 1)
+    print("plugin seconds: _main (host get_object) %.4f, uploads + projection %.4f, smr_hip_draw %.4f, wait %.4f" % (st8[0], st8[2], st8[3], st8[4]))
 dev = [tuple(sa.DeviceArray.from_numpy(a) for a in arrs) for _, arrs in rules]
 cv = sa.Canvas(W, H, DPI, 0xffffff)
 for rep in range(2):
