@@ -115,7 +115,6 @@ int orc_fill_edges(const int32_t *p, int n, tor_edge_t *out)
  * inner corner pokes through a short neighbouring segment (orc_stroke_risky below): then
  * the polygon itself is emitted (orc_stroke_outline_edges). ---- */
 
-#define ORC_POLY_MAXREFS 512
 typedef struct { int32_t x, y; } pt_t;
 static int64_t turn2(pt_t a, pt_t b, pt_t c) { return (int64_t) (b.x - a.x) * (c.y - b.y) - (int64_t) (b.y - a.y) * (c.x - b.x); }
 
@@ -1053,7 +1052,6 @@ static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double wid
        * pieces / always the polygon, for measurements) */
       const char *mode = getenv("ORC_STROKE_OUTLINE");
       int outline = mode && mode[0] == '1' ? 1 : mode && mode[0] == '0' ? 0 : orc_stroke_risky(dev, n, width_pt / 2, c->dpi);
-      if (n >= ORC_POLY_MAXREFS) outline = 0;        /* the GPU path keeps ways this long in pieces (SMR_POLY_MAXREFS) */
       outline_used = outline;
       ne = outline ? orc_stroke_outline_edges(dev, n, width_pt / 2, c->dpi, e) : orc_stroke_edges(dev, n, width_pt / 2, c->dpi, e);
    }
@@ -1098,7 +1096,7 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
          for (int t = 0; t < 3; t++) { curves[6 * k + 2 * t] = xp[1 + 3 * k + t]; curves[6 * k + 2 * t + 1] = yp[1 + 3 * k + t]; }
    }
    else nc = orc_curve_path(xp, yp, n, closed, st->curve_fact, start, curves);
-   int cap = 64 * (nc + 2), m = 0, m_border = 0;
+   int cap = 64 * (nc + 2), m = 0;
    int32_t *pts = NULL;
    tor_edge_t *e = NULL;
    /* one decomposition per cairo_stroke / cairo_fill: the limits differ (the stroker grows the image by its reach) */
@@ -1120,8 +1118,7 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
       else bw = mm2wu(2 * st->border_width_mm, c->dpi);
       FLATTEN(orc_stroke_reach_px(bw, c->dpi));
       const char *om = getenv("ORC_STROKE_OUTLINE");
-      const int tan_outline = om && om[0] == '1' && m < ORC_POLY_MAXREFS;
-      m_border = m;
+      const int tan_outline = om && om[0] == '1';
       int ne = m < 2 ? 0 : tan_outline ? orc_stroke_outline_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e);
       c->no_cuts = !tan_outline;
       if (ne > 0) orc_layer_edges(c, e, ne, 1, has_border_col ? border_col : st->border_col);
@@ -1133,8 +1130,7 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
       double fw = mm2wu(st->fill_width_mm, c->dpi);
       FLATTEN(closed ? 0.0 : orc_stroke_reach_px(fw, c->dpi));
       const char *om = getenv("ORC_STROKE_OUTLINE");
-      /* (the length that keeps a way in pieces is the border's decomposition when there is one: the GPU path decomposes once) */
-      const int tan_outline = om && om[0] == '1' && (st->border_used ? m_border : m) < ORC_POLY_MAXREFS;
+      const int tan_outline = om && om[0] == '1';
       int ne = m < 2 ? 0 : closed ? orc_fill_edges(pts, m, e) : tan_outline ? orc_stroke_outline_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e);
       c->no_cuts = !closed && !tan_outline;
       if (ne > 0) orc_layer_edges(c, e, ne, closed ? !st->evenodd : 1, col);

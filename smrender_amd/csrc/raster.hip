@@ -566,7 +566,6 @@ __global__ void k_stroke_risk(const int2 *__restrict__ pts, const int64_t *__res
    const uint8_t wf = wayflags[w];
    if (!(mode == 0 ? (wf & 2) : (wf & 8))) return;
    const int64_t a = way_off[w], b = way_off[w + 1];
-   if (b - a >= SMR_POLY_MAXREFS) return;
    if (force) { if (g == a) atomicOr(reinterpret_cast<uint32_t *>(wayflags) + (w >> 2), (mode == 0 ? 16u : 32u) << (8 * (w & 3))); return; }
    if (g + 1 >= b) return;
    const int2 p1 = pts[g], p2 = pts[g + 1];
@@ -1145,6 +1144,7 @@ struct smr_bigacc_t
    uint32_t item_flags, prim_id, valid;          /* SMR_PF_* of the items; the id the items carry (compound or own); set by k_big_finish */
    int32_t clip0, clip1;                         /* the rows the primitive may touch (a window of an atlas), else 0 .. H */
    int32_t lim_l, lim_r, lim_on;                 /* smr_setup_cuts, for k_big_vrows */
+   int32_t sparse;                               /* a stroke's arena (8 slots per ref or 4 per piece, empty ones zeroed), pieces or the stroker's polygon */
 };
 
 struct setup_args_t
@@ -1305,7 +1305,6 @@ __device__ __forceinline__ void smr_setup_edge(const smr_oedge_t &o, int row0, i
 
 #define SMR_SCANCAP (64u * (SMR_ACTCAP + 1))      /* act0 / act1 of setup_lds_t as flat arrays */
 #define SMR_BIG_SLOTS 4096u   /* edge slots from which a primitive with an overflowing row-spanning list goes to k_big_rows */
-static_assert(SMR_SLOTS * SMR_POLY_MAXREFS <= SMR_BIG_SLOTS, "a stroke polygon must stay a small primitive");
 
 /* analysis of the vertex-free rows of one primitive: which of them libcairo's scan converter sub-samples after all
  * because two of the edges spanning the row cross inside it.  Used by the wavefront that sets the primitive up and,
@@ -1661,7 +1660,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          smr_bigacc_t a;
          a.minx = a.miny = INT32_MAX; a.maxx = a.maxy = a.bin_maxx = INT32_MIN;
          a.item_flags = item_flags; a.prim_id = A.compound != 0xffffffffu ? A.compound : (uint32_t) p; a.valid = 0;
-         a.clip0 = clip0; a.clip1 = clip1;
+         a.clip0 = clip0; a.clip1 = clip1; a.sparse = sparse;
          a.lim_l = A.lim_l; a.lim_r = A.lim_r;
          a.lim_on = A.lim_on && (!pieces || (role == 0 ? pob != nullptr && !A.solid_border : role == 1 ? A.po_dots != nullptr : (wf & 8) && A.po_open != nullptr && !A.solid_open));
          A.bigacc[b] = a;
@@ -1869,7 +1868,7 @@ __global__ __launch_bounds__(256) void k_big_items(const smr_prim_t *__restrict_
       const uint32_t item0 = biglist[2 + 2 * b], nitems = (P.edge_cnt + 63u) >> 6;
       if (first + nitems <= lo) { first += nitems; continue; }
       const uint32_t item_flags = acc[b].item_flags, prim_id = acc[b].prim_id;
-      const bool pieces = (item_flags & SMR_PF_PIECES) != 0;
+      const bool sparse = acc[b].sparse != 0;       /* as in smr_prim_setup_one: a fill polygon has a vertex in every slot, a stroke's empty slots are all zero */
       const smr_edge_t *E = edges + P.edge_off;
       int amnx = INT32_MAX, amny = INT32_MAX, amxx = INT32_MIN, amxy = INT32_MIN, abmx = INT32_MIN;
       const uint32_t k0 = lo > first ? (uint32_t) (lo - first) : 0u, k1 = (uint32_t) min((uint64_t) nitems, hi - first);
@@ -1878,8 +1877,8 @@ __global__ __launch_bounds__(256) void k_big_items(const smr_prim_t *__restrict_
          const uint32_t idx = k * 64u + (uint32_t) lane;
          smr_edge_t e; e.x1 = e.y1 = e.x2 = e.y2 = 0;
          if (idx < P.edge_cnt) e = E[idx];
-         bool has = idx < P.edge_cnt && (e.x1 != e.x2 || e.y1 != e.y2 || !pieces);
-         if (pieces && e.x1 == 0 && e.y1 == 0 && e.x2 == 0 && e.y2 == 0) has = false;
+         bool has = idx < P.edge_cnt && (e.x1 != e.x2 || e.y1 != e.y2 || !sparse);
+         if (sparse && e.x1 == 0 && e.y1 == 0 && e.x2 == 0 && e.y2 == 0) has = false;
          int mnx = has ? min(e.x1, e.x2) : INT32_MAX, mxx = has ? max(e.x1, e.x2) : INT32_MIN;
          int mny = has ? min(e.y1, e.y2) : INT32_MAX, mxy = has ? max(e.y1, e.y2) : INT32_MIN;
          int ext = 0;                     /* as in smr_prim_setup_one: the reach of the exact full-row path beyond an edge's end points */

@@ -13,7 +13,6 @@
 #define SMR_BKS 31           /* bucket stride in uint16 (odd dword count would be better; 31 halves keeps banks spread) */
 #define SMR_ROWCAP 64        /* active edges per pixel row that the exact full-row path handles */
 #define SMR_SLOTS 8          /* stroke edge slots per segment */
-#define SMR_POLY_MAXREFS 512  /* a way of this many refs or more is never stroked as its polygon: the long-primitive path (k_big_*) takes a stroke's slots as pieces only */
 
 /* one polygon edge in device space, 24.8 fixed point; direction carries the winding sign.
  * y1 == y2 marks an empty slot (horizontal edges never contribute). */

@@ -116,3 +116,35 @@ def test_full_size_c3_windows_vs_oracle(hip):
         o = po.oracle_scene([(st_ring, rways)], dpi, S, S, 0xc0d8f0, wx, wy, image=(0, 0, W, H))
         assert np.array_equal(g, o), (wx, wy, int((g != o).sum()))
         assert len(np.unique(g)) > 2
+
+
+@pytest.mark.parametrize("mode", ["default", "polygon"])
+def test_long_contour_lines_as_the_strokers_polygon(hip, mode, monkeypatch):
+    """Contour lines of 10 000 and 8 000 nodes, 1.5 px from node to node under a 1.8-px pen: nearly every join pokes through its
+    neighbour, so libcairo's image is the stroker's polygon and nothing else.  Their 80 000 slots go through the long-primitive
+    set-up (k_big_*), which used to read a stroke's arena as pieces only (empty slots of a polygon counted as vertices at the
+    origin; ways of 512 refs and more were therefore kept in pieces)."""
+    sa = hip
+    if mode == "polygon":
+        monkeypatch.setenv("SMR_HIP_STROKE", "polygon")
+        monkeypatch.setenv("ORC_STROKE_OUTLINE", "1")
+    W = H = 6000
+    dpi = 300
+    _, rings = synth.synth_coast(40000, 0, 2, W, H, seed=99)
+    x, y, off, ref = rings
+    assert list(np.diff(off)) == [10001, 8001]
+    st = po.Style(0, 1, 0, 0x203060, 0, 0.15, 0)
+    cv = sa.Canvas(W, H, dpi, 0xffffff)
+    cv.draw(draw_style(sa, st), sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off.astype(np.int64)),
+            sa.DeviceArray.from_numpy(ref.astype(np.int32)), len(off) - 1, len(ref))
+    status = sa.lib().smr_hip_draw_status()
+    S = 200
+    wins = [(min(max(int(x[k]) - S // 2, 0), W - S), min(max(int(y[k]) - S // 2, 0), H - S)) for k in (0, 2500, 7777, 10000 + 4000)]
+    got = [cv.read(wx, wy, S, S) for wx, wy in wins]
+    cv.close()
+    ways = po.ways_from_arrays(x, y, off, ref)
+    for (wx, wy), g in zip(wins, got):
+        o = po.oracle_scene([(st, ways)], dpi, S, S, 0xffffff, wx, wy, image=(0, 0, W, H))
+        assert np.array_equal(g, o), (mode, status, wx, wy, int((g != o).sum()))
+        assert len(np.unique(g)) > 2
+    assert status & 1 == 0       # no SMR_DRAW_DEGRADED_ROWS (SMR_DRAW_SECOND_PASS is informational: a tile of the ring's tangent rows overflowed the fast lists)
