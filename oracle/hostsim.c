@@ -5,8 +5,9 @@
  * (/root/reference/libsmrender/smrender.h, /root/reference/src/rdata.h: read at build time,
  * never copied) and linked with oracle/_ref/libsmrender_ref.so, which oracle/Makefile builds
  * from the reference's untouched libsmrender sources (bstring.c bxtree.c lists.c osm_func.c
- * smlog.c smutil.c; no config.h needed: every use is behind #ifdef HAVE_CONFIG_H, so the
- * library's own defaults apply -- bx_hash_t = uint32_t, BX_RES = 8: object ids must fit 32 bits).
+ * smlog.c smutil.c; no config.h needed: every use is behind #ifdef HAVE_CONFIG_H; the two settings
+ * bxtree.h takes from outside come on the compiler's command line as smrender's configure sets them,
+ * configure.ac:21-22: bx_hash_t = int64_t, BX_RES = 4 -- object ids are 64 bits as in production).
  * So get_param, get_object, put_object, match_attr, realloc_tags, malloc_node/way, log_msg
  * are the REAL host functions and smrule_t/action_t/osm_*_t have the REAL layout; the
  * _Static_asserts below pin smrender_amd/csrc/smr_abi.h to them.

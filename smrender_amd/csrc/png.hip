@@ -18,6 +18,7 @@
  *                  Adler-32 combined) or, for tiles, one whole PNG per worker at a time.
  * A job is a w x h rectangle of the band; a PNG of a region is one job cut into strips, a tile set is nx*ny jobs. */
 #include <zlib.h>
+#include <algorithm>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -171,6 +172,166 @@ __global__ __launch_bounds__(256) void k_png_rows(png_args_t A)
 }
 
 /* ---------------------------------------------------------------------------------------- */
+/* deflate on the device (level SMR_PNG_DEVICE_DEFLATE)                                            */
+/* ---------------------------------------------------------------------------------------- */
+/* zlib on sixteen host threads takes nine times as long as the chart took to draw, and the filtered rows cross PCIe for it.
+ * Here the rows stay on the device: every strip becomes ONE deflate block with a Huffman code of its own (RFC 1951 3.2.7).
+ * The matcher is what PNG's filters leave to do on a chart: runs.  A filtered row of flat colour is zeros, so a lane walks its
+ * segment of a row (SMR_DFL_SEG bytes; segments never straddle rows, whose filter byte ends a run anyway) and turns every run of
+ * a byte into the byte and one match of distance 1 (3..258 bytes).  Three passes of the same walk: (0) histogram of the
+ * literal/length symbols (LDS, then global) and the strip's Adler-32 sums; the host builds the length-limited code from the 286
+ * counts; (1) bits per segment with that code, summed per workgroup; a scan; (2) every lane writes its bits at its bit offset:
+ * whole words of its own by plain stores, its first and last word (shared with its neighbours) by atomicOr into zeroed memory.
+ * Only the compressed bytes cross PCIe; the host adds the block header, the end-of-block code and the CRCs of the IDAT chunks. */
+#define SMR_DFL_SEG 256u
+#define SMR_DFL_NSYM 286
+
+struct dfl_args_t
+{
+   const unsigned char *rows;        /* row r at rows + r * stride, its 1 + rowbytes bytes from +3 on */
+   uint32_t stride, rowlen, spr;     /* bytes from row to row; 1 + rowbytes; segments per row */
+   uint32_t nseg;                    /* nrows * spr */
+   uint64_t nbytes;                  /* nrows * rowlen */
+   const uint32_t *code;             /* [286] bits << 16 | the code, bit-reversed (as it goes into the stream, low bit first) */
+   uint32_t *hist;                   /* [288] */
+   unsigned long long *adler;        /* [2]: sum of bytes, sum of byte * (bytes from it to the strip's end), both mod 65521 per lane */
+   uint32_t *bits;                   /* [nseg] */
+   uint32_t *blocksum;               /* [blocks] */
+   const uint64_t *blockstart;       /* [blocks] */
+   uint32_t *out;
+   uint64_t bit0;                    /* where the first segment's bits start (behind the block's header) */
+};
+
+/* length 3..258 -> symbol, number of extra bits, their value (RFC 1951 3.2.5) */
+__device__ __forceinline__ void dfl_len_sym(uint32_t m, uint32_t &sym, uint32_t &eb, uint32_t &ev)
+{
+   if (m == 258u) { sym = 285u; eb = 0; ev = 0; return; }
+   const uint32_t l = m - 3u;
+   if (l < 8u) { sym = 257u + l; eb = 0; ev = 0; return; }
+   const uint32_t e = 29u - (uint32_t) __clz(l);
+   sym = 261u + 4u * e + ((l >> e) - 4u); eb = e; ev = l & ((1u << e) - 1u);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_dfl(dfl_args_t A)
+{
+   __shared__ uint32_t lh[288];
+   __shared__ uint32_t wsum[4];
+   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   if (MODE == 0) { for (int i = threadIdx.x; i < 288; i += 256) lh[i] = 0; __syncthreads(); }
+   const bool on = s < A.nseg;
+   uint32_t nbits = 0;
+   unsigned long long acc = 0; uint32_t nb = 0, wpos = 0, first_w = 0, last_w = 0;
+   unsigned long long sa = 0, sb = 0;
+
+   if (MODE == 2)
+   {
+      /* the segment's bit offset: the workgroup's, plus the segments before it in the workgroup */
+      uint32_t b = on ? A.bits[s] : 0u;
+      uint32_t incl = (uint32_t) smr_wave_scan((int) b);
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      uint32_t before = 0;
+      for (int w = 0; w < wave; w++) before += wsum[w];
+      const uint64_t B0 = A.bit0 + A.blockstart[blockIdx.x] + before + (incl - b);
+      wpos = (uint32_t) (B0 >> 5); nb = (uint32_t) (B0 & 31u); first_w = wpos; last_w = (uint32_t) ((B0 + b - 1u) >> 5);
+   }
+
+   auto put = [&](uint32_t v, uint32_t n)         /* n <= 32 bits, low bit first */
+   {
+      if (MODE == 1) { nbits += n; return; }
+      acc |= (unsigned long long) v << nb; nb += n;
+      if (nb >= 32u)
+      {
+         const uint32_t w = (uint32_t) acc;
+         if (wpos == first_w || wpos == last_w) atomicOr(&A.out[wpos], w); else A.out[wpos] = w;
+         wpos++; acc >>= 32; nb -= 32u;
+      }
+   };
+   auto lit = [&](uint32_t v)
+   {
+      if (MODE == 0) { atomicAdd(&lh[v], 1u); return; }
+      const uint32_t c = A.code[v];
+      put(c & 0xffffu, c >> 16);
+   };
+   auto flush = [&](uint32_t v, uint32_t run)     /* a run of `run` bytes v: the byte, then the rest as a match on the byte before */
+   {
+      lit(v);
+      const uint32_t m = run - 1u;
+      if (m >= 3u)
+      {
+         uint32_t sym, eb, ev;
+         dfl_len_sym(m, sym, eb, ev);
+         if (MODE == 0) { atomicAdd(&lh[sym], 1u); return; }
+         const uint32_t c = A.code[sym];
+         put((c & 0xffffu) | ev << (c >> 16), (c >> 16) + eb + 1u);      /* the code, its extra bits, distance code 0 (one bit) */
+      }
+      else for (uint32_t i = 0; i < m; i++) lit(v);
+   };
+
+   if (on)
+   {
+      const uint32_t row = s / A.spr, k = s - row * A.spr;
+      const uint32_t n = min(SMR_DFL_SEG, A.rowlen - k * SMR_DFL_SEG);
+      const uint32_t *p = reinterpret_cast<const uint32_t *>(A.rows + (size_t) row * A.stride + (size_t) k * SMR_DFL_SEG);      /* the bytes from p + 3 on */
+      uint32_t w = p[0], prev = 0xffffffffu, run = 0;
+      for (uint32_t j = 0; j < n; j++)
+      {
+         const uint32_t bo = 3u + j;
+         if ((bo & 3u) == 0u) w = p[bo >> 2];
+         const uint32_t b = (w >> (8u * (bo & 3u))) & 255u;
+         if (MODE == 0) { sa += b; sb += (unsigned long long) b * (n - j); }
+         if (b == prev && run < 259u) run++;
+         else { if (run) flush(prev, run); prev = b; run = 1u; }
+      }
+      flush(prev, run);
+      if (MODE == 2 && nb) atomicOr(&A.out[wpos], (uint32_t) acc);
+      if (MODE == 0)
+      {
+         const unsigned long long after = A.nbytes - ((unsigned long long) row * A.rowlen + (unsigned long long) k * SMR_DFL_SEG + n);
+         sb = (sb + sa * (after % 65521ull)) % 65521ull;
+      }
+   }
+   if (MODE == 0)
+   {
+      for (int o = 32; o; o >>= 1) { sa += __shfl_down(sa, o); sb += __shfl_down(sb, o); }
+      if (lane == 0) { atomicAdd(&A.adler[0], sa); atomicAdd(&A.adler[1], sb); }
+      __syncthreads();
+      for (int i = threadIdx.x; i < 288; i += 256) if (lh[i]) atomicAdd(&A.hist[i], lh[i]);
+   }
+   if (MODE == 1)
+   {
+      if (on) A.bits[s] = nbits;
+      uint32_t t = nbits;
+      for (int o = 32; o; o >>= 1) t += __shfl_down(t, o);
+      if (lane == 0) wsum[wave] = t;
+      __syncthreads();
+      if (threadIdx.x == 0) A.blocksum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+   }
+}
+
+/* exclusive scan of the workgroups' bit counts (one workgroup: a strip has at most a few thousand of them); [n] = the total */
+__global__ __launch_bounds__(1024) void k_dfl_scan(const uint32_t *__restrict__ sum, uint64_t *__restrict__ start, uint32_t n)
+{
+   __shared__ unsigned long long part[1024];
+   const uint32_t per = (n + 1023u) / 1024u, i0 = threadIdx.x * per, i1 = min(n, i0 + per);
+   unsigned long long t = 0;
+   for (uint32_t i = i0; i < i1; i++) t += sum[i];
+   part[threadIdx.x] = t;
+   __syncthreads();
+   if (threadIdx.x == 0)
+   {
+      unsigned long long run = 0;
+      for (int i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+      start[n] = run;
+   }
+   __syncthreads();
+   unsigned long long run = part[threadIdx.x];
+   for (uint32_t i = i0; i < i1; i++) { start[i] = run; run += sum[i]; }
+}
+
+/* ---------------------------------------------------------------------------------------- */
 /* host side                                                                                 */
 /* ---------------------------------------------------------------------------------------- */
 static void be32(unsigned char *o, uint32_t v) { o[0] = (unsigned char) (v >> 24); o[1] = (unsigned char) (v >> 16); o[2] = (unsigned char) (v >> 8); o[3] = (unsigned char) v; }
@@ -254,11 +415,11 @@ struct png_staging_t
       for (int k = 0; k < 2; k++) { if (d[k]) hipFree(d[k]); if (h[k]) hipHostFree(h[k]); if (ev[k]) hipEventDestroy(ev[k]); }
       if (d_opaque) hipFree(d_opaque);
    }
-   int setup(size_t bytes, size_t njobs)
+   int setup(size_t bytes, size_t njobs, bool host = true)
    {
       for (int k = 0; k < 2; k++)
       {
-         if (hipMalloc((void **) &d[k], bytes) != hipSuccess || hipHostMalloc((void **) &h[k], bytes, hipHostMallocDefault) != hipSuccess ||
+         if (hipMalloc((void **) &d[k], bytes) != hipSuccess || (host && hipHostMalloc((void **) &h[k], bytes, hipHostMallocDefault) != hipSuccess) ||
              hipEventCreateWithFlags(&ev[k], hipEventDisableTiming) != hipSuccess)
             return smr_fail(SMR_E_NOMEM, "png: staging buffers of %zu bytes", bytes);
       }
@@ -291,20 +452,187 @@ static int png_check_rect(smr_canvas_t *c, const char *who, int x, int y, int64_
    return SMR_OK;
 }
 
+/* ---- the host's share of the device deflate: the strip's Huffman code and its block header ---- */
+/* code lengths of at most 15 bits for the symbols with a count (Huffman's algorithm; should a code come out longer, the counts
+ * are halved, keeping every used symbol, and it runs again: a flatter distribution gives a shallower tree) */
+static void huff_lengths(const uint32_t *count, int n, unsigned char *len)
+{
+   std::vector<uint64_t> f((size_t) n);
+   for (int i = 0; i < n; i++) f[(size_t) i] = count[i];
+   for (;;)
+   {
+      struct node_t { uint64_t w; int l, r; };
+      std::vector<node_t> t;
+      std::vector<int> live;
+      for (int i = 0; i < n; i++) { t.push_back({ f[(size_t) i], -1, -1 }); if (f[(size_t) i]) live.push_back(i); }
+      memset(len, 0, (size_t) n);
+      if (live.size() == 1) { len[live[0]] = 1; return; }
+      auto cmp = [&](int a, int b) { return t[(size_t) a].w != t[(size_t) b].w ? t[(size_t) a].w > t[(size_t) b].w : a > b; };
+      std::make_heap(live.begin(), live.end(), cmp);
+      while (live.size() > 1)
+      {
+         std::pop_heap(live.begin(), live.end(), cmp); const int a = live.back(); live.pop_back();
+         std::pop_heap(live.begin(), live.end(), cmp); const int b = live.back(); live.pop_back();
+         t.push_back({ t[(size_t) a].w + t[(size_t) b].w, a, b });
+         live.push_back((int) t.size() - 1);
+         std::push_heap(live.begin(), live.end(), cmp);
+      }
+      int deepest = 0;
+      std::vector<std::pair<int, int>> st;
+      st.push_back({ live[0], 0 });
+      while (!st.empty())
+      {
+         const auto [v, d] = st.back(); st.pop_back();
+         if (t[(size_t) v].l < 0) { len[v] = (unsigned char) d; deepest = std::max(deepest, d); }
+         else { st.push_back({ t[(size_t) v].l, d + 1 }); st.push_back({ t[(size_t) v].r, d + 1 }); }
+      }
+      if (deepest <= 15) return;
+      for (int i = 0; i < n; i++) if (f[(size_t) i]) f[(size_t) i] = (f[(size_t) i] + 1) / 2;
+   }
+}
+
+static uint32_t bit_reverse(uint32_t v, int n) { uint32_t r = 0; for (int i = 0; i < n; i++) r |= ((v >> i) & 1u) << (n - 1 - i); return r; }
+
+/* canonical codes (RFC 1951 3.2.2), each as the device wants it: bits << 16 | the code with its first bit lowest */
+static void huff_codes(const unsigned char *len, int n, uint32_t *code)
+{
+   uint32_t bl_count[16] = { 0 }, next[16] = { 0 };
+   for (int i = 0; i < n; i++) bl_count[len[i]]++;
+   bl_count[0] = 0;
+   uint32_t c = 0;
+   for (int b = 1; b <= 15; b++) { c = (c + bl_count[b - 1]) << 1; next[b] = c; }
+   for (int i = 0; i < n; i++) code[i] = len[i] ? ((uint32_t) len[i] << 16 | bit_reverse(next[len[i]]++, len[i])) : 0u;
+}
+
+struct bitbuf_t
+{
+   std::vector<unsigned char> b; uint64_t n = 0;
+   void put(uint32_t v, int bits) { for (int i = 0; i < bits; i++, n++) { if ((n >> 3) >= b.size()) b.push_back(0); b[(size_t) (n >> 3)] |= (unsigned char) (((v >> i) & 1u) << (n & 7u)); } }
+};
+
+/* BFINAL, BTYPE = 2, and the two codes' lengths (RFC 1951 3.2.7).  The lengths go out one by one under a code-length code that
+ * gives each of 0..15 four bits (no repeat symbols: 150 bytes per strip do not matter); one distance code, of one bit */
+static void dfl_block_header(bitbuf_t &h, bool last, const unsigned char *len)
+{
+   static const int order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+   h.put(last ? 1u : 0u, 1); h.put(2u, 2);
+   h.put(SMR_DFL_NSYM - 257, 5); h.put(0u, 5); h.put(19 - 4, 4);
+   for (int i = 0; i < 19; i++) h.put(order[i] >= 16 ? 0u : 4u, 3);
+   for (int i = 0; i < SMR_DFL_NSYM; i++) h.put(bit_reverse(len[i], 4), 4);      /* symbol v of the code-length code is the 4-bit code v */
+   h.put(bit_reverse(1u, 4), 4);                                                  /* distance code 0: length 1 */
+}
+
+struct dfl_dev_t
+{
+   uint32_t *code = nullptr, *hist = nullptr, *bits = nullptr, *blocksum = nullptr, *out = nullptr;
+   uint64_t *blockstart = nullptr;
+   unsigned long long *adler = nullptr;
+   unsigned char *h_out = nullptr;
+   size_t out_cap = 0, nseg_cap = 0;
+   ~dfl_dev_t()
+   {
+      if (code) hipFree(code); if (hist) hipFree(hist); if (bits) hipFree(bits); if (blocksum) hipFree(blocksum); if (out) hipFree(out);
+      if (blockstart) hipFree(blockstart); if (adler) hipFree(adler); if (h_out) hipHostFree(h_out);
+   }
+   int setup(size_t nseg)
+   {
+      const size_t nblk = (nseg + 255) / 256;
+      if (hipMalloc((void **) &code, 288 * 4) != hipSuccess || hipMalloc((void **) &hist, 288 * 4) != hipSuccess || hipMalloc((void **) &adler, 16) != hipSuccess ||
+          hipMalloc((void **) &bits, nseg * 4) != hipSuccess || hipMalloc((void **) &blocksum, nblk * 4) != hipSuccess ||
+          hipMalloc((void **) &blockstart, (nblk + 1) * 8) != hipSuccess)
+         return smr_fail(SMR_E_NOMEM, "png: tables of the device deflate for %zu segments", nseg);
+      nseg_cap = nseg;
+      return SMR_OK;
+   }
+   int room(size_t bytes)
+   {
+      if (bytes <= out_cap) return SMR_OK;
+      if (out) hipFree(out);
+      if (h_out) hipHostFree(h_out);
+      out = nullptr; h_out = nullptr; out_cap = 0;
+      const size_t cap = bytes + bytes / 4 + 65536;
+      if (hipMalloc((void **) &out, cap) != hipSuccess || hipHostMalloc((void **) &h_out, cap, hipHostMallocDefault) != hipSuccess)
+         return smr_fail(SMR_E_NOMEM, "png: %zu bytes for a compressed strip", cap);
+      out_cap = cap;
+      return SMR_OK;
+   }
+};
+
+/* one strip of filtered rows (on the device) -> one deflate block in D.h_out, *nbytes long, ending on a byte boundary (an empty
+ * stored block follows it unless it is the stream's last); *ad: the strip's Adler-32 by itself */
+static int dfl_strip(dfl_dev_t &D, const unsigned char *d_rows, uint32_t stride, size_t rowbytes, int nrows, bool last, size_t *nbytes, uLong *ad)
+{
+   hipStream_t s = smr_g.stream;
+   dfl_args_t A;
+   memset(&A, 0, sizeof(A));
+   A.rows = d_rows; A.stride = stride; A.rowlen = (uint32_t) rowbytes + 1u; A.spr = (A.rowlen + SMR_DFL_SEG - 1u) / SMR_DFL_SEG;
+   const uint64_t nseg = (uint64_t) nrows * A.spr;
+   if (nseg > D.nseg_cap) return smr_fail(SMR_E_HIP, "png: internal: a strip of %llu segments", (unsigned long long) nseg);
+   A.nseg = (uint32_t) nseg; A.nbytes = (uint64_t) nrows * A.rowlen;
+   A.code = D.code; A.hist = D.hist; A.adler = D.adler; A.bits = D.bits; A.blocksum = D.blocksum; A.blockstart = D.blockstart;
+   const unsigned nblk = (unsigned) ((nseg + 255) / 256);
+   SMR_HIP(hipMemsetAsync(D.hist, 0, 288 * 4, s));
+   SMR_HIP(hipMemsetAsync(D.adler, 0, 16, s));
+   k_dfl<0><<<nblk, 256, 0, s>>>(A);
+   SMR_HIP(hipGetLastError());
+   uint32_t h_hist[288]; unsigned long long h_ad[2];
+   SMR_HIP(hipMemcpyAsync(h_hist, D.hist, sizeof(h_hist), hipMemcpyDeviceToHost, s));
+   SMR_HIP(hipMemcpyAsync(h_ad, D.adler, sizeof(h_ad), hipMemcpyDeviceToHost, s));
+   SMR_HIP(hipStreamSynchronize(s));
+   h_hist[256] = 1;                                                  /* the end-of-block code */
+   unsigned char len[288]; uint32_t code[288];
+   memset(len, 0, sizeof(len)); memset(code, 0, sizeof(code));
+   huff_lengths(h_hist, SMR_DFL_NSYM, len);
+   huff_codes(len, SMR_DFL_NSYM, code);
+   bitbuf_t hdr;
+   dfl_block_header(hdr, last, len);
+   A.bit0 = hdr.n;
+   SMR_HIP(hipMemcpyAsync(D.code, code, sizeof(code), hipMemcpyHostToDevice, s));
+   k_dfl<1><<<nblk, 256, 0, s>>>(A);
+   k_dfl_scan<<<1, 1024, 0, s>>>(D.blocksum, D.blockstart, nblk);
+   SMR_HIP(hipGetLastError());
+   uint64_t total = 0;
+   SMR_HIP(hipMemcpyAsync(&total, D.blockstart + nblk, 8, hipMemcpyDeviceToHost, s));
+   SMR_HIP(hipStreamSynchronize(s));
+   uint64_t nbits = hdr.n + total + (code[256] >> 16) + (last ? 0u : 3u);
+   const size_t body = (size_t) ((nbits + 7) >> 3);
+   SMR_TRY(D.room(body + 16));
+   A.out = D.out;
+   SMR_HIP(hipMemsetAsync(D.out, 0, (body + 16 + 3) & ~(size_t) 3, s));
+   k_dfl<2><<<nblk, 256, 0, s>>>(A);
+   SMR_HIP(hipGetLastError());
+   SMR_HIP(hipMemcpyAsync(D.h_out, D.out, body, hipMemcpyDeviceToHost, s));
+   SMR_HIP(hipStreamSynchronize(s));
+   for (size_t i = 0; i < hdr.b.size(); i++) D.h_out[i] |= hdr.b[i];
+   {
+      const uint64_t at = hdr.n + total;                             /* the end-of-block code; the three bits of the stored block's header are zeros */
+      const uint32_t c = code[256] & 0xffffu;
+      for (uint32_t i = 0; i < (code[256] >> 16); i++) D.h_out[(size_t) ((at + i) >> 3)] |= (unsigned char) (((c >> i) & 1u) << ((at + i) & 7u));
+   }
+   size_t n = body;
+   if (!last) { D.h_out[n++] = 0; D.h_out[n++] = 0; D.h_out[n++] = 0xff; D.h_out[n++] = 0xff; }
+   *nbytes = n;
+   const uLong M = 65521;
+   *ad = (uLong) (((A.nbytes + h_ad[1]) % M) << 16 | ((1 + h_ad[0]) % M));
+   return SMR_OK;
+}
+
 extern "C" int smr_hip_canvas_write_png(smr_canvas_t *c, int x, int y, int w, int h, const char *path, int level, int threads,
                                         smr_png_stats_t *st)
 {
    SMR_NEED_INIT();
    SMR_TRY(png_check_rect(c, "canvas_write_png", x, y, w, h));
    if (!path) return smr_fail(SMR_E_INVAL, "canvas_write_png: no path");
-   if (level < -1 || level > 9) return smr_fail(SMR_E_INVAL, "canvas_write_png: compression level %d (zlib: -1, 0..9)", level);
+   const bool on_device = level == SMR_PNG_DEVICE_DEFLATE;
+   if ((level < -1 || level > 9) && !on_device)
+      return smr_fail(SMR_E_INVAL, "canvas_write_png: compression level %d (zlib: -1, 0..9; %d: deflate on the device)", level, SMR_PNG_DEVICE_DEFLATE);
    const double t0 = now_ms();
    hipStream_t s = smr_g.stream;
    const int T = n_workers(threads);
    const uint32_t stride = 4u + 4u * (uint32_t) w;
    const int strip_rows = (int) std::max<uint64_t>(1, std::min<uint64_t>((uint64_t) h, SMR_PNG_STRIP_BYTES / stride));
    png_staging_t S;
-   SMR_TRY(S.setup((size_t) strip_rows * stride, 1));
+   SMR_TRY(S.setup((size_t) strip_rows * stride, 1, !on_device));
    std::vector<uint32_t> flags;
    SMR_TRY(png_opaque(c, x, y, w, h, 1, 1, S.d_opaque, flags));
    const bool opaque = flags[0] != 0;
@@ -327,7 +655,7 @@ extern "C" int smr_hip_canvas_write_png(smr_canvas_t *c, int x, int y, int w, in
       A.job0 = 0; A.njobs = 1; A.opaque = S.d_opaque; A.out = S.d[k & 1]; A.stride = stride;
       k_png_rows<<<(unsigned) A.nrows, 256, 0, s>>>(A);
       SMR_HIP(hipGetLastError());
-      SMR_HIP(hipMemcpyAsync(S.h[k & 1], S.d[k & 1], (size_t) A.nrows * stride, hipMemcpyDeviceToHost, s));
+      if (!on_device) SMR_HIP(hipMemcpyAsync(S.h[k & 1], S.d[k & 1], (size_t) A.nrows * stride, hipMemcpyDeviceToHost, s));
       SMR_HIP(hipEventRecord(S.ev[k & 1], s));
       return SMR_OK;
    };
@@ -339,7 +667,37 @@ extern "C" int smr_hip_canvas_write_png(smr_canvas_t *c, int x, int y, int w, in
    std::vector<uLong> ads((size_t) T);
    std::vector<int> ok((size_t) T);
    std::vector<unsigned char> chunked;
-   for (int k = 0; k < nstrips && rc == SMR_OK; k++)
+   dfl_dev_t D;
+   if (on_device && rc == SMR_OK) rc = D.setup((size_t) strip_rows * ((rowbytes + 1 + SMR_DFL_SEG - 1) / SMR_DFL_SEG));
+   for (int k = 0; k < nstrips && rc == SMR_OK && on_device; k++)
+   {
+      /* the strip's rows are filtered, deflated and copied out by the one stream; the next strip's filter pass is queued behind */
+      const int row0 = k * strip_rows, nrows = std::min(strip_rows, h - row0);
+      const double td = now_ms();
+      size_t n = 0; uLong ad = 0;
+      if ((rc = dfl_strip(D, S.d[k & 1], stride, rowbytes, nrows, k == nstrips - 1, &n, &ad)) != SMR_OK) break;
+      if (k + 1 < nstrips && (rc = launch(k + 1, row0 + nrows)) != SMR_OK) break;
+      deflate_ms += now_ms() - td;
+      adler = adler32_combine(adler, ad, (z_off_t) ((int64_t) nrows * (int64_t) (rowbytes + 1)));
+      bytes_in += (uint64_t) nrows * (rowbytes + 1);
+      /* one IDAT chunk per worker: their CRCs are the host's share */
+      const int nt = (int) std::max<size_t>(1, std::min<size_t>((size_t) T, n >> 16));
+      std::vector<std::thread> th;
+      for (int t = 0; t < nt; t++)
+         th.emplace_back([&, t]()
+         {
+            const size_t a = n * (size_t) t / (size_t) nt, b = n * (size_t) (t + 1) / (size_t) nt;
+            outs[(size_t) t].clear();
+            png_chunk(outs[(size_t) t], "IDAT", D.h_out + a, b - a);
+         });
+      for (auto &t : th) t.join();
+      for (int t = 0; t < nt; t++)
+      {
+         io_ok = io_ok && fwrite(outs[(size_t) t].data(), 1, outs[(size_t) t].size(), f) == outs[(size_t) t].size();
+         bytes_out += outs[(size_t) t].size();
+      }
+   }
+   for (int k = 0; k < nstrips && rc == SMR_OK && !on_device; k++)
    {
       const int row0 = k * strip_rows, nrows = std::min(strip_rows, h - row0);
       if (hipEventSynchronize(S.ev[k & 1]) != hipSuccess) { rc = smr_fail(SMR_E_HIP, "canvas_write_png: strip %d did not arrive", k); break; }

@@ -50,13 +50,14 @@ def chart_replay(hip):
 _next_id = [1000]
 
 
-def load_ways(sa, proj, arrs, tags=None):
+def load_ways(sa, proj, arrs, tags=None, base=None):
     """puts the synthetic ways into the host's object tree; returns (way ids, oracle way list)"""
     from smrender_amd import synth
     x, y, off, ref = arrs
     lat, lon = synth.px_to_geo(proj, x, y)
-    base = _next_id[0]
-    _next_id[0] += len(x) + len(off) + 10
+    if base is None:
+        base = _next_id[0]
+        _next_id[0] += len(x) + len(off) + 10
     hs.add_nodes(base + np.arange(len(x)), lat, lon)
     wids = []
     for w in range(len(off) - 1):
@@ -76,6 +77,25 @@ def test_draw_rule_through_the_action_api(chart):
     want = po.oracle_scene([(po.Style(1, 1, 0x4080c0, 0, 0, 0.1, 0), oways)], DPI, W, H, 0xfff8e0)
     got = plugin_canvas(sa)
     assert np.array_equal(got, want)
+
+
+def test_object_ids_beyond_32_bits(chart):
+    """OSM ids passed 2^32 years ago, and smrender gives its own objects negative ones: the host's tree is built as smrender's
+    configure builds it (bx_hash_t = int64_t, BX_RES = 4: oracle/Makefile), and two sets of ways whose ids differ by exactly 2^32
+    (one object under a 32-bit hash) are two sets of ways at the boundary"""
+    sa, proj = chart
+    a = po.synth_ways(30, W, H, seed=301)
+    b = po.synth_ways(30, W, H, seed=302)
+    big = 6_000_000_000_000
+    wa, oa = load_ways(sa, proj, a, base=big)
+    wb, ob = load_ways(sa, proj, b, base=big + (1 << 32))
+    wn, on = load_ways(sa, proj, po.synth_ways(10, W, H, seed=303), base=-7_000_000_000)
+    assert hs.way_refs(wb[0])[0] == big + (1 << 32) + int(b[3][0]) and hs.way_refs(wa[0])[0] == big + int(a[3][0])
+    ids = sorted(wn) + wa + wb                   # the tree hands objects over in id order
+    rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", ids)
+    assert rc == 0, sa.lib().smr_hip_last_error()
+    want = po.oracle_scene([(po.Style(1, 1, 0x4080c0, 0, 0, 0.1, 0), on + oa + ob)], DPI, W, H, 0xfff8e0)
+    assert np.array_equal(plugin_canvas(sa), want)
 
 
 def test_draw_relation_members_and_key_colours(chart):

@@ -132,3 +132,60 @@ def test_bad_requests_are_refused(hip, tmp_path):
         cv.write_tiles(tmp_path / "t", 0, 0, 2, 1, tile_px=256)          # 512 px do not fit into 300
     assert not os.path.exists(tmp_path / "x.png")
     cv.close()
+
+
+DEVICE = 100          # SMR_PNG_DEVICE_DEFLATE
+
+
+@pytest.mark.parametrize("bg,translucent", [(0xfff8e0, False), (0x60f0e0d0, True)])
+def test_png_deflated_on_the_device(hip, tmp_path, bg, translucent):
+    """level SMR_PNG_DEVICE_DEFLATE: the zlib stream comes from the device (one dynamic-Huffman block per strip over literals and
+    runs); zlib itself inflates it here (its Adler-32 check included) and the pixels are libcairo's"""
+    sa = hip
+    W, H = 701, 517
+    cv = scene(sa, W, H, bg, translucent=translucent)
+    # flat stretches (runs of 258 and more), and noise (every byte value, codes of many lengths)
+    rng = np.random.default_rng(3)
+    noise = rng.integers(0, 1 << 32, (90, 300), dtype=np.uint64).astype(np.uint32)
+    noise = (noise | 0xff000000) if not translucent else noise
+    if translucent:            # premultiplied: no colour above its alpha
+        a = noise >> 24
+        ch = [np.minimum((noise >> s) & 255, a) for s in (16, 8, 0)]
+        noise = (a << 24 | ch[0] << 16 | ch[1] << 8 | ch[2]).astype(np.uint32)
+    cv.blit([(350, 20, noise), (10, 400, np.full((100, 640), 0xff336699, np.uint32))])
+    img = cv.read()
+    f = tmp_path / "dev.png"
+    st = cv.write_png(f, level=DEVICE)
+    got = po.png_decode(f)
+    assert np.array_equal(got, po.png_pixels(img)), int((got != po.png_pixels(img)).sum())
+    assert st.bytes_written == os.path.getsize(f) and st.bytes_filtered == H * (1 + W * got.shape[2])
+    g = tmp_path / "zlib.png"
+    stz = cv.write_png(g)
+    assert st.bytes_written < 3 * stz.bytes_written
+    # a sub-rectangle; a single row; a single pixel
+    for rect in ((33, 41, 257, 130), (0, 77, 701, 1), (5, 5, 1, 1)):
+        cv.write_png(f, rect=rect, level=DEVICE)
+        x, y, w, h = rect
+        assert np.array_equal(po.png_decode(f), po.png_pixels(img[y:y + h, x:x + w])), rect
+    cv.close()
+
+
+def test_png_deflated_on_the_device_in_several_strips(hip, tmp_path):
+    """two strips: two deflate blocks with an empty stored block between them, ONE zlib stream whose Adler-32 is the strips' combined;
+    and a blank canvas (nothing but runs)"""
+    sa = hip
+    W, H = 8192, 2300
+    cv = scene(sa, W, H, 0xfff8e0, n_ways=4000)
+    img = cv.read()
+    f = tmp_path / "big.png"
+    st = cv.write_png(f, level=DEVICE, threads=16)
+    got, info = po.png_decode(f, with_info=True)
+    assert np.array_equal(got, po.png_pixels(img))
+    assert st.n_opaque == 1 and info["idat_chunks"] >= 4
+    cv.clear()
+    st = cv.write_png(f, level=DEVICE)
+    assert np.array_equal(po.png_decode(f), po.png_pixels(cv.read()))
+    assert st.bytes_written < st.bytes_filtered / 60          # a run of 258 bytes is a symbol or two
+    cv.close()
+    with pytest.raises(sa.SmrHipError):
+        sa.Canvas(64, 64, 300, 0).write_png(f, level=11)

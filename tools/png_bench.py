@@ -19,7 +19,7 @@ cv.draw(sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 0.1, 0, 0, 0, 0, 0, 0), D(x)
 sa.sync()
 out = {"chart": f"{size}x{size} px, {ways} closed ways fill+border", "runs": []}
 tmp = tempfile.mkdtemp(prefix="smr_png_", dir="/tmp")
-for level, threads in [(-1, 16), (1, 16), (-1, 1)]:
+for level, threads in [(100, 16), (-1, 16), (1, 16), (-1, 1)]:
     f = os.path.join(tmp, "chart.png")
     best = None
     for rep in range(2):

@@ -52,13 +52,14 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     if kind < 0.3:
         st = st.with_curve(float(rng.choice([0.2, 0.35])))
     elif kind < 0.5 and DASH:
-        # dashed / dotted borders (and dashed fill strokes of open ways); round caps stay with the border (a solid fill stroke
-        # after round caps is refused, tests/test_gpu_raster.py)
+        # dashed / dotted / rounddot / pipe borders and fill strokes of open ways (round caps are sticky: cairo_smr_dash :909-921)
         S = po.Style
-        bs = int(rng.choice([S.DASHED, S.DOTTED])) if bu else 0
-        fs = int(rng.choice([0, S.DASHED, S.DOTTED])) if fu else 0
+        bs = int(rng.choice([S.DASHED, S.DOTTED, S.ROUNDDOT, S.PIPE, 0])) if bu else 0
+        fs = int(rng.choice([0, S.DASHED, S.DOTTED, S.ROUNDDOT, S.PIPE])) if fu else 0
         bd = tuple(float(v) for v in rng.uniform(1, 8, 2)) if rng.uniform() < 0.5 else None
         st = st.with_dash(border_style=bs, fill_style=fs, border_dash=bd)
+    if rng.uniform() < 0.2:
+        st = st.with_evenodd()
     ways = po.ways_from_arrays(x, y, off, ref)
     directional = DIR and st.curve == 0 and st.fill_used and st.border_style == 0 and st.fill_style == 0 and rng.uniform() < 0.6
     want = po.oracle_directional(st, ways, dpi, W, H, 0xffffff) if directional else po.oracle_scene([(st, ways)], dpi, W, H, 0xffffff)
