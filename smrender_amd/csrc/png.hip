@@ -188,18 +188,18 @@ __global__ __launch_bounds__(256) void k_png_rows(png_args_t A)
 
 struct dfl_args_t
 {
-   const unsigned char *rows;        /* row r at rows + r * stride, its 1 + rowbytes bytes from +3 on */
-   uint32_t stride, rowlen, spr;     /* bytes from row to row; 1 + rowbytes; segments per row */
-   uint32_t nseg;                    /* nrows * spr */
-   uint64_t nbytes;                  /* nrows * rowlen */
-   const uint32_t *code;             /* [286] bits << 16 | the code, bit-reversed (as it goes into the stream, low bit first) */
-   uint32_t *hist;                   /* [288] */
-   unsigned long long *adler;        /* [2]: sum of bytes, sum of byte * (bytes from it to the strip's end), both mod 65521 per lane */
-   uint32_t *bits;                   /* [nseg] */
-   uint32_t *blocksum;               /* [blocks] */
-   const uint64_t *blockstart;       /* [blocks] */
+   const unsigned char *rows;        /* row r of job j (of this launch) at rows + (j * nrows + r) * stride, its 1 + rowbytes bytes from +3 on */
+   uint32_t stride, w, nrows;        /* bytes from row to row; pixels per row; rows per job */
+   uint32_t bpj;                     /* workgroups per job: 256 segments each, the last ones of a job partly idle */
+   const uint32_t *opaque;           /* per job: 3 or 4 bytes per pixel */
+   const uint32_t *code;             /* [job][288] bits << 16 | the code, bit-reversed (as it goes into the stream, low bit first) */
+   uint32_t *hist;                   /* [job][288] */
+   unsigned long long *adler;        /* [job][2]: sum of bytes, sum of byte * (bytes from it to the job's end), both mod 65521 per lane */
+   uint32_t *bits;                   /* [workgroup][256] */
+   uint32_t *blocksum;               /* [workgroup] */
+   const uint64_t *blockstart;       /* [workgroup], from the job's first segment */
+   const uint64_t *jobbit0;          /* [job] where the job's first segment's bits start in out (behind its block's header) */
    uint32_t *out;
-   uint64_t bit0;                    /* where the first segment's bits start (behind the block's header) */
 };
 
 /* length 3..258 -> symbol, number of extra bits, their value (RFC 1951 3.2.5) */
@@ -217,24 +217,26 @@ __global__ __launch_bounds__(256) void k_dfl(dfl_args_t A)
 {
    __shared__ uint32_t lh[288];
    __shared__ uint32_t wsum[4];
-   const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+   const uint32_t job = blockIdx.x / A.bpj, sl = (blockIdx.x - job * A.bpj) * 256u + threadIdx.x;      /* the job, the segment of the job */
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
    if (MODE == 0) { for (int i = threadIdx.x; i < 288; i += 256) lh[i] = 0; __syncthreads(); }
-   const bool on = s < A.nseg;
+   const uint32_t rowlen = 1u + A.w * (A.opaque[job] ? 3u : 4u), spr = (rowlen + SMR_DFL_SEG - 1u) / SMR_DFL_SEG;
+   const bool on = sl < A.nrows * spr;
+   const uint32_t *const code = A.code + (size_t) job * 288u;
    uint32_t nbits = 0;
    unsigned long long acc = 0; uint32_t nb = 0, wpos = 0, first_w = 0, last_w = 0;
    unsigned long long sa = 0, sb = 0;
 
    if (MODE == 2)
    {
-      /* the segment's bit offset: the workgroup's, plus the segments before it in the workgroup */
-      uint32_t b = on ? A.bits[s] : 0u;
+      /* the segment's bit offset: the job's, the workgroup's within the job, the segments before it in the workgroup */
+      uint32_t b = on ? A.bits[blockIdx.x * 256u + threadIdx.x] : 0u;
       uint32_t incl = (uint32_t) smr_wave_scan((int) b);
       if (lane == 63) wsum[wave] = incl;
       __syncthreads();
       uint32_t before = 0;
       for (int w = 0; w < wave; w++) before += wsum[w];
-      const uint64_t B0 = A.bit0 + A.blockstart[blockIdx.x] + before + (incl - b);
+      const uint64_t B0 = A.jobbit0[job] + A.blockstart[blockIdx.x] + before + (incl - b);
       wpos = (uint32_t) (B0 >> 5); nb = (uint32_t) (B0 & 31u); first_w = wpos; last_w = (uint32_t) ((B0 + b - 1u) >> 5);
    }
 
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void k_dfl(dfl_args_t A)
    auto lit = [&](uint32_t v)
    {
       if (MODE == 0) { atomicAdd(&lh[v], 1u); return; }
-      const uint32_t c = A.code[v];
+      const uint32_t c = code[v];
       put(c & 0xffffu, c >> 16);
    };
    auto flush = [&](uint32_t v, uint32_t run)     /* a run of `run` bytes v: the byte, then the rest as a match on the byte before */
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(256) void k_dfl(dfl_args_t A)
          uint32_t sym, eb, ev;
          dfl_len_sym(m, sym, eb, ev);
          if (MODE == 0) { atomicAdd(&lh[sym], 1u); return; }
-         const uint32_t c = A.code[sym];
+         const uint32_t c = code[sym];
          put((c & 0xffffu) | ev << (c >> 16), (c >> 16) + eb + 1u);      /* the code, its extra bits, distance code 0 (one bit) */
       }
       else for (uint32_t i = 0; i < m; i++) lit(v);
@@ -272,9 +274,9 @@ __global__ __launch_bounds__(256) void k_dfl(dfl_args_t A)
 
    if (on)
    {
-      const uint32_t row = s / A.spr, k = s - row * A.spr;
-      const uint32_t n = min(SMR_DFL_SEG, A.rowlen - k * SMR_DFL_SEG);
-      const uint32_t *p = reinterpret_cast<const uint32_t *>(A.rows + (size_t) row * A.stride + (size_t) k * SMR_DFL_SEG);      /* the bytes from p + 3 on */
+      const uint32_t row = sl / spr, k = sl - row * spr;
+      const uint32_t n = min(SMR_DFL_SEG, rowlen - k * SMR_DFL_SEG);
+      const uint32_t *p = reinterpret_cast<const uint32_t *>(A.rows + ((size_t) job * A.nrows + row) * A.stride + (size_t) k * SMR_DFL_SEG);      /* the bytes from p + 3 on */
       uint32_t w = p[0], prev = 0xffffffffu, run = 0;
       for (uint32_t j = 0; j < n; j++)
       {
@@ -289,20 +291,20 @@ __global__ __launch_bounds__(256) void k_dfl(dfl_args_t A)
       if (MODE == 2 && nb) atomicOr(&A.out[wpos], (uint32_t) acc);
       if (MODE == 0)
       {
-         const unsigned long long after = A.nbytes - ((unsigned long long) row * A.rowlen + (unsigned long long) k * SMR_DFL_SEG + n);
+         const unsigned long long after = (unsigned long long) A.nrows * rowlen - ((unsigned long long) row * rowlen + (unsigned long long) k * SMR_DFL_SEG + n);
          sb = (sb + sa * (after % 65521ull)) % 65521ull;
       }
    }
    if (MODE == 0)
    {
       for (int o = 32; o; o >>= 1) { sa += __shfl_down(sa, o); sb += __shfl_down(sb, o); }
-      if (lane == 0) { atomicAdd(&A.adler[0], sa); atomicAdd(&A.adler[1], sb); }
+      if (lane == 0) { atomicAdd(&A.adler[2u * job], sa); atomicAdd(&A.adler[2u * job + 1u], sb); }
       __syncthreads();
-      for (int i = threadIdx.x; i < 288; i += 256) if (lh[i]) atomicAdd(&A.hist[i], lh[i]);
+      for (int i = threadIdx.x; i < 288; i += 256) if (lh[i]) atomicAdd(&A.hist[(size_t) job * 288u + i], lh[i]);
    }
    if (MODE == 1)
    {
-      if (on) A.bits[s] = nbits;
+      A.bits[blockIdx.x * 256u + threadIdx.x] = nbits;
       uint32_t t = nbits;
       for (int o = 32; o; o >>= 1) t += __shfl_down(t, o);
       if (lane == 0) wsum[wave] = t;
@@ -311,24 +313,25 @@ __global__ __launch_bounds__(256) void k_dfl(dfl_args_t A)
    }
 }
 
-/* exclusive scan of the workgroups' bit counts (one workgroup: a strip has at most a few thousand of them); [n] = the total */
-__global__ __launch_bounds__(1024) void k_dfl_scan(const uint32_t *__restrict__ sum, uint64_t *__restrict__ start, uint32_t n)
+/* per job (one workgroup each): exclusive scan of its workgroups' bit counts, and their total */
+__global__ __launch_bounds__(256) void k_dfl_scan(const uint32_t *__restrict__ sum, uint64_t *__restrict__ start, uint64_t *__restrict__ total, uint32_t bpj)
 {
-   __shared__ unsigned long long part[1024];
-   const uint32_t per = (n + 1023u) / 1024u, i0 = threadIdx.x * per, i1 = min(n, i0 + per);
+   __shared__ unsigned long long part[256];
+   const uint32_t base = blockIdx.x * bpj;
+   const uint32_t per = (bpj + 255u) / 256u, i0 = min(bpj, threadIdx.x * per), i1 = min(bpj, i0 + per);
    unsigned long long t = 0;
-   for (uint32_t i = i0; i < i1; i++) t += sum[i];
+   for (uint32_t i = i0; i < i1; i++) t += sum[base + i];
    part[threadIdx.x] = t;
    __syncthreads();
    if (threadIdx.x == 0)
    {
       unsigned long long run = 0;
-      for (int i = 0; i < 1024; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
-      start[n] = run;
+      for (int i = 0; i < 256; i++) { const unsigned long long v = part[i]; part[i] = run; run += v; }
+      total[blockIdx.x] = run;
    }
    __syncthreads();
    unsigned long long run = part[threadIdx.x];
-   for (uint32_t i = i0; i < i1; i++) { start[i] = run; run += sum[i]; }
+   for (uint32_t i = i0; i < i1; i++) { start[base + i] = run; run += sum[base + i]; }
 }
 
 /* ---------------------------------------------------------------------------------------- */
@@ -525,23 +528,29 @@ static void dfl_block_header(bitbuf_t &h, bool last, const unsigned char *len)
 struct dfl_dev_t
 {
    uint32_t *code = nullptr, *hist = nullptr, *bits = nullptr, *blocksum = nullptr, *out = nullptr;
-   uint64_t *blockstart = nullptr;
+   uint64_t *blockstart = nullptr, *jobtotal = nullptr, *jobbit0 = nullptr;
    unsigned long long *adler = nullptr;
    unsigned char *h_out = nullptr;
-   size_t out_cap = 0, nseg_cap = 0;
+   size_t out_cap = 0, nblk_cap = 0, njobs_cap = 0;
+   /* per job of the last batch: where its block lies in h_out, how long it is, its input's Adler-32 */
+   std::vector<size_t> off, size;
+   std::vector<uint64_t> nbit;             /* the block's bits (size = those rounded up to bytes) */
+   std::vector<uLong> ad;
    ~dfl_dev_t()
    {
-      if (code) hipFree(code); if (hist) hipFree(hist); if (bits) hipFree(bits); if (blocksum) hipFree(blocksum); if (out) hipFree(out);
-      if (blockstart) hipFree(blockstart); if (adler) hipFree(adler); if (h_out) hipHostFree(h_out);
+      void *all[] = { code, hist, bits, blocksum, out, blockstart, jobtotal, jobbit0, adler };
+      for (void *q : all) if (q) hipFree(q);
+      if (h_out) hipHostFree(h_out);
    }
-   int setup(size_t nseg)
+   int setup(size_t njobs, size_t bpj)
    {
-      const size_t nblk = (nseg + 255) / 256;
-      if (hipMalloc((void **) &code, 288 * 4) != hipSuccess || hipMalloc((void **) &hist, 288 * 4) != hipSuccess || hipMalloc((void **) &adler, 16) != hipSuccess ||
-          hipMalloc((void **) &bits, nseg * 4) != hipSuccess || hipMalloc((void **) &blocksum, nblk * 4) != hipSuccess ||
-          hipMalloc((void **) &blockstart, (nblk + 1) * 8) != hipSuccess)
-         return smr_fail(SMR_E_NOMEM, "png: tables of the device deflate for %zu segments", nseg);
-      nseg_cap = nseg;
+      const size_t nblk = njobs * bpj;
+      if (hipMalloc((void **) &code, njobs * 288 * 4) != hipSuccess || hipMalloc((void **) &hist, njobs * 288 * 4) != hipSuccess ||
+          hipMalloc((void **) &adler, njobs * 16) != hipSuccess || hipMalloc((void **) &bits, nblk * 256 * 4) != hipSuccess ||
+          hipMalloc((void **) &blocksum, nblk * 4) != hipSuccess || hipMalloc((void **) &blockstart, nblk * 8) != hipSuccess ||
+          hipMalloc((void **) &jobtotal, njobs * 8) != hipSuccess || hipMalloc((void **) &jobbit0, njobs * 8) != hipSuccess)
+         return smr_fail(SMR_E_NOMEM, "png: tables of the device deflate for %zu jobs of %zu workgroups", njobs, bpj);
+      nblk_cap = nblk; njobs_cap = njobs;
       return SMR_OK;
    }
    int room(size_t bytes)
@@ -552,68 +561,98 @@ struct dfl_dev_t
       out = nullptr; h_out = nullptr; out_cap = 0;
       const size_t cap = bytes + bytes / 4 + 65536;
       if (hipMalloc((void **) &out, cap) != hipSuccess || hipHostMalloc((void **) &h_out, cap, hipHostMallocDefault) != hipSuccess)
-         return smr_fail(SMR_E_NOMEM, "png: %zu bytes for a compressed strip", cap);
+         return smr_fail(SMR_E_NOMEM, "png: %zu bytes for a batch of compressed rows", cap);
       out_cap = cap;
       return SMR_OK;
    }
 };
 
-/* one strip of filtered rows (on the device) -> one deflate block in D.h_out, *nbytes long, ending on a byte boundary (an empty
- * stored block follows it unless it is the stream's last); *ad: the strip's Adler-32 by itself */
-static int dfl_strip(dfl_dev_t &D, const unsigned char *d_rows, uint32_t stride, size_t rowbytes, int nrows, bool last, size_t *nbytes, uLong *ad)
+/* njobs jobs of nrows filtered rows each (on the device, job after job) -> one deflate block per job in D.h_out: job j's at
+ * D.off[j], D.size[j] bytes that end on a byte boundary, BFINAL set if `last`; D.ad[j]: the Adler-32 of the job's rows by themselves.
+ * pre: bytes left free in front of every block (a tile's zlib header).  T: host threads for the jobs' Huffman codes. */
+static int dfl_batch(dfl_dev_t &D, const unsigned char *d_rows, uint32_t stride, int w, int nrows, int njobs, const uint32_t *d_opaque,
+                     const uint32_t *h_opaque, bool last, size_t pre, int T)
 {
    hipStream_t s = smr_g.stream;
+   const uint32_t spr_max = (1u + 4u * (uint32_t) w + SMR_DFL_SEG - 1u) / SMR_DFL_SEG;
+   const uint32_t bpj = (uint32_t) (((uint64_t) nrows * spr_max + 255u) / 256u);
+   const size_t nblk = (size_t) njobs * bpj;
+   if (nblk > D.nblk_cap || (size_t) njobs > D.njobs_cap || nblk > 0x7fffffffu) return smr_fail(SMR_E_HIP, "png: internal: a batch of %zu workgroups", nblk);
    dfl_args_t A;
    memset(&A, 0, sizeof(A));
-   A.rows = d_rows; A.stride = stride; A.rowlen = (uint32_t) rowbytes + 1u; A.spr = (A.rowlen + SMR_DFL_SEG - 1u) / SMR_DFL_SEG;
-   const uint64_t nseg = (uint64_t) nrows * A.spr;
-   if (nseg > D.nseg_cap) return smr_fail(SMR_E_HIP, "png: internal: a strip of %llu segments", (unsigned long long) nseg);
-   A.nseg = (uint32_t) nseg; A.nbytes = (uint64_t) nrows * A.rowlen;
-   A.code = D.code; A.hist = D.hist; A.adler = D.adler; A.bits = D.bits; A.blocksum = D.blocksum; A.blockstart = D.blockstart;
-   const unsigned nblk = (unsigned) ((nseg + 255) / 256);
-   SMR_HIP(hipMemsetAsync(D.hist, 0, 288 * 4, s));
-   SMR_HIP(hipMemsetAsync(D.adler, 0, 16, s));
-   k_dfl<0><<<nblk, 256, 0, s>>>(A);
+   A.rows = d_rows; A.stride = stride; A.w = (uint32_t) w; A.nrows = (uint32_t) nrows; A.bpj = bpj; A.opaque = d_opaque;
+   A.code = D.code; A.hist = D.hist; A.adler = D.adler; A.bits = D.bits; A.blocksum = D.blocksum; A.blockstart = D.blockstart; A.jobbit0 = D.jobbit0;
+   SMR_HIP(hipMemsetAsync(D.hist, 0, (size_t) njobs * 288 * 4, s));
+   SMR_HIP(hipMemsetAsync(D.adler, 0, (size_t) njobs * 16, s));
+   k_dfl<0><<<(unsigned) nblk, 256, 0, s>>>(A);
    SMR_HIP(hipGetLastError());
-   uint32_t h_hist[288]; unsigned long long h_ad[2];
-   SMR_HIP(hipMemcpyAsync(h_hist, D.hist, sizeof(h_hist), hipMemcpyDeviceToHost, s));
-   SMR_HIP(hipMemcpyAsync(h_ad, D.adler, sizeof(h_ad), hipMemcpyDeviceToHost, s));
+   std::vector<uint32_t> h_hist((size_t) njobs * 288), code((size_t) njobs * 288, 0u);
+   std::vector<unsigned long long> h_ad((size_t) njobs * 2);
+   SMR_HIP(hipMemcpyAsync(h_hist.data(), D.hist, h_hist.size() * 4, hipMemcpyDeviceToHost, s));
+   SMR_HIP(hipMemcpyAsync(h_ad.data(), D.adler, h_ad.size() * 8, hipMemcpyDeviceToHost, s));
    SMR_HIP(hipStreamSynchronize(s));
-   h_hist[256] = 1;                                                  /* the end-of-block code */
-   unsigned char len[288]; uint32_t code[288];
-   memset(len, 0, sizeof(len)); memset(code, 0, sizeof(code));
-   huff_lengths(h_hist, SMR_DFL_NSYM, len);
-   huff_codes(len, SMR_DFL_NSYM, code);
-   bitbuf_t hdr;
-   dfl_block_header(hdr, last, len);
-   A.bit0 = hdr.n;
-   SMR_HIP(hipMemcpyAsync(D.code, code, sizeof(code), hipMemcpyHostToDevice, s));
-   k_dfl<1><<<nblk, 256, 0, s>>>(A);
-   k_dfl_scan<<<1, 1024, 0, s>>>(D.blocksum, D.blockstart, nblk);
-   SMR_HIP(hipGetLastError());
-   uint64_t total = 0;
-   SMR_HIP(hipMemcpyAsync(&total, D.blockstart + nblk, 8, hipMemcpyDeviceToHost, s));
-   SMR_HIP(hipStreamSynchronize(s));
-   uint64_t nbits = hdr.n + total + (code[256] >> 16) + (last ? 0u : 3u);
-   const size_t body = (size_t) ((nbits + 7) >> 3);
-   SMR_TRY(D.room(body + 16));
-   A.out = D.out;
-   SMR_HIP(hipMemsetAsync(D.out, 0, (body + 16 + 3) & ~(size_t) 3, s));
-   k_dfl<2><<<nblk, 256, 0, s>>>(A);
-   SMR_HIP(hipGetLastError());
-   SMR_HIP(hipMemcpyAsync(D.h_out, D.out, body, hipMemcpyDeviceToHost, s));
-   SMR_HIP(hipStreamSynchronize(s));
-   for (size_t i = 0; i < hdr.b.size(); i++) D.h_out[i] |= hdr.b[i];
+   std::vector<bitbuf_t> hdr((size_t) njobs);
    {
-      const uint64_t at = hdr.n + total;                             /* the end-of-block code; the three bits of the stored block's header are zeros */
-      const uint32_t c = code[256] & 0xffffu;
-      for (uint32_t i = 0; i < (code[256] >> 16); i++) D.h_out[(size_t) ((at + i) >> 3)] |= (unsigned char) (((c >> i) & 1u) << ((at + i) & 7u));
+      std::atomic<int> next(0);
+      auto work = [&]()
+      {
+         unsigned char len[288];
+         for (;;)
+         {
+            const int j = next.fetch_add(1);
+            if (j >= njobs) break;
+            uint32_t *h = &h_hist[(size_t) j * 288];
+            h[256] = 1;                                              /* the end-of-block code */
+            memset(len, 0, sizeof(len));
+            huff_lengths(h, SMR_DFL_NSYM, len);
+            huff_codes(len, SMR_DFL_NSYM, &code[(size_t) j * 288]);
+            dfl_block_header(hdr[(size_t) j], last, len);
+         }
+      };
+      const int nt = std::max(1, std::min(T, njobs / 4));
+      if (nt == 1) work();
+      else { std::vector<std::thread> th; for (int t = 0; t < nt; t++) th.emplace_back(work); for (auto &t : th) t.join(); }
    }
-   size_t n = body;
-   if (!last) { D.h_out[n++] = 0; D.h_out[n++] = 0; D.h_out[n++] = 0xff; D.h_out[n++] = 0xff; }
-   *nbytes = n;
+   SMR_HIP(hipMemcpyAsync(D.code, code.data(), code.size() * 4, hipMemcpyHostToDevice, s));
+   k_dfl<1><<<(unsigned) nblk, 256, 0, s>>>(A);
+   k_dfl_scan<<<(unsigned) njobs, 256, 0, s>>>(D.blocksum, D.blockstart, D.jobtotal, bpj);
+   SMR_HIP(hipGetLastError());
+   std::vector<uint64_t> total((size_t) njobs), bit0((size_t) njobs);
+   SMR_HIP(hipMemcpyAsync(total.data(), D.jobtotal, (size_t) njobs * 8, hipMemcpyDeviceToHost, s));
+   SMR_HIP(hipStreamSynchronize(s));
+   /* the jobs' blocks one behind the other, each from a dword boundary on (no word of the stream belongs to two jobs) */
+   D.off.assign((size_t) njobs, 0); D.size.assign((size_t) njobs, 0); D.ad.assign((size_t) njobs, 0); D.nbit.assign((size_t) njobs, 0);
+   size_t at = 0;
+   for (int j = 0; j < njobs; j++)
+   {
+      const uint32_t eob = code[(size_t) j * 288 + 256] >> 16;
+      at = (at + pre + 3) & ~(size_t) 3;
+      D.off[(size_t) j] = at;
+      D.nbit[(size_t) j] = hdr[(size_t) j].n + total[(size_t) j] + eob;
+      D.size[(size_t) j] = (size_t) ((D.nbit[(size_t) j] + 7) >> 3);
+      bit0[(size_t) j] = (uint64_t) at * 8 + hdr[(size_t) j].n;
+      at += D.size[(size_t) j] + 8;                                  /* room behind it: the stored block's four bytes, a tile's Adler-32 */
+   }
+   SMR_TRY(D.room(at + 16));
+   A.out = D.out;
+   SMR_HIP(hipMemcpyAsync(D.jobbit0, bit0.data(), (size_t) njobs * 8, hipMemcpyHostToDevice, s));
+   SMR_HIP(hipMemsetAsync(D.out, 0, (at + 16 + 3) & ~(size_t) 3, s));
+   k_dfl<2><<<(unsigned) nblk, 256, 0, s>>>(A);
+   SMR_HIP(hipGetLastError());
+   SMR_HIP(hipMemcpyAsync(D.h_out, D.out, at, hipMemcpyDeviceToHost, s));
+   SMR_HIP(hipStreamSynchronize(s));
    const uLong M = 65521;
-   *ad = (uLong) (((A.nbytes + h_ad[1]) % M) << 16 | ((1 + h_ad[0]) % M));
+   for (int j = 0; j < njobs; j++)
+   {
+      unsigned char *o = D.h_out + D.off[(size_t) j];
+      const bitbuf_t &h = hdr[(size_t) j];
+      for (size_t i = 0; i < h.b.size(); i++) o[i] |= h.b[i];
+      const uint64_t e0 = h.n + total[(size_t) j];                   /* the end-of-block code; what follows it in the byte are zeros */
+      const uint32_t c = code[(size_t) j * 288 + 256];
+      for (uint32_t i = 0; i < (c >> 16); i++) o[(size_t) ((e0 + i) >> 3)] |= (unsigned char) (((c >> i) & 1u) << ((e0 + i) & 7u));
+      const uint64_t nbytes = (uint64_t) nrows * (1u + (uint64_t) w * (h_opaque[j] ? 3u : 4u));
+      D.ad[(size_t) j] = (uLong) (((nbytes + h_ad[(size_t) j * 2 + 1]) % M) << 16 | ((1 + h_ad[(size_t) j * 2]) % M));
+   }
    return SMR_OK;
 }
 
@@ -668,17 +707,27 @@ extern "C" int smr_hip_canvas_write_png(smr_canvas_t *c, int x, int y, int w, in
    std::vector<int> ok((size_t) T);
    std::vector<unsigned char> chunked;
    dfl_dev_t D;
-   if (on_device && rc == SMR_OK) rc = D.setup((size_t) strip_rows * ((rowbytes + 1 + SMR_DFL_SEG - 1) / SMR_DFL_SEG));
+   if (on_device && rc == SMR_OK)
+      rc = D.setup(1, ((size_t) strip_rows * ((1u + 4u * (size_t) w + SMR_DFL_SEG - 1) / SMR_DFL_SEG) + 255) / 256);
    for (int k = 0; k < nstrips && rc == SMR_OK && on_device; k++)
    {
       /* the strip's rows are filtered, deflated and copied out by the one stream; the next strip's filter pass is queued behind */
       const int row0 = k * strip_rows, nrows = std::min(strip_rows, h - row0);
+      const bool last = k == nstrips - 1;
       const double td = now_ms();
-      size_t n = 0; uLong ad = 0;
-      if ((rc = dfl_strip(D, S.d[k & 1], stride, rowbytes, nrows, k == nstrips - 1, &n, &ad)) != SMR_OK) break;
+      if ((rc = dfl_batch(D, S.d[k & 1], stride, w, nrows, 1, S.d_opaque, flags.data(), last, 0, 1)) != SMR_OK) break;
       if (k + 1 < nstrips && (rc = launch(k + 1, row0 + nrows)) != SMR_OK) break;
       deflate_ms += now_ms() - td;
-      adler = adler32_combine(adler, ad, (z_off_t) ((int64_t) nrows * (int64_t) (rowbytes + 1)));
+      /* a strip that is not the last ends in an empty stored block: its three header bits are zeros left in the block's last byte, or
+       * one more byte when fewer are left, then LEN and NLEN on the byte boundary */
+      unsigned char *z = D.h_out + D.off[0];
+      size_t n = D.size[0];
+      if (!last)
+      {
+         if ((uint64_t) n * 8 - D.nbit[0] < 3) z[n++] = 0;
+         z[n++] = 0; z[n++] = 0; z[n++] = 0xff; z[n++] = 0xff;
+      }
+      adler = adler32_combine(adler, D.ad[0], (z_off_t) ((int64_t) nrows * (int64_t) (rowbytes + 1)));
       bytes_in += (uint64_t) nrows * (rowbytes + 1);
       /* one IDAT chunk per worker: their CRCs are the host's share */
       const int nt = (int) std::max<size_t>(1, std::min<size_t>((size_t) T, n >> 16));
@@ -688,7 +737,7 @@ extern "C" int smr_hip_canvas_write_png(smr_canvas_t *c, int x, int y, int w, in
          {
             const size_t a = n * (size_t) t / (size_t) nt, b = n * (size_t) (t + 1) / (size_t) nt;
             outs[(size_t) t].clear();
-            png_chunk(outs[(size_t) t], "IDAT", D.h_out + a, b - a);
+            png_chunk(outs[(size_t) t], "IDAT", z + a, b - a);
          });
       for (auto &t : th) t.join();
       for (int t = 0; t < nt; t++)
@@ -768,7 +817,9 @@ extern "C" int smr_hip_canvas_write_tiles(smr_canvas_t *c, int x, int y, int nx,
    if (nx <= 0 || ny <= 0 || tile_px <= 0 || tile_px > 16384 || !dir) return smr_fail(SMR_E_INVAL, "canvas_write_tiles: bad tile grid");
    SMR_TRY(png_check_rect(c, "canvas_write_tiles", x, y, (int64_t) nx * tile_px, (int64_t) ny * tile_px));
    if ((int64_t) nx * ny > 0x7fffffff / tile_px) return smr_fail(SMR_E_INVAL, "canvas_write_tiles: %d x %d tiles are too many for one call", nx, ny);
-   if (level < -1 || level > 9) return smr_fail(SMR_E_INVAL, "canvas_write_tiles: compression level %d (zlib: -1, 0..9)", level);
+   const bool on_device = level == SMR_PNG_DEVICE_DEFLATE;
+   if ((level < -1 || level > 9) && !on_device)
+      return smr_fail(SMR_E_INVAL, "canvas_write_tiles: compression level %d (zlib: -1, 0..9; %d: deflate on the device)", level, SMR_PNG_DEVICE_DEFLATE);
    const double t0 = now_ms();
    hipStream_t s = smr_g.stream;
    const int T = n_workers(threads), njobs = nx * ny;
@@ -776,7 +827,9 @@ extern "C" int smr_hip_canvas_write_tiles(smr_canvas_t *c, int x, int y, int nx,
    const size_t tile_bytes = (size_t) tile_px * stride;
    const int per_batch = (int) std::max<size_t>(1, std::min<size_t>((size_t) njobs, SMR_PNG_STRIP_BYTES / tile_bytes));
    png_staging_t S;
-   SMR_TRY(S.setup((size_t) per_batch * tile_bytes, (size_t) njobs));
+   SMR_TRY(S.setup((size_t) per_batch * tile_bytes, (size_t) njobs, !on_device));
+   dfl_dev_t D;
+   if (on_device) SMR_TRY(D.setup((size_t) per_batch, ((size_t) tile_px * ((1u + 4u * (size_t) tile_px + SMR_DFL_SEG - 1) / SMR_DFL_SEG) + 255) / 256));
    std::vector<uint32_t> flags;
    SMR_TRY(png_opaque(c, x, y, tile_px, tile_px, nx, njobs, S.d_opaque, flags));
    /* <dir>/<x>/<y>.png, the layout of create_tiles (src/smtile.c:186-212) below its zoom directory */
@@ -792,7 +845,7 @@ extern "C" int smr_hip_canvas_write_tiles(smr_canvas_t *c, int x, int y, int nx,
       A.job0 = job0; A.njobs = std::min(per_batch, njobs - job0); A.opaque = S.d_opaque; A.out = S.d[k & 1]; A.stride = stride;
       k_png_rows<<<(unsigned) ((int64_t) A.njobs * tile_px), 256, 0, s>>>(A);
       SMR_HIP(hipGetLastError());
-      SMR_HIP(hipMemcpyAsync(S.h[k & 1], S.d[k & 1], (size_t) A.njobs * tile_bytes, hipMemcpyDeviceToHost, s));
+      if (!on_device) SMR_HIP(hipMemcpyAsync(S.h[k & 1], S.d[k & 1], (size_t) A.njobs * tile_bytes, hipMemcpyDeviceToHost, s));
       SMR_HIP(hipEventRecord(S.ev[k & 1], s));
       return SMR_OK;
    };
@@ -807,8 +860,10 @@ extern "C" int smr_hip_canvas_write_tiles(smr_canvas_t *c, int x, int y, int nx,
    {
       const int job0 = k * per_batch, nj = std::min(per_batch, njobs - job0);
       if (hipEventSynchronize(S.ev[k & 1]) != hipSuccess) { rc = smr_fail(SMR_E_HIP, "canvas_write_tiles: batch %d did not arrive", k); break; }
-      if (k + 1 < nbatches && (rc = launch(k + 1, job0 + nj)) != SMR_OK) break;
       const double td = now_ms();
+      /* on the device: every tile of the batch one deflate block (a zlib stream of its own: two bytes in front, its Adler-32 behind) */
+      if (on_device && (rc = dfl_batch(D, S.d[k & 1], stride, tile_px, tile_px, nj, S.d_opaque + job0, &flags[(size_t) job0], true, 2, T)) != SMR_OK) break;
+      if (k + 1 < nbatches && (rc = launch(k + 1, job0 + nj)) != SMR_OK) break;
       std::atomic<int> next(0);
       std::vector<std::thread> th;
       for (int t = 0; t < std::min(T, nj); t++)
@@ -821,11 +876,23 @@ extern "C" int smr_hip_canvas_write_tiles(smr_canvas_t *c, int x, int y, int nx,
                if (jl >= nj) break;
                const int j = job0 + jl;
                const bool opaque = flags[(size_t) j] != 0;
-               if (deflate_rows(S.h[k & 1] + (size_t) jl * tile_bytes, stride, (size_t) tile_px * (opaque ? 3 : 4), 0, tile_px, level, 15, true, z, nullptr))
-               { failed.store(1); continue; }
+               const unsigned char *zp; size_t zn;
+               if (on_device)
+               {
+                  unsigned char *o = D.h_out + D.off[(size_t) jl];
+                  o[-2] = 0x78; o[-1] = 0x9c;
+                  be32(o + D.size[(size_t) jl], (uint32_t) D.ad[(size_t) jl]);
+                  zp = o - 2; zn = D.size[(size_t) jl] + 6;
+               }
+               else
+               {
+                  if (deflate_rows(S.h[k & 1] + (size_t) jl * tile_bytes, stride, (size_t) tile_px * (opaque ? 3 : 4), 0, tile_px, level, 15, true, z, nullptr))
+                  { failed.store(1); continue; }
+                  zp = z.data(); zn = z.size();
+               }
                file.clear();
                png_head(file, tile_px, tile_px, opaque);
-               png_chunk(file, "IDAT", z.data(), z.size());
+               png_chunk(file, "IDAT", zp, zn);
                png_chunk(file, "IEND", nullptr, 0);
                const std::string p = std::string(dir) + "/" + std::to_string(tx0 + j % nx) + "/" + std::to_string(ty0 + j / nx) + ".png";
                FILE *f = fopen(p.c_str(), "wb");

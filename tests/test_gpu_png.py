@@ -63,7 +63,8 @@ def test_png_in_several_strips_and_chunks(hip, tmp_path):
     cv.close()
 
 
-def test_tiles_are_the_canvas_cut_on_the_tile_grid(hip, tmp_path):
+@pytest.mark.parametrize("level", [-1, 100])          # zlib on the host; deflate on the device (SMR_PNG_DEVICE_DEFLATE)
+def test_tiles_are_the_canvas_cut_on_the_tile_grid(hip, tmp_path, level):
     sa = hip
     W, H = 1100, 900
     cv = scene(sa, W, H, 0x60f0e0d0, n_ways=60, translucent=True)
@@ -72,7 +73,7 @@ def test_tiles_are_the_canvas_cut_on_the_tile_grid(hip, tmp_path):
     img = cv.read()
     d = tmp_path / "tiles" / "12"
     os.makedirs(tmp_path / "tiles")
-    st = cv.write_tiles(d, 40, 60, 4, 3, tile_px=256, tx0=2200, ty0=1400, threads=3)
+    st = cv.write_tiles(d, 40, 60, 4, 3, tile_px=256, tx0=2200, ty0=1400, threads=3, level=level)
     assert st.n_files == 12
     n_rgb = 0
     for j in range(3):
@@ -88,13 +89,14 @@ def test_tiles_are_the_canvas_cut_on_the_tile_grid(hip, tmp_path):
     cv.close()
 
 
-def test_tiles_in_several_batches(hip, tmp_path):
+@pytest.mark.parametrize("level", [-1, 100])
+def test_tiles_in_several_batches(hip, tmp_path, level):
     """more tiles than one 64 MB staging buffer holds (255 tiles of 256 px): 18 x 16 = 288 tiles go in two batches"""
     sa = hip
     W, H = 18 * 256, 16 * 256
     cv = scene(sa, W, H, 0xfff8e0, n_ways=3000)
     img = cv.read()
-    st = cv.write_tiles(tmp_path / "z", 0, 0, 18, 16)
+    st = cv.write_tiles(tmp_path / "z", 0, 0, 18, 16, level=level)
     assert st.n_files == 288
     rng = np.random.default_rng(1)
     for i, j in [(0, 0), (17, 15), (14, 14), (3, 15)] + [tuple(rng.integers(0, 16, 2)) for _ in range(12)]:
@@ -113,8 +115,13 @@ def test_banded_canvas_writes_its_own_rows(hip, tmp_path):
     for k, st in enumerate([po.Style(1, 1, 0x4080c0, 0x000000, 0, 0.15, 0), po.Style(0, 1, 0, 0xa02030, 0, 0.4, 0)]):
         x, y, off, ref = po.synth_ways(120, W, H, seed=5 + k)
         cv.draw(draw_style(sa, st), D(x), D(y), D(off.astype(np.int64)), D(ref.astype(np.int32)), len(off) - 1, len(ref))
-    cv.write_png(tmp_path / "band.png")
-    assert np.array_equal(po.png_decode(tmp_path / "band.png"), po.png_pixels(img[128:278]))
+    for level in (-1, 100):
+        cv.write_png(tmp_path / "band.png", level=level)
+        assert np.array_equal(po.png_decode(tmp_path / "band.png"), po.png_pixels(img[128:278]))
+    # tiles of an odd size (a row is not a whole number of segments, a tile not a whole number of workgroups)
+    cv.write_tiles(tmp_path / "t", 7, 3, 3, 1, tile_px=97, level=100)
+    for i in range(3):
+        assert np.array_equal(po.png_decode(tmp_path / "t" / str(i) / "0.png"), po.png_pixels(img[131:228, 7 + 97 * i:7 + 97 * (i + 1)]))
     cv.close()
 
 

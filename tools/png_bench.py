@@ -31,11 +31,12 @@ for level, threads in [(100, 16), (-1, 16), (1, 16), (-1, 1)]:
                         "deflate_ms": round(st.deflate_ms, 1), "MB_filtered": round(st.bytes_filtered / 1e6, 1), "MB_file": round(st.bytes_written / 1e6, 2),
                         "rgb": bool(st.n_opaque)})
 n = size // 256
-t0 = time.perf_counter()
-st = cv.write_tiles(os.path.join(tmp, "z"), 0, 0, n, n, threads=16)
-dt = time.perf_counter() - t0
-out["runs"].append({"what": "write_tiles", "tiles": n * n, "threads": 16, "seconds": round(dt, 4), "tiles_per_s": round(n * n / dt), "Mpx_per_s": round(size * size / dt / 1e6, 1),
-                    "MB_files": round(st.bytes_written / 1e6, 2)})
+for level in (100, -1):
+    t0 = time.perf_counter()
+    st = cv.write_tiles(os.path.join(tmp, f"z{level}"), 0, 0, n, n, threads=16, level=level)
+    dt = time.perf_counter() - t0
+    out["runs"].append({"what": "write_tiles", "level": level, "tiles": n * n, "threads": 16, "seconds": round(dt, 4), "tiles_per_s": round(n * n / dt),
+                        "Mpx_per_s": round(size * size / dt / 1e6, 1), "deflate_ms": round(st.deflate_ms, 1), "MB_files": round(st.bytes_written / 1e6, 2)})
 # the reference's way: libcairo's writer (libpng, one thread) on the same pixels -- read back first, which the reference does not need
 img = cv.read()
 sys.path.insert(0, os.path.join(R, "tests"))
