@@ -788,7 +788,7 @@ static int draw_finish(draw_rule_t *d)
       if (n & 1) { d->lat.push_back(d->lat.back()); d->lon.push_back(d->lon.back()); n++; }
       /* a rule that is kept for the caption scan's windows owns its arrays; otherwise they come from the grow-only pool */
       /* (an image fill is not replayed into the cut-outs of later caption scans: they see the rule's colours only) */
-      const bool keep = cutout_replay() && P.band_y0 == 0 && P.band_h == P.H && (d->st.fill_used || d->st.border_used);
+      const bool keep = cutout_replay() && (d->st.fill_used || d->st.border_used);
       auto own_put = [&](int i, const void *h, size_t bytes) -> void *
       {
          if (!keep) return h ? pool_put(i, h, bytes) : pool_get(i, bytes);
@@ -1059,10 +1059,12 @@ static int cap_ini(smr_smrule_t *r)
       plog(SMR_LOG_ERR, "cap: host symbols match_attr/realloc_tags not found");
       return -1;
    }
-   if (autorot && (P.band_y0 != 0 || P.band_h != P.H))
+   if (autorot && !cutout_replay() && (P.band_y0 != 0 || P.band_h != P.H))
    {
-      /* a caption's cut-out reaches into the neighbouring bands; the plugin is one process and exchanges no halo rows */
-      plog(SMR_LOG_ERR, "cap: the canvas is a row band (SMR_HIP_BAND_Y0/_H): the auto-rotation scan needs the neighbours' rows, which only a "
+      /* a crop of the canvas near the band's edge reaches into the neighbouring bands; the plugin is one process and exchanges no
+       * halo rows.  (The default, cut-outs rendered again from the kept rules, does not look at the canvas: every rank of a banded
+       * chart scans all captions from the geometry it holds anyway and composites the glyphs that fall into its rows.) */
+      plog(SMR_LOG_ERR, "cap: the canvas is a row band (SMR_HIP_BAND_Y0/_H) and SMR_HIP_CUTOUT=crop: crops need the neighbours' rows, which only a "
                         "driver of the C-ABI exchanges (smr_hip_canvas_set_halo, smrender_amd/dist.py)");
       return 1;
    }
@@ -2165,7 +2167,7 @@ static int img_ini(smr_smrule_t *r)
       g->autorot = false; g->angle = 0;
    }
    g->alignkey = H.get_param("alignkey", nullptr, r->act);
-   if (g->autorot && (P.band_y0 != 0 || P.band_h != P.H))
+   if (g->autorot && !cutout_replay() && (P.band_y0 != 0 || P.band_h != P.H))
    {
       plog(SMR_LOG_ERR, "img: angle=auto on a row band needs the neighbours' rows (see cap)");
       CR.surface_destroy(g->img); delete g;

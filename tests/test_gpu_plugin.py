@@ -662,8 +662,9 @@ def test_cap_glyphs_are_composited_onto_the_device_canvas(chart):
 
 
 def test_cap_on_a_banded_plugin_canvas_is_refused(chart, monkeypatch):
-    """the scan of a caption near a band boundary needs the neighbour's rows; the plugin has nobody to ask, so a
-    banded plugin canvas draws but refuses cap ('Two canvases'); dist.py is the banded caption path"""
+    """SMR_HIP_CUTOUT=crop (this fixture): the crop of a caption near a band boundary needs the neighbour's rows; the plugin has
+    nobody to ask, so a banded plugin canvas draws but refuses cap ('Two canvases'); dist.py is the banded crop
+    path.  With the default cut-outs a banded canvas scans: test_cap_on_a_banded_plugin_canvas_with_the_references_cutouts"""
     sa, proj = chart
     monkeypatch.setenv("SMR_HIP_BAND_Y0", "100")
     monkeypatch.setenv("SMR_HIP_BAND_H", "100")
@@ -1218,6 +1219,49 @@ def test_cap_tags_from_the_references_own_cutouts(chart_replay):
     # and the crop convention gives other tags for some of them: the two paths really differ on this chart
     crop, _ = oracle_caption_tags(plugin_canvas(sa), names, px, py, 1.6, 0x203040, 1.0)
     assert sum(crop[k][0] != want[k][0] for k in range(n)) >= 1
+
+
+def test_cap_on_a_banded_plugin_canvas_with_the_references_cutouts(chart_replay, monkeypatch):
+    """a rank of a chart rendered in row bands (SMR_HIP_BAND_Y0/_H) runs the whole rule set over the whole object tree; with the
+    default cut-outs (rendered again from the kept rules, not cropped from the canvas) its cap rules need nothing of the other
+    bands: the tags are those of the one-canvas run, and its rows, glyphs included, are the chart's"""
+    sa, proj = chart_replay
+    from smrender_amd import synth
+    if po.cairo() is None:
+        pytest.skip("libcairo (text extents) not loadable")
+    a1 = po.synth_ways(70, W, H, seed=191)
+    rng = np.random.default_rng(19)
+    cx, cy = rng.uniform(30, W - 30, 12), np.concatenate([rng.uniform(30, H - 30, 8), [118.0, 122.5, 176.0, 181.0]])      # some astride the band's edges
+    lat, lon = synth.px_to_geo(proj, cx, cy)
+    names = [f"Band {k}" for k in range(12)]
+    params = "key=name;size=1.6;angle=auto;color=#203040;halign=east;font=serif;weight=1.0"
+    runs = []
+    for band in (None, (120, 60)):
+        sa.lib().smr_hip_plugin_reset()
+        if band:
+            monkeypatch.setenv("SMR_HIP_BAND_Y0", str(band[0])); monkeypatch.setenv("SMR_HIP_BAND_H", str(band[1]))
+        hs.set_chart(proj, 0xfff8e0)
+        w1, _ = load_ways(sa, proj, a1)
+        base = _next_id[0]; _next_id[0] += 20
+        nids = base + np.arange(12)
+        hs.add_nodes(nids, lat, lon, [f"name={t}" for t in names])
+        try:
+            assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, "color=#4080c0;bcolor=black;bwidth=0.1", w1) == 0
+            assert hs.apply_rule(sa.lib(), "cap", hs.OSM_NODE, params, nids) == 0, sa.lib().smr_hip_last_error()
+            tags = [(hs.get_tag(hs.OSM_NODE, i, "name:autoangle"), hs.get_tag(hs.OSM_NODE, i, "name:autoalign")) for i in nids]
+            h = band[1] if band else H
+            pix = np.empty((h, W), np.uint32)
+            assert sa.lib().smr_hip_canvas_read(sa.lib().smr_hip_plugin_canvas(), 0, 0, W, h, pix.ctypes.data) == 0
+            runs.append((tags, pix))
+        finally:
+            if band:
+                monkeypatch.undo()
+                sa.lib().smr_hip_plugin_reset()
+    (t_full, p_full), (t_band, p_band) = runs
+    assert all(t[0] is not None for t in t_full) and len(set(t[0] for t in t_full)) > 3
+    assert t_band == t_full
+    assert np.array_equal(p_band, p_full[120:180])
+    assert (p_full[120:180] != 0xfffff8e0).any()
 
 
 def test_a_way_with_a_node_far_off_the_chart_is_clipped_not_refused(chart):
