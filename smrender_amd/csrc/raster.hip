@@ -1172,6 +1172,7 @@ struct setup_args_t
    int band_y0, band_h;                                /* this canvas's rows (k_cover's arenas are sized for them) */
    uint32_t *biglist;                                  /* long primitives, left to the k_big_* kernels ([0] = their number, then (id, first item)) */
    struct smr_bigacc_t *bigacc;                        /* [biglist entry] what those kernels need of them */
+   int cv_split;                                       /* k_cover will take a primitive's strips in parts: their strip-table entries are handed out here (small[15]) */
    const int2 *way_clip;                               /* [n_ways] rows [x, y) a way's primitives may touch: its window of an atlas (smr_hip_draw_windows); NULL: the chart */
    int32_t lim_l, lim_r; int lim_on;                   /* the replay's clip box, left and right side, 24.8 (smr_setup_cuts) */
    int evenodd;                                        /* fill polygons take libcairo's EVEN_ODD rule (smr_draw_style_t.evenodd) */
@@ -1795,7 +1796,6 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    }
    for (uint32_t i = lane; i < nwords; i += 64) A.mask[moff + i] = lmask[i];
    P.mask_off = moff;
-   if (lane == 0) A.prims[p] = P;
    first_valid = min(first_valid, A.compound != 0xffffffffu ? A.compound : (uint32_t) p);
    /* what k_cover will need for this primitive at most: one alpha word per column of its box and strip of four rows */
    if (A.compound == 0xffffffffu && P.edge_cnt <= SMR_CV_MAXSLOTS)
@@ -1807,8 +1807,10 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          const int first = A.band_y0 + ((dr0 - A.band_y0) & ~(SMR_TH - 1));
          const uint32_t nstrips = (uint32_t) ((dr1 - 1 - first) >> 2) + 1u;
          need_alpha += (unsigned long long) nstrips * (uint32_t) wp; need_strips += nstrips;
+         if (A.cv_split && lane == 0) P.drow_off = atomicAdd(&A.small[15], nstrips);
       }
    }
+   if (lane == 0) A.prims[p] = P;
 }
 
 #ifndef SMR_SETUP_WAVES
@@ -2256,6 +2258,7 @@ struct sort_args_t
    uint32_t *tile_cnt;        /* [n_tiles] entries of the tile's work stream (entries that bring nothing are left out) */
    int vec;                   /* a sparse rule: every wavefront looks at 64 tiles at once and sorts the few that hold anything */
    uint32_t pure_bit;         /* SMR_TILE_PURE, or 0 when every tile goes to k_raster: ORed into tile_cnt of a tile whose stream is k_cover's alpha words only */
+   uint32_t *pure_list, *pure_n;   /* a sparse rule (vec): the tiles that got the bit, for k_blend to go by instead of looking at every tile of the chart */
 };
 
 /* SORT_WAVES independent wavefronts per workgroup, one tile each (a chart of 4 M tiles is 4 M one-wave workgroups otherwise,
@@ -2397,7 +2400,12 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
       kept += (uint32_t) __popcll(km);
       if (valid && in_lds && n >= 2) A.entries[beg + i] = idx;
    }
-   if (lane == 0) A.tile_cnt[tile] = kept | (kept && !other ? A.pure_bit : 0u);
+   if (lane == 0)
+   {
+      const bool pure = kept && !other && A.pure_bit;
+      A.tile_cnt[tile] = kept | (pure ? A.pure_bit : 0u);
+      if (pure && A.pure_list) A.pure_list[atomicAdd(A.pure_n, 1u)] = tile;
+   }
    SMR_WAVE_SYNC();            /* the next tile of this wavefront reuses the LDS block */
    }
 }
@@ -2416,6 +2424,7 @@ __device__ __forceinline__ uint32_t smr_pat_pix(const uint32_t *__restrict__ pat
 
 struct raster_args_t
 {
+   const uint32_t *blend_list, *blend_list_n;      /* k_blend, a sparse rule: the tiles to blend (k_tile_sort's list) */
    const smr_prim_t *prims;
    const smr_thdr_t *hdrs;    /* per-tile sorted work stream (k_tile_sort) */
    const smr_edge_t *edges;
@@ -3206,101 +3215,121 @@ __global__ __launch_bounds__(64 * SMR_BLEND_WAVES) void k_blend(raster_args_t A)
    const uint32_t TYt = A.n_tiles / A.TX;
    const uint32_t ncol = ((uint32_t) A.TX + 7u - xcd) >> 3;
    const uint32_t ktotal = ncol * TYt;
-   /* the tiles are handed out dynamically: with k_raster's static share this kernel took 14.6 ms instead of 11.3 on C2 (and with
-    * sixteen queues per XCD instead of one the same 11.0: the queue's atomics are not what it waits for) */
-   uint32_t *const ctr = A.blend_ctr + 8u * xcd;
+   /* one loop for both ways of finding tiles (the body once: as a function called from two places it went to scratch memory):
+    * a sparse rule goes by k_tile_sort's list of its few tiles, a chart full of tiles looks at the tiles of its XCD's share */
+   const bool by_list = A.blend_list != nullptr;
+   uint32_t *const ctr = by_list ? A.blend_ctr + 65u : A.blend_ctr + 8u * xcd;
+   const uint32_t n_list = by_list ? *A.blend_list_n : 0u;
+   /* (list) as many tiles per take as leaves every wavefront of the launch one take: a short list is spread one tile per wavefront */
+   const uint32_t take = by_list ? max(1u, min(64u, n_list / (gridDim.x * SMR_BLEND_WAVES))) : A.chunk;
+   uint32_t kb = 0, k1 = 0;
    for (;;)
    {
-      uint32_t k0 = 0;
-      if (lane == 0) k0 = atomicAdd(ctr, A.chunk);
-      k0 = __builtin_amdgcn_readfirstlane(k0);
-      if (k0 >= ktotal) break;                         /* (every wavefront gets here: the queue only grows) */
-      const uint32_t k1 = min(k0 + A.chunk, ktotal);
-      for (uint32_t kb = k0; kb < k1; kb += 64u)
+      uint32_t tile_l;
+      unsigned long long todo;
+      if (kb >= k1)
+      {
+         /* the tiles are handed out dynamically: with k_raster's static share this kernel took 14.6 ms instead of 11.3 on C2 (and with
+          * sixteen queues per XCD instead of one the same 11.0: the queue's atomics are not what it waits for) */
+         uint32_t k0 = 0;
+         if (lane == 0) k0 = atomicAdd(ctr, take);
+         k0 = __builtin_amdgcn_readfirstlane(k0);
+         if (k0 >= (by_list ? n_list : ktotal)) break;  /* (every wavefront gets here: the queue only grows) */
+         kb = k0; k1 = min(k0 + take, by_list ? n_list : ktotal);
+      }
       {
          const uint32_t kl = kb + (uint32_t) lane;
-         const uint32_t tc = kl < k1 ? A.tile_cnt[(uint32_t) (kl % TYt) * A.TX + (xcd + 8u * (kl / TYt))] : 0u;
-         unsigned long long todo = __ballot((tc & SMR_TILE_PURE) != 0u);
-         while (todo)
+         if (by_list)
          {
-            const uint32_t kg = kb + (uint32_t) __ffsll((long long) todo) - 1u;
-            todo &= todo - 1ull;
-            const uint32_t tile = (uint32_t) (kg % TYt) * A.TX + (xcd + 8u * (kg / TYt));
-            const int tx = (int) (tile % (uint32_t) A.TX), ty = (int) (tile / (uint32_t) A.TX);
-            const uint32_t beg = A.tile_off[tile], end = beg + (A.tile_cnt[tile] & ~SMR_TILE_PURE);
-            const int px = tx * SMR_TW + lane;
-            /* (four names, not an array: the compiler copied the whole array wherever two paths of a row met) */
-            uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
-            if (A.direct && px < A.W)
+            tile_l = kl < k1 ? A.blend_list[kl] : 0u;
+            todo = __ballot(kl < k1);
+         }
+         else
+         {
+            tile_l = (uint32_t) (kl % TYt) * A.TX + (xcd + 8u * (kl / TYt));
+            const uint32_t tc = kl < k1 ? A.tile_cnt[tile_l] : 0u;
+            todo = __ballot((tc & SMR_TILE_PURE) != 0u);
+         }
+         kb += 64u;
+      }
+      while (todo)
+      {
+         const uint32_t tile = (uint32_t) __builtin_amdgcn_readlane((int) tile_l, __ffsll((long long) todo) - 1);
+         todo &= todo - 1ull;
+         const int tx = (int) (tile % (uint32_t) A.TX), ty = (int) (tile / (uint32_t) A.TX);
+         const uint32_t beg = A.tile_off[tile], end = beg + (A.tile_cnt[tile] & ~SMR_TILE_PURE);
+         const int px = tx * SMR_TW + lane;
+         /* (four names, not an array: the compiler copied the whole array wherever two paths of a row met) */
+         uint32_t l0 = 0, l1 = 0, l2 = 0, l3 = 0;
+         if (A.direct && px < A.W)
+         {
+            const uint32_t *cp = A.canvas + (size_t) (ty * SMR_TH) * A.W + px;
+            const int nr = A.band_h - ty * SMR_TH;
+            if (nr > 0) l0 = cp[0];
+            if (nr > 1) l1 = cp[A.W];
+            if (nr > 2) l2 = cp[2 * (size_t) A.W];
+            if (nr > 3) l3 = cp[3 * (size_t) A.W];
+         }
+         uint32_t cur = 0xffffffffu;
+         for (uint32_t bbase = beg; bbase < end; bbase += 64u)
+         {
+            uint4 hb0 = make_uint4(0u, 0xffffffffu, 0u, 0u);
+            uint32_t hinfo = 0;
+            const uint32_t k = bbase + (uint32_t) lane;
+            if (k < end)
             {
-               const uint32_t *cp = A.canvas + (size_t) (ty * SMR_TH) * A.W + px;
-               const int nr = A.band_h - ty * SMR_TH;
-               if (nr > 0) l0 = cp[0];
-               if (nr > 1) l1 = cp[A.W];
-               if (nr > 2) l2 = cp[2 * (size_t) A.W];
-               if (nr > 3) l3 = cp[3 * (size_t) A.W];
+               const uint4 *hp = reinterpret_cast<const uint4 *>(&A.hdrs[k]);
+               hb0 = hp[0]; hinfo = hp[1].w;
             }
-            uint32_t cur = 0xffffffffu;
-            for (uint32_t bbase = beg; bbase < end; bbase += 64u)
+            const int n = (int) min(64u, end - bbase);
+            for (int j0 = 0; j0 < n; j0 += 4)
             {
-               uint4 hb0 = make_uint4(0u, 0xffffffffu, 0u, 0u);
-               uint32_t hinfo = 0;
-               const uint32_t k = bbase + (uint32_t) lane;
-               if (k < end)
-               {
-                  const uint4 *hp = reinterpret_cast<const uint4 *>(&A.hdrs[k]);
-                  hb0 = hp[0]; hinfo = hp[1].w;
-               }
-               const int n = (int) min(64u, end - bbase);
-               for (int j0 = 0; j0 < n; j0 += 4)
-               {
-                  uint32_t a4[4], prim[4], color[4], first[4];
+               uint32_t a4[4], prim[4], color[4], first[4];
 #pragma unroll
-                  for (int u = 0; u < 4; u++)
+               for (int u = 0; u < 4; u++)
+               {
+                  a4[u] = 0; prim[u] = 0xffffffffu; color[u] = 0; first[u] = 0;
+                  if (j0 + u < n)
                   {
-                     a4[u] = 0; prim[u] = 0xffffffffu; color[u] = 0; first[u] = 0;
-                     if (j0 + u < n)
-                     {
-                        const uint32_t eo = __builtin_amdgcn_readlane(hb0.x, j0 + u), info = __builtin_amdgcn_readlane(hinfo, j0 + u);
-                        prim[u] = __builtin_amdgcn_readlane(hb0.y, j0 + u); color[u] = __builtin_amdgcn_readlane(hb0.w, j0 + u);
-                        first[u] = (__builtin_amdgcn_readlane(hb0.z, j0 + u) >> 16) & 1u;
-                        const uint32_t i = (uint32_t) (px - smr_strip_x0(info));
-                        if (i < smr_strip_n(info)) a4[u] = A.alpha[(size_t) eo + i];
-                     }
+                     const uint32_t eo = __builtin_amdgcn_readlane(hb0.x, j0 + u), info = __builtin_amdgcn_readlane(hinfo, j0 + u);
+                     prim[u] = __builtin_amdgcn_readlane(hb0.y, j0 + u); color[u] = __builtin_amdgcn_readlane(hb0.w, j0 + u);
+                     first[u] = (__builtin_amdgcn_readlane(hb0.z, j0 + u) >> 16) & 1u;
+                     const uint32_t i = (uint32_t) (px - smr_strip_x0(info));
+                     if (i < smr_strip_n(info)) a4[u] = A.alpha[(size_t) eo + i];
                   }
+               }
 #pragma unroll
-                  for (int u = 0; u < 4; u++)
-                  {
-                     if (j0 + u >= n || prim[u] == cur) continue;      /* (further entries of a primitive bring nothing) */
-                     cur = prim[u];
-                     if (!__ballot(a4[u] != 0)) continue;
-                     const uint32_t spix = color[u];
-                     const bool lerp = (spix >> 24) == 255u || (first[u] && !A.direct);
-                     /* k_raster's statements for such an entry, the blends without their per-lane shortcuts (the arithmetic gives
-                      * the same for a = 0 and a = 255: smr_blend_lerp_all) */
+               for (int u = 0; u < 4; u++)
+               {
+                  if (j0 + u >= n || prim[u] == cur) continue;      /* (further entries of a primitive bring nothing) */
+                  cur = prim[u];
+                  if (!__ballot(a4[u] != 0)) continue;
+                  const uint32_t spix = color[u];
+                  const bool lerp = (spix >> 24) == 255u || (first[u] && !A.direct);
+                  /* k_raster's statements for such an entry, the blends without their per-lane shortcuts (the arithmetic gives
+                   * the same for a = 0 and a = 255: smr_blend_lerp_all) */
 #define SMR_BLEND_ROW(L, R) do { \
-                        const uint32_t a = (a4[u] >> (8 * (R))) & 255u; \
-                        if (__ballot(a != 0)) \
-                        { \
-                           if (A.pat) L = smr_blend_over_mask_all(smr_pat_pix(A.pat, A.pat_w, A.pat_h, px, A.band_y0 + ty * SMR_TH + (R)), a, L); \
-                           else if (!lerp) L = smr_blend_over_mask_all(spix, a, L); \
-                           else if (!__ballot(a != 255u && a != 0)) L = a ? spix : L;      /* no edge pixel on the row */ \
-                           else L = smr_blend_lerp_all(spix, a, L); \
-                        } } while (0)
-                     SMR_BLEND_ROW(l0, 0); SMR_BLEND_ROW(l1, 1); SMR_BLEND_ROW(l2, 2); SMR_BLEND_ROW(l3, 3);
+                     const uint32_t a = (a4[u] >> (8 * (R))) & 255u; \
+                     if (__ballot(a != 0)) \
+                     { \
+                        if (A.pat) L = smr_blend_over_mask_all(smr_pat_pix(A.pat, A.pat_w, A.pat_h, px, A.band_y0 + ty * SMR_TH + (R)), a, L); \
+                        else if (!lerp) L = smr_blend_over_mask_all(spix, a, L); \
+                        else if (!__ballot(a != 255u && a != 0)) L = a ? spix : L;      /* no edge pixel on the row */ \
+                        else L = smr_blend_lerp_all(spix, a, L); \
+                     } } while (0)
+                  SMR_BLEND_ROW(l0, 0); SMR_BLEND_ROW(l1, 1); SMR_BLEND_ROW(l2, 2); SMR_BLEND_ROW(l3, 3);
 #undef SMR_BLEND_ROW
-                  }
                }
             }
-            /* pop_group_to_source + paint: layer OVER canvas */
-            if (px < A.W)
-            {
-               uint32_t *cp = A.canvas + (size_t) (ty * SMR_TH) * A.W + px;
-               const int nr = A.band_h - ty * SMR_TH;
+         }
+         /* pop_group_to_source + paint: layer OVER canvas */
+         if (px < A.W)
+         {
+            uint32_t *cp = A.canvas + (size_t) (ty * SMR_TH) * A.W + px;
+            const int nr = A.band_h - ty * SMR_TH;
 #define SMR_BLEND_OUT(L, R) do { if (nr > (R) && (L || A.direct)) { uint32_t *d = cp + (size_t) (R) * A.W; *d = A.direct ? L : smr_blend_over(L, *d); } } while (0)
-               SMR_BLEND_OUT(l0, 0); SMR_BLEND_OUT(l1, 1); SMR_BLEND_OUT(l2, 2); SMR_BLEND_OUT(l3, 3);
+            SMR_BLEND_OUT(l0, 0); SMR_BLEND_OUT(l1, 1); SMR_BLEND_OUT(l2, 2); SMR_BLEND_OUT(l3, 3);
 #undef SMR_BLEND_OUT
-            }
          }
       }
    }
@@ -3333,6 +3362,9 @@ struct cover_args_t
    int band_y0, band_h;
    uint32_t chunk;            /* primitives a wavefront takes from the queue with one atomic: SMR_CV_CHUNK on a full chart, fewer when the rule is small */
    uint32_t linear;           /* fills that pass the star test take the crossing-by-crossing path (SMR_HIP_LINEAR=0: none does) */
+   uint32_t split;            /* a rule of few primitives: every primitive's strips in `split` parts, a wavefront each (a wavefront alone on its
+                                 SIMD needs 200 us and more for a polygon of 100 rows, and the pass waits for the slowest); the strip table's
+                                 entries were handed out by k_prim_setup then (drow_off), and the part that finishes last sets SMR_PF_DELTA */
 };
 
 struct cover_lds_t
@@ -3393,17 +3425,18 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
    uint32_t p0 = 0;
    if (lane == 0) p0 = atomicAdd(&A.ctr[0], A.chunk);
    p0 = __builtin_amdgcn_readfirstlane(p0);
-   if (p0 >= A.n_prims) break;
-   const uint32_t p1 = min(p0 + A.chunk, A.n_prims);
-   for (uint32_t p = p0; p < p1; p++)
+   if (p0 >= A.n_prims * A.split) break;
+   const uint32_t p1 = min(p0 + A.chunk, A.n_prims * A.split);
+   for (uint32_t wi = p0; wi < p1; wi++)
    {
+      const uint32_t p = wi / A.split, part = wi - p * A.split;
       const smr_prim_t P = A.prims[p];
       if (!(P.flags & SMR_PF_VALID) || P.edge_cnt == 0) continue;
       const int cx0 = (P.minx >> 8) - 1;                   /* cell 0 is a guard: the exact rows reach half a sub-row beyond an edge's ends */
       const int wp = (P.maxx >> 8) - cx0 + 2;
       const int dr0 = max(P.row0, A.band_y0), dr1 = min(P.row0 + P.nrows, A.band_y0 + A.band_h);
       if (dr1 <= dr0) continue;
-      if (P.edge_cnt > SMR_CV_MAXSLOTS || wp > SMR_CV_WC) { n_left++; continue; }
+      if (P.edge_cnt > SMR_CV_MAXSLOTS || wp > SMR_CV_WC) { if (part == 0) n_left++; continue; }
 #ifdef SMR_CV_ONLY
       if (((P.flags & SMR_PF_PIECES) != 0) != (SMR_CV_ONLY == 2)) { n_left++; continue; }
 #endif
@@ -3417,8 +3450,12 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
       /* the primitive's strips in the strip table */
       const int cr_first = A.band_y0 + ((dr0 - A.band_y0) & ~(SMR_TH - 1));
       const uint32_t nstrips = (uint32_t) ((dr1 - 1 - cr_first) >> 2) + 1u;
+      /* this wavefront's part of them: rows [part_r0, part_r1) */
+      const int part_r0 = cr_first + SMR_TH * (int) ((uint64_t) nstrips * part / A.split);
+      const int part_r1 = min(dr1, cr_first + SMR_TH * (int) ((uint64_t) nstrips * (part + 1u) / A.split));
       uint32_t rbase;
-      if (nstrips > rleft)
+      if (A.split > 1u) rbase = P.drow_off;
+      else if (nstrips > rleft)
       {
          const uint32_t take = nstrips > SMR_CV_RBLOCK / 4 ? nstrips : SMR_CV_RBLOCK;
          uint32_t b = 0;
@@ -3553,9 +3590,9 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
             uint32_t mw = 0;
             if ((uint32_t) lane < (((uint32_t) P.nrows + 31u) >> 5)) mw = A.mask[P.mask_off + lane];
             bool fail = false;
-            for (int c0r = cr_first; c0r < dr1 && !bad && !fail; c0r += R)
+            for (int c0r = part_r0; c0r < part_r1 && !bad && !fail; c0r += R)
             {
-               const int c1r = min(c0r + R, dr1), nr = c1r - c0r;
+               const int c1r = min(c0r + R, part_r1), nr = c1r - c0r;
                for (int i = 2 * lane; i < nr * stride; i += 128) *reinterpret_cast<int2 *>(pool + i) = make_int2(0, 0);
                rowcnt[lane] = 0;
                SMR_WAVE_SYNC();
@@ -3685,12 +3722,12 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
                SMR_WAVE_SYNC();
             }
             linear_done = !fail;
-            if (linear_done && !bad) n_lin++;
+            if (linear_done && !bad && part == 0) n_lin++;         /* (a tally of primitives: the first part speaks for the others) */
          }
       }
 
       CVTICK(0);
-      for (int crow = cr_first; crow < dr1 && !bad && !linear_done; crow += SMR_TH)
+      for (int crow = part_r0; crow < part_r1 && !bad && !linear_done; crow += SMR_TH)
       {
          /* the strip's rows: sub-sampled (bit of the row mask set), exact (clear), or not the primitive's */
          uint32_t partial, full_bits;
@@ -4013,7 +4050,16 @@ __global__ __launch_bounds__(64 * SMR_CV_WAVES) void k_cover(cover_args_t A)
          continue;
       }
       if (bad) { n_left++; continue; }
-      if (lane == 0) { A.prims[p].flags = P.flags | SMR_PF_DELTA; A.prims[p].drow_off = rbase; }
+      if (A.split > 1u)
+      {
+         /* the parts that came through are counted in the primitive's spare word; the one that completes the count sets the flag
+          * (a part that did not come through adds nothing: the primitive stays k_raster's) */
+         uint32_t before = 0;
+         if (lane == 0) before = atomicAdd(&A.prims[p].pad_[0], 1u);
+         if ((uint32_t) __builtin_amdgcn_readfirstlane(before) + 1u != A.split) continue;
+         if (lane == 0) A.prims[p].flags = P.flags | SMR_PF_DELTA;
+      }
+      else if (lane == 0) { A.prims[p].flags = P.flags | SMR_PF_DELTA; A.prims[p].drow_off = rbase; }
       n_done++;
    }
    }
@@ -4475,6 +4521,13 @@ static bool linear_enabled()
    return !(e && *e == '0');
 }
 
+/* SMR_HIP_SPLIT=0: a primitive's strips are never shared out among wavefronts (A/B timing, parity) */
+static bool split_enabled()
+{
+   const char *e = getenv("SMR_HIP_SPLIT");
+   return !(e && *e == '0');
+}
+
 static bool blend_enabled()
 {
    const char *e = getenv("SMR_HIP_BLEND");
@@ -4796,6 +4849,10 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    SMR_HIP(hipGetLastError());
    T.mark(s);                                                   /* 1: edges done */
 
+   /* a rule of few primitives: k_cover takes every primitive's strips in parts (cover_args_t::split), up to eight, as long as the
+    * parts are fewer than the wavefronts the chip holds of it */
+   const uint32_t cv_split = mode != SMR_PASS_COMPOUND && !c->strict_rows && smr_cover_enabled() && split_enabled() ?
+                             (uint32_t) std::max<int64_t>(1, std::min<int64_t>(8, 8192 / std::max<int64_t>(1, n_prims))) : 1u;
    /* primitive set-up (items, boxes, row masks); the mask arena grows on demand */
    uint32_t *maskbuf;
    /* a multiple of 8, and at least 8: every XCD's share of the primitives needs a workgroup (k_prim_setup) */
@@ -4830,6 +4887,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SMR_TRY(c->ensure(SMR_BUF_BIGLIST, ((size_t) n_prims * 2 + 2) * 4, (void **) &biglist));
       SMR_HIP(hipMemsetAsync(biglist, 0, 4, s));
       SA.band_y0 = c->band_y0; SA.band_h = c->band_h;
+      SA.cv_split = cv_split > 1;
       SA.biglist = biglist; SA.scancap = c->strict_rows ? SMR_ROWCAP : SMR_SCANCAP;
       /* a long primitive has at least SMR_BIG_SLOTS edge slots */
       smr_bigacc_t *bigacc;
@@ -4850,17 +4908,17 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       const int setup_chunk = (int) std::max<int64_t>(1, std::min<int64_t>(SMR_SETUP_CHUNK, n_prims / ((int64_t) setup_wg * SMR_SETUP_WAVES * 8)));
       SMR_HIP(hipMemsetAsync(small + 128, 0, 256, s));           /* the set-up's queues start at zero on every attempt */
       SMR_HIP(hipMemsetAsync(small + 11, 0, 12, s));             /* and so does its tally of what k_cover will need */
+      SMR_HIP(hipMemsetAsync(small + 15, 0, 4, s));              /* and the strip-table entries it hands out (cv_split) */
       k_prim_setup<<<setup_wg, 64 * SMR_SETUP_WAVES, (size_t) mask_words * 4 * SMR_SETUP_WAVES, s>>>(SA, mask_words, setup_chunk);
       SMR_HIP(hipGetLastError());
+      uint32_t nbig = 0;
       SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
+      SMR_HIP(hipMemcpyAsync(&nbig, biglist, 4, hipMemcpyDeviceToHost, s));
       SMR_HIP(hipStreamSynchronize(s));
       if (!(h_small[2] & SMR_ST_MASK_ARENA))
       {
          /* long primitives: items and box, rows and mask words, vertex rows, then the vertex-free rows window by window, each step on
           * as many wavefronts as it has items or windows */
-         uint32_t nbig = 0;
-         SMR_HIP(hipMemcpyAsync(&nbig, biglist, 4, hipMemcpyDeviceToHost, s));
-         SMR_HIP(hipStreamSynchronize(s));
          if (nbig)
          {
             k_big_items<<<256 * 4, 256, 0, s>>>(prims, edges, items, biglist, bigacc);
@@ -4915,8 +4973,9 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
        * remaining primitives to k_raster's own path */
       /* a small rule is spread over as many wavefronts as it has primitives (a wavefront needs ~30 us per primitive) */
       const unsigned max_wg = 256 * 20 / SMR_CV_WAVES;
-      const uint32_t cv_chunk = (uint32_t) std::max<int64_t>(1, std::min<int64_t>(SMR_CV_CHUNK, n_prims / ((int64_t) max_wg * SMR_CV_WAVES)));
-      const unsigned nwg = (unsigned) std::min<int64_t>((n_prims + cv_chunk * SMR_CV_WAVES - 1) / (cv_chunk * SMR_CV_WAVES), max_wg);
+      const int64_t n_work = n_prims * cv_split;
+      const uint32_t cv_chunk = (uint32_t) std::max<int64_t>(1, std::min<int64_t>(SMR_CV_CHUNK, n_work / ((int64_t) max_wg * SMR_CV_WAVES)));
+      const unsigned nwg = (unsigned) std::min<int64_t>((n_work + cv_chunk * SMR_CV_WAVES - 1) / (cv_chunk * SMR_CV_WAVES), max_wg);
       uint64_t need_a = (uint64_t) h_small[12] | ((uint64_t) h_small[13] << 32);
       uint64_t acap = need_a + (uint64_t) nwg * SMR_CV_WAVES * SMR_CV_DBLOCK + 65536;
       uint64_t rcap = (uint64_t) h_small[11] + (uint64_t) nwg * SMR_CV_WAVES * SMR_CV_RBLOCK + 65536;
@@ -4928,6 +4987,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       CV.prims = prims; CV.n_prims = (uint32_t) n_prims; CV.edges = edges; CV.mask = maskbuf;
       CV.alpha = alpha; CV.alpha_cap = (uint32_t) acap; CV.drows = drows; CV.drow_cap = (uint32_t) rcap;
       CV.ctr = cvctr; CV.band_y0 = c->band_y0; CV.band_h = c->band_h; CV.chunk = cv_chunk; CV.linear = linear_enabled() ? 1u : 0u;
+      CV.split = cv_split;
       k_cover<<<nwg, 64 * SMR_CV_WAVES, 0, s>>>(CV);
       SMR_HIP(hipGetLastError());
    }
@@ -4965,7 +5025,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SMR_HIP(hipStreamWaitEvent(s, smr_g.ev_join, 0));
    }
    smr_thdr_t *hdrs;
-   uint32_t *tile_cnt;
+   uint32_t *tile_cnt, *pure_list = nullptr;
    SMR_TRY(c->ensure(SMR_BUF_TILECNT, (size_t) n_tiles * 4, (void **) &tile_cnt));
    SMR_TRY(c->ensure(SMR_BUF_HDRS, ((size_t) n_entries + 1) * sizeof(smr_thdr_t), (void **) &hdrs));
    {
@@ -4977,6 +5037,12 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SO.lds_cap = cap;
       SO.vec = (uint64_t) n_entries * 16ull < n_tiles ? 1 : 0;
       SO.pure_bit = alpha && blend_enabled() ? SMR_TILE_PURE : 0u;
+      SO.pure_list = nullptr; SO.pure_n = &small[320];
+      /* a rule of few entries: k_blend goes by a list of its tiles (an atomic per tile here; a chart full of tiles finds them faster by
+       * looking, and a wavefront that finds 64 neighbouring tiles of one big polygon in its share blends them one after the other) */
+      if ((SO.vec || n_entries <= 16384u) && SO.pure_bit)
+         SMR_TRY(c->ensure(SMR_BUF_PURELIST, ((size_t) std::min<uint64_t>(n_entries, n_tiles) + 1) * 4, (void **) &SO.pure_list));
+      pure_list = SO.pure_list;
       const uint32_t nwork = SO.vec ? (n_tiles + 63u) / 64u : n_tiles;
       k_tile_sort<<<(nwork + SORT_WAVES - 1) / SORT_WAVES, 64 * SORT_WAVES, (size_t) SORT_WAVES * cap * 4, s>>>(SO);
    }
@@ -4994,6 +5060,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    A.prims = prims; A.hdrs = hdrs; A.edges = edges; A.tile_off = tile_off; A.tile_cnt = tile_cnt;
    A.tile_ctr = &small[64];       /* zero since the memset at the top of the pass */
    A.blend_ctr = &small[256];
+   A.blend_list = pure_list; A.blend_list_n = &small[320];
    A.canvas = c->pix; A.status = &small[2]; A.W = c->W; A.band_y0 = c->band_y0; A.band_h = c->band_h; A.TX = TX;
    A.n_tiles = n_tiles;
    A.chunk = n_entries >= 8ull * n_tiles ? SMR_TILE_CHUNK : n_entries >= 2ull * n_tiles ? 2 * SMR_TILE_CHUNK : n_entries * 16ull >= n_tiles ? 4 * SMR_TILE_CHUNK : 64;
@@ -5017,7 +5084,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       A.strided = 0;
       if (alpha && blend_enabled())
       {
-         unsigned bwg = std::min<unsigned>((n_tiles + SMR_BLEND_WAVES - 1) / SMR_BLEND_WAVES, 256u * 8u);
+         unsigned bwg = std::min<unsigned>((unsigned) ((std::min<uint64_t>(pure_list ? n_entries : n_tiles, n_tiles) + SMR_BLEND_WAVES - 1) / SMR_BLEND_WAVES), 256u * 8u);
          k_blend<<<(bwg + 7u) & ~7u, 64 * SMR_BLEND_WAVES, 0, s>>>(A);
          A.strided = 1;
       }
