@@ -220,7 +220,20 @@ def other_charts(args):
     arrs = synth.synth_ways(1000000, S, S, seed=4242, mean_nodes=10)
     cv = sa.Canvas(S, S, 300, 0xffffff)
     ms = timed(cv, [(sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0, 0, 0, 0, 0, 0), dev(arrs))])
+    # the fixed cost of a pass: a chart's rule set is hundreds of small rules (the canvas is not cleared in between)
+    small = {}
+    for n_small in (10, 2000):
+        r = [(sa.DrawStyle(1, 1, 0x4080c0, 0x000000, 0.0, 25.4 / 300, 0, 0, 0, 0, 0, 0), dev(synth.synth_ways(n_small, S, S, seed=5)))]
+        for st, (dx, dy, doff, dref, nw, nr) in r * 3:
+            cv.draw(st, dx, dy, doff, dref, nw, nr)
+        sa.sync()
+        t0 = time.perf_counter()
+        for st, (dx, dy, doff, dref, nw, nr) in r * 20:
+            cv.draw(st, dx, dy, doff, dref, nw, nr)
+        sa.sync()
+        small[f"{n_small}_ways_ms"] = round((time.perf_counter() - t0) * 1e3 / 20, 3)
     cv.close()
+    out["small_rules"] = dict(small, workload=f"one rule of 10 / 2000 closed ways (fill + 2 px border) on the {S}x{S} canvas, mean of 20 draws")
     out["target_32k"] = {"workload": f"1000000 closed ways / {len(arrs[0])} nodes, fill + 2 px border, {S}x{S} px @ 300 dpi (draw only, nodes projected)",
                          "ms": round(ms, 2), "Mpx_per_s": round(S * S / 1e6 / (ms * 1e-3), 1)}
     W, H = 19866, 28087
