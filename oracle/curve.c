@@ -58,6 +58,7 @@ typedef struct { pt_t a, b, c, d; } knots_t;
 typedef struct
 {
    int32_t *pts, *tin, *tout;
+   uint8_t *flag;                  /* optional, per point: 1 = a curve_to ends here (or the move_to), 2 = that curve_to was a line_to */
    int m, cap, overflow;
    pt_t last;
 } sink_t;
@@ -68,6 +69,7 @@ static void sink_point(sink_t *s, pt_t p, int32_t tdx, int32_t tdy)
    s->pts[2 * s->m] = p.x; s->pts[2 * s->m + 1] = p.y;
    s->tin[2 * s->m] = tdx; s->tin[2 * s->m + 1] = tdy;
    s->tout[2 * s->m] = tdx; s->tout[2 * s->m + 1] = tdy;
+   if (s->flag) s->flag[s->m] = 0;
    s->m++;
 }
 
@@ -169,6 +171,7 @@ static void curve_to(sink_t *s, pt_t a, pt_t b, pt_t c, pt_t d, const int32_t *l
       if (a.x == d.x && a.y == d.y) return;             /* line_to the current point: nothing */
       if (tout_a) { tout_a[0] = d.x - a.x; tout_a[1] = d.y - a.y; }
       sink_point(s, d, d.x - a.x, d.y - a.y);
+      if (s->flag && !s->overflow) s->flag[s->m - 1] = 3;
       return;
    }
    if (tout_a) { tout_a[0] = is.x; tout_a[1] = is.y; }
@@ -176,6 +179,7 @@ static void curve_to(sink_t *s, pt_t a, pt_t b, pt_t c, pt_t d, const int32_t *l
    s->last = a;
    decompose_into(&k, 0.1 * 0.1, s, 0);
    sink_point(s, d, fs.x, fs.y);
+   if (s->flag && !s->overflow) s->flag[s->m - 1] = 1;
 }
 
 /* The recorded path replayed at dpi/72 (fixed * fixed(dpi/72) >> 8 per coordinate, like every vertex:
@@ -186,15 +190,26 @@ static void curve_to(sink_t *s, pt_t a, pt_t b, pt_t c, pt_t d, const int32_t *l
 static int32_t flatten_shift_[2];
 void orc_curve_set_shift(int32_t sx, int32_t sy) { flatten_shift_[0] = sx; flatten_shift_[1] = sy; }
 
+int orc_curve_flatten_flags(const double *start_pt, const double *curves_pt, int ncurves, int dpi, const int32_t *lim,
+                            int32_t *pts, int32_t *tin, int32_t *tout, uint8_t *flag, int cap);
 int orc_curve_flatten(const double *start_pt, const double *curves_pt, int ncurves, int dpi, const int32_t *lim,
                       int32_t *pts, int32_t *tin, int32_t *tout, int cap)
 {
-   sink_t s; s.pts = pts; s.tin = tin; s.tout = tout; s.m = 0; s.cap = cap; s.overflow = 0;
+   return orc_curve_flatten_flags(start_pt, curves_pt, ncurves, dpi, lim, pts, tin, tout, NULL, cap);
+}
+
+/* the same with, per point, where the path's curve_to calls end (the dashing stroker puts its faces along the chords inside a
+ * curve and along the tangents where one ends, orc_dash_edges_curve) */
+int orc_curve_flatten_flags(const double *start_pt, const double *curves_pt, int ncurves, int dpi, const int32_t *lim,
+                            int32_t *pts, int32_t *tin, int32_t *tout, uint8_t *flag, int cap)
+{
+   sink_t s; s.pts = pts; s.tin = tin; s.tout = tout; s.flag = flag; s.m = 0; s.cap = cap; s.overflow = 0;
    int32_t dv[6];
    orc_pt_to_dev(start_pt, 1, dpi, dv);
    dv[0] += flatten_shift_[0]; dv[1] += flatten_shift_[1];
    pt_t cur = { dv[0], dv[1] };
    sink_point(&s, cur, 0, 0);
+   if (flag && cap > 0) flag[0] = 1;
    for (int k = 0; k < ncurves; k++)
    {
       orc_pt_to_dev(curves_pt + 6 * k, 3, dpi, dv);

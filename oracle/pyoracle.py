@@ -435,7 +435,7 @@ def curve_path(xy_pt, closed, factor, explicit=False):
 
 
 def _cairo_curve_way(L, st, xy, closed, dpi):
-    """render_poly_line (:953-1016) with cairo_smr_poly -> cairo_smr_poly_curve; solid strokes"""
+    """render_poly_line (:953-1016) with cairo_smr_poly -> cairo_smr_poly_curve; cairo_smr_dash before every stroke (:898-923)"""
     start, curves = curve_path(xy, closed, st.curve_fact, st.curve == 2)
     if st.border_used:
         if not st.fill_used:
@@ -444,11 +444,17 @@ def _cairo_curve_way(L, st, xy, closed, dpi):
             bw = mm2wu(2 * st.border_width_mm, dpi) + mm2wu(st.fill_width_mm, dpi)
         else:
             bw = mm2wu(2 * st.border_width_mm, dpi)
+        _cd_dash(L, 1 if st.border_style == 4 else st.border_style, st.border_width_mm, st.border_dash, st.border_ndash, dpi)
         L.cd_poly_curve(start[0], start[1], P(curves), len(curves))
         L.cd_stroke(st.border_col, bw)
+        if st.border_style == 4:
+            _cd_dash(L, 4, st.border_width_mm, st.border_dash, st.border_ndash, dpi)
+            L.cd_poly_curve(start[0], start[1], P(curves), len(curves))
+            L.cd_stroke(st.border_col, bw * 2.5)
     if st.fill_used:
         L.cd_poly_curve(start[0], start[1], P(curves), len(curves))
         if not closed:
+            _cd_dash(L, st.fill_style, st.border_width_mm, st.fill_dash, st.fill_ndash, dpi)
             L.cd_stroke(st.fill_col, mm2wu(st.fill_width_mm, dpi))
         else:
             L.cd_fill(st.fill_col)

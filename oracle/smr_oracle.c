@@ -600,32 +600,15 @@ static int pen_active_ccw(const dasher_t *d, slope_t sl)       /* _cairo_pen_fin
    return i;
 }
 
+static int d_fan_points(const dasher_t *d, pt_t mid, slope_t in, slope_t outv, pt_t from, pt_t to, pt_t *poly);
+
 /* round cap at face f, f pointing out of the stroke: half disc ccw -> pen vertices -> cw */
 static void d_round_cap(dasher_t *d, const dface_t *f)
 {
-   const int n = d->npen;
    slope_t in = f->dev, outv = { -f->dev.dx, -f->dev.dy };
-   int start = pen_active_ccw(d, in);
-   if (slope_cmp(d->pccw[start], in) < 0) start = start == 0 ? n - 1 : start - 1;
-   int stop = pen_active_ccw(d, outv);
-   if (slope_cmp(d->pcw[stop], outv) > 0)
-   {
-      stop = stop + 1 == n ? 0 : stop + 1;
-      if (slope_cmp(d->pccw[stop], in) < 0) return;
-   }
-   int npoints = start - stop;
-   stop = stop == 0 ? n - 1 : stop - 1;
-   if (npoints < 0) npoints += n;
-   if (npoints <= 1) return;
    pt_t poly[ORC_PEN_MAX + 2];
-   int m = 0;
-   poly[m++] = f->ccw;
-   for (int i = start; i != stop; i = i == 0 ? n - 1 : i - 1)
-   {
-      pt_t p = { f->point.x + d->pvx[i], f->point.y + d->pvy[i] };
-      poly[m++] = p;
-   }
-   poly[m++] = f->cw;
+   int m = d_fan_points(d, f->point, in, outv, f->ccw, f->cw, poly);
+   if (m <= 2) return;
    /* convex: fan of quads from the first point */
    for (int k = 1; k + 1 < m; k += 2)
    {
@@ -673,82 +656,220 @@ static void d_join(dasher_t *d, const dface_t *in, const dface_t *out)
    d_emit(d, q, 3);
 }
 
+/* the pen's vertices the stroker passes between the directions `in` and `outv` on the side of the ccw corners (_tessellate_fan
+ * with _cairo_pen_find_active_ccw_vertices): poly = from, vertices..., to; a round cap is the case outv = -in */
+static int d_fan_points(const dasher_t *d, pt_t mid, slope_t in, slope_t outv, pt_t from, pt_t to, pt_t *poly)
+{
+   const int n = d->npen;
+   int m = 0;
+   poly[m++] = from;
+   if (n > 0)
+   {
+      int start = pen_active_ccw(d, in);
+      if (slope_cmp(d->pccw[start], in) < 0) start = start == 0 ? n - 1 : start - 1;
+      int stop = pen_active_ccw(d, outv), none = 0;
+      if (slope_cmp(d->pcw[stop], outv) > 0)
+      {
+         stop = stop + 1 == n ? 0 : stop + 1;
+         if (slope_cmp(d->pccw[stop], in) < 0) none = 1;
+      }
+      int npoints = start - stop;
+      stop = stop == 0 ? n - 1 : stop - 1;
+      if (npoints < 0) npoints += n;
+      if (!none && npoints > 1)
+         for (int i = start; i != stop; i = i == 0 ? n - 1 : i - 1)
+         {
+            pt_t p = { mid.x + d->pvx[i], mid.y + d->pvy[i] };
+            poly[m++] = p;
+         }
+   }
+   poly[m++] = to;
+   return m;
+}
+
+/* a ROUND join (what the dashing stroker puts between the segments of a decomposed curve): the fan over the pen's vertices on
+ * the outer side, from the pivot; with no vertex in between it is the bevel's triangle */
+static void d_join_round(dasher_t *d, const dface_t *in, const dface_t *out)
+{
+   if (in->cw.x == out->cw.x && in->cw.y == out->cw.y && in->ccw.x == out->ccw.x && in->ccw.y == out->ccw.y) return;
+   slope_t so = { out->cw.x - out->point.x, out->cw.y - out->point.y }, si = { in->cw.x - in->point.x, in->cw.y - in->point.y };
+   int clockwise = slope_cmp(so, si) < 0;
+   pt_t poly[ORC_PEN_MAX + 3];
+   int m;
+   if (clockwise) m = d_fan_points(d, in->point, in->dev, out->dev, in->ccw, out->ccw, poly + 1);
+   else
+   {
+      /* the other side: the same walk along the reversed path, whose ccw corners are this one's cw corners */
+      slope_t ri = { -out->dev.dx, -out->dev.dy }, ro = { -in->dev.dx, -in->dev.dy };
+      m = d_fan_points(d, in->point, ri, ro, out->cw, in->cw, poly + 1);
+   }
+   poly[0] = in->point;
+   m++;
+   for (int k = 1; k + 1 < m; k += 2)
+   {
+      pt_t q[4] = { poly[0], poly[k], poly[k + 1], poly[k + 2 < m ? k + 2 : k + 1] };
+      d_emit(d, q, k + 2 < m ? 4 : 3);
+   }
+}
+
+/* the dash state along a path (_cairo_stroker_dash_start with offset 0, _cairo_stroker_dash_step) and the stroker's faces */
+typedef struct
+{
+   const double *dash; int ndash, di, on;
+   double dash_remain;
+   int has_first, has_cur;
+   dface_t first, cur;
+   pt_t p1;
+} dstate_t;
+
+static void d_pen_init(dasher_t *D, double hw_pt, int dpi, int need_pen)
+{
+   D->npen = need_pen ? orc_pen(hw_pt, dpi, D->pvx, D->pvy, ORC_PEN_MAX) : 0;
+   for (int i = 0; i < D->npen; i++)
+   {
+      int pr = i == 0 ? D->npen - 1 : i - 1, nx = i + 1 == D->npen ? 0 : i + 1;
+      D->pcw[i].dx = D->pvx[i] - D->pvx[pr]; D->pcw[i].dy = D->pvy[i] - D->pvy[pr];
+      D->pccw[i].dx = D->pvx[nx] - D->pvx[i]; D->pccw[i].dy = D->pvy[nx] - D->pvy[i];
+   }
+}
+
+/* _cairo_stroker_line_to_dashed; round_join: inside a decomposed curve */
+static void d_line_to(dasher_t *D, dstate_t *S, pt_t p2, int round_join)
+{
+   const int starts_on = 1;
+   const pt_t p1 = S->p1;
+   if (p1.x == p2.x && p1.y == p2.y) return;
+   slope_t dev = { p2.x - p1.x, p2.y - p1.y };
+   double sdx = dev.dx / 256.0 * (1.0 / D->s), sdy = dev.dy / 256.0 * (1.0 / D->s);
+   double mag = normalize_slope(&sdx, &sdy);
+   double remain = mag;
+   pt_t a = p1;
+   while (remain)
+   {
+      double step = S->dash_remain < remain ? S->dash_remain : remain;
+      remain -= step;
+      double dx2 = sdx * (mag - remain) * D->s, dy2 = sdy * (mag - remain) * D->s;
+      pt_t b = { orc_fixed_from_double(dx2) + p1.x, orc_fixed_from_double(dy2) + p1.y };
+      if (S->on)
+      {
+         dface_t ss, se;
+         d_face(D, a, dev, sdx, sdy, &ss);
+         se = ss;
+         if (a.x != b.x || a.y != b.y)
+         {
+            se.point = b;
+            se.ccw.x += b.x - a.x; se.ccw.y += b.y - a.y; se.cw.x += b.x - a.x; se.cw.y += b.y - a.y;
+            pt_t q[4] = { ss.ccw, se.ccw, se.cw, ss.cw };
+            d_emit(D, q, 4);
+         }
+         if (S->has_cur) { if (round_join) d_join_round(D, &S->cur, &ss); else d_join(D, &S->cur, &ss); S->has_cur = 0; }
+         else if (!S->has_first && starts_on) { S->first = ss; S->has_first = 1; }
+         else d_cap_leading(D, &ss);
+         if (remain) d_cap_trailing(D, &se);
+         else { S->cur = se; S->has_cur = 1; }
+      }
+      else if (S->has_cur) { d_cap_trailing(D, &S->cur); S->has_cur = 0; }
+      /* _cairo_stroker_dash_step */
+      S->dash_remain -= step;
+      if (S->dash_remain < 1.0 / 512)
+      {
+         if (++S->di == S->ndash) S->di = 0;
+         S->on = !S->on;
+         S->dash_remain += S->dash[S->di];
+      }
+      a = b;
+   }
+   if (S->on && !S->has_cur)
+   {
+      /* the segment ends exactly where a dash begins: a (degenerate) leading cap at the vertex */
+      d_face(D, p2, dev, sdx, sdy, &S->cur);
+      d_cap_leading(D, &S->cur);
+      S->has_cur = 1;
+   }
+   S->p1 = p2;
+}
+
+static void d_state_init(dstate_t *S, const double *dash, int ndash, pt_t p0)
+{
+   S->dash = dash; S->ndash = ndash; S->di = 0; S->on = 1; S->dash_remain = dash[0];
+   S->has_first = S->has_cur = 0; S->p1 = p0;
+}
+
 int orc_dash_edges(const int32_t *xy, int n, double hw_pt, int dpi, const double *dash, int ndash, int round_cap, tor_edge_t *out)
 {
    dasher_t D;
    D.s = (double) dpi / 72; D.hw = hw_pt; D.round_cap = round_cap; D.out = out; D.cnt = 0;
-   D.npen = round_cap ? orc_pen(hw_pt, dpi, D.pvx, D.pvy, ORC_PEN_MAX) : 0;
+   d_pen_init(&D, hw_pt, dpi, round_cap);
    if (D.npen < 0) return -1;
-   for (int i = 0; i < D.npen; i++)
-   {
-      int pr = i == 0 ? D.npen - 1 : i - 1, nx = i + 1 == D.npen ? 0 : i + 1;
-      D.pcw[i].dx = D.pvx[i] - D.pvx[pr]; D.pcw[i].dy = D.pvy[i] - D.pvy[pr];
-      D.pccw[i].dx = D.pvx[nx] - D.pvx[i]; D.pccw[i].dy = D.pvy[nx] - D.pvy[i];
-   }
-   /* _cairo_stroker_dash_start with offset 0 */
-   int di = 0, on = 1;
-   const int starts_on = 1;
-   double dash_remain = dash[0];
-   int has_first = 0, has_cur = 0;
-   dface_t first, cur;
-   pt_t p1 = { xy[0], xy[1] };
+   dstate_t S;
+   pt_t p0 = { xy[0], xy[1] };
+   d_state_init(&S, dash, ndash, p0);
    for (int i = 1; i < n; i++)
    {
       pt_t p2 = { xy[2 * i], xy[2 * i + 1] };
-      if (p1.x == p2.x && p1.y == p2.y) continue;
-      slope_t dev = { p2.x - p1.x, p2.y - p1.y };
-      double sdx = dev.dx / 256.0 * (1.0 / D.s), sdy = dev.dy / 256.0 * (1.0 / D.s);
-      double mag = normalize_slope(&sdx, &sdy);
-      double remain = mag;
-      pt_t a = p1;
-      while (remain)
-      {
-         double step = dash_remain < remain ? dash_remain : remain;
-         remain -= step;
-         double dx2 = sdx * (mag - remain) * D.s, dy2 = sdy * (mag - remain) * D.s;
-         pt_t b = { orc_fixed_from_double(dx2) + p1.x, orc_fixed_from_double(dy2) + p1.y };
-         if (on)
-         {
-            dface_t ss, se;
-            d_face(&D, a, dev, sdx, sdy, &ss);
-            se = ss;
-            if (a.x != b.x || a.y != b.y)
-            {
-               se.point = b;
-               se.ccw.x += b.x - a.x; se.ccw.y += b.y - a.y; se.cw.x += b.x - a.x; se.cw.y += b.y - a.y;
-               pt_t q[4] = { ss.ccw, se.ccw, se.cw, ss.cw };
-               d_emit(&D, q, 4);
-            }
-            if (has_cur) { d_join(&D, &cur, &ss); has_cur = 0; }
-            else if (!has_first && starts_on) { first = ss; has_first = 1; }
-            else d_cap_leading(&D, &ss);
-            if (remain) d_cap_trailing(&D, &se);
-            else { cur = se; has_cur = 1; }
-         }
-         else if (has_cur) { d_cap_trailing(&D, &cur); has_cur = 0; }
-         /* _cairo_stroker_dash_step */
-         dash_remain -= step;
-         if (dash_remain < 1.0 / 512)
-         {
-            if (++di == ndash) di = 0;
-            on = !on;
-            dash_remain += dash[di];
-         }
-         a = b;
-      }
-      if (on && !has_cur)
-      {
-         /* the segment ends exactly where a dash begins: a (degenerate) leading cap at the vertex */
-         d_face(&D, p2, dev, sdx, sdy, &cur);
-         d_cap_leading(&D, &cur);
-         has_cur = 1;
-      }
-      p1 = p2;
+      d_line_to(&D, &S, p2, 0);
    }
    /* _cairo_stroker_add_caps; a path of coincident points only draws nothing with our dash arrays
     * unless caps are round -- the reference's ways with >= 2 distinct nodes never get there */
-   if (has_first) d_cap_leading(&D, &first);
-   if (has_cur) d_cap_trailing(&D, &cur);
+   if (S.has_first) d_cap_leading(&D, &S.first);
+   if (S.has_cur) d_cap_trailing(&D, &S.cur);
+   return D.cnt;
+}
+
+/* The dashing stroker along a decomposed Bezier chain (_cairo_stroker_curve_to of libcairo 1.16's cairo-path-stroke.c): where a
+ * curve begins and a dash is on, a face along the curve's initial tangent, joined to what came before with the context's join
+ * (miter); the decomposed points are plain dashed line_to's, faces along the CHORDS, joined with ROUND joins; where the curve
+ * ends, a face along its final tangent, round-joined to the last chord's.  flag: orc_curve_flatten_flags. */
+int orc_dash_edges_curve(const int32_t *xy, const int32_t *tin, const int32_t *tout, const uint8_t *flag, int m, double hw_pt, int dpi,
+                         const double *dash, int ndash, int round_cap, tor_edge_t *out)
+{
+   dasher_t D;
+   D.s = (double) dpi / 72; D.hw = hw_pt; D.round_cap = round_cap; D.out = out; D.cnt = 0;
+   d_pen_init(&D, hw_pt, dpi, 1);
+   if (D.npen < 0) return -1;
+   dstate_t S;
+   pt_t p0 = { xy[0], xy[1] };
+   d_state_init(&S, dash, ndash, p0);
+   for (int i = 1; i < m;)
+   {
+      int j = i;
+      while (j < m - 1 && !(flag[j] & 1)) j++;
+      if (flag[j] & 2)
+      {
+         for (int k = i; k <= j; k++) { pt_t p = { xy[2 * k], xy[2 * k + 1] }; d_line_to(&D, &S, p, 0); }
+         i = j + 1;
+         continue;
+      }
+      if (S.on)
+      {
+         slope_t is = { tout[2 * (i - 1)], tout[2 * (i - 1) + 1] };
+         double ux = is.dx / 256.0 * (1.0 / D.s), uy = is.dy / 256.0 * (1.0 / D.s);
+         dface_t f;
+         if (normalize_slope(&ux, &uy) != 0)
+         {
+            d_face(&D, S.p1, is, ux, uy, &f);
+            if (S.has_cur) d_join(&D, &S.cur, &f);
+            else if (!S.has_first) { S.first = f; S.has_first = 1; }
+            S.cur = f; S.has_cur = 1;
+         }
+      }
+      for (int k = i; k <= j; k++) { pt_t p = { xy[2 * k], xy[2 * k + 1] }; d_line_to(&D, &S, p, 1); }
+      if (S.on)
+      {
+         slope_t fs = { tin[2 * j], tin[2 * j + 1] };
+         double ux = fs.dx / 256.0 * (1.0 / D.s), uy = fs.dy / 256.0 * (1.0 / D.s);
+         dface_t f;
+         if (normalize_slope(&ux, &uy) != 0)
+         {
+            d_face(&D, S.p1, fs, ux, uy, &f);
+            if (S.has_cur) d_join_round(&D, &S.cur, &f);
+            S.cur = f; S.has_cur = 1;
+         }
+      }
+      i = j + 1;
+   }
+   if (S.has_first) d_cap_leading(&D, &S.first);
+   if (S.has_cur) d_cap_trailing(&D, &S.cur);
    return D.cnt;
 }
 
@@ -1027,8 +1148,9 @@ static double mm2wu(double mm, int dpi) { return mm == 0.0 ? 1.0 * 72 / dpi : mm
 /* cairo_smr_dash (:898-923) + cairo_stroke: dash lengths = mm2wu(border width) * ds[i]; rounddot and the pipe's
  * dots switch the context to round caps, and nothing ever switches it back (c->cap_round lives as long as
  * the rule's context) */
+typedef struct { const int32_t *tin, *tout; const uint8_t *flag; } curve_faces_t;      /* a decomposed curve (orc_curve_flatten_flags), or NULL */
 static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double width_pt, int style, double bwidth_mm,
-                          const double *ds, int len, uint32_t col)
+                          const double *ds, int len, uint32_t col, const curve_faces_t *cf)
 {
    double dash[4], l = 0;
    int nd = 0;
@@ -1057,9 +1179,11 @@ static void stroke_styled(orc_canvas_t *c, const int32_t *dev, int n, double wid
    }
    else
    {
-      ne = orc_dash_edges(dev, n, width_pt / 2, c->dpi, dash, nd, c->cap_round, NULL);
+      if (cf) ne = orc_dash_edges_curve(dev, cf->tin, cf->tout, cf->flag, n, width_pt / 2, c->dpi, dash, nd, c->cap_round, NULL);
+      else ne = orc_dash_edges(dev, n, width_pt / 2, c->dpi, dash, nd, c->cap_round, NULL);
       e = malloc(sizeof(tor_edge_t) * (ne > 0 ? ne : 1));
-      if (ne > 0) orc_dash_edges(dev, n, width_pt / 2, c->dpi, dash, nd, c->cap_round, e);
+      if (ne > 0 && cf) orc_dash_edges_curve(dev, cf->tin, cf->tout, cf->flag, n, width_pt / 2, c->dpi, dash, nd, c->cap_round, e);
+      else if (ne > 0) orc_dash_edges(dev, n, width_pt / 2, c->dpi, dash, nd, c->cap_round, e);
    }
    /* a dashed stroke goes through libcairo's other stroker, which adds every dash, join and cap as a polygon of its own: those
     * pieces ARE its edges, and are cut at the page's sides like any; the pieces of a solid stroke are ours */
@@ -1078,7 +1202,6 @@ int orc_curve_unsupported_;
 static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const double *x_px, const double *y_px, int n, int closed,
                            int has_fill_col, uint32_t fill_col, int has_border_col, uint32_t border_col)
 {
-   if ((st->border_used && st->border_style != 0) || (st->fill_used && !closed && st->fill_style != 0)) { orc_curve_unsupported_ = 1; return; }
    double *xp = malloc(sizeof(double) * 2 * n), *yp = xp + n, start[2];
    double *curves = malloc(sizeof(double) * 6 * n);
    for (int i = 0; i < n; i++) { xp[i] = x_px[i] * 72 / c->dpi; yp[i] = y_px[i] * 72 / c->dpi; }     /* geo2pt */
@@ -1100,6 +1223,14 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
    int32_t *pts = NULL;
    tor_edge_t *e = NULL;
    /* one decomposition per cairo_stroke / cairo_fill: the limits differ (the stroker grows the image by its reach) */
+   /* a dashed stroke: libcairo's other stroker, which knows no limits for curves; with the points, where the curve_to's end */
+   uint8_t *flag = NULL;
+   #define FLATTEN_DASHED() do { \
+      for (;;) { \
+         pts = realloc(pts, sizeof(int32_t) * 6 * cap); flag = realloc(flag, cap); \
+         m = orc_curve_flatten_flags(start, curves, nc, c->dpi, NULL, pts, pts + 2 * cap, pts + 4 * cap, flag, cap); \
+         if (m >= 0) break; \
+         cap *= 4; } } while (0)
    #define FLATTEN(reach_px) do { \
       int32_t lim[4]; double rf = (reach_px); \
       lim[0] = c->img[0] * 256 - orc_fixed_from_double(rf); lim[1] = c->img[1] * 256 - orc_fixed_from_double(rf); \
@@ -1116,6 +1247,19 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
       if (!st->fill_used) bw = mm2wu(st->border_width_mm, c->dpi);
       else if (!closed) bw = mm2wu(2 * st->border_width_mm, c->dpi) + mm2wu(st->fill_width_mm, c->dpi);
       else bw = mm2wu(2 * st->border_width_mm, c->dpi);
+      if (st->border_ndash > 0)                      /* (a dash array makes a dashed stroke whatever the style says: stroke_styled) */
+      {
+         FLATTEN_DASHED();
+         curve_faces_t cf = { pts + 2 * cap, pts + 4 * cap, flag };
+         uint32_t col = has_border_col ? border_col : st->border_col;
+         if (m >= 2)
+         {
+            stroke_styled(c, pts, m, bw, st->border_style == 4 ? 1 : st->border_style, st->border_width_mm, st->border_dash, st->border_ndash, col, &cf);
+            if (st->border_style == 4) stroke_styled(c, pts, m, bw * 2.5, 4, st->border_width_mm, st->border_dash, st->border_ndash, col, &cf);
+         }
+         goto border_done;
+      }
+      if (c->cap_round) { orc_curve_unsupported_ = 1; goto all_done; }      /* a solid curve with the rule's caps gone round: not restated */
       FLATTEN(orc_stroke_reach_px(bw, c->dpi));
       const char *om = getenv("ORC_STROKE_OUTLINE");
       const int tan_outline = om && om[0] == '1';
@@ -1124,10 +1268,19 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
       if (ne > 0) orc_layer_edges(c, e, ne, 1, has_border_col ? border_col : st->border_col);
       c->no_cuts = 0;
    }
+   border_done:
    if (st->fill_used)
    {
       uint32_t col = has_fill_col ? fill_col : st->fill_col;
       double fw = mm2wu(st->fill_width_mm, c->dpi);
+      if (!closed && st->fill_ndash > 0)
+      {
+         FLATTEN_DASHED();
+         curve_faces_t cf = { pts + 2 * cap, pts + 4 * cap, flag };
+         if (m >= 2) stroke_styled(c, pts, m, fw, st->fill_style, st->border_width_mm, st->fill_dash, st->fill_ndash, col, &cf);
+         goto all_done;
+      }
+      if (!closed && c->cap_round) { orc_curve_unsupported_ = 1; goto all_done; }
       FLATTEN(closed ? 0.0 : orc_stroke_reach_px(fw, c->dpi));
       const char *om = getenv("ORC_STROKE_OUTLINE");
       const int tan_outline = om && om[0] == '1';
@@ -1136,8 +1289,10 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
       if (ne > 0) orc_layer_edges(c, e, ne, closed ? !st->evenodd : 1, col);
       c->no_cuts = 0;
    }
+   all_done:
    #undef FLATTEN
-   free(e); free(pts); free(curves); free(xp);
+   #undef FLATTEN_DASHED
+   free(e); free(pts); free(curves); free(xp); free(flag);
 }
 
 /* render_poly_line, src/smrules_cairo.c:953-1016 (no image/curve) */
@@ -1159,9 +1314,9 @@ void orc_draw_way(orc_canvas_t *c, const orc_draw_style_t *st, const double *x_p
       else if (!closed) bw = mm2wu(2 * st->border_width_mm, c->dpi) + mm2wu(st->fill_width_mm, c->dpi);
       else bw = mm2wu(2 * st->border_width_mm, c->dpi);
       uint32_t col = has_border_col ? border_col : st->border_col;
-      stroke_styled(c, dev, n, bw, st->border_style == 4 ? 1 : st->border_style, st->border_width_mm, st->border_dash, st->border_ndash, col);
+      stroke_styled(c, dev, n, bw, st->border_style == 4 ? 1 : st->border_style, st->border_width_mm, st->border_dash, st->border_ndash, col, NULL);
       if (st->border_style == 4)       /* the pipe's dots, :979-986 */
-         stroke_styled(c, dev, n, bw * 2.5, 4, st->border_width_mm, st->border_dash, st->border_ndash, col);
+         stroke_styled(c, dev, n, bw * 2.5, 4, st->border_width_mm, st->border_dash, st->border_ndash, col, NULL);
    }
    if (st->fill_used)
    {
@@ -1169,7 +1324,7 @@ void orc_draw_way(orc_canvas_t *c, const orc_draw_style_t *st, const double *x_p
       if (!closed)
       {
          /* :1005-1007; the fill's dashes scale with the BORDER width */
-         stroke_styled(c, dev, n, mm2wu(st->fill_width_mm, c->dpi), st->fill_style, st->border_width_mm, st->fill_dash, st->fill_ndash, col);
+         stroke_styled(c, dev, n, mm2wu(st->fill_width_mm, c->dpi), st->fill_style, st->border_width_mm, st->fill_dash, st->fill_ndash, col, NULL);
       }
       else
       {

@@ -44,6 +44,10 @@ int orc_stroke_edges_round(const int32_t *xy_dev, int n, double hw_pt, int dpi, 
  * libcairo's cairo-path-stroke.c dasher.  out == NULL: only counts.  Returns #edges (-1: pen too large). */
 #define ORC_PEN_MAX 256
 int orc_dash_edges(const int32_t *xy_dev, int n, double hw_pt, int dpi, const double *dash_pt, int ndash, int round_cap, tor_edge_t *out);
+int orc_dash_edges_curve(const int32_t *xy_dev, const int32_t *tin, const int32_t *tout, const uint8_t *flag, int m, double hw_pt, int dpi,
+                         const double *dash_pt, int ndash, int round_cap, tor_edge_t *out);
+int orc_curve_flatten_flags(const double *start_pt, const double *curves_pt, int ncurves, int dpi, const int32_t *lim,
+                            int32_t *pts, int32_t *tin, int32_t *tout, uint8_t *flag, int cap);
 /* the pen (_cairo_pen_init, tolerance 0.1): vertex offsets in device 24.8; returns #vertices, -needed if > cap */
 int orc_pen(double hw_pt, int dpi, int32_t *vx, int32_t *vy, int cap);
 /* curve=1 (oracle/curve.c): control points (src/bspline_ctrl.c:64-105), the Bezier chain of a way in pt

@@ -428,13 +428,20 @@ static int draw_ini(smr_smrule_t *r)
    d->st.fill_ndash = parse_dashes(H.get_param("dash", nullptr, r->act), d->st.fill_dash);
    d->st.border_ndash = parse_dashes(H.get_param("bdash", nullptr, r->act), d->st.border_dash);
 
+   /* dash styles along curves are drawn (k_dash walks the decomposed curve as libcairo's dashing stroker does); two combinations are
+    * not, and whether the rule meets an open way, which both need, is not known here: a dashed fill stroke beside a solid border, and a
+    * solid fill stroke whose caps the border's style (pipe, rounddot) has made round (smr_hip_draw would refuse the batch) */
    const char *why = nullptr;
-   if (d->st.curve != 0 && ((d->st.border_used && (d->st.border_style != 0 || d->st.border_ndash)) ||
-                                 (d->st.fill_used && (d->st.fill_style != 0 || d->st.fill_ndash))))
-      why = "dashed or round-capped strokes along curves (curve=1 or wavy=1 with style/bstyle/dash/bdash)";
+   if (d->st.curve != 0 && d->st.fill_used && d->st.border_used && !d->st.ignore_open)
+   {
+      const bool fill_dashed = d->st.fill_style != 0 || d->st.fill_ndash, border_dashed = d->st.border_style != 0 || d->st.border_ndash;
+      if (fill_dashed && !border_dashed) why = "a dashed fill stroke beside a solid border along curves (curve=1 or wavy=1)";
+      else if (!fill_dashed && (d->st.border_style == SMR_STYLE_PIPE || d->st.border_style == SMR_STYLE_ROUNDDOT))
+         why = "solid fill strokes with round caps along curves (curve=1 or wavy=1 with bstyle=pipe|rounddot)";
+   }
    if (why)
    {
-      plog(SMR_LOG_ERR, "draw: %s are not implemented on the GPU path yet; use the built-in draw for this rule", why);
+      plog(SMR_LOG_ERR, "draw: %s: not implemented on the GPU path yet; use the built-in draw for this rule", why);
       delete d;
       return 1;
    }

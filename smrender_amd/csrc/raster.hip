@@ -152,6 +152,8 @@ struct curve_args_t
    const uint32_t *off;                /* emit pass: first point of every slot */
    int2 *fpts, *tin, *tout; int32_t *frefway; int64_t *fway_off;
    uint8_t *fskip;                     /* 1: the point exists for the border stroke only, 2: the fill arrives here by a line_to (see k_curve) */
+   uint8_t *pflag;                     /* dashed strokes (k_dash): 1 = a curve_to ends at the point (or the move_to), 3 = that curve_to was a line_to */
+   int border_dashed, fill_dashed;     /* libcairo's dashing stroker knows no image limits for curves: its decomposition is never a line_to for them */
    uint32_t *status;
    /* ill-conditioned control points (see smr_control_points): recorded by the first count pass (fix_n counts them, fix their
     * slot and inputs), computed on the host with its libm, and looked up by slot (sorted) in the passes that follow */
@@ -243,10 +245,11 @@ __global__ void k_curve(curve_args_t A)
    const uint32_t base = EMIT ? A.off[g] : 0;
    int2 last = make_int2(0, 0);
    bool fill_line = false;
-   auto sink = [&](int2 p, int32_t tdx, int32_t tdy, bool interior)
+   auto sink = [&](int2 p, int32_t tdx, int32_t tdy, bool interior, bool is_line = false)
    {
       if (EMIT)
       {
+         if (A.pflag) A.pflag[base + cnt] = interior ? 0 : is_line ? 3 : 1;
          /* a tangent of zero length would take libcairo's cusp branch (a fan over the pen): the chord stands in */
          if (tdx == 0 && tdy == 0) { tdx = p.x - last.x; tdy = p.y - last.y; }
          const uint32_t q = base + cnt;
@@ -333,7 +336,9 @@ __global__ void k_curve(curve_args_t A)
                if (lx0 <= kk[t].x && kk[t].x <= lx1 && ly0 <= kk[t].y && kk[t].y <= ly1) inside = true;
                x0 = min(x0, kk[t].x); x1 = max(x1, kk[t].x); y0 = min(y0, kk[t].y); y1 = max(y1, kk[t].y);
             }
-            if (!inside && (x1 <= lx0 || x0 >= lx1 || y1 <= ly0 || y0 >= ly1)) line = true;
+            const bool fill_unlimited = !closed && A.fill_dashed;
+            const bool unlimited = A.border_used ? A.border_dashed != 0 : fill_unlimited;
+            if (!unlimited && !inside && (x1 <= lx0 || x0 >= lx1 || y1 <= ly0 || y0 >= ly1)) line = true;
             /* the fill of a bordered way has limits of its own (the image; grown by the fill stroke's reach for open ways):
              * a curve inside the border's reach but outside those is decomposed for the border and a line_to for the fill,
              * which skips its inner points (k_fill_edges, k_stroke_edges mode 1) */
@@ -343,7 +348,7 @@ __global__ void k_curve(curve_args_t A)
                bool in0 = false;
 #pragma unroll
                for (int t = 0; t < 4; t++) if (-r2 <= kk[t].x && kk[t].x <= A.W256 + r2 && iy0 - r2 <= kk[t].y && kk[t].y <= iy1 + r2) in0 = true;
-               fill_line = !in0 && (x1 <= -r2 || x0 >= A.W256 + r2 || y1 <= iy0 - r2 || y0 >= iy1 + r2);
+               fill_line = !fill_unlimited && !in0 && (x1 <= -r2 || x0 >= A.W256 + r2 || y1 <= iy0 - r2 || y0 >= iy1 + r2);
             }
          }
          int2 is = make_int2(0, 0), fs = make_int2(0, 0);
@@ -365,7 +370,7 @@ __global__ void k_curve(curve_args_t A)
             if (K.a.x != K.d.x || K.a.y != K.d.y)
             {
                if (EMIT) A.tout[base - 1] = make_int2(K.d.x - K.a.x, K.d.y - K.a.y);
-               sink(K.d, K.d.x - K.a.x, K.d.y - K.a.y, false);
+               sink(K.d, K.d.x - K.a.x, K.d.y - K.a.y, false, true);
             }
          }
          else
@@ -829,6 +834,8 @@ struct dash_args_t
    uint32_t *piece_cnt;            /* count pass */
    const uint32_t *piece_off;      /* emit pass */
    smr_edge_t *edges;
+   /* a decomposed curve (k_curve): the slopes at the points and where the curve_to's end; NULL for straight ways */
+   const int2 *tin, *tout; const uint8_t *pflag;
 };
 
 struct smr_dasher_t
@@ -872,15 +879,17 @@ struct smr_dasher_t
       }
       return i < 0 ? npen - 1 : i;
    }
-   /* which pen vertices a round cap on a face of direction (dx, dy) takes: start, (exclusive) stop, stepping down */
-   __device__ bool fan_range(int32_t dx, int32_t dy, int &start, int &stop) const
+   /* which pen vertices the stroker passes between the directions (dx, dy) and (ox, oy) on the side of the ccw corners
+    * (_tessellate_fan with _cairo_pen_find_active_ccw_vertices; oracle: d_fan_points): start, (exclusive) stop, stepping down */
+   __device__ bool fan_range2(int32_t dx, int32_t dy, int32_t ox, int32_t oy, int &start, int &stop) const
    {
       const int n = npen;
+      if (n <= 0) return false;
       start = active_ccw(dx, dy);
       { const int2 c = pccw(start); if (smr_slope_cmp(c.x, c.y, dx, dy) < 0) start = start == 0 ? n - 1 : start - 1; }
-      stop = active_ccw(-dx, -dy);
+      stop = active_ccw(ox, oy);
       { const int2 w = pcw(stop);
-        if (smr_slope_cmp(w.x, w.y, -dx, -dy) > 0)
+        if (smr_slope_cmp(w.x, w.y, ox, oy) > 0)
         {
            stop = stop + 1 == n ? 0 : stop + 1;
            const int2 c = pccw(stop);
@@ -890,6 +899,39 @@ struct smr_dasher_t
       stop = stop == 0 ? n - 1 : stop - 1;
       if (npoints < 0) npoints += n;
       return npoints > 1;
+   }
+   /* a round cap on a face of direction (dx, dy): the half turn to (-dx, -dy) */
+   __device__ bool fan_range(int32_t dx, int32_t dy, int &start, int &stop) const { return fan_range2(dx, dy, -dx, -dy, start, stop); }
+   /* a ROUND join (between the segments of a decomposed curve): the fan over the pen's vertices on the outer side, from the pivot;
+    * with no vertex in between it is the bevel's triangle (oracle: d_join_round) */
+   __device__ void join_round(const smr_dface_t &in, const smr_dface_t &o)
+   {
+      if (in.cw.x == o.cw.x && in.cw.y == o.cw.y && in.ccw.x == o.ccw.x && in.ccw.y == o.ccw.y) return;
+      const bool clockwise = smr_slope_cmp(o.cw.x - o.point.x, o.cw.y - o.point.y, in.cw.x - in.point.x, in.cw.y - in.point.y) < 0;
+      int start = 0, stop = 0;
+      bool have;
+      int2 from, to;
+      if (clockwise) { have = fan_range2(in.ddx, in.ddy, o.ddx, o.ddy, start, stop); from = in.ccw; to = o.ccw; }
+      else { have = fan_range2(-o.ddx, -o.ddy, -in.ddx, -in.ddy, start, stop); from = o.cw; to = in.cw; }   /* the reversed path's ccw side */
+      const int n = npen;
+      int m = 3;                                  /* the pivot, from, to */
+      if (have) for (int i = start; i != stop; i = i == 0 ? n - 1 : i - 1) m++;
+      const int2 mid = in.point;
+      auto poly = [&](int j) -> int2
+      {
+         if (j == 0) return mid;
+         if (j == 1) return from;
+         if (j == m - 1) return to;
+         int i = start - (j - 2);
+         if (i < 0) i += n;
+         const int2 v = pen[i];
+         return make_int2(mid.x + v.x, mid.y + v.y);
+      };
+      for (int k = 1; k + 1 < m; k += 2)
+      {
+         int2 q[4] = { mid, poly(k), poly(k + 1), poly(k + 2 < m ? k + 2 : k + 1) };
+         piece(q, k + 2 < m ? 4 : 3);
+      }
    }
    /* half disc ccw -> pen vertices -> cw, cut into a fan of quads from the first point */
    __device__ void round_cap(int2 ccw, int2 cw, int2 mid, int start, int stop)
@@ -1002,10 +1044,10 @@ __global__ void k_dash(dash_args_t A)
       bool has_first = false, has_cur = false;
       smr_dface_t first, cur;
       int2 p1 = A.pts[a];
-      for (int64_t g = a + 1; g < b; g++)
+      /* _cairo_stroker_line_to_dashed; round_join: inside a decomposed curve */
+      auto line_to = [&](const int2 p2, const bool round_join)
       {
-         const int2 p2 = A.pts[g];
-         if (p1.x == p2.x && p1.y == p2.y) continue;
+         if (p1.x == p2.x && p1.y == p2.y) return;
          const int32_t ddx = p2.x - p1.x, ddy = p2.y - p1.y;
          double sdx = ddx / 256.0 * (1.0 / D.s), sdy = ddy / 256.0 * (1.0 / D.s), mag;
          if (sdx == 0.0) { if (sdy > 0.0) { mag = sdy; sdy = 1.0; } else { mag = -sdy; sdy = -1.0; } }
@@ -1034,7 +1076,7 @@ __global__ void k_dash(dash_args_t A)
                   int2 q[4] = { ss.ccw, se.ccw, se.cw, ss.cw };
                   D.piece(q, 4);
                }
-               if (has_cur) { D.join(cur, ss); has_cur = false; }
+               if (has_cur) { if (round_join) D.join_round(cur, ss); else D.join(cur, ss); has_cur = false; }
                else if (!has_first) { first = ss; has_first = true; }                    /* the dash pattern starts "on" */
                else if (lcap) D.round_cap(ss.cw, ss.ccw, ss.point, ls, le);            /* leading cap: the face turned round */
                if (remain) { if (tcap) D.round_cap(se.ccw, se.cw, se.point, ts, te); }
@@ -1068,7 +1110,56 @@ __global__ void k_dash(dash_args_t A)
             has_cur = true;
          }
          p1 = p2;
-      }
+      };
+      /* a face at the current point along a curve's tangent */
+      auto tangent_face = [&](const int2 t) -> smr_dface_t
+      {
+         double sdx = t.x / 256.0 * (1.0 / D.s), sdy = t.y / 256.0 * (1.0 / D.s);
+         if (sdx == 0.0) sdy = sdy > 0.0 ? 1.0 : -1.0;
+         else if (sdy == 0.0) sdx = sdx > 0.0 ? 1.0 : -1.0;
+         else { const double mag = smr_hypot(sdx, sdy); sdx = sdx / mag; sdy = sdy / mag; }
+         return D.face(p1, t.x, t.y, sdx, sdy);
+      };
+      if (!A.pflag)
+         for (int64_t g = a + 1; g < b; g++) line_to(A.pts[g], false);
+      else
+         /* _cairo_stroker_curve_to of libcairo's dashing stroker (oracle: orc_dash_edges_curve): where a curve begins and a dash is
+          * on, a face along its initial tangent, joined to what came before with the context's join; the decomposed points are
+          * dashed line_to's with faces along the chords and ROUND joins; where it ends, a face along the final tangent */
+         for (int64_t i = a + 1; i < b;)
+         {
+            int64_t j = i;
+            while (j < b - 1 && !(A.pflag[j] & 1)) j++;
+            if (A.pflag[j] & 2)
+            {
+               for (int64_t k = i; k <= j; k++) line_to(A.pts[k], false);
+               i = j + 1;
+               continue;
+            }
+            if (dash_on)
+            {
+               const int2 t = A.tout[i - 1];
+               if (t.x != 0 || t.y != 0)
+               {
+                  const smr_dface_t f = tangent_face(t);
+                  if (has_cur) D.join(cur, f);
+                  else if (!has_first) { first = f; has_first = true; }
+                  cur = f; has_cur = true;
+               }
+            }
+            for (int64_t k = i; k <= j; k++) line_to(A.pts[k], true);
+            if (dash_on)
+            {
+               const int2 t = A.tin[j];
+               if (t.x != 0 || t.y != 0)
+               {
+                  const smr_dface_t f = tangent_face(t);
+                  if (has_cur) D.join_round(cur, f);
+                  cur = f; has_cur = true;
+               }
+            }
+            i = j + 1;
+         }
       /* _cairo_stroker_add_caps */
       if (D.round)
       {
@@ -4627,11 +4718,17 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    /* dashed strokes: count the pieces of every way, place them with a scan */
    const bool dash_b = st->border_used && dsb.n > 0, dash_o = open_fill && dso.n > 0;
    int2 *tin = nullptr, *tout = nullptr;
-   uint8_t *fskip = nullptr;
+   uint8_t *fskip = nullptr, *pflag = nullptr;
    if (st->curve != 0)
    {
-      if (dash_b || dash_o)
-         return smr_fail(SMR_E_UNSUPPORTED, "draw: a dashed or round-capped stroke along a curve (curve=1 with style/bstyle/dash/bdash) is not implemented on the GPU path");
+      /* dashed strokes along curves: k_dash walks the decomposition like libcairo's dashing stroker (faces along the chords, round
+       * joins, tangent faces where a curve_to ends).  Not restated: a SOLID stroke of a curve whose caps an earlier stroke of the rule
+       * has made round, and a dashed fill stroke beside a solid border (the two strokers decompose under different limits: the
+       * one decomposition of this pass cannot be both) */
+      if (solid_open || solid_border)
+         return smr_fail(SMR_E_UNSUPPORTED, "draw: a solid stroke with round caps along a curve (curve=1 after style=pipe|rounddot on the rule's other stroke) is not implemented on the GPU path");
+      if (dash_o && st->border_used && !dash_b)
+         return smr_fail(SMR_E_UNSUPPORTED, "draw: a dashed fill stroke beside a solid border along a curve (curve=1 with style/dash and a plain bstyle) is not implemented on the GPU path");
       uint32_t *ccnt, *sums; int2 *fpts; int32_t *frefway; int64_t *fway_off;
       SMR_TRY(c->ensure(SMR_BUF_CURVE_CNT, ((size_t) n_refs + 1) * 4, (void **) &ccnt));
       SMR_TRY(c->ensure(SMR_BUF_SUMS, ((size_t) n_refs / SCAN_B + 2) * 4, (void **) &sums));
@@ -4650,6 +4747,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          CA.reach[i] = (int32_t) nearbyint(r * 256.0);
       }
       CA.cnt = ccnt; CA.off = nullptr; CA.fpts = nullptr; CA.tin = CA.tout = nullptr; CA.frefway = nullptr; CA.fway_off = nullptr; CA.fskip = nullptr;
+      CA.pflag = nullptr; CA.border_dashed = dash_b ? 1 : 0; CA.fill_dashed = dash_o ? 1 : 0;
       CA.status = &small[2];
       uint32_t *fixbuf;
       SMR_TRY(c->ensure(SMR_BUF_CURVEFIX, 16 + (size_t) SMR_CURVEFIX_CAP * sizeof(smr_curvefix_t), (void **) &fixbuf));
@@ -4695,6 +4793,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SMR_TRY(c->ensure(SMR_BUF_FREFWAY, (size_t) total * 4, (void **) &frefway));
       SMR_TRY(c->ensure(SMR_BUF_FWAYOFF, ((size_t) n_ways + 1) * 8, (void **) &fway_off));
       SMR_TRY(c->ensure(SMR_BUF_FSKIP, (size_t) total, (void **) &fskip));
+      if (dash_b || dash_o) SMR_TRY(c->ensure(SMR_BUF_PFLAG, (size_t) total, (void **) &pflag));
+      CA.pflag = pflag;
       CA.cnt = nullptr; CA.off = ccnt; CA.fpts = fpts; CA.tin = tin; CA.tout = tout; CA.frefway = frefway; CA.fway_off = fway_off; CA.fskip = fskip;
       k_curve_finish<<<blocks(n_ways + 1, TB), TB, 0, s>>>(fway_off, way_off, ccnt, wayflags, n_ways, total);
       k_curve<true><<<blocks(n_refs, 64), 64, 0, s>>>(CA);
@@ -4719,7 +4819,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       for (int i = 0; i < 7; i++)
       {
          pen_off[i] = (int) pens.size(); pen_n[i] = 0;
-         const bool need = i < 3 ? (dash_b && cap_b != 0) : i < 6 ? pipe : (dash_o && cap_o != 0);
+         /* (along a curve the round joins between its segments take the pen's vertices whatever the caps) */
+         const bool need = i < 3 ? (dash_b && (cap_b != 0 || pflag)) : i < 6 ? pipe : (dash_o && (cap_o != 0 || pflag));
          if (need) { SMR_TRY(host_pen(pw[i], c->dpi, pens)); pen_n[i] = (int) pens.size() - pen_off[i]; }
       }
       int2 *d_pen;
@@ -4734,6 +4835,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          A.ndash = ds.n; A.cap_mode = cap_mode; A.first_way = cap_mode == 3 ? &small[14] : &small[5]; A.pen = d_pen; A.round_only = 0; A.solid = 0;
          for (int i = 0; i < 3; i++) { A.pen_off[i] = pen_off[dmode == 1 ? 6 : pen0 + i]; A.pen_n[i] = pen_n[dmode == 1 ? 6 : pen0 + i]; }
          A.piece_cnt = nullptr; A.piece_off = nullptr; A.edges = nullptr;
+         A.tin = pflag ? tin : nullptr; A.tout = pflag ? tout : nullptr; A.pflag = pflag;
       };
       /* the group counts need the per-way piece COUNTS: keep them beside the offsets */
       uint32_t *cnt_keep = dbuf + 4 * stride;

@@ -119,7 +119,8 @@ def test_draw_relation_members_and_key_colours(chart):
 
 def test_unsupported_draw_styles_are_refused_loudly(chart):
     sa, proj = chart
-    for params in ("color=red;wavy=1;style=dashed", "bcolor=red;curve=1;bstyle=dashed"):
+    # along curves: a dashed fill stroke beside a solid border; a solid fill stroke whose caps the border's style makes round
+    for params in ("color=red;bcolor=black;wavy=1;style=dashed", "color=red;bcolor=red;curve=1;bstyle=rounddot"):
         assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, []) == 2001      # "Rule will be ignored"
 
 
@@ -162,6 +163,26 @@ def test_dashed_rule_through_the_action_api(chart, params, style):
     assert np.array_equal(plugin_canvas(sa), want)
 
 
+@pytest.mark.parametrize("params,st", [
+    ("bcolor=#203060;bwidth=0.3;curve=1;bstyle=dashed", po.Style(0, 1, 0, 0x203060, 0, 0.3, 0).with_dash(border_style=1)),
+    ("bcolor=#203060;bwidth=0.4;curve=1;bstyle=rounddot;curve_factor=0.35", po.Style(0, 1, 0, 0x203060, 0, 0.4, 0).with_dash(border_style=5)),
+    ("color=#4080c0;width=0.4;bcolor=black;bwidth=0.15;curve=1;bstyle=dotted;style=dashed", po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(border_style=2, fill_style=1)),
+    ("color=#a02040;width=0.4;curve=1;style=pipe;ignore_open=0", po.Style(1, 0, 0xa02040, 0, 0.4, 0, 0).with_dash(fill_style=4))])
+def test_dashed_curve_rules_through_the_action_api(chart, params, st):
+    """dash styles along curve=1 ways (round 3): accepted by act_draw_ini and drawn as the oracle's dashing stroker does along the
+    decomposed curve (pinned on libcairo: tests/test_oracle_cairo.py::test_dashed_curves)"""
+    from test_oracle_cairo import _dash_scene
+    from test_gpu_raster import _ways_to_arrays
+    sa, proj = chart
+    wids, oways = load_ways(sa, proj, _ways_to_arrays(_dash_scene(W, H, 9)))
+    rc = hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, wids)
+    assert rc == 0, sa.lib().smr_hip_last_error()
+    want = po.oracle_scene([(st.with_curve(0.35 if "curve_factor" in params else 0.2), oways)], DPI, W, H, 0xfff8e0)
+    got = plugin_canvas(sa)
+    assert (got != 0xfffff8e0).sum() > 2000
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
 @pytest.mark.parametrize("params,factor", [("color=#4080c0;bcolor=black;bwidth=0.2;curve=1", 0.2),
                                            ("color=#4080c0;bcolor=black;bwidth=0.2;width=0.3;curve=yes;curve_factor=0.35", 0.35)])
 def test_curve_rule_through_the_action_api(chart, params, factor):
@@ -178,7 +199,8 @@ def test_curve_rule_through_the_action_api(chart, params, factor):
 
 
 @pytest.mark.parametrize("params,width_mm,length_mm", [("color=#ff00ff;wavy=yes", 0.0, None),                    # rules/available/seamark_area.osm:38 (magenta)
-                                                     ("color=#ff00ff;width=.2;wavy=yes;wavy_length=1.5", 0.2, 1.5)])   # test/rules/0131.osm
+                                                     ("color=#ff00ff;width=.2;wavy=yes;wavy_length=1.5", 0.2, 1.5),    # test/rules/0131.osm
+                                                     ("color=#ff00ff;width=.3;wavy=yes;wavy_length=1.5;style=dashed;ignore_open=0", 0.3, 1.5)])   # dashes along the waves (round 3)
 def test_wavy_rule_through_the_action_api(chart, params, width_mm, length_mm):
     """wavy=1 / wavy_length= (act_draw_ini :632-642): the plugin resamples the way on the host as cairo_smr_wavy does (:752-840)
     and hands the knots to the GPU as explicit Bezier paths; the expected picture takes the knots from the oracle's own
@@ -217,7 +239,10 @@ def test_wavy_rule_through_the_action_api(chart, params, width_mm, length_mm):
             ox, oy, _, _, _ = po.project(op, ola[:m], olo[:m])
             oways.append((ox, oy, ring_w))
     assert len(oways) >= 4 and oways[-1][2]
-    want = po.oracle_scene([(po.Style(1, 0, 0xff00ff, 0, width_mm, 0, 0).with_knots(), oways)], DPI, W, H, 0xfff8e0)
+    st = po.Style(1, 0, 0xff00ff, 0, width_mm, 0, 0)
+    if "style=dashed" in params:
+        st = st.with_dash(fill_style=1)
+    want = po.oracle_scene([(st.with_knots(), oways)], DPI, W, H, 0xfff8e0)
     got = plugin_canvas(sa)
     assert len(np.unique(got)) > 2
     assert np.array_equal(got, want), int((got != want).sum())

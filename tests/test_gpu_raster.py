@@ -165,7 +165,7 @@ def test_curve_refusals(hip):
     cv = sa.Canvas(64, 64, 300, 0xffffff)
     d = sa.DeviceArray.from_numpy(np.array([5.0, 20, 40, 50]))
     off = sa.DeviceArray.from_numpy(np.array([0, 4], np.int64))
-    gs = sa.DrawStyle(0, 1, 0, 0, 0, 0.2, 0, 0, 1, 0, 0, 0).set_curve()       # bstyle=dashed along a curve
+    gs = sa.DrawStyle(1, 1, 0, 0, 0.3, 0.2, 0, 0, 5, 0, 0, 0).set_curve()     # an open way's solid fill stroke after bstyle=rounddot, along a curve
     with pytest.raises(sa.SmrHipError) as e:
         cv.draw(gs, d, d, off, None, 1, 4)
     assert e.value.code == -5
@@ -527,7 +527,7 @@ def test_dash_styles_the_gpu_path_refuses(hip):
     args = (sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off),
             sa.DeviceArray.from_numpy(ref), 1, len(ref))
     S = po.Style
-    for st in (S(1, 1, 0, 0, 0.3, 0.1, 0).with_curve().with_dash(border_style=S.DASHED),   # dashes along a curve
+    for st in (S(1, 1, 0, 0, 0.3, 0.1, 0).with_curve().with_dash(fill_style=S.DASHED),   # along a curve: a dashed fill stroke beside a solid border
                S(0, 1, 0, 0, 0, 0.1, 0).with_dash(border_style=S.DASHED, border_dash=(0, 0))):   # libcairo: invalid dash
         with pytest.raises(sa.SmrHipError):
             cv.draw(draw_style(sa, st), *args)
@@ -954,3 +954,44 @@ def test_image_fill_bit_exact(hip, alpha, style):
     for y0, h in ((0, 60), (60, 100)):
         band = gpu(y0, h)
         assert np.array_equal(band, want[y0:y0 + h]), (y0, report(band, want[y0:y0 + h]))
+
+
+# ---- dash styles along curves (round 3): libcairo's dashing stroker walks the decomposed curve with faces along the chords, round
+# joins between them and tangent faces where a curve_to ends (oracle: orc_dash_edges_curve, pinned on libcairo in
+# tests/test_oracle_cairo.py::test_dashed_curves); k_dash does the same walk, one lane per way
+DASHED_CURVE_STYLES = {
+    "dashed-border": po.Style(0, 1, 0, 0x203060, 0, 0.3, 0).with_dash(border_style=1),
+    "dotted-border": po.Style(0, 1, 0, 0x203060, 0, 0.4, 0).with_dash(border_style=2),
+    "rounddot-border": po.Style(0, 1, 0, 0x203060, 0, 0.5, 0).with_dash(border_style=5),
+    "pipe-border": po.Style(0, 1, 0, 0x203060, 0, 0.2, 0).with_dash(border_style=4),
+    "dashed-fill-stroke": po.Style(1, 0, 0xa02040, 0, 0.4, 0.2, 0).with_dash(fill_style=1),
+    "wide-dashes": po.Style(0, 1, 0, 0x40203060, 0, 1.0, 0).with_dash(border_style=1, border_dash=(3, 1, 1, 1)),
+    "fill+dashed-border": po.Style(1, 1, 0x4080c0, 0x000000, 0.3, 0.2, 0).with_dash(border_style=1),
+    "both-dashed": po.Style(1, 1, 0x4080c0, 0x000000, 0.4, 0.15, 0).with_dash(border_style=2, fill_style=1),
+}
+
+
+@pytest.mark.parametrize("factor", [0.2, 0.35])
+@pytest.mark.parametrize("name", list(DASHED_CURVE_STYLES))
+def test_dashed_curves_bit_exact(hip, name, factor):
+    W, H = 400, 300
+    st = DASHED_CURVE_STYLES[name].with_curve(factor)
+    closed = synth.synth_ways(14, W, H, seed=41, rmin=12.0, rmax=70.0)
+    rules = [(st, closed), (st, _open_ways(16, W, H, seed=42))]
+    want = oracle_of(rules, 300, W, H, 0xfff8e0)
+    got = gpu_scene(hip, rules, 300, W, H, 0xfff8e0)
+    assert np.array_equal(got, want), report(got, want)
+    assert (want != 0xfffff8e0).sum() > 3000
+    for y0, h in ((0, 120), (120, 180)):
+        band = gpu_scene(hip, rules, 300, W, H, 0xfff8e0, y0, h)
+        assert np.array_equal(band, want[y0:y0 + h]), report(band, want[y0:y0 + h])
+
+
+def test_curve_combinations_still_refused(hip):
+    """a solid fill stroke whose caps the border's style has made round, and a dashed fill stroke beside a solid border, along curves"""
+    sa = hip
+    arrs = _open_ways(4, 200, 150, seed=7)
+    for st in (po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(border_style=5).with_curve(), po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(fill_style=1).with_curve()):
+        with pytest.raises(sa.SmrHipError) as e:
+            gpu_scene(sa, [(st, arrs)], 300, 200, 150, 0xffffff)
+        assert e.value.code == -5

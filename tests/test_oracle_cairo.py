@@ -273,6 +273,37 @@ def test_curves(case):
     assert (d <= 2).mean() >= bar2 and (d == 0).mean() >= bar0, ((d > 2).sum(), (d > 0).sum(), d.max())
 
 
+# dash styles along curves: libcairo's dashing stroker (cairo-path-stroke.c, _cairo_stroker_curve_to) puts its faces along the CHORDS of
+# the decomposed curve, joins them with ROUND joins and adds faces along the tangents where a curve_to begins and ends; the oracle
+# (orc_dash_edges_curve) restates that walk as pieces.  libcairo's polygon has the same outline but its edges run through the pivots
+# of the joins, so long nearly horizontal sides sample a little differently: a few levels on some edge pixels, most of them where a way
+# ends, and more of them under a wide pen -- every case stays inside the north_star bar (>= 99.5 % of the pixels within +-2)
+DASHED_CURVE_CASES = {
+    #                                                                                  scene     within 2   differing / touched
+    "dashed_border_closed": (po.Style(0, 1, 0, 0x203060, 0, 0.3, 0).with_dash(border_style=1), "closed", 0.998, 0.09),
+    "dotted_border_open": (po.Style(0, 1, 0, 0x203060, 0, 0.4, 0).with_dash(border_style=2), "open", 0.999, 0.03),
+    "rounddot_border_open": (po.Style(0, 1, 0, 0x203060, 0, 0.5, 0).with_dash(border_style=5), "open", 0.9999, 0.003),
+    "pipe_border_open": (po.Style(0, 1, 0, 0x203060, 0, 0.2, 0).with_dash(border_style=4), "open", 0.9995, 0.02),
+    "dashed_fill_stroke_open": (po.Style(1, 0, 0xa02040, 0, 0.4, 0.2, 0).with_dash(fill_style=1), "open", 0.999, 0.03),
+    "dashed_1mm_open": (po.Style(0, 1, 0, 0x203060, 0, 1.0, 0).with_dash(border_style=1), "open", 0.996, 0.04),
+    "fill_dashed_border_closed": (po.Style(1, 1, 0x4080c0, 0x000000, 0, 0.2, 0).with_dash(border_style=1), "closed", 0.9975, 0.03),
+}
+
+
+@pytest.mark.parametrize("factor", [0.2, 0.35])
+@pytest.mark.parametrize("case", list(DASHED_CURVE_CASES))
+def test_dashed_curves(case, factor):
+    st, scene, bar2, bar0 = DASHED_CURVE_CASES[case]
+    st = st.with_curve(factor)
+    ways = po.ways_from_arrays(*po.synth_ways(12, 256, 200, seed=5, rmin=10.0, rmax=60.0)) if scene == "closed" else _open_ways(14, 256, 200, 82)
+    a = po.oracle_scene([(st, ways)], 300, 256, 200, 0xffffff)
+    b = po.cairo_scene([(st, ways)], 300, 256, 200, 0xffffff)
+    d = po.chan_diff(a, b)
+    touched = (a != 0xffffffff) | (b != 0xffffffff)
+    assert touched.sum() > 4000
+    assert (d <= 2).mean() >= max(bar2, 0.995) and (d > 0).sum() <= bar0 * touched.sum(), ((d > 2).sum(), (d > 0).sum(), int(touched.sum()), d.max())
+
+
 def test_single_beziers_decompose_like_libcairo():
     """one Bezier at a time, given in exact 24.8 device coordinates and filled straight onto an image: the decomposition
     (points and their number) must reproduce libcairo's coverage bit for bit"""

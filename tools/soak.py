@@ -51,12 +51,18 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
     kind = rng.uniform()
     if kind < 0.3:
         st = st.with_curve(float(rng.choice([0.2, 0.35])))
-    elif kind < 0.5 and DASH:
+    if (0.15 < kind < 0.5) and DASH:
         # dashed / dotted / rounddot / pipe borders and fill strokes of open ways (round caps are sticky: cairo_smr_dash :909-921)
         S = po.Style
         bs = int(rng.choice([S.DASHED, S.DOTTED, S.ROUNDDOT, S.PIPE, 0])) if bu else 0
         fs = int(rng.choice([0, S.DASHED, S.DOTTED, S.ROUNDDOT, S.PIPE])) if fu else 0
         bd = tuple(float(v) for v in rng.uniform(1, 8, 2)) if rng.uniform() < 0.5 else None
+        if st.curve and fu and bu:
+            # along curves: no dashed fill stroke beside a solid border, no solid fill stroke after a round-capped border
+            if fs and not bs:
+                bs = int(S.DASHED)
+            if not fs and bs in (S.PIPE, S.ROUNDDOT):
+                fs = int(S.DOTTED)
         st = st.with_dash(border_style=bs, fill_style=fs, border_dash=bd)
     if rng.uniform() < 0.2:
         st = st.with_evenodd()
