@@ -333,6 +333,9 @@ WAVY_CASES = {
     "hairline": (po.Style(1, 0, 0xff00ff, 0, 0.0, 0, 0), 1.0, 0.9999),             # draw:color=magenta;wavy=yes (the shipped rule)
     "line_02": (po.Style(1, 0, 0xff00ff, 0, 0.2, 0, 0), 0.9995, 0.999),           # test/rules/0131.osm: width=.2
     "bordered": (po.Style(1, 1, 0xff00ff, 0x000000, 0.2, 0.1, 0), 0.999, 0.998),
+    # dashes along the waves (round 3: orc_dash_edges_curve): open ways' fill strokes dashed; a dashed border
+    "dashed_line_03": (po.Style(1, 0, 0xff00ff, 0, 0.3, 0, 0).with_dash(fill_style=1), 0.998, 0.99),
+    "dotted_border": (po.Style(0, 1, 0, 0x204060, 0, 0.3, 0).with_dash(border_style=2), 0.998, 0.99),
 }
 
 
