@@ -153,6 +153,8 @@ struct curve_args_t
    int2 *fpts, *tin, *tout; int32_t *frefway; int64_t *fway_off;
    uint8_t *fskip;                     /* 1: the point exists for the border stroke only, 2: the fill arrives here by a line_to (see k_curve) */
    uint8_t *pflag;                     /* dashed strokes (k_dash): 1 = a curve_to ends at the point (or the move_to), 3 = that curve_to was a line_to */
+   uint8_t *bskip;                     /* a solid border beside a dashed fill stroke (open ways): fskip's marks for the BORDER, whose stroker has image
+                                          limits where the fill stroke's dashing stroker, which the decomposition then follows, has none */
    int border_dashed, fill_dashed;     /* libcairo's dashing stroker knows no image limits for curves: its decomposition is never a line_to for them */
    uint32_t *status;
    /* ill-conditioned control points (see smr_control_points): recorded by the first count pass (fix_n counts them, fix their
@@ -244,12 +246,13 @@ __global__ void k_curve(curve_args_t A)
    uint32_t cnt = 0;
    const uint32_t base = EMIT ? A.off[g] : 0;
    int2 last = make_int2(0, 0);
-   bool fill_line = false;
+   bool fill_line = false, border_line = false;
    auto sink = [&](int2 p, int32_t tdx, int32_t tdy, bool interior, bool is_line = false)
    {
       if (EMIT)
       {
          if (A.pflag) A.pflag[base + cnt] = interior ? 0 : is_line ? 3 : 1;
+         if (A.bskip) A.bskip[base + cnt] = !border_line ? 0 : interior ? 1 : 2;
          /* a tangent of zero length would take libcairo's cusp branch (a fan over the pen): the chord stands in */
          if (tdx == 0 && tdy == 0) { tdx = p.x - last.x; tdy = p.y - last.y; }
          const uint32_t q = base + cnt;
@@ -337,8 +340,13 @@ __global__ void k_curve(curve_args_t A)
                x0 = min(x0, kk[t].x); x1 = max(x1, kk[t].x); y0 = min(y0, kk[t].y); y1 = max(y1, kk[t].y);
             }
             const bool fill_unlimited = !closed && A.fill_dashed;
-            const bool unlimited = A.border_used ? A.border_dashed != 0 : fill_unlimited;
-            if (!unlimited && !inside && (x1 <= lx0 || x0 >= lx1 || y1 <= ly0 || y0 >= ly1)) line = true;
+            /* an open way's dashed fill stroke beside a SOLID border: the decomposition follows the fill stroke's stroker (no limits),
+             * and the border passes over what its own limits would have made a line_to (bskip) */
+            const bool follow_fill = A.border_used && !A.border_dashed && A.fill_used && fill_unlimited;
+            const bool unlimited = A.border_used ? (A.border_dashed != 0 || follow_fill) : fill_unlimited;
+            const bool outside = !inside && (x1 <= lx0 || x0 >= lx1 || y1 <= ly0 || y0 >= ly1);
+            if (!unlimited && outside) line = true;
+            border_line = follow_fill && outside && !line;
             /* the fill of a bordered way has limits of its own (the image; grown by the fill stroke's reach for open ways):
              * a curve inside the border's reach but outside those is decomposed for the border and a line_to for the fill,
              * which skips its inner points (k_fill_edges, k_stroke_edges mode 1) */
@@ -615,7 +623,7 @@ __global__ void k_stroke_edges(const int2 *__restrict__ pts, const int64_t *__re
    bool on = mode == 0 ? (wf & 2) != 0 : (wf & 8) != 0;
    /* TAN, fill stroke of a bordered open way: points that only the border's decomposition has are passed over, and the
     * segment across them is the line_to libcairo's stroker draws there, faces along the chord (k_curve) */
-   const bool sk = TAN && mode == 1 && skip != nullptr;
+   const bool sk = TAN && skip != nullptr;      /* (mode 0: bskip, a solid border beside a dashed fill stroke) */
    if (sk && skip[g] == 1) on = false;
    if (on && g + 1 < b)
    {
@@ -4718,17 +4726,16 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    /* dashed strokes: count the pieces of every way, place them with a scan */
    const bool dash_b = st->border_used && dsb.n > 0, dash_o = open_fill && dso.n > 0;
    int2 *tin = nullptr, *tout = nullptr;
-   uint8_t *fskip = nullptr, *pflag = nullptr;
+   uint8_t *fskip = nullptr, *pflag = nullptr, *bskip = nullptr;
    if (st->curve != 0)
    {
       /* dashed strokes along curves: k_dash walks the decomposition like libcairo's dashing stroker (faces along the chords, round
        * joins, tangent faces where a curve_to ends).  Not restated: a SOLID stroke of a curve whose caps an earlier stroke of the rule
-       * has made round, and a dashed fill stroke beside a solid border (the two strokers decompose under different limits: the
-       * one decomposition of this pass cannot be both) */
+       * has made round.  (A dashed fill stroke beside a solid border: the two strokers decompose under different limits; the pass's
+       * one decomposition follows the dashing stroker and the border skips what its own limits leave out, k_curve's bskip.) */
       if (solid_open || solid_border)
          return smr_fail(SMR_E_UNSUPPORTED, "draw: a solid stroke with round caps along a curve (curve=1 after style=pipe|rounddot on the rule's other stroke) is not implemented on the GPU path");
-      if (dash_o && st->border_used && !dash_b)
-         return smr_fail(SMR_E_UNSUPPORTED, "draw: a dashed fill stroke beside a solid border along a curve (curve=1 with style/dash and a plain bstyle) is not implemented on the GPU path");
+
       uint32_t *ccnt, *sums; int2 *fpts; int32_t *frefway; int64_t *fway_off;
       SMR_TRY(c->ensure(SMR_BUF_CURVE_CNT, ((size_t) n_refs + 1) * 4, (void **) &ccnt));
       SMR_TRY(c->ensure(SMR_BUF_SUMS, ((size_t) n_refs / SCAN_B + 2) * 4, (void **) &sums));
@@ -4747,7 +4754,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          CA.reach[i] = (int32_t) nearbyint(r * 256.0);
       }
       CA.cnt = ccnt; CA.off = nullptr; CA.fpts = nullptr; CA.tin = CA.tout = nullptr; CA.frefway = nullptr; CA.fway_off = nullptr; CA.fskip = nullptr;
-      CA.pflag = nullptr; CA.border_dashed = dash_b ? 1 : 0; CA.fill_dashed = dash_o ? 1 : 0;
+      CA.pflag = nullptr; CA.bskip = nullptr; CA.border_dashed = dash_b ? 1 : 0; CA.fill_dashed = dash_o ? 1 : 0;
       CA.status = &small[2];
       uint32_t *fixbuf;
       SMR_TRY(c->ensure(SMR_BUF_CURVEFIX, 16 + (size_t) SMR_CURVEFIX_CAP * sizeof(smr_curvefix_t), (void **) &fixbuf));
@@ -4795,6 +4802,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SMR_TRY(c->ensure(SMR_BUF_FSKIP, (size_t) total, (void **) &fskip));
       if (dash_b || dash_o) SMR_TRY(c->ensure(SMR_BUF_PFLAG, (size_t) total, (void **) &pflag));
       CA.pflag = pflag;
+      if (dash_o && st->border_used && !dash_b) SMR_TRY(c->ensure(SMR_BUF_BSKIP, (size_t) total, (void **) &bskip));
+      CA.bskip = bskip;
       CA.cnt = nullptr; CA.off = ccnt; CA.fpts = fpts; CA.tin = tin; CA.tout = tout; CA.frefway = frefway; CA.fway_off = fway_off; CA.fskip = fskip;
       k_curve_finish<<<blocks(n_ways + 1, TB), TB, 0, s>>>(fway_off, way_off, ccnt, wayflags, n_ways, total);
       k_curve<true><<<blocks(n_refs, 64), 64, 0, s>>>(CA);
@@ -4913,7 +4922,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          if (stroke_polygon_always())
             k_stroke_risk<<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill, hw_open, hw_closed, hw_fill, st->fill_used, 1);
          k_stroke_edges<true><<<blocks(n_refs, TB), TB, 0, s>>>(pts, way_off, refway, n_refs, wayflags, 0, c->dpi, hw_nofill,
-                                                                hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border, tin, tout, fskip);
+                                                                hw_open, hw_closed, hw_fill, st->fill_used, edges + off_border, tin, tout, bskip);
       }
       else
       {

@@ -119,8 +119,8 @@ def test_draw_relation_members_and_key_colours(chart):
 
 def test_unsupported_draw_styles_are_refused_loudly(chart):
     sa, proj = chart
-    # along curves: a dashed fill stroke beside a solid border; a solid fill stroke whose caps the border's style makes round
-    for params in ("color=red;bcolor=black;wavy=1;style=dashed", "color=red;bcolor=red;curve=1;bstyle=rounddot"):
+    # along curves: a solid stroke whose caps the rule's other stroke makes round
+    for params in ("color=red;bcolor=black;wavy=1;style=pipe", "color=red;bcolor=red;curve=1;bstyle=rounddot"):
         assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, []) == 2001      # "Rule will be ignored"
 
 
@@ -167,7 +167,8 @@ def test_dashed_rule_through_the_action_api(chart, params, style):
     ("bcolor=#203060;bwidth=0.3;curve=1;bstyle=dashed", po.Style(0, 1, 0, 0x203060, 0, 0.3, 0).with_dash(border_style=1)),
     ("bcolor=#203060;bwidth=0.4;curve=1;bstyle=rounddot;curve_factor=0.35", po.Style(0, 1, 0, 0x203060, 0, 0.4, 0).with_dash(border_style=5)),
     ("color=#4080c0;width=0.4;bcolor=black;bwidth=0.15;curve=1;bstyle=dotted;style=dashed", po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(border_style=2, fill_style=1)),
-    ("color=#a02040;width=0.4;curve=1;style=pipe;ignore_open=0", po.Style(1, 0, 0xa02040, 0, 0.4, 0, 0).with_dash(fill_style=4))])
+    ("color=#a02040;width=0.4;curve=1;style=pipe;ignore_open=0", po.Style(1, 0, 0xa02040, 0, 0.4, 0, 0).with_dash(fill_style=4)),
+    ("color=#4080c0;width=0.4;bcolor=black;bwidth=0.15;curve=1;style=dashed", po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(fill_style=1))])
 def test_dashed_curve_rules_through_the_action_api(chart, params, st):
     """dash styles along curve=1 ways (round 3): accepted by act_draw_ini and drawn as the oracle's dashing stroker does along the
     decomposed curve (pinned on libcairo: tests/test_oracle_cairo.py::test_dashed_curves)"""

@@ -527,7 +527,7 @@ def test_dash_styles_the_gpu_path_refuses(hip):
     args = (sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off),
             sa.DeviceArray.from_numpy(ref), 1, len(ref))
     S = po.Style
-    for st in (S(1, 1, 0, 0, 0.3, 0.1, 0).with_curve().with_dash(fill_style=S.DASHED),   # along a curve: a dashed fill stroke beside a solid border
+    for st in (S(1, 1, 0, 0, 0.3, 0.1, 0).with_curve().with_dash(fill_style=S.ROUNDDOT),   # along a curve: a solid border after a round-capped fill stroke
                S(0, 1, 0, 0, 0, 0.1, 0).with_dash(border_style=S.DASHED, border_dash=(0, 0))):   # libcairo: invalid dash
         with pytest.raises(sa.SmrHipError):
             cv.draw(draw_style(sa, st), *args)
@@ -968,6 +968,8 @@ DASHED_CURVE_STYLES = {
     "wide-dashes": po.Style(0, 1, 0, 0x40203060, 0, 1.0, 0).with_dash(border_style=1, border_dash=(3, 1, 1, 1)),
     "fill+dashed-border": po.Style(1, 1, 0x4080c0, 0x000000, 0.3, 0.2, 0).with_dash(border_style=1),
     "both-dashed": po.Style(1, 1, 0x4080c0, 0x000000, 0.4, 0.15, 0).with_dash(border_style=2, fill_style=1),
+    # the solid stroker has image limits for curves, the dashing one has none: one decomposition, the border skips (k_curve's bskip)
+    "solid-border+dashed-fill-stroke": po.Style(1, 1, 0x4080c0, 0x000000, 0.4, 0.15, 0).with_dash(fill_style=1),
 }
 
 
@@ -977,7 +979,10 @@ def test_dashed_curves_bit_exact(hip, name, factor):
     W, H = 400, 300
     st = DASHED_CURVE_STYLES[name].with_curve(factor)
     closed = synth.synth_ways(14, W, H, seed=41, rmin=12.0, rmax=70.0)
-    rules = [(st, closed), (st, _open_ways(16, W, H, seed=42))]
+    # (some open ways with legs far beyond the image: the solid stroker's limits turn curves out there into line_to's)
+    far = [(np.array([30.0, -900.0, -700.0, 120.0, 200.0]), np.array([40.0, 100.0, -800.0, -1200.0, 150.0]), False),
+           (np.array([380.0, 1500.0, 1700.0, 300.0]), np.array([250.0, 300.0, 1600.0, 1400.0]), False)]
+    rules = [(st, closed), (st, _open_ways(16, W, H, seed=42)), (st, _ways_to_arrays(far))]
     want = oracle_of(rules, 300, W, H, 0xfff8e0)
     got = gpu_scene(hip, rules, 300, W, H, 0xfff8e0)
     assert np.array_equal(got, want), report(got, want)
@@ -988,10 +993,10 @@ def test_dashed_curves_bit_exact(hip, name, factor):
 
 
 def test_curve_combinations_still_refused(hip):
-    """a solid fill stroke whose caps the border's style has made round, and a dashed fill stroke beside a solid border, along curves"""
+    """along curves: a solid stroke whose caps the rule's other stroke has made round"""
     sa = hip
     arrs = _open_ways(4, 200, 150, seed=7)
-    for st in (po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(border_style=5).with_curve(), po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(fill_style=1).with_curve()):
+    for st in (po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(border_style=5).with_curve(), po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(fill_style=4).with_curve()):
         with pytest.raises(sa.SmrHipError) as e:
             gpu_scene(sa, [(st, arrs)], 300, 200, 150, 0xffffff)
         assert e.value.code == -5
