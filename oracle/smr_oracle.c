@@ -908,6 +908,27 @@ int orc_stroke_edges_round(const int32_t *xy, int n, double hw_pt, int dpi, tor_
    return D.cnt;
 }
 
+/* the same along a decomposed curve: the tangent stroker's pieces (orc_stroke_edges_tan) and a half disc at either end, the end
+ * faces along the curve's first and last tangent */
+int orc_stroke_edges_round_tan(const int32_t *xy, const int32_t *tin, const int32_t *tout, int m, double hw_pt, int dpi, tor_edge_t *out)
+{
+   if (m < 2) return 0;
+   int cnt = orc_stroke_edges_tan(xy, tin, tout, m, hw_pt, dpi, out);
+   dasher_t D;
+   D.s = (double) dpi / 72; D.hw = hw_pt; D.round_cap = 1; D.out = out; D.cnt = cnt;
+   d_pen_init(&D, hw_pt, dpi, 1);
+   if (D.npen < 0) return -1;
+   face_t f;
+   dface_t first, last;
+   pt_t p0 = { xy[0], xy[1] }, pe = { xy[2 * m - 2], xy[2 * m - 1] };
+   compute_face(p0, tout[0], tout[1], hw_pt, D.s, &f);
+   first.ccw = f.ccw; first.cw = f.cw; first.point = p0; first.ux = f.sx; first.uy = f.sy; first.dev.dx = tout[0]; first.dev.dy = tout[1];
+   compute_face(pe, tin[2 * m - 2], tin[2 * m - 1], hw_pt, D.s, &f);
+   last.ccw = f.ccw; last.cw = f.cw; last.point = pe; last.ux = f.sx; last.uy = f.sy; last.dev.dx = tin[2 * m - 2]; last.dev.dy = tin[2 * m - 1];
+   d_cap_leading(&D, &first); d_cap_trailing(&D, &last);
+   return D.cnt;
+}
+
 /* ---------------- colour + compositing ---------------- */
 
 static uint32_t d2s(double d)   /* _cairo_color_double_to_short as libcairo 1.16 has it (cairo-color.c): round to nearest of d * 65535.
@@ -1240,7 +1261,7 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
          m = orc_curve_flatten(start, curves, nc, c->dpi, lim, pts, pts + 2 * cap, pts + 4 * cap, cap); \
          if (m >= 0) break; \
          cap *= 4; } \
-      e = realloc(e, sizeof(tor_edge_t) * 8 * (m + 1)); } while (0)
+      e = realloc(e, sizeof(tor_edge_t) * (8 * (m + 1) + 4 * ORC_PEN_MAX)); } while (0)
    if (st->border_used)
    {
       double bw;
@@ -1259,11 +1280,11 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
          }
          goto border_done;
       }
-      if (c->cap_round) { orc_curve_unsupported_ = 1; goto all_done; }      /* a solid curve with the rule's caps gone round: not restated */
       FLATTEN(orc_stroke_reach_px(bw, c->dpi));
       const char *om = getenv("ORC_STROKE_OUTLINE");
-      const int tan_outline = om && om[0] == '1';
-      int ne = m < 2 ? 0 : tan_outline ? orc_stroke_outline_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e);
+      /* (the rule's caps gone round, :909-921: always the pieces, with a half disc at either end, as for straight ways) */
+      const int tan_outline = om && om[0] == '1' && !c->cap_round;
+      int ne = m < 2 ? 0 : c->cap_round ? orc_stroke_edges_round_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e) : tan_outline ? orc_stroke_outline_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, bw / 2, c->dpi, e);
       c->no_cuts = !tan_outline;
       if (ne > 0) orc_layer_edges(c, e, ne, 1, has_border_col ? border_col : st->border_col);
       c->no_cuts = 0;
@@ -1280,11 +1301,10 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
          if (m >= 2) stroke_styled(c, pts, m, fw, st->fill_style, st->border_width_mm, st->fill_dash, st->fill_ndash, col, &cf);
          goto all_done;
       }
-      if (!closed && c->cap_round) { orc_curve_unsupported_ = 1; goto all_done; }
       FLATTEN(closed ? 0.0 : orc_stroke_reach_px(fw, c->dpi));
       const char *om = getenv("ORC_STROKE_OUTLINE");
-      const int tan_outline = om && om[0] == '1';
-      int ne = m < 2 ? 0 : closed ? orc_fill_edges(pts, m, e) : tan_outline ? orc_stroke_outline_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e);
+      const int tan_outline = om && om[0] == '1' && !c->cap_round;
+      int ne = m < 2 ? 0 : closed ? orc_fill_edges(pts, m, e) : c->cap_round ? orc_stroke_edges_round_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e) : tan_outline ? orc_stroke_outline_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e);
       c->no_cuts = !closed && !tan_outline;
       if (ne > 0) orc_layer_edges(c, e, ne, closed ? !st->evenodd : 1, col);
       c->no_cuts = 0;

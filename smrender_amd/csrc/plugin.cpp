@@ -428,24 +428,8 @@ static int draw_ini(smr_smrule_t *r)
    d->st.fill_ndash = parse_dashes(H.get_param("dash", nullptr, r->act), d->st.fill_dash);
    d->st.border_ndash = parse_dashes(H.get_param("bdash", nullptr, r->act), d->st.border_dash);
 
-   /* dash styles along curves are drawn (k_dash walks the decomposed curve as libcairo's dashing stroker does); one combination is
-    * not, and whether the rule meets an open way, which it needs, is not known here: a SOLID stroke whose caps the rule's other
-    * stroke (pipe, rounddot) has made round (smr_hip_draw would refuse the batch) */
-   const char *why = nullptr;
-   if (d->st.curve != 0 && d->st.fill_used && d->st.border_used && !d->st.ignore_open)
-   {
-      const bool fill_dashed = d->st.fill_style != 0 || d->st.fill_ndash, border_dashed = d->st.border_style != 0 || d->st.border_ndash;
-      const bool fill_round = d->st.fill_style == SMR_STYLE_PIPE || d->st.fill_style == SMR_STYLE_ROUNDDOT;
-      const bool border_round = d->st.border_style == SMR_STYLE_PIPE || d->st.border_style == SMR_STYLE_ROUNDDOT;
-      if ((!fill_dashed && border_round) || (!border_dashed && fill_round))
-         why = "solid strokes with round caps along curves (curve=1 or wavy=1 with style|bstyle=pipe|rounddot beside a plain stroke)";
-   }
-   if (why)
-   {
-      plog(SMR_LOG_ERR, "draw: %s: not implemented on the GPU path yet; use the built-in draw for this rule", why);
-      delete d;
-      return 1;
-   }
+   /* dash styles along curves are drawn too (k_dash walks the decomposed curve as libcairo's dashing stroker does; a solid stroke whose
+    * caps the rule's other stroke has made round keeps the polygon stroker's tangent pieces): nothing of draw's styles is refused here */
    /* file= (:662-671): the closed ways are filled with the image, too */
    if (H.get_param("file", nullptr, r->act) != nullptr)
    {

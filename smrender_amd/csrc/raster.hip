@@ -826,6 +826,61 @@ __device__ bool smr_stroke_ref_pieces(const int2 *__restrict__ pts, int64_t a, i
    return true;
 }
 
+/* The same for segment g of a decomposed curve, as k_stroke_edges<true> cuts its pieces: faces along the tangents (along the chord
+ * where skip marks a line_to), the points skip passes over left out, the quad's hull.  The faces at the segment's two ends come back
+ * for the caps (oracle: orc_stroke_edges_round_tan). */
+__device__ bool smr_stroke_ref_pieces_tan(const int2 *__restrict__ pts, const int2 *__restrict__ tin, const int2 *__restrict__ tout,
+                                          const uint8_t *__restrict__ skip, int64_t a, int64_t b, int64_t g, double hw, double s, smr_edge_t *loc,
+                                          smr_face_t &start_face, int2 &start_dir, smr_face_t &end_face, int2 &end_dir, int2 &end_pt)
+{
+   const bool sk = skip != nullptr;
+   if ((sk && skip[g] == 1) || g + 1 >= b) return false;
+   int64_t nx = g + 1, pv = g - 1;
+   if (sk) { while (nx + 1 < b && skip[nx] == 1) nx++; while (pv > a && skip[pv] == 1) pv--; }
+   const bool chord_out = sk && skip[nx] == 2, chord_in = sk && skip[g] == 2;
+   const int2 p1 = pts[g], p2 = pts[nx];
+   int32_t ddx = p2.x - p1.x, ddy = p2.y - p1.y;
+   if (!chord_out) { const int2 t = tout[g]; ddx = t.x; ddy = t.y; }
+   const smr_face_t start = smr_face(p1, ddx, ddy, hw, s);
+   int2 c_ccw0 = start.ccw, c_cw0 = start.cw;
+   const int2 te = !chord_out ? tin[nx] : make_int2(ddx, ddy);
+   const smr_face_t endf = smr_face(p2, te.x, te.y, hw, s);
+   int2 c_ccw1 = endf.ccw, c_cw1 = endf.cw;
+   if (g > a)
+   {
+      const int2 t = !chord_in ? tin[g] : make_int2(p1.x - pts[pv].x, p1.y - pts[pv].y);
+      const smr_face_t cur = smr_face(p1, t.x, t.y, hw, s);
+      const smr_join_t j = smr_join(cur, start, p1);
+      const int2 in_inner = j.clockwise ? cur.ccw : cur.cw, out_inner = j.clockwise ? start.ccw : start.cw;
+      const int2 in_outer = j.clockwise ? cur.cw : cur.ccw, out_outer = j.clockwise ? start.cw : start.ccw;
+      if (j.kind == 1)
+      {
+         if (j.clockwise) c_cw0 = j.m; else c_ccw0 = j.m;
+         int2 q[3] = { p1, in_inner, out_inner };
+         smr_emit_poly(q, 3, loc);
+      }
+      else if (j.kind == 2)
+      {
+         int2 q[4] = { p1, in_outer, out_outer, in_inner };
+         smr_emit_poly(q, 4, loc);
+      }
+   }
+   if (nx + 1 < b)
+   {
+      int64_t nn = nx + 1;
+      if (sk) while (nn + 1 < b && skip[nn] == 1) nn++;
+      const int2 t = !(sk && skip[nn] == 2) ? tout[nx] : make_int2(pts[nn].x - p2.x, pts[nn].y - p2.y);
+      const smr_face_t nstart = smr_face(p2, t.x, t.y, hw, s);
+      const smr_join_t j = smr_join(endf, nstart, p2);
+      if (j.kind == 1) { if (j.clockwise) c_cw1 = j.m; else c_ccw1 = j.m; }
+   }
+   int2 q[4] = { c_ccw0, c_ccw1, c_cw1, c_cw0 }, h[4];
+   const int nh = smr_hull4(q, h);
+   smr_emit_poly(h, nh, loc + 4);
+   start_face = start; start_dir = make_int2(ddx, ddy); end_face = endf; end_dir = te; end_pt = p2;
+   return true;
+}
+
 struct dash_args_t
 {
    const int2 *pts; const int64_t *way_off; const uint8_t *wayflags; int64_t n_ways;
@@ -844,6 +899,7 @@ struct dash_args_t
    smr_edge_t *edges;
    /* a decomposed curve (k_curve): the slopes at the points and where the curve_to's end; NULL for straight ways */
    const int2 *tin, *tout; const uint8_t *pflag;
+   const uint8_t *skip;            /* solid: the points of the one decomposition this stroke passes over (k_curve's fskip / bskip) */
 };
 
 struct smr_dasher_t
@@ -1032,6 +1088,16 @@ __global__ void k_dash(dash_args_t A)
             smr_edge_t z; z.x1 = z.y1 = z.x2 = z.y2 = 0;
             for (int i = 0; i < 8; i++) loc[i] = z;
             smr_face_t sf; int32_t ddx, ddy;
+            if (A.tin)
+            {
+               /* along a decomposed curve: the end faces lie along the tangents */
+               smr_face_t ef; int2 sd, ed, ep;
+               if (!smr_stroke_ref_pieces_tan(A.pts, A.tin, A.tout, A.skip, a, b, g, D.hw, D.s, loc, sf, sd, ef, ed, ep)) continue;
+               D.raw4(loc); D.raw4(loc + 4);
+               if (!has_first) { has_first = true; ff = sf; fdx = sd.x; fdy = sd.y; fpt = A.pts[g]; }
+               lf = ef; ldx = ed.x; ldy = ed.y; lpt = ep;
+               continue;
+            }
             if (!smr_stroke_ref_pieces(A.pts, a, b, g, D.hw, D.s, loc, sf, ddx, ddy)) continue;
             D.raw4(loc); D.raw4(loc + 4);
             if (!has_first) { has_first = true; ff = sf; fdx = ddx; fdy = ddy; fpt = A.pts[g]; }
@@ -4730,12 +4796,9 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    if (st->curve != 0)
    {
       /* dashed strokes along curves: k_dash walks the decomposition like libcairo's dashing stroker (faces along the chords, round
-       * joins, tangent faces where a curve_to ends).  Not restated: a SOLID stroke of a curve whose caps an earlier stroke of the rule
-       * has made round.  (A dashed fill stroke beside a solid border: the two strokers decompose under different limits; the pass's
+       * joins, tangent faces where a curve_to ends).  A SOLID stroke of a curve whose caps an earlier stroke of the rule has made round
+       * stays the polygon stroker's: its tangent pieces and a half disc at either end (k_dash's solid branch).  (A dashed fill stroke beside a solid border: the two strokers decompose under different limits; the pass's
        * one decomposition follows the dashing stroker and the border skips what its own limits leave out, k_curve's bskip.) */
-      if (solid_open || solid_border)
-         return smr_fail(SMR_E_UNSUPPORTED, "draw: a solid stroke with round caps along a curve (curve=1 after style=pipe|rounddot on the rule's other stroke) is not implemented on the GPU path");
-
       uint32_t *ccnt, *sums; int2 *fpts; int32_t *frefway; int64_t *fway_off;
       SMR_TRY(c->ensure(SMR_BUF_CURVE_CNT, ((size_t) n_refs + 1) * 4, (void **) &ccnt));
       SMR_TRY(c->ensure(SMR_BUF_SUMS, ((size_t) n_refs / SCAN_B + 2) * 4, (void **) &sums));
@@ -4754,7 +4817,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          CA.reach[i] = (int32_t) nearbyint(r * 256.0);
       }
       CA.cnt = ccnt; CA.off = nullptr; CA.fpts = nullptr; CA.tin = CA.tout = nullptr; CA.frefway = nullptr; CA.fway_off = nullptr; CA.fskip = nullptr;
-      CA.pflag = nullptr; CA.bskip = nullptr; CA.border_dashed = dash_b ? 1 : 0; CA.fill_dashed = dash_o ? 1 : 0;
+      CA.pflag = nullptr; CA.bskip = nullptr; CA.border_dashed = dash_b && !solid_border ? 1 : 0; CA.fill_dashed = dash_o && !solid_open ? 1 : 0;      /* (a solid stroke with round caps is the polygon stroker's) */
       CA.status = &small[2];
       uint32_t *fixbuf;
       SMR_TRY(c->ensure(SMR_BUF_CURVEFIX, 16 + (size_t) SMR_CURVEFIX_CAP * sizeof(smr_curvefix_t), (void **) &fixbuf));
@@ -4802,7 +4865,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SMR_TRY(c->ensure(SMR_BUF_FSKIP, (size_t) total, (void **) &fskip));
       if (dash_b || dash_o) SMR_TRY(c->ensure(SMR_BUF_PFLAG, (size_t) total, (void **) &pflag));
       CA.pflag = pflag;
-      if (dash_o && st->border_used && !dash_b) SMR_TRY(c->ensure(SMR_BUF_BSKIP, (size_t) total, (void **) &bskip));
+      if (dash_o && !solid_open && st->border_used && (!dash_b || solid_border)) SMR_TRY(c->ensure(SMR_BUF_BSKIP, (size_t) total, (void **) &bskip));
       CA.bskip = bskip;
       CA.cnt = nullptr; CA.off = ccnt; CA.fpts = fpts; CA.tin = tin; CA.tout = tout; CA.frefway = frefway; CA.fway_off = fway_off; CA.fskip = fskip;
       k_curve_finish<<<blocks(n_ways + 1, TB), TB, 0, s>>>(fway_off, way_off, ccnt, wayflags, n_ways, total);
@@ -4845,6 +4908,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          for (int i = 0; i < 3; i++) { A.pen_off[i] = pen_off[dmode == 1 ? 6 : pen0 + i]; A.pen_n[i] = pen_n[dmode == 1 ? 6 : pen0 + i]; }
          A.piece_cnt = nullptr; A.piece_off = nullptr; A.edges = nullptr;
          A.tin = pflag ? tin : nullptr; A.tout = pflag ? tout : nullptr; A.pflag = pflag;
+         A.skip = dmode == 0 ? bskip : dmode == 1 ? fskip : nullptr;
       };
       /* the group counts need the per-way piece COUNTS: keep them beside the offsets */
       uint32_t *cnt_keep = dbuf + 4 * stride;

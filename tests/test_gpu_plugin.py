@@ -117,13 +117,6 @@ def test_draw_relation_members_and_key_colours(chart):
     assert np.array_equal(plugin_canvas(sa), want)
 
 
-def test_unsupported_draw_styles_are_refused_loudly(chart):
-    sa, proj = chart
-    # along curves: a solid stroke whose caps the rule's other stroke makes round
-    for params in ("color=red;bcolor=black;wavy=1;style=pipe", "color=red;bcolor=red;curve=1;bstyle=rounddot"):
-        assert hs.apply_rule(sa.lib(), "draw", hs.OSM_WAY, params, []) == 2001      # "Rule will be ignored"
-
-
 @pytest.mark.parametrize("params,style", [
     ("color=#c04020;width=0.5;bcolor=black;bwidth=0.2;style=pipe", dict(fill_style=4)),
     ("color=#c04020;width=0.4;bcolor=#204060;bwidth=0.15;style=rounddot", dict(fill_style=5)),
@@ -168,7 +161,10 @@ def test_dashed_rule_through_the_action_api(chart, params, style):
     ("bcolor=#203060;bwidth=0.4;curve=1;bstyle=rounddot;curve_factor=0.35", po.Style(0, 1, 0, 0x203060, 0, 0.4, 0).with_dash(border_style=5)),
     ("color=#4080c0;width=0.4;bcolor=black;bwidth=0.15;curve=1;bstyle=dotted;style=dashed", po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(border_style=2, fill_style=1)),
     ("color=#a02040;width=0.4;curve=1;style=pipe;ignore_open=0", po.Style(1, 0, 0xa02040, 0, 0.4, 0, 0).with_dash(fill_style=4)),
-    ("color=#4080c0;width=0.4;bcolor=black;bwidth=0.15;curve=1;style=dashed", po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(fill_style=1))])
+    ("color=#4080c0;width=0.4;bcolor=black;bwidth=0.15;curve=1;style=dashed", po.Style(1, 1, 0x4080c0, 0, 0.4, 0.15, 0).with_dash(fill_style=1)),
+    # a solid stroke whose caps the rule's other stroke has made round (the last combination refused until round 3)
+    ("color=#c04020;width=0.5;bcolor=black;bwidth=0.2;curve=1;style=pipe", po.Style(1, 1, 0xc04020, 0, 0.5, 0.2, 0).with_dash(fill_style=4)),
+    ("color=#4080c0;width=0.5;bcolor=black;bwidth=0.15;curve=1;bstyle=rounddot", po.Style(1, 1, 0x4080c0, 0, 0.5, 0.15, 0).with_dash(border_style=5))])
 def test_dashed_curve_rules_through_the_action_api(chart, params, st):
     """dash styles along curve=1 ways (round 3): accepted by act_draw_ini and drawn as the oracle's dashing stroker does along the
     decomposed curve (pinned on libcairo: tests/test_oracle_cairo.py::test_dashed_curves)"""

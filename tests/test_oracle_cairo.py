@@ -304,6 +304,29 @@ def test_dashed_curves(case, factor):
     assert (d <= 2).mean() >= max(bar2, 0.995) and (d > 0).sum() <= bar0 * touched.sum(), ((d > 2).sum(), (d > 0).sum(), int(touched.sum()), d.max())
 
 
+@pytest.mark.parametrize("factor", [0.2, 0.35])
+@pytest.mark.parametrize("case", ["rounddot-border+solid-fill-stroke", "pipe-border+solid-fill-stroke", "solid-border+pipe-fill-stroke",
+                                  "solid-border+rounddot-fill-stroke"])
+def test_sticky_round_caps_along_curves(case, factor):
+    """the same stickiness along curves: a solid stroke whose caps an earlier rounddot / pipe stroke has made round -- the tangent
+    stroker's pieces and a half disc at either end (orc_stroke_edges_round_tan), against the real libcairo"""
+    st = STICKY_CASES[case].with_curve(factor)
+    ways = _open_ways(14, 256, 200, 82)
+    a = po.oracle_scene([(st, ways)], 300, 256, 200, 0xffffff)
+    b = po.cairo_scene([(st, ways)], 300, 256, 200, 0xffffff)
+    d = po.chan_diff(a, b)
+    touched = (a != 0xffffffff) | (b != 0xffffffff)
+    assert touched.sum() > 4000
+    assert (d <= 2).mean() >= 0.995, ((d > 2).sum(), (d > 0).sum(), int(touched.sum()), d.max())
+    import os
+    os.environ["ORC_NO_STICKY_CAPS"] = "1"
+    try:
+        c = po.oracle_scene([(st, ways)], 300, 256, 200, 0xffffff)
+    finally:
+        del os.environ["ORC_NO_STICKY_CAPS"]
+    assert (po.chan_diff(c, b) > 2).sum() > 10 * max(1, (d > 2).sum()), ((po.chan_diff(c, b) > 2).sum(), (d > 2).sum())
+
+
 def test_single_beziers_decompose_like_libcairo():
     """one Bezier at a time, given in exact 24.8 device coordinates and filled straight onto an image: the decomposition
     (points and their number) must reproduce libcairo's coverage bit for bit"""

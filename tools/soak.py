@@ -57,12 +57,6 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 40):
         bs = int(rng.choice([S.DASHED, S.DOTTED, S.ROUNDDOT, S.PIPE, 0])) if bu else 0
         fs = int(rng.choice([0, S.DASHED, S.DOTTED, S.ROUNDDOT, S.PIPE])) if fu else 0
         bd = tuple(float(v) for v in rng.uniform(1, 8, 2)) if rng.uniform() < 0.5 else None
-        if st.curve and fu and bu:
-            # along curves: no solid stroke after a round-capped one
-            if not fs and bs in (S.PIPE, S.ROUNDDOT):
-                fs = int(S.DOTTED)
-            if not bs and bd is None and fs in (S.PIPE, S.ROUNDDOT):
-                bs = int(S.DASHED)
         st = st.with_dash(border_style=bs, fill_style=fs, border_dash=bd)
     if rng.uniform() < 0.2:
         st = st.with_evenodd()
