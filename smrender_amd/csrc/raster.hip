@@ -3373,9 +3373,16 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
  * every lane its column's word of each entry, four entries in flight, and blends the four rows into the layer in registers:
  * the statements of k_raster's own branch for such an entry, so the pixels are the same.  Twice k_raster's wavefronts per SIMD. */
 #define SMR_BLEND_WAVES 4
+#ifndef SMR_BLEND_BATCH
+#define SMR_BLEND_BATCH 16      /* entries whose words a wavefront holds in LDS at a time (at most 32: one mask word per lane; 16: 4 KB per wavefront, ten wavefronts per SIMD -- with 32 the kernel was as slow as without the rounds, with 8 slower than with 16) */
+#endif
+#ifndef SMR_BLEND_FLIGHT
+#define SMR_BLEND_FLIGHT 4      /* loads in flight */
+#endif
 __global__ __launch_bounds__(64 * SMR_BLEND_WAVES) void k_blend(raster_args_t A)
 {
-   const int lane = threadIdx.x & 63;
+   __shared__ uint32_t qa[SMR_BLEND_WAVES][SMR_BLEND_BATCH][64];     /* per wavefront: the words of 32 entries, column by column */
+   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const uint32_t xcd = blockIdx.x & 7u;                /* k_raster's tile order: an XCD walks its tile columns top to bottom */
    const uint32_t TYt = A.n_tiles / A.TX;
    const uint32_t ncol = ((uint32_t) A.TX + 7u - xcd) >> 3;
@@ -3447,40 +3454,67 @@ __global__ __launch_bounds__(64 * SMR_BLEND_WAVES) void k_blend(raster_args_t A)
                hb0 = hp[0]; hinfo = hp[1].w;
             }
             const int n = (int) min(64u, end - bbase);
-            for (int j0 = 0; j0 < n; j0 += 4)
+            /* 32 entries at a time.  A lane's column is empty in most entries of a tile (a border's strip is two short runs with
+             * nothing between them, a fill ends somewhere), and a blend costs the whole wavefront ~25 instructions per row whoever
+             * needs it: so every lane first notes WHICH of the 32 entries have a word for it (the words go to LDS), then the
+             * wavefront blends in rounds, every lane its own next entry -- as many rounds as the busiest column has entries,
+             * each lane's entries in the tile's order, so every pixel sees the blends it saw before */
+            for (int jb = 0; jb < n; jb += SMR_BLEND_BATCH)
             {
-               uint32_t a4[4], prim[4], color[4], first[4];
-#pragma unroll
-               for (int u = 0; u < 4; u++)
+               const int nb = min(SMR_BLEND_BATCH, n - jb);
+               uint32_t nz = 0, firstmask = 0;
+               for (int j0 = 0; j0 < nb; j0 += SMR_BLEND_FLIGHT)
                {
-                  a4[u] = 0; prim[u] = 0xffffffffu; color[u] = 0; first[u] = 0;
-                  if (j0 + u < n)
+                  uint32_t a4[SMR_BLEND_FLIGHT];
+                  bool take[SMR_BLEND_FLIGHT];
+#pragma unroll
+                  for (int u = 0; u < SMR_BLEND_FLIGHT; u++)
                   {
-                     const uint32_t eo = __builtin_amdgcn_readlane(hb0.x, j0 + u), info = __builtin_amdgcn_readlane(hinfo, j0 + u);
-                     prim[u] = __builtin_amdgcn_readlane(hb0.y, j0 + u); color[u] = __builtin_amdgcn_readlane(hb0.w, j0 + u);
-                     first[u] = (__builtin_amdgcn_readlane(hb0.z, j0 + u) >> 16) & 1u;
-                     const uint32_t i = (uint32_t) (px - smr_strip_x0(info));
-                     if (i < smr_strip_n(info)) a4[u] = A.alpha[(size_t) eo + i];
+                     a4[u] = 0; take[u] = false;
+                     if (j0 + u < nb)
+                     {
+                        const int jj = jb + j0 + u;
+                        const uint32_t prim = __builtin_amdgcn_readlane(hb0.y, jj);
+                        if (prim == cur) continue;                       /* (further entries of a primitive bring nothing) */
+                        cur = prim; take[u] = true;
+                        const uint32_t eo = __builtin_amdgcn_readlane(hb0.x, jj), info = __builtin_amdgcn_readlane(hinfo, jj);
+                        firstmask |= ((__builtin_amdgcn_readlane(hb0.z, jj) >> 16) & 1u) << (j0 + u);
+                        const uint32_t i = (uint32_t) (px - smr_strip_x0(info));
+                        if (i < smr_strip_n(info)) a4[u] = A.alpha[(size_t) eo + i];
+                     }
                   }
-               }
 #pragma unroll
-               for (int u = 0; u < 4; u++)
+                  for (int u = 0; u < SMR_BLEND_FLIGHT; u++)
+                     if (take[u])
+                     {
+                        qa[wv][j0 + u][lane] = a4[u];
+                        nz |= (a4[u] != 0 ? 1u : 0u) << (j0 + u);
+                     }
+               }
+               while (__ballot(nz != 0))
                {
-                  if (j0 + u >= n || prim[u] == cur) continue;      /* (further entries of a primitive bring nothing) */
-                  cur = prim[u];
-                  if (!__ballot(a4[u] != 0)) continue;
-                  const uint32_t spix = color[u];
-                  const bool lerp = (spix >> 24) == 255u || (first[u] && !A.direct);
+                  const bool have = nz != 0;
+                  const int jq = have ? __ffs((int) nz) - 1 : 0;
+                  nz &= nz - 1u;
+                  const uint32_t aw = have ? qa[wv][jq][lane] : 0u;
+                  const uint32_t spix = (uint32_t) __builtin_amdgcn_ds_bpermute((jb + jq) << 2, (int) hb0.w);
+                  const bool le = (spix >> 24) == 255u || (((firstmask >> jq) & 1u) != 0u && !A.direct);
                   /* k_raster's statements for such an entry, the blends without their per-lane shortcuts (the arithmetic gives
                    * the same for a = 0 and a = 255: smr_blend_lerp_all) */
 #define SMR_BLEND_ROW(L, R) do { \
-                     const uint32_t a = (a4[u] >> (8 * (R))) & 255u; \
+                     const uint32_t a = (aw >> (8 * (R))) & 255u; \
                      if (__ballot(a != 0)) \
                      { \
                         if (A.pat) L = smr_blend_over_mask_all(smr_pat_pix(A.pat, A.pat_w, A.pat_h, px, A.band_y0 + ty * SMR_TH + (R)), a, L); \
-                        else if (!lerp) L = smr_blend_over_mask_all(spix, a, L); \
-                        else if (!__ballot(a != 255u && a != 0)) L = a ? spix : L;      /* no edge pixel on the row */ \
-                        else L = smr_blend_lerp_all(spix, a, L); \
+                        else \
+                        { \
+                           if (__ballot(a != 0 && !le)) { const uint32_t t = smr_blend_over_mask_all(spix, a, L); L = le ? L : t; } \
+                           if (__ballot(a != 0 && le)) \
+                           { \
+                              if (!__ballot(le && a != 255u && a != 0)) L = le && a ? spix : L;      /* no edge pixel on the row */ \
+                              else { const uint32_t t = smr_blend_lerp_all(spix, a, L); L = le ? t : L; } \
+                           } \
+                        } \
                      } } while (0)
                   SMR_BLEND_ROW(l0, 0); SMR_BLEND_ROW(l1, 1); SMR_BLEND_ROW(l2, 2); SMR_BLEND_ROW(l3, 3);
 #undef SMR_BLEND_ROW
