@@ -3381,7 +3381,7 @@ __global__ __launch_bounds__(64 * SMR_RASTER_WAVES) void k_raster(raster_args_t 
 #endif
 __global__ __launch_bounds__(64 * SMR_BLEND_WAVES) void k_blend(raster_args_t A)
 {
-   __shared__ uint32_t qa[SMR_BLEND_WAVES][SMR_BLEND_BATCH][64];     /* per wavefront: the words of 32 entries, column by column */
+   __shared__ uint32_t qa[SMR_BLEND_WAVES][SMR_BLEND_BATCH][64];     /* per wavefront: the words of a batch of entries, column by column */
    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
    const uint32_t xcd = blockIdx.x & 7u;                /* k_raster's tile order: an XCD walks its tile columns top to bottom */
    const uint32_t TYt = A.n_tiles / A.TX;
@@ -3454,9 +3454,13 @@ __global__ __launch_bounds__(64 * SMR_BLEND_WAVES) void k_blend(raster_args_t A)
                hb0 = hp[0]; hinfo = hp[1].w;
             }
             const int n = (int) min(64u, end - bbase);
-            /* 32 entries at a time.  A lane's column is empty in most entries of a tile (a border's strip is two short runs with
+            /* the headers are here before the first word is asked for: the loop below reads them with v_readlane on several paths, and
+             * a wait for "the headers, wherever they are still on their way" placed behind a word's load is a wait for that word too
+             * (one counter, in order): the words came one after the other */
+            __builtin_amdgcn_s_waitcnt(0x0f70);         /* vmcnt(0) */
+            /* SMR_BLEND_BATCH entries at a time.  A lane's column is empty in most entries of a tile (a border's strip is two short runs with
              * nothing between them, a fill ends somewhere), and a blend costs the whole wavefront ~25 instructions per row whoever
-             * needs it: so every lane first notes WHICH of the 32 entries have a word for it (the words go to LDS), then the
+             * needs it: so every lane first notes WHICH of the batch's entries have a word for it (the words go to LDS), then the
              * wavefront blends in rounds, every lane its own next entry -- as many rounds as the busiest column has entries,
              * each lane's entries in the tile's order, so every pixel sees the blends it saw before */
             for (int jb = 0; jb < n; jb += SMR_BLEND_BATCH)
