@@ -991,3 +991,38 @@ def test_dashed_curves_bit_exact(hip, name, factor):
     for y0, h in ((0, 120), (120, 180)):
         band = gpu_scene(hip, rules, 300, W, H, 0xfff8e0, y0, h)
         assert np.array_equal(band, want[y0:y0 + h]), report(band, want[y0:y0 + h])
+
+
+@pytest.mark.gpu
+def test_deep_overdraw_with_opaque_and_translucent_colours_per_way(hip):
+    """k_blend's rounds (every lane blends its own next entry): hundreds of large polygons over one another on a small canvas, so
+    that a tile holds far more than 64 entries (several header batches, several 16-entry batches of words), with a colour per way,
+    opaque and translucent ones interleaved: lanes of one round meet pixman's lerp and its OVER side by side"""
+    sa = hip
+    W, H = 320, 96
+    rng = np.random.default_rng(17)
+    n_ways = 360
+    x, y, off, ref = synth.synth_ways(n_ways, W, H, seed=23, rmin=20.0, rmax=110.0)
+    fill_col = rng.integers(0, 1 << 24, n_ways).astype(np.uint32)
+    border_col = rng.integers(0, 1 << 24, n_ways).astype(np.uint32)
+    tr = rng.uniform(size=n_ways) < 0.5
+    fill_col[tr] |= (rng.integers(0x10, 0x70, int(tr.sum())).astype(np.uint32) << 24)
+    tb = rng.uniform(size=n_ways) < 0.3
+    border_col[tb] |= (rng.integers(0x10, 0x70, int(tb.sum())).astype(np.uint32) << 24)
+    st = po.Style(1, 1, 0, 0, 0, 0.15, 0)
+    ways = [(wx, wy, c, int(fill_col[k]), int(border_col[k])) for k, (wx, wy, c) in enumerate(po.ways_from_arrays(x, y, off, ref))]
+    want = po.oracle_scene([(st, ways)], 300, W, H, 0xfff8e0)
+    cv = sa.Canvas(W, H, 300, 0xfff8e0)
+    gs = draw_style(sa, st)
+    sa.set_profiling(True)
+    try:
+        cv.draw(gs, sa.DeviceArray.from_numpy(x), sa.DeviceArray.from_numpy(y), sa.DeviceArray.from_numpy(off.astype(np.int64)),
+                sa.DeviceArray.from_numpy(ref.astype(np.int32)), len(off) - 1, len(ref),
+                sa.DeviceArray.from_numpy(fill_col), sa.DeviceArray.from_numpy(border_col))
+        t = sa.timings()
+    finally:
+        sa.set_profiling(False)
+    got = cv.read()
+    cv.close()
+    assert np.array_equal(got, want), report(got, want)
+    assert t["n_tile_refs"] > 100 * t["n_tiles"] or t["n_tile_refs"] > 20000
