@@ -1001,6 +1001,7 @@ struct orc_canvas
    int img[4];           /* the image's rectangle on the chart, px (curve limits) */
    int cap_round;        /* line cap of the current rule's context (cairo_set_line_cap is never undone) */
    int32_t shift_x, shift_y;   /* 24.8: the translation of a replay at an offset (cairo_smr_cut_out), added to every device vertex */
+   int win_lim_on; int32_t win_lim[2];      /* a replay at an offset (orc_canvas_set_shift): the sides of the image libcairo replays into, 24.8 */
    int no_cuts;          /* the edges of the next orc_layer_edges are a stroke's PIECES: their inner edges are not the polygon's, no cuts at the image's sides */
    const uint32_t *pat; int pat_w, pat_h;   /* orc_canvas_set_pattern: the source of orc_layer_edges is this image, repeated from the chart's origin */
 };
@@ -1026,6 +1027,20 @@ void orc_canvas_set_shift(orc_canvas_t *c, double tx_pt, double ty_pt)
 {
    double s = (double) c->dpi / 72;
    c->shift_x = orc_fixed_from_double(tx_pt * s); c->shift_y = orc_fixed_from_double(ty_pt * s);
+   /* What the replay is limited to.  libcairo does not replay the recording onto the cut-out's image: the image compositor makes the
+    * source's pixels first (_pixman_image_for_recording of cairo-image-source.c), in an image of its own that covers the SAMPLED area
+    * of the source, and that area is whole units of the SOURCE, i.e. whole pt (_cairo_pattern_sampled_area: the centres of the corner
+    * pixels through the pattern's matrix, 0.495 of a source unit further out for a bilinear filter, floor and ceil), taken back to
+    * device pixels with floor and ceil again.  A polygon that leaves that image is limited to it (cairo-spans-compositor.c), and the
+    * cuts at its left and right side add vertices, which decide the rows the scan converter sub-samples: at 300 dpi the sides lie 2 to
+    * 6 px beyond the cut-out's own, wherever the anchor's fraction of a pt puts them.  (Top and bottom change no row inside the
+    * cut-out.  Near the page's sides the sampled area is the recording's extents at most: left out.) */
+   {
+      const double X = -tx_pt;                                      /* the source coordinate of the cut-out's left side */
+      const double sx1 = floor(0.5 / s + X - 0.495), sx2 = floor(((double) c->W - 0.5) / s + X + 0.495) + 1.0;
+      c->win_lim_on = 1;
+      c->win_lim[0] = (int32_t) floor((sx1 - X) * s) * 256; c->win_lim[1] = (int32_t) ceil((sx2 - X) * s) * 256;
+   }
    orc_curve_set_shift(c->shift_x, c->shift_y);      /* curve.c keeps it for orc_curve_flatten (one shifted canvas at a time) */
 }
 
@@ -1092,7 +1107,9 @@ void orc_layer_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, u
        * replay's 24.8 scale -- at 300 dpi a little MORE than the page, at 600 dpi a little less */
       const int32_t sc = orc_fixed_from_double((double) c->dpi / 72);
       const int32_t xl = fixed_mul((int32_t) floor((double) c->img[0] * 72 / c->dpi) * 256, sc), xr = fixed_mul((int32_t) ceil((double) c->img[2] * 72 / c->dpi) * 256, sc);
-      /* (a replay at an offset, cairo_smr_cut_out: the page's sides are somewhere else, rarely inside the cut-out; left out) */
+      /* (a replay at an offset, cairo_smr_cut_out: limited to the image libcairo makes of the source there, orc_canvas_set_shift) */
+      if (c->win_lim_on && !c->no_cuts && getenv("ORC_NO_LIMITS") == NULL) tor_set_limits(1, c->win_lim[0], c->win_lim[1]);
+      else
       tor_set_limits(getenv("ORC_NO_LIMITS") == NULL && !c->no_cuts && !c->shift_x && !c->shift_y, xl, xr);
    }
    tor_coverage(e, n, nonzero, c->x0 + bx0, c->y0 + by0, bw, bh, c->cov);

@@ -1340,6 +1340,7 @@ struct setup_args_t
    int cv_split;                                       /* k_cover will take a primitive's strips in parts: their strip-table entries are handed out here (small[15]) */
    const int2 *way_clip;                               /* [n_ways] rows [x, y) a way's primitives may touch: its window of an atlas (smr_hip_draw_windows); NULL: the chart */
    int32_t lim_l, lim_r; int lim_on;                   /* the replay's clip box, left and right side, 24.8 (smr_setup_cuts) */
+   const int2 *way_lim;                                /* [n_ways] the same per way (a window of an atlas: the image libcairo makes of the source there); NULL: lim_l, lim_r */
    int evenodd;                                        /* fill polygons take libcairo's EVEN_ODD rule (smr_draw_style_t.evenodd) */
    /* solid strokes with round caps (the rule's caps are sticky, src/smrules_cairo.c:909-921) come as piece lists of the dasher with
     * one endless dash: they stay OUR pieces (no cuts at the page's sides).  mix_border: only the ways after small[14] (the first
@@ -1788,6 +1789,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    const bool pieces = sparse && !(role == 0 ? (wf & 16) != 0 && !pob : role == 2 ? (wf & 32) != 0 && !A.po_open : false);
    /* libcairo limits a polygon to the image it renders into; for a window of an atlas that image is the window's rows */
    const int clip0 = A.way_clip ? A.way_clip[w].x : 0, clip1 = A.way_clip ? A.way_clip[w].y : A.H;
+   const int32_t lim_l = A.way_lim ? A.way_lim[w].x : A.lim_l, lim_r = A.way_lim ? A.way_lim[w].y : A.lim_r;
    smr_prim_t P;
    P.edge_off = 0; P.edge_cnt = 0; P.color = 0; P.minx = P.miny = INT32_MAX; P.maxx = P.maxy = INT32_MIN;
    P.flags = 0; P.mask_off = 0; P.row0 = 0; P.nrows = 0; P.drow_off = 0; P.pad_[0] = P.pad_[1] = P.pad_[2] = 0;
@@ -1827,7 +1829,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          a.minx = a.miny = INT32_MAX; a.maxx = a.maxy = a.bin_maxx = INT32_MIN;
          a.item_flags = item_flags; a.prim_id = A.compound != 0xffffffffu ? A.compound : (uint32_t) p; a.valid = 0;
          a.clip0 = clip0; a.clip1 = clip1; a.sparse = sparse;
-         a.lim_l = A.lim_l; a.lim_r = A.lim_r;
+         a.lim_l = lim_l; a.lim_r = lim_r;
          a.lim_on = A.lim_on && (!pieces || (role == 0 ? pob != nullptr && !A.solid_border : role == 1 ? A.po_dots != nullptr : (wf & 8) && A.po_open != nullptr && !A.solid_open));
          A.bigacc[b] = a;
          A.prims[p] = P;                 /* edge range and colour; not valid before k_big_finish */
@@ -1906,10 +1908,10 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    /* cuts at the page's sides: for edges that are libcairo's own -- fills, strokes as polygons, and the pieces of a DASHED stroke
     * (its other stroker adds every dash, join and cap as a polygon of its own); not the pieces of a solid stroke */
    const bool dashed = role == 0 ? pob != nullptr && !A.solid_border : role == 1 ? A.po_dots != nullptr : (wf & 8) && A.po_open != nullptr && !A.solid_open;
-   const bool cuts = A.lim_on && (!pieces || dashed) && (P.minx < A.lim_l || P.maxx > A.lim_r);
+   const bool cuts = A.lim_on && (!pieces || dashed) && (P.minx < lim_l || P.maxx > lim_r);
    if (nitems == 1)
    {
-      if ((uint32_t) lane < P.edge_cnt) { smr_setup_edge(smr_orient(e0), P.row0, P.nrows, lmask, L); if (cuts) smr_setup_cuts(e0, A.lim_l, A.lim_r, P.row0, P.nrows, lmask); }
+      if ((uint32_t) lane < P.edge_cnt) { smr_setup_edge(smr_orient(e0), P.row0, P.nrows, lmask, L); if (cuts) smr_setup_cuts(e0, lim_l, lim_r, P.row0, P.nrows, lmask); }
    }
    else
    {
@@ -1917,7 +1919,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
       {
          const smr_edge_t e = E[idx];
          smr_setup_edge(smr_orient(e), P.row0, P.nrows, lmask, L);
-         if (cuts) smr_setup_cuts(e, A.lim_l, A.lim_r, P.row0, P.nrows, lmask);
+         if (cuts) smr_setup_cuts(e, lim_l, lim_r, P.row0, P.nrows, lmask);
       }
    }
    SMR_WAVE_SYNC();
@@ -4343,6 +4345,7 @@ extern "C" int smr_hip_canvas_destroy(smr_canvas_t *c)
    if (c->d_win_shift) hipFree(c->d_win_shift);
    if (c->d_win_box) hipFree(c->d_win_box);
    if (c->d_win_clip) hipFree(c->d_win_clip);
+   if (c->d_win_lim) hipFree(c->d_win_lim);
    if (c->d_grid_off) hipFree(c->d_grid_off);
    if (c->d_grid_win) hipFree(c->d_grid_win);
    if (c->halo_above) hipFree(c->halo_above);
@@ -5088,11 +5091,13 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       {
          /* the recording surface's rectangle is the page in WHOLE pt (cairo_recording_surface_create floors / ceils the doubles of
           * cairo_smr_init_main_image, src/smrules_cairo.c:308-330); the replay's 24.8 scale takes it to device units.  A window of
-          * an atlas is a replay at an offset: the page's sides are rarely inside it, and are left out there */
+          * an atlas is a replay at an offset: its ways come with the sides of the image libcairo makes of the source there
+          * (way_lim, windows_setup); the page's own sides are rarely inside it, and are left out there */
          const int32_t sc = (int32_t) nearbyint((double) c->dpi / 72 * 256.0);
          const int chart_w = c->win_n ? c->chart_w : c->W;
          SA.lim_l = 0; SA.lim_r = (int32_t) (((int64_t) ((int32_t) ceil((double) chart_w * 72 / c->dpi) * 256) * sc) >> 8);
-         SA.lim_on = wc == nullptr && !limits_off();
+         SA.way_lim = wc ? wc->way_lim : nullptr;
+         SA.lim_on = (wc == nullptr || wc->way_lim != nullptr) && !limits_off();
       }
       SA.K = K; SA.off_dots = off_dots; SA.po_border = po_border; SA.po_dots = po_dots; SA.po_open = po_open; SA.id_off = id_off;
       SA.solid_border = solid_border; SA.solid_open = solid_open; SA.mix_border = solid_border; SA.off_border_po = off_border + off_border_po;

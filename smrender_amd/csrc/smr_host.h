@@ -40,7 +40,7 @@ enum { SMR_BUF_PTS, SMR_BUF_WAYFLAGS, SMR_BUF_SMALL, SMR_BUF_PRIMS, SMR_BUF_EDGE
        SMR_BUF_TILEOFF, SMR_BUF_SUMS, SMR_BUF_ENTRIES, SMR_BUF_CAP0, SMR_BUF_CAP1, SMR_BUF_REFWAY, SMR_BUF_ITEMS, SMR_BUF_MASK, SMR_BUF_HDRS, SMR_BUF_COVERED, SMR_BUF_DASH, SMR_BUF_PEN,
        SMR_BUF_CURVE_CNT, SMR_BUF_FPTS, SMR_BUF_FTIN, SMR_BUF_FTOUT, SMR_BUF_FREFWAY, SMR_BUF_FWAYOFF, SMR_BUF_FSKIP, SMR_BUF_BIGLIST, SMR_BUF_BIGACC, SMR_BUF_CURVEFIX, SMR_BUF_SNAPSHOT, SMR_BUF_OVFLIST, SMR_BUF_BIGBUCKET, SMR_BUF_DELTAS, SMR_BUF_DROWS, SMR_BUF_TILECNT, SMR_BUF_BLIT,
        SMR_BUF_WIN_WB, SMR_BUF_WIN_BOX, SMR_BUF_WIN_CNT, SMR_BUF_WIN_SUMS, SMR_BUF_WIN_TOT, SMR_BUF_WIN_IWAY, SMR_BUF_WIN_IWIN, SMR_BUF_WIN_IOFF, SMR_BUF_WIN_X, SMR_BUF_WIN_Y,
-       SMR_BUF_WIN_REF, SMR_BUF_WIN_NODEWIN, SMR_BUF_WIN_WAYOFF, SMR_BUF_WIN_CLIP, SMR_BUF_WIN_FCOL, SMR_BUF_WIN_BCOL, SMR_BUF_WIN_KEYS, SMR_BUF_WIN_KEYS2, SMR_BUF_WIN_TMP, SMR_BUF_PATTERN, SMR_BUF_PURELIST, SMR_BUF_PFLAG, SMR_BUF_BSKIP, SMR_BUF_MAX };
+       SMR_BUF_WIN_REF, SMR_BUF_WIN_NODEWIN, SMR_BUF_WIN_WAYOFF, SMR_BUF_WIN_CLIP, SMR_BUF_WIN_LIM, SMR_BUF_WIN_FCOL, SMR_BUF_WIN_BCOL, SMR_BUF_WIN_KEYS, SMR_BUF_WIN_KEYS2, SMR_BUF_WIN_TMP, SMR_BUF_PATTERN, SMR_BUF_PURELIST, SMR_BUF_PFLAG, SMR_BUF_BSKIP, SMR_BUF_MAX };
 
 struct smr_devbuf_t { void *p = nullptr; size_t cap = 0; };
 
@@ -54,7 +54,7 @@ struct smr_canvas
    /* an atlas of caption cut-outs (windows.hip): win_n windows of win_size px, one every win_pitch rows; per window the 24.8 shift of
     * its replay (atlas placement included) and its box on the chart in px */
    int win_n = 0, win_size = 0, win_pitch = 0, chart_w = 0, chart_h = 0;
-   int2 *d_win_shift = nullptr, *d_win_clip = nullptr; void *d_win_box = nullptr;
+   int2 *d_win_shift = nullptr, *d_win_clip = nullptr, *d_win_lim = nullptr; void *d_win_box = nullptr;
    int win_cap = 0;                         /* windows the atlas has rows and tables for (smr_hip_windows_reset) */
    /* a uniform grid over the chart (cells of grid_cell px from (-grid_cell, -grid_cell) on): per cell the windows whose box meets it */
    uint32_t *d_grid_off = nullptr, *d_grid_win = nullptr; int grid_nx = 0, grid_ny = 0, grid_cell = 0; size_t grid_win_cap = 0;
@@ -84,7 +84,7 @@ struct smr_canvas
 
 /* a batch whose ways are instances for the windows of an atlas (smr_hip_draw_windows): per node its window, per window the 24.8
  * shift of its replay, per way the atlas rows of its window */
-struct smr_win_ctx_t { const int32_t *node_win; const int2 *win_shift; const int2 *way_clip; };
+struct smr_win_ctx_t { const int32_t *node_win; const int2 *win_shift; const int2 *way_clip; const int2 *way_lim; };      /* way_lim: left and right side of what libcairo limits a way's polygons to, 24.8 (windows_setup) */
 /* raster.hip: smr_hip_draw with the window context; the in-place exclusive scan of the draw pass on the library's stream
  * (buf[n] = total, which also comes back) */
 int smr_draw_instances(smr_canvas *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, const smr_win_ctx_t *wc);

@@ -66,3 +66,52 @@ def test_gpu_scan_at_c4_shape_equals_the_stored_angles(hip):
         got = d.numpy()
         assert np.array_equal(got, G[tag + "_gpu"]), int((got != G[tag + "_gpu"]).sum())
     cv.close()
+
+
+def test_a_shifted_replay_is_limited_to_the_image_libcairo_makes_of_the_source():
+    """cairo_smr_cut_out paints the recording through a surface pattern: libcairo's image compositor first makes the source's
+    pixels in an image of its own that covers the sampled area in WHOLE source units (pt), and limits every polygon of the replay to
+    that image: its sides lie 2 to 6 px beyond the cut-out's at 300 dpi, and the cuts there decide rows the scan converter
+    sub-samples (orc_canvas_set_shift).  Pinned on libcairo's own cut-outs of fills (strokes keep the residual of the stroke's
+    pieces): with the limits 25 cut-outs of 271 px differ from libcairo's in a pixel or two altogether, without them
+    in dozens."""
+    cd = po.cairo()
+    if cd is None:
+        pytest.skip("libcairo not loadable here")
+    L = po.orc()
+    L.orc_canvas_set_shift.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    (x, y, off, ref), _ = scene()
+    ways = po.ways_from_arrays(x, y, off, ref)
+    box = np.array([[w[0].min(), w[0].max(), w[1].min(), w[1].max()] for w in ways])
+    st = po.Style(1, 0, 0x4080c0, 0, 0.0, 0, 0)
+    po.cairo_scene([(st, ways)], DPI, W, H, 0xffffff)          # leaves the recording in the driver for cd_cut_out
+    fw, fh, fx = (int(v) for v in G["c4_plane"])
+    r = C.c_int(); L.orc_num_steps(fw, fh, DPI, C.byref(r)); r = r.value
+    r_pt = np.hypot(fw, fh) * 72 / DPI
+    sub = np.zeros((r + 2) * (r + 2), np.uint32)
+    differing = {}
+    for mode in ("limits", "none"):
+        if mode == "none":
+            os.environ["ORC_NO_LIMITS"] = "1"
+        try:
+            tot = 0
+            for k in range(0, 2000, 80):
+                cx, cy = float(G["c4_cx"][k]), float(G["c4_cy"][k])
+                assert cd.cd_cut_out(cx * 72 / DPI, cy * 72 / DPI, r_pt, float(DPI), po.P(sub), len(sub)) == r
+                want = sub[:r * r].reshape(r, r)
+                m = r / 2 + 8
+                sel = np.nonzero(~((box[:, 1] < cx - m) | (box[:, 0] > cx + m) | (box[:, 3] < cy - m) | (box[:, 2] > cy + m)))[0]
+                c = L.orc_canvas_new(0, 0, r, r, DPI, 0xffffff)
+                L.orc_canvas_set_shift(c, -cx * 72 / DPI + r_pt / 2, -cy * 72 / DPI + r_pt / 2)
+                L.orc_rule_begin(c)
+                for i in sel:
+                    wx, wy, closed = ways[i]
+                    L.orc_draw_way(c, C.byref(st), po.P(np.ascontiguousarray(wx)), po.P(np.ascontiguousarray(wy)), len(wx), int(closed), 0, 0, 0, 0)
+                L.orc_rule_end(c)
+                got = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (r, r))
+                tot += int((got != want).sum())
+                L.orc_canvas_free(c)
+            differing[mode] = tot
+        finally:
+            os.environ.pop("ORC_NO_LIMITS", None)
+    assert differing["limits"] <= 3 and differing["none"] >= 8 * max(1, differing["limits"]), differing
