@@ -1040,6 +1040,11 @@ void orc_canvas_set_shift(orc_canvas_t *c, double tx_pt, double ty_pt)
       const double sx1 = floor(0.5 / s + X - 0.495), sx2 = floor(((double) c->W - 0.5) / s + X + 0.495) + 1.0;
       c->win_lim_on = 1;
       c->win_lim[0] = (int32_t) floor((sx1 - X) * s) * 256; c->win_lim[1] = (int32_t) ceil((sx2 - X) * s) * 256;
+      /* and the image a decomposed curve is tested against (draw_way_curve's limits), top and bottom likewise */
+      const double Y = -ty_pt;
+      const double sy1 = floor(0.5 / s + Y - 0.495), sy2 = floor(((double) c->H - 0.5) / s + Y + 0.495) + 1.0;
+      c->img[0] = c->win_lim[0] / 256; c->img[2] = c->win_lim[1] / 256;
+      c->img[1] = (int) floor((sy1 - Y) * s); c->img[3] = (int) ceil((sy2 - Y) * s);
    }
    orc_curve_set_shift(c->shift_x, c->shift_y);      /* curve.c keeps it for orc_curve_flatten (one shifted canvas at a time) */
 }

@@ -161,7 +161,7 @@ struct curve_args_t
     * slot and inputs), computed on the host with its libm, and looked up by slot (sorted) in the passes that follow */
    uint32_t *fix_n; struct smr_curvefix_t *fix; uint32_t fix_cnt;
    /* windows of an atlas (smr_hip_draw_windows): the shift of a node's window, the rows that are a way's image */
-   const int32_t *node_win; const int2 *win_shift; const int2 *way_clip;
+   const int32_t *node_win; const int2 *win_shift; const int2 *way_clip; const int4 *way_lim;
 };
 
 #define SMR_CURVEFIX_CAP 8192u
@@ -328,8 +328,10 @@ __global__ void k_curve(curve_args_t A)
          /* _cairo_spline_intersects against the image (grown by the stroke's reach): a curve that cannot reach it is a line_to */
          {
             const int32_t r = A.border_used ? A.reach[!A.fill_used ? 0 : closed ? 2 : 1] : closed ? 0 : A.reach[3];
-            const int32_t iy0 = A.way_clip ? A.way_clip[w].x * 256 : 0, iy1 = A.way_clip ? A.way_clip[w].y * 256 : A.H256;      /* the image's rows */
-            const int32_t lx0 = -r, ly0 = iy0 - r, lx1 = A.W256 + r, ly1 = iy1 + r;
+            /* the image: the chart, or for a window of an atlas the image libcairo makes of the source there (way_lim, windows_setup) */
+            const int32_t ix0 = A.way_lim ? A.way_lim[w].x : 0, ix1 = A.way_lim ? A.way_lim[w].y : A.W256;
+            const int32_t iy0 = A.way_lim ? A.way_lim[w].z : A.way_clip ? A.way_clip[w].x * 256 : 0, iy1 = A.way_lim ? A.way_lim[w].w : A.way_clip ? A.way_clip[w].y * 256 : A.H256;
+            const int32_t lx0 = ix0 - r, ly0 = iy0 - r, lx1 = ix1 + r, ly1 = iy1 + r;
             const int2 kk[4] = { K.a, K.b, K.c, K.d };
             bool inside = false;
             int32_t x0 = K.a.x, x1 = K.a.x, y0 = K.a.y, y1 = K.a.y;
@@ -355,8 +357,8 @@ __global__ void k_curve(curve_args_t A)
                const int32_t r2 = closed ? 0 : A.reach[3];       /* open ways: the fill is a stroke of the fill width */
                bool in0 = false;
 #pragma unroll
-               for (int t = 0; t < 4; t++) if (-r2 <= kk[t].x && kk[t].x <= A.W256 + r2 && iy0 - r2 <= kk[t].y && kk[t].y <= iy1 + r2) in0 = true;
-               fill_line = !fill_unlimited && !in0 && (x1 <= -r2 || x0 >= A.W256 + r2 || y1 <= iy0 - r2 || y0 >= iy1 + r2);
+               for (int t = 0; t < 4; t++) if (ix0 - r2 <= kk[t].x && kk[t].x <= ix1 + r2 && iy0 - r2 <= kk[t].y && kk[t].y <= iy1 + r2) in0 = true;
+               fill_line = !fill_unlimited && !in0 && (x1 <= ix0 - r2 || x0 >= ix1 + r2 || y1 <= iy0 - r2 || y0 >= iy1 + r2);
             }
          }
          int2 is = make_int2(0, 0), fs = make_int2(0, 0);
@@ -1340,7 +1342,7 @@ struct setup_args_t
    int cv_split;                                       /* k_cover will take a primitive's strips in parts: their strip-table entries are handed out here (small[15]) */
    const int2 *way_clip;                               /* [n_ways] rows [x, y) a way's primitives may touch: its window of an atlas (smr_hip_draw_windows); NULL: the chart */
    int32_t lim_l, lim_r; int lim_on;                   /* the replay's clip box, left and right side, 24.8 (smr_setup_cuts) */
-   const int2 *way_lim;                                /* [n_ways] the same per way (a window of an atlas: the image libcairo makes of the source there); NULL: lim_l, lim_r */
+   const int4 *way_lim;                                /* [n_ways] the same per way (x, y; z, w: its top and bottom, for k_curve) (a window of an atlas: the image libcairo makes of the source there); NULL: lim_l, lim_r */
    int evenodd;                                        /* fill polygons take libcairo's EVEN_ODD rule (smr_draw_style_t.evenodd) */
    /* solid strokes with round caps (the rule's caps are sticky, src/smrules_cairo.c:909-921) come as piece lists of the dasher with
     * one endless dash: they stay OUR pieces (no cuts at the page's sides).  mix_border: only the ways after small[14] (the first
@@ -4846,7 +4848,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       curve_args_t CA;
       CA.x = b->d_x; CA.y = b->d_y; CA.ref = b->d_ref; CA.pts = pts; CA.way_off = way_off; CA.refway = refway; CA.wayflags = wayflags;
       CA.n_refs = n_refs; CA.n_ways = n_ways; CA.dpi = c->dpi; CA.sfix = sfix; CA.f = st->curve_factor; CA.knots = st->curve == 2;
-      CA.node_win = wc ? wc->node_win : nullptr; CA.win_shift = wc ? wc->win_shift : nullptr; CA.way_clip = wc ? wc->way_clip : nullptr;
+      CA.node_win = wc ? wc->node_win : nullptr; CA.win_shift = wc ? wc->win_shift : nullptr; CA.way_clip = wc ? wc->way_clip : nullptr; CA.way_lim = wc ? wc->way_lim : nullptr;
       CA.border_used = st->border_used; CA.fill_used = st->fill_used;
       CA.W256 = c->W * 256; CA.H256 = c->H * 256;
       /* _cairo_stroke_style_max_distance_from_path: miter joins, limit 10 -> sqrt(2) * 10 line widths, in device px */

@@ -54,7 +54,7 @@ struct smr_canvas
    /* an atlas of caption cut-outs (windows.hip): win_n windows of win_size px, one every win_pitch rows; per window the 24.8 shift of
     * its replay (atlas placement included) and its box on the chart in px */
    int win_n = 0, win_size = 0, win_pitch = 0, chart_w = 0, chart_h = 0;
-   int2 *d_win_shift = nullptr, *d_win_clip = nullptr, *d_win_lim = nullptr; void *d_win_box = nullptr;
+   int2 *d_win_shift = nullptr, *d_win_clip = nullptr; int4 *d_win_lim = nullptr; void *d_win_box = nullptr;
    int win_cap = 0;                         /* windows the atlas has rows and tables for (smr_hip_windows_reset) */
    /* a uniform grid over the chart (cells of grid_cell px from (-grid_cell, -grid_cell) on): per cell the windows whose box meets it */
    uint32_t *d_grid_off = nullptr, *d_grid_win = nullptr; int grid_nx = 0, grid_ny = 0, grid_cell = 0; size_t grid_win_cap = 0;
@@ -84,7 +84,7 @@ struct smr_canvas
 
 /* a batch whose ways are instances for the windows of an atlas (smr_hip_draw_windows): per node its window, per window the 24.8
  * shift of its replay, per way the atlas rows of its window */
-struct smr_win_ctx_t { const int32_t *node_win; const int2 *win_shift; const int2 *way_clip; const int2 *way_lim; };      /* way_lim: left and right side of what libcairo limits a way's polygons to, 24.8 (windows_setup) */
+struct smr_win_ctx_t { const int32_t *node_win; const int2 *win_shift; const int2 *way_clip; const int4 *way_lim; };      /* way_lim: left, right, top, bottom of what libcairo limits a way's polygons to, 24.8 (windows_setup) */
 /* raster.hip: smr_hip_draw with the window context; the in-place exclusive scan of the draw pass on the library's stream
  * (buf[n] = total, which also comes back) */
 int smr_draw_instances(smr_canvas *c, const smr_draw_style_t *st, const smr_draw_batch_t *b, const smr_win_ctx_t *wc);

@@ -156,8 +156,8 @@ struct win_fill_args_t
    const uint32_t *way_fill_col, *way_border_col;
    const uint32_t *inst_way, *inst_win, *inst_off;      /* inst_off[n_inst] = all refs */
    uint32_t n_inst, n_out;
-   const int2 *win_clip, *win_lim;
-   double *ox, *oy; int32_t *oref, *onode_win; int64_t *oway_off; int2 *oway_clip, *oway_lim; uint32_t *ofill_col, *oborder_col;
+   const int2 *win_clip; const int4 *win_lim;
+   double *ox, *oy; int32_t *oref, *onode_win; int64_t *oway_off; int2 *oway_clip; int4 *oway_lim; uint32_t *ofill_col, *oborder_col;
 };
 
 /* one thread per ref of the instance batch */
@@ -261,8 +261,8 @@ static int windows_setup(smr_canvas_t *c, const smr_windows_t *w, int maxsize)
     * units of the source, i.e. whole pt (_cairo_pattern_sampled_area: the centres of the corner pixels through the pattern's
     * matrix, 0.495 of a unit further out for a bilinear filter, floor and ceil), taken back to device pixels with floor and ceil
     * again: at 300 dpi its sides lie 2 to 6 px beyond the cut-out's own.  (oracle: orc_canvas_set_shift.  Top and bottom change no
-    * row inside the cut-out; near the page's sides the sampled area is the recording's extents at most: left out.) */
-   std::vector<int2> lim((size_t) w->n);
+    * row inside the cut-out, but they belong to the image a decomposed curve is tested against, k_curve; near the page's sides the sampled area is the recording's extents at most: left out.) */
+   std::vector<int4> lim((size_t) w->n);
    /* the grid: cells as large as the largest window, one ring of cells around the chart for windows that hang over its edge */
    const int cell = std::max(maxsize, 64);
    const int nx = (chart_w + cell - 1) / cell + 2, ny = (chart_h + cell - 1) / cell + 2;
@@ -276,9 +276,11 @@ static int windows_setup(smr_canvas_t *c, const smr_windows_t *w, int maxsize)
       const double tx = -x_pt + r_pt / 2, ty = -y_pt + r_pt / 2;
       shift[(size_t) k] = make_int2((int32_t) nearbyint(tx * s * 256.0), (int32_t) nearbyint(ty * s * 256.0) + (int32_t) k * pitch * 256);
       {
-         const double X = -tx;                                      /* the source coordinate of the cut-out's left side */
+         const double X = -tx, Y = -ty;                             /* the source coordinates of the cut-out's left side and top */
          const double sx1 = floor(0.5 / s + X - 0.495), sx2 = floor(((double) w->size[k] - 0.5) / s + X + 0.495) + 1.0;
-         lim[(size_t) k] = make_int2((int32_t) floor((sx1 - X) * s) * 256, (int32_t) ceil((sx2 - X) * s) * 256);
+         const double sy1 = floor(0.5 / s + Y - 0.495), sy2 = floor(((double) w->size[k] - 0.5) / s + Y + 0.495) + 1.0;
+         lim[(size_t) k] = make_int4((int32_t) floor((sx1 - X) * s) * 256, (int32_t) ceil((sx2 - X) * s) * 256,
+                                     ((int32_t) floor((sy1 - Y) * s) + (int32_t) k * pitch) * 256, ((int32_t) ceil((sy2 - Y) * s) + (int32_t) k * pitch) * 256);
       }
       /* the window on the chart, in chart px (what lies further than a rule's reach from it cannot touch it) */
       box[(size_t) k] = { -tx * s, -ty * s, -tx * s + c->W, -ty * s + w->size[k] };
@@ -314,7 +316,7 @@ static int windows_setup(smr_canvas_t *c, const smr_windows_t *w, int maxsize)
    SMR_HIP(hipMemcpyAsync(c->d_grid_win, gwin.data(), gwin.size() * 4, hipMemcpyHostToDevice, smr_g.stream));
    SMR_HIP(hipMemcpyAsync(c->d_win_shift, shift.data(), (size_t) w->n * sizeof(int2), hipMemcpyHostToDevice, smr_g.stream));
    SMR_HIP(hipMemcpyAsync(c->d_win_clip, clip.data(), (size_t) w->n * sizeof(int2), hipMemcpyHostToDevice, smr_g.stream));
-   SMR_HIP(hipMemcpyAsync(c->d_win_lim, lim.data(), (size_t) w->n * sizeof(int2), hipMemcpyHostToDevice, smr_g.stream));
+   SMR_HIP(hipMemcpyAsync(c->d_win_lim, lim.data(), (size_t) w->n * sizeof(int4), hipMemcpyHostToDevice, smr_g.stream));
    SMR_HIP(hipMemcpyAsync(c->d_win_box, box.data(), (size_t) w->n * sizeof(win_box_t), hipMemcpyHostToDevice, smr_g.stream));
    SMR_HIP(hipStreamSynchronize(smr_g.stream));            /* the host vectors go out of scope */
    /* the chart's background: cairo_smr_recording_surface_from_bg paints it onto the recording, whose extents bound the paint;
@@ -392,7 +394,7 @@ extern "C" int smr_hip_windows_create(int chart_w, int chart_h, int dpi, uint32_
    SMR_TRY(smr_hip_canvas_create(maxsize, (int) w->n * pitch, dpi, 0, 0, (int) w->n * pitch, &c));
    c->win_pitch = pitch; c->chart_w = chart_w; c->chart_h = chart_h; c->win_cap = (int) w->n; c->bg = bgcolor;
    int rc = SMR_OK;
-   if (hipMalloc((void **) &c->d_win_shift, (size_t) w->n * sizeof(int2)) != hipSuccess || hipMalloc((void **) &c->d_win_clip, (size_t) w->n * sizeof(int2)) != hipSuccess || hipMalloc((void **) &c->d_win_lim, (size_t) w->n * sizeof(int2)) != hipSuccess || hipMalloc((void **) &c->d_win_box, (size_t) w->n * sizeof(win_box_t)) != hipSuccess)
+   if (hipMalloc((void **) &c->d_win_shift, (size_t) w->n * sizeof(int2)) != hipSuccess || hipMalloc((void **) &c->d_win_clip, (size_t) w->n * sizeof(int2)) != hipSuccess || hipMalloc((void **) &c->d_win_lim, (size_t) w->n * sizeof(int4)) != hipSuccess || hipMalloc((void **) &c->d_win_box, (size_t) w->n * sizeof(win_box_t)) != hipSuccess)
       rc = smr_fail(SMR_E_NOMEM, "windows_create: window tables");
    if (rc == SMR_OK) rc = windows_setup(c, w, maxsize);
    if (rc != SMR_OK) { smr_hip_canvas_destroy(c); return rc; }      /* (one way out for every failure after the canvas exists) */
@@ -500,14 +502,14 @@ static int draw_windows_range(smr_canvas_t *c, const smr_draw_style_t *st, const
       if (n_out == 0) return SMR_OK;
       if (n_out > 0x7ffffff0u) return smr_fail(SMR_E_CAPACITY, "draw_windows: %u refs in the windows' instances of one rule", n_out);
    }
-   double *ox, *oy; int32_t *oref, *onw; int64_t *owo; int2 *oclip, *olim; uint32_t *ofc = nullptr, *obc = nullptr;
+   double *ox, *oy; int32_t *oref, *onw; int64_t *owo; int2 *oclip; int4 *olim; uint32_t *ofc = nullptr, *obc = nullptr;
    SMR_TRY(c->ensure(SMR_BUF_WIN_X, (size_t) n_out * 8, (void **) &ox));
    SMR_TRY(c->ensure(SMR_BUF_WIN_Y, (size_t) n_out * 8, (void **) &oy));
    SMR_TRY(c->ensure(SMR_BUF_WIN_REF, (size_t) n_out * 4, (void **) &oref));
    SMR_TRY(c->ensure(SMR_BUF_WIN_NODEWIN, (size_t) n_out * 4, (void **) &onw));
    SMR_TRY(c->ensure(SMR_BUF_WIN_WAYOFF, ((size_t) n_inst + 1) * 8, (void **) &owo));
    SMR_TRY(c->ensure(SMR_BUF_WIN_CLIP, (size_t) n_inst * sizeof(int2), (void **) &oclip));
-   SMR_TRY(c->ensure(SMR_BUF_WIN_LIM, (size_t) n_inst * sizeof(int2), (void **) &olim));
+   SMR_TRY(c->ensure(SMR_BUF_WIN_LIM, (size_t) n_inst * sizeof(int4), (void **) &olim));
    if (b->d_way_fill_col) SMR_TRY(c->ensure(SMR_BUF_WIN_FCOL, (size_t) n_inst * 4, (void **) &ofc));
    if (b->d_way_border_col) SMR_TRY(c->ensure(SMR_BUF_WIN_BCOL, (size_t) n_inst * 4, (void **) &obc));
    win_fill_args_t F;
