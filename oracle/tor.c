@@ -261,6 +261,15 @@ void tor_coverage(const tor_edge_t *in, int n, int nonzero, int x0, int y0, int 
             edge_t *e = act[i];
             e->x = edge_x(e, ys0); e->cell = cell_of(e, e->x);
             e->xn = edge_x(e, ys1); e->celln = cell_of(e, e->xn);
+            if (lim_on_ && getenv("ORC_NO_PROJECT") == NULL)
+            {
+               /* what lies beyond a side of the limits libcairo has projected onto that side (_add_clipped_edge: a vertical edge
+                * there) before the scan converter looks: two edges that cross out there do not cross for it.  (An edge that
+                * crosses a side inside this row has a cut here, and the row is sub-sampled anyway.) */
+               const int64_t L = lim_x0_ - (int64_t) x0 * 256, R = lim_x1_ - (int64_t) x0 * 256;
+               if (e->cell < L) e->cell = L; else if (e->cell > R) e->cell = R;
+               if (e->celln < L) e->celln = L; else if (e->celln > R) e->celln = R;
+            }
          }
          qsort(act, na, sizeof(*act), cmp_row);
          int64_t prev = INT64_MIN;

@@ -1490,6 +1490,9 @@ struct smr_rowscan_t
    uint32_t list_n;               /* entries of L->l_edge that count; more than SMR_LONGCAP: the list overflowed, scan every slot */
    const smr_item_t *items;       /* the primitive's items (64 slots each, with their boxes), or NULL: build_list skips the items that
                                      cannot reach the window instead of reading every slot of a long primitive once per window */
+   int32_t cl_lo, cl_hi;          /* the sides of the limits libcairo has projected the edges beyond them onto before its scan converter looks
+                                     (_add_clipped_edge: a vertical edge at the side): two edges that cross out there do not cross for it.
+                                     INT32_MIN / INT32_MAX: no limits (oracle: tor_coverage's row decision) */
    uint32_t cap;                  /* spanning edges per row that row_by_wave compares: SMR_ROWCAP for fills (what k_raster's exact path
                                      holds of one row in one tile: fill chunks bring every edge left of a tile along), SMR_SCANCAP for
                                      strokes, whose pieces reach a tile only with the items binned there */
@@ -1545,15 +1548,15 @@ struct smr_rowscan_t
                   const int rem = __mul24(q, -D) + n;
                   return p1x + q + (rem >= D ? 1 : 0) + (rem >> 31);
                };
-               f0[pos] = cell32(n0);
-               f1[pos] = cell32(n0 + __mul24(2 * dxs, 512 * SMR_GRID_Y));
+               f0[pos] = min(max(cell32(n0), cl_lo), cl_hi);
+               f1[pos] = min(max(cell32(n0 + __mul24(2 * dxs, 512 * SMR_GRID_Y)), cl_lo), cl_hi);
             }
             else
             {
                const int64_t ec = 256 - 30ll * p1y;
                const double inv = smr_rcp((double) D);
-               f0[pos] = smr_edge_cell(ec, 2 * dxs, D, inv, p1x, rs0);
-               f1[pos] = smr_edge_cell(ec, 2 * dxs, D, inv, p1x, rs1);
+               f0[pos] = min(max(smr_edge_cell(ec, 2 * dxs, D, inv, p1x, rs0), cl_lo), cl_hi);
+               f1[pos] = min(max(smr_edge_cell(ec, 2 * dxs, D, inv, p1x, rs1), cl_lo), cl_hi);
             }
          }
          cnt += __popcll(am);
@@ -1695,7 +1698,7 @@ struct smr_rowscan_t
          /* the lane's cells into registers once (2 cnt reads instead of 2 cnt^2), then every pair */
          int c0[SMR_ACTCAP], c1[SMR_ACTCAP];
 #pragma unroll
-         for (int i = 0; i < SMR_ACTCAP; i++) { c0[i] = i < cnt ? L->act0[lane][i] : INT32_MAX; c1[i] = i < cnt ? L->act1[lane][i] : INT32_MAX; }
+         for (int i = 0; i < SMR_ACTCAP; i++) { c0[i] = i < cnt ? min(max(L->act0[lane][i], cl_lo), cl_hi) : INT32_MAX; c1[i] = i < cnt ? min(max(L->act1[lane][i], cl_lo), cl_hi) : INT32_MAX; }
          /* a slot beyond cnt holds (MAX, MAX): it is never left of anything at the top, and nothing is right of it at the bottom */
 #pragma unroll
          for (int i = 0; i < SMR_ACTCAP; i++)
@@ -1929,6 +1932,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    smr_rowscan_t RS;
    RS.row0 = P.row0; RS.nrows = P.nrows; RS.edge_cnt = P.edge_cnt; RS.E = E; RS.L = &L; RS.lmask = lmask; RS.lane = lane;
    RS.status = &A.small[2]; RS.list_n = nlong; RS.mbase = 0;
+   { const bool lim = A.lim_on && (!pieces || dashed); RS.cl_lo = lim ? lim_l : INT32_MIN; RS.cl_hi = lim ? lim_r : INT32_MAX; }
    RS.items = nitems > 64 ? A.items + item0 : nullptr;
    RS.cap = pieces ? A.scancap : SMR_ROWCAP;
 #ifdef SMR_KO_SETUP
@@ -2165,7 +2169,7 @@ __global__ __launch_bounds__(256) void k_big_vrows(const smr_prim_t *__restrict_
  * edges with one pass over the primitive's slots and ORs the rows found crossing back into the arena */
 __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_big_rows(const smr_prim_t *__restrict__ prims, const smr_edge_t *__restrict__ edges,
                                                                    const smr_item_t *__restrict__ items, const uint32_t *__restrict__ biglist, uint32_t *mask, uint32_t *status,
-                                                                   uint32_t scancap)
+                                                                   uint32_t scancap, const smr_bigacc_t *__restrict__ acc)
 {
    __shared__ setup_lds_t LL[SMR_SETUP_WAVES];
    __shared__ uint32_t wmask[SMR_SETUP_WAVES][2];
@@ -2190,6 +2194,7 @@ __global__ __launch_bounds__(64 * SMR_SETUP_WAVES) void k_big_rows(const smr_pri
          RS.lmask = &wmask[wv][0]; RS.mbase = rb;
          RS.lane = lane; RS.status = status; RS.list_n = 0; RS.items = items + biglist[2 + 2 * b];
          RS.cap = (P.flags & SMR_PF_PIECES) ? scancap : SMR_ROWCAP;
+         RS.cl_lo = acc[b].lim_on ? acc[b].lim_l : INT32_MIN; RS.cl_hi = acc[b].lim_on ? acc[b].lim_r : INT32_MAX;
          const uint32_t before0 = wmask[wv][0], before1 = wmask[wv][1];
          if (RS.build_list(rb)) RS.window(rb);
          SMR_WAVE_SYNC();
@@ -2242,7 +2247,8 @@ __global__ void k_compound_merge(smr_prim_t *prims, int64_t n_ways, uint32_t com
  * where the result may leave libcairo's arithmetic, by the difference between 15 samples and the exact
  * trapezoid on that row's edge pixels). */
 __global__ __launch_bounds__(64) void k_compound_rows(const smr_edge_t *__restrict__ edges, const smr_item_t *__restrict__ items, int64_t n_items,
-                                                      uint32_t compound, uint32_t *mask, const uint32_t *__restrict__ covered, int H, uint32_t *status)
+                                                      uint32_t compound, uint32_t *mask, const uint32_t *__restrict__ covered, int H, uint32_t *status,
+                                                      int lim_on, int32_t lim_l, int32_t lim_r, const int4 *__restrict__ win_lim, int win_pitch)
 {
    __shared__ int f0[SMR_ROWCAP], f1[SMR_ROWCAP];
    const int r = blockIdx.x, lane = threadIdx.x;
@@ -2250,6 +2256,10 @@ __global__ __launch_bounds__(64) void k_compound_rows(const smr_edge_t *__restri
    if (!((covered[r >> 5] >> (r & 31)) & 1u) || ((mask[r >> 5] >> (r & 31)) & 1u)) return;
    const int rs0 = r * SMR_GRID_Y, rs1 = rs0 + SMR_GRID_Y;
    uint32_t cnt = 0;
+   /* (what lies beyond a side of libcairo's limits is projected onto that side before its scan converter looks: smr_rowscan_t;
+    * in an atlas the row's window has the limits) */
+   int32_t cl_lo = lim_on ? lim_l : INT32_MIN, cl_hi = lim_on ? lim_r : INT32_MAX;
+   if (lim_on && win_lim) { const int4 wl = win_lim[r / win_pitch]; cl_lo = wl.x; cl_hi = wl.y; }
    /* lanes = 64 items at a time: only the members' items whose box meets the row hold a candidate */
    for (int64_t kb = 0; kb < n_items; kb += 64)
    {
@@ -2275,8 +2285,8 @@ __global__ __launch_bounds__(64) void k_compound_rows(const smr_edge_t *__restri
          {
             const int64_t ec = 256 - 30ll * o.p1y;
             const double inv = smr_rcp((double) o.D);
-            f0[pos] = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs0);
-            f1[pos] = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs1);
+            f0[pos] = min(max(smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs0), cl_lo), cl_hi);
+            f1[pos] = min(max(smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs1), cl_lo), cl_hi);
          }
          cnt += __popcll(am);
       }
@@ -5144,7 +5154,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
             k_big_items<<<256 * 4, 256, 0, s>>>(prims, edges, items, biglist, bigacc);
             k_big_finish<<<(nbig + 63) / 64, 64, 0, s>>>(prims, biglist, bigacc, maskbuf, SA.mask_cap, small, c->W, c->H);
             k_big_vrows<<<256 * 4, 256, 0, s>>>(prims, edges, items, biglist, bigacc, maskbuf);
-            k_big_rows<<<256 * 16 / SMR_SETUP_WAVES, 64 * SMR_SETUP_WAVES, 0, s>>>(prims, edges, items, biglist, maskbuf, &small[2], c->strict_rows ? SMR_ROWCAP : SMR_SCANCAP);
+            k_big_rows<<<256 * 16 / SMR_SETUP_WAVES, 64 * SMR_SETUP_WAVES, 0, s>>>(prims, edges, items, biglist, maskbuf, &small[2], c->strict_rows ? SMR_ROWCAP : SMR_SCANCAP, bigacc);
             SMR_HIP(hipGetLastError());
             SMR_HIP(hipMemcpyAsync(h_small, small, sizeof(h_small), hipMemcpyDeviceToHost, s));
             SMR_HIP(hipStreamSynchronize(s));
@@ -5156,7 +5166,8 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          {
             uint32_t *covered = (uint32_t *) c->buf[SMR_BUF_COVERED].p;
             k_compound_merge<<<blocks(n_ways, TB), TB, 0, s>>>(prims, n_ways, compound, maskbuf, covered);
-            k_compound_rows<<<(unsigned) c->H, 64, 0, s>>>(edges, items, n_items, compound, maskbuf, covered, c->H, &small[2]);
+            k_compound_rows<<<(unsigned) c->H, 64, 0, s>>>(edges, items, n_items, compound, maskbuf, covered, c->H, &small[2],
+                                                           SA.lim_on, SA.lim_l, SA.lim_r, wc && wc->way_lim ? c->d_win_lim : nullptr, c->win_pitch);
             SMR_HIP(hipGetLastError());
          }
          break;
