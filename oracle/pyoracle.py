@@ -110,12 +110,14 @@ def orc():
         L.orc_rule_begin.argtypes = [C.c_void_p]
         L.orc_rule_end.argtypes = [C.c_void_p]
         L.orc_layer_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint32]
+        L.orc_canvas_set_fill_poly.argtypes = [C.c_void_p, C.c_int]
         L.orc_direct_fill_pt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32]
         L.orc_canvas_pixels_rw.restype = C.c_void_p
         L.orc_canvas_pixels_rw.argtypes = [C.c_void_p]
         L.orc_draw_way.argtypes = [C.c_void_p, C.POINTER(Style), C.c_void_p, C.c_void_p, C.c_int, C.c_int,
                                    C.c_int, C.c_uint32, C.c_int, C.c_uint32]
         L.tor_coverage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.tor_set_path_order.argtypes = [C.c_int]
         L.orc_rot_paint.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double]
         L.orc_dist.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double)]
         L.orc_dist.restype = C.c_double
@@ -195,10 +197,15 @@ def mm2wu(mm, dpi):
     return 72.0 / dpi if mm == 0 else mm * 72 / 25.4
 
 
-def tor_coverage(edges, W, H, x0=0, y0=0, nonzero=1):
+def tor_coverage(edges, W, H, x0=0, y0=0, nonzero=1, path_order=False):
+    """path_order: the edges are a fill's, one per segment in the path's order (tor.c: tor_set_path_order)"""
     e = np.ascontiguousarray(edges, np.int32)
     out = np.zeros((H, W), np.uint8)
-    orc().tor_coverage(P(e), len(e), nonzero, x0, y0, W, H, P(out))
+    orc().tor_set_path_order(1 if path_order else 0)
+    try:
+        orc().tor_coverage(P(e), len(e), nonzero, x0, y0, W, H, P(out))
+    finally:
+        orc().tor_set_path_order(0)
     return out
 
 
@@ -366,13 +373,17 @@ def oracle_directional(st, ways, dpi, W, H, bg, x0=0, y0=0, image=None, pattern=
         e = np.ascontiguousarray(np.concatenate(edges))
         L.orc_canvas_set_pattern(c, P(pattern), pattern.shape[1], pattern.shape[0])
         L.orc_rule_begin(c)
+        L.orc_canvas_set_fill_poly(c, 1)
         L.orc_layer_edges(c, P(e), len(e), 0 if st.evenodd else 1, 0)
+        L.orc_canvas_set_fill_poly(c, 0)
         L.orc_rule_end(c)
         L.orc_canvas_set_pattern(c, None, 0, 0)
     L.orc_rule_begin(c)
     if edges and st.fill_used:
         e = np.ascontiguousarray(np.concatenate(edges))
+        L.orc_canvas_set_fill_poly(c, 1)
         L.orc_layer_edges(c, P(e), len(e), 0 if st.evenodd else 1, st.fill_col)
+        L.orc_canvas_set_fill_poly(c, 0)
     L.orc_rule_end(c)
     out = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (H, W)).copy()
     L.orc_canvas_free(c)

@@ -1002,6 +1002,7 @@ struct orc_canvas
    int cap_round;        /* line cap of the current rule's context (cairo_set_line_cap is never undone) */
    int32_t shift_x, shift_y;   /* 24.8: the translation of a replay at an offset (cairo_smr_cut_out), added to every device vertex */
    int win_lim_on; int32_t win_lim[2];      /* a replay at an offset (orc_canvas_set_shift): the sides of the image libcairo replays into, 24.8 */
+   int fill_poly;        /* the edges of the next orc_layer_edges are a fill's, one per segment in the path's order (tor_set_path_order) */
    int no_cuts;          /* the edges of the next orc_layer_edges are a stroke's PIECES: their inner edges are not the polygon's, no cuts at the image's sides */
    const uint32_t *pat; int pat_w, pat_h;   /* orc_canvas_set_pattern: the source of orc_layer_edges is this image, repeated from the chart's origin */
 };
@@ -1081,6 +1082,9 @@ void orc_rule_end(orc_canvas_t *c)
  * = one image pixel per chart pixel at angle 0, CAIRO_EXTEND_REPEAT; render_poly_line :989-997 / img_fill :2742-2751 fill the
  * closed ways with it): while a pattern is set, orc_layer_edges takes every pixel's source from the image (premultiplied ARGB32,
  * kept by the caller) and composites it as pixman does an image source through a mask: (s IN m) OVER d.  NULL: colours again. */
+/* the next orc_layer_edges calls of a caller of its own (the compound fill of a directional rule) bring fills in the path's order */
+void orc_canvas_set_fill_poly(orc_canvas_t *c, int on) { c->fill_poly = on; }
+
 void orc_canvas_set_pattern(orc_canvas_t *c, const uint32_t *pix, int w, int h) { c->pat = pix; c->pat_w = w; c->pat_h = h; }
 
 void orc_layer_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, uint32_t smr_col)
@@ -1117,7 +1121,9 @@ void orc_layer_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, u
       else
       tor_set_limits(getenv("ORC_NO_LIMITS") == NULL && !c->no_cuts && !c->shift_x && !c->shift_y, xl, xr);
    }
+   tor_set_path_order(c->fill_poly);
    tor_coverage(e, n, nonzero, c->x0 + bx0, c->y0 + by0, bw, bh, c->cov);
+   tor_set_path_order(0);
    tor_set_limits(0, 0, 0);
    for (int y = 0; y < bh; y++)
       for (int x = 0; x < bw; x++)
@@ -1161,7 +1167,9 @@ void orc_direct_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, 
    if (by1 > c->H) by1 = c->H;
    if (bx0 >= bx1 || by0 >= by1) return;
    int bw = bx1 - bx0, bh = by1 - by0;
+   tor_set_path_order(1);                                                           /* (only fills come this way) */
    tor_coverage(e, n, nonzero, c->x0 + bx0, c->y0 + by0, bw, bh, c->cov);      /* (straight onto an image: no clip, no limits) */
+   tor_set_path_order(0);
    for (int y = 0; y < bh; y++)
       for (int x = 0; x < bw; x++)
       {
@@ -1328,7 +1336,9 @@ static void draw_way_curve(orc_canvas_t *c, const orc_draw_style_t *st, const do
       const int tan_outline = om && om[0] == '1' && !c->cap_round;
       int ne = m < 2 ? 0 : closed ? orc_fill_edges(pts, m, e) : c->cap_round ? orc_stroke_edges_round_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e) : tan_outline ? orc_stroke_outline_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e) : orc_stroke_edges_tan(pts, pts + 2 * cap, pts + 4 * cap, m, fw / 2, c->dpi, e);
       c->no_cuts = !closed && !tan_outline;
+      c->fill_poly = closed;
       if (ne > 0) orc_layer_edges(c, e, ne, closed ? !st->evenodd : 1, col);
+      c->fill_poly = 0;
       c->no_cuts = 0;
    }
    all_done:
@@ -1371,7 +1381,9 @@ void orc_draw_way(orc_canvas_t *c, const orc_draw_style_t *st, const double *x_p
       else
       {
          int ne = orc_fill_edges(dev, n, e);                                                     /* :1012 */
+         c->fill_poly = 1;
          orc_layer_edges(c, e, ne, !st->evenodd, col);
+         c->fill_poly = 0;
       }
    }
    free(dev); free(e);

@@ -78,6 +78,7 @@ const uint32_t *orc_canvas_pixels(const orc_canvas_t *c);
 void orc_rule_begin(orc_canvas_t *c);
 void orc_rule_end(orc_canvas_t *c);
 void orc_layer_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, uint32_t smr_col);
+void orc_canvas_set_fill_poly(orc_canvas_t *c, int on);      /* the edges of the next orc_layer_edges calls are fills in the path's order */
 void orc_canvas_set_pattern(orc_canvas_t *c, const uint32_t *pix, int w, int h);
 
 void orc_direct_edges(orc_canvas_t *c, const tor_edge_t *e, int n, int nonzero, uint32_t smr_col);

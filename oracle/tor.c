@@ -22,6 +22,8 @@ typedef struct
    /* per-row scratch */
    quorem_t x; int64_t cell; quorem_t xn; int64_t celln;
    int ncut, cut[2];
+   int ytop_raw;               /* ytop before it is clamped to the first row */
+   int32_t topx, topy;         /* the edge's upper end point */
 } edge_t;
 
 static int to_grid_y(int64_t y) { return (int) ((GRID_Y * y + 128) >> 8); }
@@ -29,6 +31,14 @@ static int to_grid_y(int64_t y) { return (int) ((GRID_Y * y + 128) >> 8); }
 static int lim_on_;
 static int64_t lim_x0_, lim_x1_;
 void tor_set_limits(int on, int32_t x_left, int32_t x_right) { lim_on_ = on; lim_x0_ = x_left; lim_x1_ = x_right; }
+
+/* The edges come in the order in which the path added them to libcairo's polygon (a fill: one edge per segment of the path).  Then
+ * two edges that START at a row's first sub-row in the same cell, the two sides of a vertex a hair above the row's first sample line,
+ * stand in libcairo's active list in that order (merge_sorted_edges keeps ties as they come), and when it is right side before left
+ * side their cells at the row's bottom come out descending: can_do_full_row says no, the row is sub-sampled.  Seen on libcairo 1.16
+ * itself (6 000 triangles with such a vertex: tests/test_oracle_cairo.py); off for edges in an order of our own (strokes). */
+static int path_order_;
+void tor_set_path_order(int on) { path_order_ = on; }
 
 static int64_t floor_div(int64_t a, int64_t b)
 {
@@ -178,10 +188,13 @@ static void render_edge(cells_t *c, const edge_t *e, quorem_t x1, quorem_t x2, i
    cell_add(c, ix2, (int) (sign * (GRID_Y - y_last)), (int) (sign * (GRID_Y - y_last) * fx2));
 }
 
+static int cmp_ys0_;
 static int cmp_row(const void *a, const void *b)
 {
    const edge_t *p = *(edge_t * const *) a, *q = *(edge_t * const *) b;
    if (p->cell != q->cell) return p->cell < q->cell ? -1 : 1;
+   /* the two sides of one vertex at the row's top: as the path added them (tor_set_path_order) */
+   if (path_order_ && p->ytop_raw == cmp_ys0_ && q->ytop_raw == cmp_ys0_ && p->topx == q->topx && p->topy == q->topy) return p < q ? -1 : p > q;
    if (p->celln != q->celln) return p->celln < q->celln ? -1 : 1;
    return 0;
 }
@@ -212,6 +225,7 @@ void tor_coverage(const tor_edge_t *in, int n, int nonzero, int x0, int y0, int 
       if (ay > by) { int32_t t = ax; ax = bx; bx = t; t = ay; ay = by; by = t; dir = -1; }
       edge_t *e = &ed[m];
       e->ytop = to_grid_y(ay); e->ybot = to_grid_y(by);
+      e->ytop_raw = e->ytop; e->topx = ax; e->topy = ay;
       if (e->ytop < 0) e->ytop = 0;
       if (e->ybot > H * GRID_Y) e->ybot = H * GRID_Y;
       if (e->ybot <= e->ytop) continue;
@@ -271,6 +285,7 @@ void tor_coverage(const tor_edge_t *in, int n, int nonzero, int x0, int y0, int 
                if (e->celln < L) e->celln = L; else if (e->celln > R) e->celln = R;
             }
          }
+         cmp_ys0_ = ys0;
          qsort(act, na, sizeof(*act), cmp_row);
          int64_t prev = INT64_MIN;
          for (int i = 0; i < na && full; i++)

@@ -17,6 +17,7 @@ typedef struct { int32_t x1, y1, x2, y2; } tor_edge_t;   /* 24.8 fixed, directio
 
 /* Rasterise `n` edges into an 8-bit coverage window: W x H pixels whose top-left
  * pixel is (x0,y0) in device space.  nonzero: 1 = winding rule, 0 = even-odd. */
+void tor_set_path_order(int on);      /* the edges of the next tor_coverage calls are a fill's, in the path's order (tor.c) */
 void tor_coverage(const tor_edge_t *e, int n, int nonzero, int x0, int y0, int W, int H, uint8_t *alpha);
 void tor_set_limits(int on, int32_t x_left, int32_t x_right);
 

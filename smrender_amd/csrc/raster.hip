@@ -1472,6 +1472,40 @@ __device__ __forceinline__ void smr_setup_edge(const smr_oedge_t &o, int row0, i
    }
 }
 
+/* A fill's slots are the path's segments in the path's order, the order in which libcairo's polygon got its edges.  Two edges that
+ * START at a row's first sub-row in the same cell -- the two sides of a vertex a hair above the row's first sample line -- stand in
+ * libcairo's active list in that order (merge_sorted_edges keeps ties as they come), and when it is right side before left side
+ * their cells at the row's bottom come out descending: can_do_full_row says no and the row is sub-sampled (oracle:
+ * tor_set_path_order, pinned on libcairo).  Slot idx looks at the vertex it starts from, with the slot that ends there. */
+__device__ __forceinline__ void smr_tie_check(const smr_edge_t *__restrict__ E, uint32_t edge_cnt, uint32_t idx, const smr_edge_t &e,
+                                              int row0, int nrows, uint32_t *mask, int32_t cl_lo, int32_t cl_hi)
+{
+   if (e.y2 <= e.y1) return;                          /* the side that LEAVES the vertex downwards */
+   const smr_oedge_t o = smr_orient(e);
+   if (o.dir == 0 || o.ytop % SMR_GRID_Y != 0 || o.ybot < o.ytop + SMR_GRID_Y) return;
+   const int r = o.ytop / SMR_GRID_Y - row0;
+   if (o.ytop < 0 || r < 0 || r >= nrows) return;
+   /* the slot before, passing over empty ones (a node given twice) */
+   uint32_t p = idx;
+   smr_edge_t q;
+   for (uint32_t k = 0;; k++)
+   {
+      if (k >= edge_cnt) return;
+      p = p == 0 ? edge_cnt - 1 : p - 1;
+      q = E[p];
+      if (q.x1 != q.x2 || q.y1 != q.y2) break;
+   }
+   if (q.x2 != e.x1 || q.y2 != e.y1 || q.y1 <= q.y2) return;      /* it arrives at the same vertex from below */
+   const smr_oedge_t op = smr_orient(q);
+   if (op.dir == 0 || op.ytop != o.ytop || op.ybot < o.ytop + SMR_GRID_Y) return;
+   const int rs0 = o.ytop, rs1 = rs0 + SMR_GRID_Y;
+   auto cell = [&](const smr_oedge_t &g, int rs) { return min(max(smr_edge_cell(256 - 30ll * g.p1y, 2 * g.dxs, g.D, smr_rcp((double) g.D), g.p1x, rs), cl_lo), cl_hi); };
+   if (cell(o, rs0) != cell(op, rs0)) return;
+   const int b_this = cell(o, rs1), b_prev = cell(op, rs1);
+   const bool prev_first = p < idx;                   /* (the path's first segment stands before its last) */
+   if (prev_first ? b_prev > b_this : b_this > b_prev) atomicOr(&mask[r >> 5], 1u << (r & 31));
+}
+
 #define SMR_SCANCAP (64u * (SMR_ACTCAP + 1))      /* act0 / act1 of setup_lds_t as flat arrays */
 #define SMR_BIG_SLOTS 4096u   /* edge slots from which a primitive with an overflowing row-spanning list goes to k_big_rows */
 
@@ -1927,6 +1961,13 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
          if (cuts) smr_setup_cuts(e, lim_l, lim_r, P.row0, P.nrows, lmask);
       }
    }
+   if (!sparse)
+   {
+      /* a fill polygon: the two sides of a vertex at a row's first sample (smr_tie_check) */
+      const bool lim = A.lim_on != 0;
+      for (uint32_t idx = lane; idx < P.edge_cnt; idx += 64)
+         smr_tie_check(E, P.edge_cnt, idx, nitems == 1 ? e0 : E[idx], P.row0, P.nrows, lmask, lim ? lim_l : INT32_MIN, lim ? lim_r : INT32_MAX);
+   }
    SMR_WAVE_SYNC();
    const uint32_t nlong = L.nlong;
    smr_rowscan_t RS;
@@ -2143,6 +2184,7 @@ __global__ __launch_bounds__(256) void k_big_vrows(const smr_prim_t *__restrict_
                const smr_edge_t e = E[idx];
                const smr_oedge_t o = smr_orient(e);
                if (a.lim_on) smr_setup_cuts(e, a.lim_l, a.lim_r, P.row0, P.nrows, m);
+               if (!a.sparse) smr_tie_check(E, P.edge_cnt, idx, e, P.row0, P.nrows, m, a.lim_on ? a.lim_l : INT32_MIN, a.lim_on ? a.lim_r : INT32_MAX);
                if (o.dir != 0)
                {
                   if (o.ytop % SMR_GRID_Y != 0)

@@ -1026,3 +1026,35 @@ def test_deep_overdraw_with_opaque_and_translucent_colours_per_way(hip):
     cv.close()
     assert np.array_equal(got, want), report(got, want)
     assert t["n_tile_refs"] > 100 * t["n_tiles"] or t["n_tile_refs"] > 20000
+
+
+@pytest.mark.gpu
+def test_vertices_a_hair_above_a_rows_first_sample_line(hip):
+    """the two sides of a vertex that start at a row's first sub-row in one cell stand in libcairo's active list as the path added
+    them, and right side before left side makes it sub-sample the row (oracle: tor_set_path_order, pinned on libcairo in
+    tests/test_oracle_cairo.py; device: smr_tie_check): hundreds of triangles with such a vertex, both orientations and every
+    starting point, at 72 dpi (a pixel is a pt: the vertex sits where it is put, 8/256 px below a row's top)"""
+    sa = hip
+    rng = np.random.default_rng(11)
+    cols, rows, cell = 24, 16, 48
+    W, H = cols * cell, rows * cell
+    ways = []
+    for k in range(cols * rows):
+        ox, oy = (k % cols) * cell, (k // cols) * cell
+        R0 = int(rng.integers(8, 20))
+        vy, vx, h = R0 + 8 / 256, np.rint(rng.uniform(15, 33) * 256) / 256, rng.uniform(3, 12)
+        lx, rx = vx - rng.uniform(0.5, 12), vx + rng.uniform(0.5, 12)
+        ly, ry = vy + h * rng.uniform(0.6, 1.4), vy + h * rng.uniform(0.6, 1.4)
+        poly = [(vx, vy), (rx, ry), (lx, ly)] if rng.integers(0, 2) else [(vx, vy), (lx, ly), (rx, ry)]
+        start = int(rng.integers(0, 3))
+        poly = poly[start:] + poly[:start]
+        poly.append(poly[0])
+        ways.append((np.array([p[0] + ox for p in poly]), np.array([p[1] + oy for p in poly]), True))
+    st = po.Style(1, 0, 0x000000, 0, 0, 0, 0)
+    arrs = _ways_to_arrays(ways)
+    want = oracle_of([(st, arrs)], 72, W, H, 0xffffff)
+    got = gpu_scene(sa, [(st, arrs)], 72, W, H, 0xffffff)
+    assert np.array_equal(got, want), report(got, want)
+    for y0, h in ((0, 5 * cell + 9), (5 * cell + 9, H - 5 * cell - 9)):
+        band = gpu_scene(sa, [(st, arrs)], 72, W, H, 0xffffff, y0, h)
+        assert np.array_equal(band, want[y0:y0 + h]), report(band, want[y0:y0 + h])
