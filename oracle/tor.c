@@ -278,11 +278,17 @@ void tor_coverage(const tor_edge_t *in, int n, int nonzero, int x0, int y0, int 
             if (lim_on_ && getenv("ORC_NO_PROJECT") == NULL)
             {
                /* what lies beyond a side of the limits libcairo has projected onto that side (_add_clipped_edge: a vertical edge
-                * there) before the scan converter looks: two edges that cross out there do not cross for it.  (An edge that
-                * crosses a side inside this row has a cut here, and the row is sub-sampled anyway.) */
+                * there) before the scan converter looks: two edges that cross out there do not cross for it.  An edge is that
+                * vertical piece in this row when it is beyond the side at the row's first AND last sample; one that reaches the side
+                * at the row's bottom is still its own line here, and the cell libcairo steps it to lies beyond the side.  (An edge
+                * that crosses a side inside this row has a cut here, and the row is sub-sampled anyway.) */
                const int64_t L = lim_x0_ - (int64_t) x0 * 256, R = lim_x1_ - (int64_t) x0 * 256;
-               if (e->cell < L) e->cell = L; else if (e->cell > R) e->cell = R;
-               if (e->celln < L) e->celln = L; else if (e->celln > R) e->celln = R;
+               if (e->cell < L || e->cell > R)
+               {
+                  const int64_t last = cell_of(e, edge_x(e, ys1 - 1));
+                  if (e->cell < L && last < L) e->cell = e->celln = L;
+                  else if (e->cell > R && last > R) e->cell = e->celln = R;
+               }
             }
          }
          cmp_ys0_ = ys0;

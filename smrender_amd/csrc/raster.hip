@@ -1472,6 +1472,18 @@ __device__ __forceinline__ void smr_setup_edge(const smr_oedge_t &o, int row0, i
    }
 }
 
+/* What lies beyond a side of the limits libcairo has projected onto that side (_add_clipped_edge: a vertical edge there) before its scan
+ * converter looks: two edges that cross out there do not cross for it.  An edge is that vertical piece in a row when it is beyond the
+ * side at the row's first AND last sample (c0, cl); one that reaches the side at the row's bottom is still its own line there, and the
+ * cell libcairo steps it to (c1) lies beyond the side.  (An edge that crosses a side inside the row has a cut there, and the row is
+ * sub-sampled anyway.)  lo = INT32_MIN, hi = INT32_MAX: no limits.  Oracle: tor_coverage's row decision. */
+__device__ __forceinline__ bool smr_beyond(int c0, int32_t lo, int32_t hi) { return c0 < lo || c0 > hi; }
+__device__ __forceinline__ void smr_project(int &c0, int &c1, int cl, int32_t lo, int32_t hi)
+{
+   if (c0 < lo && cl < lo) c0 = c1 = lo;
+   else if (c0 > hi && cl > hi) c0 = c1 = hi;
+}
+
 /* A fill's slots are the path's segments in the path's order, the order in which libcairo's polygon got its edges.  Two edges that
  * START at a row's first sub-row in the same cell -- the two sides of a vertex a hair above the row's first sample line -- stand in
  * libcairo's active list in that order (merge_sorted_edges keeps ties as they come), and when it is right side before left side
@@ -1499,9 +1511,11 @@ __device__ __forceinline__ void smr_tie_check(const smr_edge_t *__restrict__ E, 
    const smr_oedge_t op = smr_orient(q);
    if (op.dir == 0 || op.ytop != o.ytop || op.ybot < o.ytop + SMR_GRID_Y) return;
    const int rs0 = o.ytop, rs1 = rs0 + SMR_GRID_Y;
-   auto cell = [&](const smr_oedge_t &g, int rs) { return min(max(smr_edge_cell(256 - 30ll * g.p1y, 2 * g.dxs, g.D, smr_rcp((double) g.D), g.p1x, rs), cl_lo), cl_hi); };
-   if (cell(o, rs0) != cell(op, rs0)) return;
-   const int b_this = cell(o, rs1), b_prev = cell(op, rs1);
+   auto cell = [&](const smr_oedge_t &g, int rs) { return smr_edge_cell(256 - 30ll * g.p1y, 2 * g.dxs, g.D, smr_rcp((double) g.D), g.p1x, rs); };
+   int t_this = cell(o, rs0), b_this = cell(o, rs1), t_prev = cell(op, rs0), b_prev = cell(op, rs1);
+   if (smr_beyond(t_this, cl_lo, cl_hi)) smr_project(t_this, b_this, cell(o, rs1 - 1), cl_lo, cl_hi);
+   if (smr_beyond(t_prev, cl_lo, cl_hi)) smr_project(t_prev, b_prev, cell(op, rs1 - 1), cl_lo, cl_hi);
+   if (t_this != t_prev) return;
    const bool prev_first = p < idx;                   /* (the path's first segment stands before its last) */
    if (prev_first ? b_prev > b_this : b_this > b_prev) atomicOr(&mask[r >> 5], 1u << (r & 31));
 }
@@ -1524,9 +1538,7 @@ struct smr_rowscan_t
    uint32_t list_n;               /* entries of L->l_edge that count; more than SMR_LONGCAP: the list overflowed, scan every slot */
    const smr_item_t *items;       /* the primitive's items (64 slots each, with their boxes), or NULL: build_list skips the items that
                                      cannot reach the window instead of reading every slot of a long primitive once per window */
-   int32_t cl_lo, cl_hi;          /* the sides of the limits libcairo has projected the edges beyond them onto before its scan converter looks
-                                     (_add_clipped_edge: a vertical edge at the side): two edges that cross out there do not cross for it.
-                                     INT32_MIN / INT32_MAX: no limits (oracle: tor_coverage's row decision) */
+   int32_t cl_lo, cl_hi;          /* the sides of the limits (smr_project); INT32_MIN / INT32_MAX: none */
    uint32_t cap;                  /* spanning edges per row that row_by_wave compares: SMR_ROWCAP for fills (what k_raster's exact path
                                      holds of one row in one tile: fill chunks bring every edge left of a tile along), SMR_SCANCAP for
                                      strokes, whose pieces reach a tile only with the items binned there */
@@ -1582,15 +1594,17 @@ struct smr_rowscan_t
                   const int rem = __mul24(q, -D) + n;
                   return p1x + q + (rem >= D ? 1 : 0) + (rem >> 31);
                };
-               f0[pos] = min(max(cell32(n0), cl_lo), cl_hi);
-               f1[pos] = min(max(cell32(n0 + __mul24(2 * dxs, 512 * SMR_GRID_Y)), cl_lo), cl_hi);
+               int c0 = cell32(n0), c1 = cell32(n0 + __mul24(2 * dxs, 512 * SMR_GRID_Y));
+               if (smr_beyond(c0, cl_lo, cl_hi)) smr_project(c0, c1, cell32(n0 + __mul24(2 * dxs, 512 * (SMR_GRID_Y - 1))), cl_lo, cl_hi);
+               f0[pos] = c0; f1[pos] = c1;
             }
             else
             {
                const int64_t ec = 256 - 30ll * p1y;
                const double inv = smr_rcp((double) D);
-               f0[pos] = min(max(smr_edge_cell(ec, 2 * dxs, D, inv, p1x, rs0), cl_lo), cl_hi);
-               f1[pos] = min(max(smr_edge_cell(ec, 2 * dxs, D, inv, p1x, rs1), cl_lo), cl_hi);
+               int c0 = smr_edge_cell(ec, 2 * dxs, D, inv, p1x, rs0), c1 = smr_edge_cell(ec, 2 * dxs, D, inv, p1x, rs1);
+               if (smr_beyond(c0, cl_lo, cl_hi)) smr_project(c0, c1, smr_edge_cell(ec, 2 * dxs, D, inv, p1x, rs1 - 1), cl_lo, cl_hi);
+               f0[pos] = c0; f1[pos] = c1;
             }
          }
          cnt += __popcll(am);
@@ -1711,16 +1725,18 @@ struct smr_rowscan_t
                   const int rem = __mul24(q, -D) + n;
                   return le.x + q + (rem >= D ? 1 : 0) + (rem >> 31);
                };
-               L->act0[lane][k] = cell32(n0);
-               L->act1[lane][k] = cell32(n0 + __mul24(2 * le.z, 512 * SMR_GRID_Y));
+               int c0 = cell32(n0), c1 = cell32(n0 + __mul24(2 * le.z, 512 * SMR_GRID_Y));
+               if (smr_beyond(c0, cl_lo, cl_hi)) smr_project(c0, c1, cell32(n0 + __mul24(2 * le.z, 512 * (SMR_GRID_Y - 1))), cl_lo, cl_hi);
+               L->act0[lane][k] = c0; L->act1[lane][k] = c1;
             }
          }
          else if (on)
          {
             const int64_t ec = 256 - 30ll * le.y;
             const double inv = smr_rcp((double) D);
-            L->act0[lane][k] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs0);
-            L->act1[lane][k] = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs1);
+            int c0 = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs0), c1 = smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs1);
+            if (smr_beyond(c0, cl_lo, cl_hi)) smr_project(c0, c1, smr_edge_cell(ec, 2 * le.z, D, inv, le.x, rs1 - 1), cl_lo, cl_hi);
+            L->act0[lane][k] = c0; L->act1[lane][k] = c1;
          }
       }
       bool viol = false;
@@ -1732,7 +1748,7 @@ struct smr_rowscan_t
          /* the lane's cells into registers once (2 cnt reads instead of 2 cnt^2), then every pair */
          int c0[SMR_ACTCAP], c1[SMR_ACTCAP];
 #pragma unroll
-         for (int i = 0; i < SMR_ACTCAP; i++) { c0[i] = i < cnt ? min(max(L->act0[lane][i], cl_lo), cl_hi) : INT32_MAX; c1[i] = i < cnt ? min(max(L->act1[lane][i], cl_lo), cl_hi) : INT32_MAX; }
+         for (int i = 0; i < SMR_ACTCAP; i++) { c0[i] = i < cnt ? L->act0[lane][i] : INT32_MAX; c1[i] = i < cnt ? L->act1[lane][i] : INT32_MAX; }
          /* a slot beyond cnt holds (MAX, MAX): it is never left of anything at the top, and nothing is right of it at the bottom */
 #pragma unroll
          for (int i = 0; i < SMR_ACTCAP; i++)
@@ -2327,8 +2343,9 @@ __global__ __launch_bounds__(64) void k_compound_rows(const smr_edge_t *__restri
          {
             const int64_t ec = 256 - 30ll * o.p1y;
             const double inv = smr_rcp((double) o.D);
-            f0[pos] = min(max(smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs0), cl_lo), cl_hi);
-            f1[pos] = min(max(smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs1), cl_lo), cl_hi);
+            int c0 = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs0), c1 = smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs1);
+            if (smr_beyond(c0, cl_lo, cl_hi)) smr_project(c0, c1, smr_edge_cell(ec, 2 * o.dxs, o.D, inv, o.p1x, rs1 - 1), cl_lo, cl_hi);
+            f0[pos] = c0; f1[pos] = c1;
          }
          cnt += __popcll(am);
       }

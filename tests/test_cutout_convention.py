@@ -73,8 +73,9 @@ def test_a_shifted_replay_is_limited_to_the_image_libcairo_makes_of_the_source()
     pixels in an image of its own that covers the sampled area in WHOLE source units (pt), and limits every polygon of the replay to
     that image: its sides lie 2 to 6 px beyond the cut-out's at 300 dpi, and the cuts there decide rows the scan converter
     sub-samples (orc_canvas_set_shift).  Pinned on libcairo's own cut-outs of fills (strokes keep the residual of the stroke's
-    pieces): with the limits 25 cut-outs of 271 px differ from libcairo's in a pixel or two altogether, without them
-    in dozens."""
+    pieces): with the limits, and with what lies beyond them projected onto their sides in the row decisions
+    (tor_coverage), 25 cut-outs of 271 px are libcairo's own pixel for pixel (250 of them: 2 pixels), without the limits they differ
+    in 18 pixels."""
     cd = po.cairo()
     if cd is None:
         pytest.skip("libcairo not loadable here")
@@ -114,4 +115,4 @@ def test_a_shifted_replay_is_limited_to_the_image_libcairo_makes_of_the_source()
             differing[mode] = tot
         finally:
             os.environ.pop("ORC_NO_LIMITS", None)
-    assert differing["limits"] <= 3 and differing["none"] >= 8 * max(1, differing["limits"]), differing
+    assert differing["limits"] <= 1 and differing["none"] >= 12, differing
