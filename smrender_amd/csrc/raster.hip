@@ -1342,6 +1342,8 @@ struct setup_args_t
    int cv_split;                                       /* k_cover will take a primitive's strips in parts: their strip-table entries are handed out here (small[15]) */
    const int2 *way_clip;                               /* [n_ways] rows [x, y) a way's primitives may touch: its window of an atlas (smr_hip_draw_windows); NULL: the chart */
    int32_t lim_l, lim_r; int lim_on;                   /* the replay's clip box, left and right side, 24.8 (smr_setup_cuts) */
+   uint32_t *win_first; int win_pitch;                  /* [windows] the first primitive that is anything in a window of an atlas (small[1] for the chart): every window is a
+                                                          replay of its own for libcairo, and the first drawing into its still-clear group is a SOURCE (k_tile_sort) */
    const int4 *way_lim;                                /* [n_ways] the same per way (x, y; z, w: its top and bottom, for k_curve) (a window of an atlas: the image libcairo makes of the source there); NULL: lim_l, lim_r */
    int evenodd;                                        /* fill polygons take libcairo's EVEN_ODD rule (smr_draw_style_t.evenodd) */
    /* solid strokes with round caps (the rule's caps are sticky, src/smrules_cairo.c:909-921) come as piece lists of the dasher with
@@ -2027,6 +2029,7 @@ __device__ __forceinline__ void smr_prim_setup_one(const setup_args_t &A, const 
    for (uint32_t i = lane; i < nwords; i += 64) A.mask[moff + i] = lmask[i];
    P.mask_off = moff;
    first_valid = min(first_valid, A.compound != 0xffffffffu ? A.compound : (uint32_t) p);
+   if (A.win_first && lane == 0) atomicMin(&A.win_first[clip0 / A.win_pitch], A.compound != 0xffffffffu ? A.compound : (uint32_t) p);
    /* what k_cover will need for this primitive at most: one alpha word per column of its box and strip of four rows */
    if (A.compound == 0xffffffffu && P.edge_cnt <= SMR_CV_MAXSLOTS)
    {
@@ -2141,7 +2144,7 @@ __global__ __launch_bounds__(256) void k_big_items(const smr_prim_t *__restrict_
 
 /* ---- step 2, one lane per long primitive: chart test, rows, mask words (zeroed here, ORed into by step 3) ---- */
 __global__ void k_big_finish(smr_prim_t *prims, const uint32_t *__restrict__ biglist, smr_bigacc_t *acc, uint32_t *mask, uint32_t mask_cap,
-                             uint32_t *small, int W, int H)
+                             uint32_t *small, int W, int H, uint32_t *win_first, int win_pitch)
 {
    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
    if (b >= biglist[0]) return;
@@ -2167,6 +2170,7 @@ __global__ void k_big_finish(smr_prim_t *prims, const uint32_t *__restrict__ big
    prims[p] = P;
    acc[b].valid = 1;
    atomicMin(&small[1], a.prim_id);
+   if (win_first) atomicMin(&win_first[a.clip0 / win_pitch], a.prim_id);
 }
 
 /* ---- step 3: the rows in which an edge starts or ends (smr_setup_edge, into the arena), and the binning box of a fill's
@@ -2488,6 +2492,7 @@ struct sort_args_t
    const smr_prim_t *prims;
    const uint32_t *mask;
    const uint32_t *first_prim;
+   const uint32_t *win_first; int win_pitch;      /* an atlas of windows: the first primitive per window (setup_args_t) */
    smr_thdr_t *hdrs;
    uint32_t n_tiles;
    uint32_t lds_cap;          /* entries of one tile that fit its wavefront's share of LDS (a power of two up to SORT_LDS) */
@@ -2582,7 +2587,7 @@ __global__ __launch_bounds__(64 * SORT_WAVES) void k_tile_sort(sort_args_t A)
    /* the work stream */
    const int tx = tile % A.TX, ty = tile / A.TX;
    const int row0 = A.band_y0 + ty * SMR_TH, col0 = tx * SMR_TW;
-   const uint32_t first_prim = *A.first_prim;
+   const uint32_t first_prim = A.win_first ? A.win_first[row0 / A.win_pitch] : *A.first_prim;
    const unsigned long long lt_mask = (1ull << lane) - 1ull;
    uint32_t kept = 0, last_prim = 0xffffffffu;
    bool other = false;         /* an entry that is not an alpha word: the tile is k_raster's */
@@ -4862,6 +4867,12 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    SMR_HIP(hipMemsetAsync(small, 0, 2048, s));                  /* [64 + 8 * xcd]: k_raster's tile queues, [128 + 8 * xcd]: k_prim_setup's, [256 + 8 * xcd]: k_blend's */
    SMR_HIP(hipMemcpyAsync(small, init_small, sizeof(init_small), hipMemcpyHostToDevice, s));
    SMR_HIP(hipMemsetAsync(&small[14], 0xff, 4, s));             /* [14] first open way with a fill stroke */
+   uint32_t *win_first = nullptr;
+   if (wc && c->win_n > 0 && c->win_pitch > 0)
+   {
+      SMR_TRY(c->ensure(SMR_BUF_WIN_FIRST, (size_t) c->win_n * 4, (void **) &win_first));
+      SMR_HIP(hipMemsetAsync(win_first, 0xff, (size_t) c->win_n * 4, s));
+   }
 
    const int TB = 256;
    auto blocks = [](int64_t n, int tb) { return (unsigned) ((n + tb - 1) / tb); };
@@ -5157,6 +5168,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
       SA.off_border = off_border; SA.off_fill = off_fill; SA.off_open = off_open;
       SA.border_pix = host_color_pixel(st->border_col); SA.fill_pix = host_color_pixel(st->fill_col);
       SA.way_border_pix = wb_pix; SA.way_fill_pix = wf_pix; SA.W = c->W; SA.H = c->H; SA.way_clip = wc ? wc->way_clip : nullptr;
+      SA.win_first = win_first; SA.win_pitch = c->win_pitch;
       SA.prims = prims; SA.items = items; SA.mask = maskbuf; SA.mask_cap = (uint32_t) std::min<size_t>(mask_cap, 0xffffffffu);
       SA.small = small; SA.compound = compound; SA.evenodd = st->evenodd != 0;
       {
@@ -5211,7 +5223,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
          if (nbig)
          {
             k_big_items<<<256 * 4, 256, 0, s>>>(prims, edges, items, biglist, bigacc);
-            k_big_finish<<<(nbig + 63) / 64, 64, 0, s>>>(prims, biglist, bigacc, maskbuf, SA.mask_cap, small, c->W, c->H);
+            k_big_finish<<<(nbig + 63) / 64, 64, 0, s>>>(prims, biglist, bigacc, maskbuf, SA.mask_cap, small, c->W, c->H, SA.win_first, SA.win_pitch);
             k_big_vrows<<<256 * 4, 256, 0, s>>>(prims, edges, items, biglist, bigacc, maskbuf);
             k_big_rows<<<256 * 16 / SMR_SETUP_WAVES, 64 * SMR_SETUP_WAVES, 0, s>>>(prims, edges, items, biglist, maskbuf, &small[2], c->strict_rows ? SMR_ROWCAP : SMR_SCANCAP, bigacc);
             SMR_HIP(hipGetLastError());
@@ -5320,7 +5332,7 @@ static int draw_pass(smr_canvas_t *c, const smr_draw_style_t *st, const smr_draw
    SMR_TRY(c->ensure(SMR_BUF_HDRS, ((size_t) n_entries + 1) * sizeof(smr_thdr_t), (void **) &hdrs));
    {
       sort_args_t SO;
-      SO.tile_off = tile_off; SO.entries = entries; SO.items = items; SO.prims = prims; SO.mask = maskbuf; SO.first_prim = &small[1];
+      SO.tile_off = tile_off; SO.entries = entries; SO.items = items; SO.prims = prims; SO.mask = maskbuf; SO.first_prim = &small[1]; SO.win_first = win_first; SO.win_pitch = c->win_pitch;
       SO.hdrs = hdrs; SO.n_tiles = n_tiles; SO.TX = TX; SO.band_y0 = c->band_y0; SO.band_h = c->band_h; SO.drows = drows; SO.tile_cnt = tile_cnt;
       uint32_t cap = 64;
       while (cap < h_small[7] && cap < SORT_LDS) cap <<= 1;       /* h_small[7]: entries of the fullest tile (k_scan_block) */

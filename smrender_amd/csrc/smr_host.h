@@ -40,7 +40,7 @@ enum { SMR_BUF_PTS, SMR_BUF_WAYFLAGS, SMR_BUF_SMALL, SMR_BUF_PRIMS, SMR_BUF_EDGE
        SMR_BUF_TILEOFF, SMR_BUF_SUMS, SMR_BUF_ENTRIES, SMR_BUF_CAP0, SMR_BUF_CAP1, SMR_BUF_REFWAY, SMR_BUF_ITEMS, SMR_BUF_MASK, SMR_BUF_HDRS, SMR_BUF_COVERED, SMR_BUF_DASH, SMR_BUF_PEN,
        SMR_BUF_CURVE_CNT, SMR_BUF_FPTS, SMR_BUF_FTIN, SMR_BUF_FTOUT, SMR_BUF_FREFWAY, SMR_BUF_FWAYOFF, SMR_BUF_FSKIP, SMR_BUF_BIGLIST, SMR_BUF_BIGACC, SMR_BUF_CURVEFIX, SMR_BUF_SNAPSHOT, SMR_BUF_OVFLIST, SMR_BUF_BIGBUCKET, SMR_BUF_DELTAS, SMR_BUF_DROWS, SMR_BUF_TILECNT, SMR_BUF_BLIT,
        SMR_BUF_WIN_WB, SMR_BUF_WIN_BOX, SMR_BUF_WIN_CNT, SMR_BUF_WIN_SUMS, SMR_BUF_WIN_TOT, SMR_BUF_WIN_IWAY, SMR_BUF_WIN_IWIN, SMR_BUF_WIN_IOFF, SMR_BUF_WIN_X, SMR_BUF_WIN_Y,
-       SMR_BUF_WIN_REF, SMR_BUF_WIN_NODEWIN, SMR_BUF_WIN_WAYOFF, SMR_BUF_WIN_CLIP, SMR_BUF_WIN_LIM, SMR_BUF_WIN_FCOL, SMR_BUF_WIN_BCOL, SMR_BUF_WIN_KEYS, SMR_BUF_WIN_KEYS2, SMR_BUF_WIN_TMP, SMR_BUF_PATTERN, SMR_BUF_PURELIST, SMR_BUF_PFLAG, SMR_BUF_BSKIP, SMR_BUF_MAX };
+       SMR_BUF_WIN_REF, SMR_BUF_WIN_NODEWIN, SMR_BUF_WIN_WAYOFF, SMR_BUF_WIN_CLIP, SMR_BUF_WIN_LIM, SMR_BUF_WIN_FIRST, SMR_BUF_WIN_FCOL, SMR_BUF_WIN_BCOL, SMR_BUF_WIN_KEYS, SMR_BUF_WIN_KEYS2, SMR_BUF_WIN_TMP, SMR_BUF_PATTERN, SMR_BUF_PURELIST, SMR_BUF_PFLAG, SMR_BUF_BSKIP, SMR_BUF_MAX };
 
 struct smr_devbuf_t { void *p = nullptr; size_t cap = 0; };
 
