@@ -56,6 +56,8 @@ for it in range(ITER):
     if kind == "polygon":
         os.environ["SMR_HIP_STROKE"] = "polygon"; os.environ["ORC_STROKE_OUTLINE"] = "1"
     n, r = int(rng.integers(4, 12)), int(rng.integers(31, 280))
+    if os.environ.get("SOAK_R_ALIGN"):                                     # window sizes (and so the atlas pitch) in multiples of this
+        q = int(os.environ["SOAK_R_ALIGN"]); r = max(q, (r + q - 1) // q * q)
     cx, cy = rng.uniform(-10, Wc + 10, n), rng.uniform(-10, Hc + 10, n)
     if it % 4 == 3:                                                        # whole and half pixels too
         cx, cy = np.round(cx * 2) / 2, np.round(cy * 2) / 2
