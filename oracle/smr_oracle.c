@@ -1024,6 +1024,10 @@ orc_canvas_t *orc_canvas_new(int x0, int y0, int W, int H, int dpi, uint32_t bgc
  * libcairo 1.16 transforms the recorded 24.8 path with the scale quantised to 24.8 and the matrix's translation x0 = tx * s
  * quantised SEPARATELY (_cairo_path_fixed_offset_and_scale: p = fixed_mul(scale, p) + fixed(x0)), so the shifted replay is the
  * unshifted device path plus one constant 24.8 vector; strokes are computed on the shifted path. */
+/* the same window further down: the canvas and the replay's shift moved by whole rows (an atlas of windows holds window k at rows
+ * k * pitch: a check that nothing depends on where a window stands).  After orc_canvas_set_shift. */
+void orc_canvas_move_rows(orc_canvas_t *c, int rows) { c->y0 += rows; c->shift_y += rows * 256; c->img[1] += rows; c->img[3] += rows; }
+
 void orc_canvas_set_shift(orc_canvas_t *c, double tx_pt, double ty_pt)
 {
    double s = (double) c->dpi / 72;

@@ -71,6 +71,9 @@ typedef struct orc_canvas orc_canvas_t;
 /* window of W x H pixels whose top-left is (x0,y0) on the full chart */
 orc_canvas_t *orc_canvas_new(int x0, int y0, int W, int H, int dpi, uint32_t bgcolor);
 void orc_canvas_free(orc_canvas_t *c);
+/* a canvas with a replay's shift (orc_canvas_set_shift) moved down by whole rows, canvas and shift alike: window k of an atlas stands at
+ * rows k * pitch, and the stroker's double arithmetic sees the rows */
+void orc_canvas_move_rows(orc_canvas_t *c, int rows);
 /* the image libcairo would render into (px on the full chart; default: the window itself): curves that cannot
  * reach it are drawn as lines (oracle/curve.c).  A window of a larger chart sets the chart's rectangle here. */
 void orc_canvas_set_image(orc_canvas_t *c, int x0, int y0, int x1, int y1);

@@ -303,3 +303,50 @@ def test_the_first_drawing_into_every_windows_group_is_a_source(hip):
             inside = (ys >= 1) & (ys + 1 <= Hc - 1)                      # the first window hangs over the chart's bottom
             assert len(np.unique(got[inside])) > 3, k
             assert np.array_equal(got[inside], want[inside]), (k, int((got[inside] != want[inside]).sum()))
+
+
+def test_stroked_windows_equal_the_oracle_at_the_atlas_rows(hip):
+    """windows beyond an atlas's first, strokes of several kinds, bit for bit against the oracle rendering window k where the atlas
+    holds it (orc_canvas_move_rows: canvas and shift moved down by k * pitch rows).  The stroker works in doubles on device
+    coordinates, and a join's vertex now and then rounds the other way some hundred rows further down: against the oracle at rows
+    0 one window in twenty-five is one level off in a pixel or two (tools/soak_windows.py), against the oracle at
+    the atlas's rows none is."""
+    sa = hip
+    from golden_io import draw_style
+    L = po.orc()
+    L.orc_canvas_set_shift.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    L.orc_canvas_move_rows.argtypes = [C.c_void_p, C.c_int]
+    Wc, Hc, dpi, bg = 1048, 474, 300, 0xfff8e0
+    x, y, off, ref = po.synth_ways(900, Wc, Hc, seed=31)
+    ways = po.ways_from_arrays(x, y, off, ref)
+    box = np.array([[w[0].min(), w[0].max(), w[1].min(), w[1].max()] for w in ways])
+    D = sa.DeviceArray.from_numpy
+    rng = np.random.default_rng(12)
+    n, r = 10, 180
+    r_pt = r * 72 / dpi
+    for sty in (po.Style(0, 1, 0, 0xb9acdd, 0.46, 0.186, 0), po.Style(1, 1, 0x4080c0, 0x102030, 0, 0.3, 0), po.Style(1, 1, 0x604080c0, 0x80102030, 0, 0.25, 0)):
+        cx, cy = rng.uniform(60, Wc - 60, n), rng.uniform(60, Hc - 60, n)
+        at = sa.Canvas.windows(Wc, Hc, dpi, bg, cx, cy, r)
+        at.draw_windows(draw_style(sa, sty), D(x), D(y), D(off.astype(np.int64)), D(ref.astype(np.int32)), len(off) - 1, len(ref))
+        img = at.read()
+        pitch = at.window_pitch
+        at.close()
+        for k in range(n):
+            c = L.orc_canvas_new(0, 0, r, r, dpi, bg)
+            tx, ty = -cx[k] * 72 / dpi + r_pt / 2, -cy[k] * 72 / dpi + r_pt / 2
+            L.orc_canvas_set_shift(c, tx, ty)
+            L.orc_canvas_move_rows(c, k * pitch)
+            L.orc_rule_begin(c)
+            m = r / 2 + 60
+            for i in np.nonzero(~((box[:, 1] < cx[k] - m) | (box[:, 0] > cx[k] + m) | (box[:, 3] < cy[k] - m) | (box[:, 2] > cy[k] + m)))[0]:
+                wx, wy, closed = ways[i]
+                L.orc_draw_way(c, C.byref(sty), po.P(np.ascontiguousarray(wx, np.float64)), po.P(np.ascontiguousarray(wy, np.float64)), len(wx), int(closed), 0, 0, 0, 0)
+            L.orc_rule_end(c)
+            want = np.ctypeslib.as_array(C.cast(L.orc_canvas_pixels(c), C.POINTER(C.c_uint32)), (r, r)).copy()
+            L.orc_canvas_free(c)
+            got = img[k * pitch:k * pitch + r]
+            xs, ys = np.arange(r) + cx[k] - r / 2, np.arange(r) + cy[k] - r / 2
+            inside = np.zeros((r, r), bool)
+            inside[np.ix_((ys >= 1) & (ys + 1 <= Hc - 1), (xs >= 1) & (xs + 1 <= Wc - 1))] = True
+            assert len(np.unique(got[inside])) > 3, k
+            assert np.array_equal(got[inside], want[inside]), (k, int((got[inside] != want[inside]).sum()))

@@ -15,10 +15,12 @@ from golden_io import draw_style
 
 SEED = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 ITER = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+ATLAS = len(sys.argv) > 3 and sys.argv[3] == "atlas"        # the oracle renders window k at the atlas's rows k * pitch, as the device does
 PROBE = len(sys.argv) > 3 and sys.argv[3] == "probe"        # take the first differing window apart way by way, then stop
 sa.init(0)
 L = po.orc()
 L.orc_canvas_set_shift.argtypes = [C.c_void_p, C.c_double, C.c_double]
+L.orc_canvas_move_rows.argtypes = [C.c_void_p, C.c_int]
 D = sa.DeviceArray.from_numpy
 rng = np.random.default_rng(SEED)
 
@@ -75,6 +77,8 @@ for it in range(ITER):
         c = L.orc_canvas_new(0, 0, r, r, dpi, bg)
         tx, ty = -cx[k] * 72 / dpi + r_pt / 2, -cy[k] * 72 / dpi + r_pt / 2
         L.orc_canvas_set_shift(c, tx, ty)
+        if ATLAS:
+            L.orc_canvas_move_rows(c, k * pitch)
         L.orc_rule_begin(c)
         m = r / 2 + reach
         for i in np.nonzero(~((box[:, 1] < cx[k] - m) | (box[:, 0] > cx[k] + m) | (box[:, 3] < cy[k] - m) | (box[:, 2] > cy[k] + m)))[0]:
